@@ -1,0 +1,95 @@
+"""ctypes binding of libfrlw_evd.so (the C-ABI in include/frlw_evd.h).
+
+There is no fallback: if the HIP library is missing or fails to load, every product entry point
+raises.  ``__graft_entry__.build()`` (or ``python frlw-evd_amd/_build.py``) produces the library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import _build
+
+FRLW_OK = 0
+FRLW_ERR_ARG = -1
+FRLW_ERR_INDEX = -2
+FRLW_ERR_WORKSPACE = -3
+FRLW_ERR_HIP = -4
+FRLW_ERR_POLARITY = -5
+FRLW_ERR_UNSUPPORTED = -6
+
+LAYOUT_XYTP_F64 = 0
+LAYOUT_DAT8 = 1
+TAF_U8_FLIP_K = 1
+
+_ERR_TEXT = {
+    FRLW_ERR_ARG: "bad argument",
+    FRLW_ERR_INDEX: "event coordinate out of range",
+    FRLW_ERR_WORKSPACE: "workspace too small",
+    FRLW_ERR_HIP: "HIP runtime error",
+    FRLW_ERR_POLARITY: "polarity outside {0, 1}",
+    FRLW_ERR_UNSUPPORTED: "unsupported size",
+}
+
+
+class FrlwEvents(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("n", C.c_int64), ("layout", C.c_int32),
+                ("row_stride", C.c_int32), ("xmap", C.c_void_p), ("ymap", C.c_void_p),
+                ("map_w", C.c_int32), ("map_h", C.c_int32)]
+
+
+# every symbol include/frlw_evd.h declares: name -> (restype, argtypes)
+_P, _I, _I64, _SZ = C.c_void_p, C.c_int, C.c_int64, C.c_size_t
+_EV = C.POINTER(FrlwEvents)
+SYMBOLS = {
+    "frlw_version": (C.c_char_p, []),
+    "frlw_encoder_workspace_bytes": (_SZ, [_I64, _I, _I]),
+    "frlw_encoder_status": (_I, [_P, _P, C.POINTER(C.c_int)]),
+    "frlw_eci_encode": (_I, [_EV, _I, _I, _P, _P, _P, _SZ, _P]),
+    "frlw_ev_encode": (_I, [_EV, _I, _I, _I, _I64, _I64, _P, _P, _P, _SZ, _P]),
+    "frlw_sae_encode": (_I, [_EV, _I, _I, C.POINTER(C.c_double), _I, _P, _P, _I64, _I64, _P, _P, _P, _SZ, _P]),
+    "frlw_taf_encode": (_I, [_EV, _I, _I, _I, _I64, _I64, _I, _P, _P, _P, _I, _P, _SZ, _P]),
+    "frlw_leaky_transform": (_I, [_P, _I64, _P, _P, _P]),
+    "frlw_resize_nearest_f32": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
+    "frlw_resize_nearest_u8": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
+    "frlw_quantize_u8": (_I, [_P, _I64, _I, _P, _P]),
+}
+
+_lib = None
+
+
+def library_path() -> str:
+    return _build.LIB
+
+
+def load():
+    """Load libfrlw_evd.so (never builds: call __graft_entry__.build() first)."""
+    global _lib
+    if _lib is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise RuntimeError(
+                f"{path} is missing: the HIP extension is not built and there is no fallback path. "
+                "Run `python -c 'import __graft_entry__ as g; g.build()'`.")
+        # torch ships its own libamdhip64 (same SONAME as /opt/rocm's).  Import it first so that this
+        # library binds to the HIP runtime that owns torch's device memory and streams; loading in the
+        # other order puts two HIP runtimes in the process and ours sees "no ROCm-capable device".
+        import torch  # noqa: F401
+        lib = C.CDLL(path)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)  # AttributeError = header and library out of sync
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str = "frlw"):
+    if rc == FRLW_OK:
+        return
+    msg = f"{what}: {_ERR_TEXT.get(rc, 'error')} ({rc})"
+    if rc == FRLW_ERR_INDEX:
+        raise IndexError(msg)
+    if rc in (FRLW_ERR_ARG, FRLW_ERR_POLARITY, FRLW_ERR_UNSUPPORTED):
+        raise ValueError(msg)
+    raise RuntimeError(msg)

@@ -1,0 +1,260 @@
+"""Event-stream -> tensor encoders: the reference's function signatures over the gfx950 kernels.
+
+Mirror of the module-level encoder functions of the reference's ``generate_*.py`` scripts (same
+names, argument meaning, return tuples and error behaviour), so their ``__main__`` harnesses run
+unchanged on top of this module:
+
+    generate_eventframe(events, shape)                         generate_eventcountimage.py:19-41
+    generate_agile_event_volume_cuda(events, shape, ...)       generate_eventvolume.py:15-42
+    generate_leaky_cuda(events, shape, lamdas, memory, now)    generate_surfaceofactiveevents.py:71-80
+    generate_taf_cuda(events, shape, past_volume, volume_bins) generate_taf.py:60-67
+    leaky_transform(ecd)                                       generate_taf.py:69-76
+
+``events`` is the reference's device tensor, ``(N, 4 or 5)`` float64 ``[x, y, t, p, (z)]``.
+The ``encode_*_dat`` functions are the fused fast path over raw 8-byte DAT records: window
+selection, f64 time normalisation, coordinate down-scale, encode, leaky transform and uint8
+truncation (the harness lines ``generate_taf.py:197-235``) happen on device in one call.
+
+All compute goes through ``libfrlw_evd.so``; a missing library raises (no fallback).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import time
+
+import torch
+
+from . import _lib
+
+_WORKSPACES = {}
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _workspace(n, H, W, device):
+    lib = _lib.load()
+    need = lib.frlw_encoder_workspace_bytes(int(n), int(H), int(W))
+    if need == 0:
+        raise ValueError(f"unsupported encode shape {H}x{W}")
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _WORKSPACES.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(int(need * 1.25) + 4096, dtype=torch.uint8, device=device)
+        _WORKSPACES[key] = ws
+    return ws
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _events_f64(events):
+    if not events.is_cuda:
+        raise RuntimeError("events must be a CUDA (ROCm) tensor: this path has no CPU implementation")
+    if events.dtype != torch.float64 or events.dim() != 2 or events.shape[1] < 4:
+        raise ValueError("events must be (N, >=4) float64 [x, y, t, p]")
+    ev = events.contiguous()
+    return ev, _lib.FrlwEvents(ev.data_ptr(), ev.shape[0], _lib.LAYOUT_XYTP_F64, ev.shape[1], None, None, 0, 0)
+
+
+def _events_dat(dat, xmap=None, ymap=None):
+    """dat: uint8 (N, 8) / int64 (N,) / any 8-byte-per-event CUDA tensor of raw DAT records."""
+    if not dat.is_cuda:
+        raise RuntimeError("dat must be a CUDA (ROCm) tensor")
+    d = dat.contiguous()
+    nbytes = d.numel() * d.element_size()
+    if nbytes % 8:
+        raise ValueError("DAT records are 8 bytes each")
+    mw = mh = 0
+    if xmap is not None:
+        assert ymap is not None and xmap.dtype == torch.int16 or xmap.dtype == torch.uint16
+        mw, mh = xmap.numel(), ymap.numel()
+    return d, _lib.FrlwEvents(d.data_ptr(), nbytes // 8, _lib.LAYOUT_DAT8, 0, _ptr(xmap), _ptr(ymap), mw, mh)
+
+
+def _finish(ws, what):
+    """Synchronise and surface data-dependent errors the way torch would (IndexError)."""
+    st = C.c_int(0)
+    _lib.check(_lib.load().frlw_encoder_status(_ptr(ws), _stream(), C.byref(st)), what)
+    _lib.check(st.value, what)
+
+
+def coordinate_maps(sensor_shape, shape, device):
+    """uint16 x/y tables equal to the harness' ``x * rw``, ``y * rh`` + ``.long()`` (generate_taf.py:216-219)."""
+    Hs, Ws = sensor_shape
+    H, W = shape
+    rw, rh = W / Ws, H / Hs
+    xmap = (torch.arange(Ws, dtype=torch.float64) * rw).long().to(torch.int16)
+    ymap = (torch.arange(Hs, dtype=torch.float64) * rh).long().to(torch.int16)
+    return xmap.to(device), ymap.to(device)
+
+
+# ------------------------------------------------------------------------------------------------
+# reference signatures
+# ------------------------------------------------------------------------------------------------
+def generate_eventframe(events, shape):
+    """generate_eventcountimage.py:19-41 -> (f32 (2, H, W) * 255, seconds)."""
+    tick = time.time()
+    H, W = int(shape[0]), int(shape[1])
+    ev, desc = _events_f64(events)
+    out = torch.empty((2, H, W), dtype=torch.float32, device=ev.device)
+    ws = _workspace(ev.shape[0], H, W, ev.device)
+    _lib.check(_lib.load().frlw_eci_encode(C.byref(desc), H, W, _ptr(out), None, _ptr(ws), ws.numel(), _stream()),
+               "generate_eventframe")
+    _finish(ws, "generate_eventframe")
+    return out, time.time() - tick
+
+
+def generate_agile_event_volume_cuda(events, shape, events_window=50000, volume_bins=5):
+    """generate_eventvolume.py:15-42 -> (f32 (2*bins, H, W), seconds).  ``events_window`` is unused there too."""
+    tick = time.time()
+    H, W = int(shape[0]), int(shape[1])
+    ev, desc = _events_f64(events)
+    out = torch.empty((2 * volume_bins, H, W), dtype=torch.float32, device=ev.device)
+    ws = _workspace(ev.shape[0], H, W, ev.device)
+    _lib.check(_lib.load().frlw_ev_encode(C.byref(desc), H, W, int(volume_bins), 0, 1, _ptr(out), None, _ptr(ws),
+                                          ws.numel(), _stream()), "generate_agile_event_volume_cuda")
+    _finish(ws, "generate_agile_event_volume_cuda")
+    return out, time.time() - tick
+
+
+def generate_leaky_cuda(events, shape, lamdas, memory, now):
+    """generate_surfaceofactiveevents.py:71-80 -> (f32 (2*len(lamdas), H, W), memory (2, H, W), seconds)."""
+    tick = time.time()
+    H, W = int(shape[0]), int(shape[1])
+    ev, desc = _events_f64(events)
+    lam = (C.c_double * len(lamdas))(*[float(l) for l in lamdas])
+    out = torch.empty((2 * len(lamdas), H, W), dtype=torch.float32, device=ev.device)
+    mem_out = torch.empty((2, H, W), dtype=torch.float32, device=ev.device)
+    mem_in = None if memory is None else memory.to(torch.float32).contiguous()
+    ws = _workspace(ev.shape[0], H, W, ev.device)
+    _lib.check(_lib.load().frlw_sae_encode(C.byref(desc), H, W, lam, len(lamdas), _ptr(mem_in), _ptr(mem_out),
+                                           int(now), 0, _ptr(out), None, _ptr(ws), ws.numel(), _stream()),
+               "generate_leaky_cuda")
+    _finish(ws, "generate_leaky_cuda")
+    return out, mem_out, time.time() - tick
+
+
+def generate_taf_cuda(events, shape, past_volume=None, volume_bins=5):
+    """generate_taf.py:60-67 -> (view (2K, H, W), state (H, W, 2, K), seconds); inputs are not mutated."""
+    tick = time.time()
+    H, W = int(shape[0]), int(shape[1])
+    K = int(volume_bins)
+    if past_volume is None:
+        raise TypeError("past_volume is required (the reference concatenates it, generate_taf.py:44)")
+    if tuple(past_volume.shape) != (H, W, 2, K):
+        raise ValueError("past_volume must be (H, W, 2, volume_bins)")
+    ev, desc = _events_f64(events)
+    state = past_volume.to(torch.float32).contiguous().clone()
+    view = torch.empty((2 * K, H, W), dtype=torch.float32, device=ev.device)
+    ws = _workspace(ev.shape[0], H, W, ev.device)
+    _lib.check(_lib.load().frlw_taf_encode(C.byref(desc), H, W, K, 0, 1, 1, _ptr(state), _ptr(view), None, 0,
+                                           _ptr(ws), ws.numel(), _stream()), "generate_taf_cuda")
+    _finish(ws, "generate_taf_cuda")
+    return view, state, time.time() - tick
+
+
+def leaky_transform(ecd):
+    """generate_taf.py:69-76."""
+    src = ecd.to(torch.float32).contiguous()
+    out = torch.empty_like(src)
+    _lib.check(_lib.load().frlw_leaky_transform(_ptr(src), src.numel(), _ptr(out), None, _stream()), "leaky_transform")
+    return out
+
+
+def resize_nearest(volume, target_shape):
+    """``F.interpolate(volume[None], size=target_shape, mode='nearest')[0]`` (generate_eventvolume.py:149)."""
+    src = volume.contiguous()
+    Cn, H, W = src.shape
+    Ho, Wo = int(target_shape[0]), int(target_shape[1])
+    out = torch.empty((Cn, Ho, Wo), dtype=src.dtype, device=src.device)
+    fn = _lib.load().frlw_resize_nearest_u8 if src.dtype == torch.uint8 else _lib.load().frlw_resize_nearest_f32
+    if src.dtype not in (torch.uint8, torch.float32):
+        raise ValueError("resize_nearest: float32 or uint8")
+    _lib.check(fn(_ptr(src), Cn, H, W, Ho, Wo, _ptr(out), _stream()), "resize_nearest")
+    return out
+
+
+def quantize_u8(volume, clip255=False):
+    """``np.where(v > 255, 255, v).astype(np.uint8)`` / plain ``.astype(np.uint8)`` on device."""
+    src = volume.to(torch.float32).contiguous()
+    out = torch.empty(src.shape, dtype=torch.uint8, device=src.device)
+    _lib.check(_lib.load().frlw_quantize_u8(_ptr(src), src.numel(), int(bool(clip255)), _ptr(out), _stream()),
+               "quantize_u8")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# fused DAT-record fast path (harness glue on device)
+# ------------------------------------------------------------------------------------------------
+def encode_taf_dat(dat, shape, state, t_start, window_us=10000, n_windows=8, volume_bins=8, want_view=False,
+                   want_u8=True, flip_k=True, xmap=None, ymap=None, check=True):
+    """generate_taf.py:193-235 in one device pass; ``state`` (H, W, 2, K) is updated IN PLACE.
+
+    Returns ``(u8 (K, 2, H, W) or None, view (2K, H, W) or None)``.  With ``flip_k`` the uint8 volume is
+    newest-slot-first like ``np.flip(ecd, axis=0)`` (:229): ``u8[:4]`` is the bins4 file, ``u8[4:]`` bins8.
+    """
+    H, W = int(shape[0]), int(shape[1])
+    K = int(volume_bins)
+    assert state.dtype == torch.float32 and state.is_contiguous() and tuple(state.shape) == (H, W, 2, K)
+    d, desc = _events_dat(dat, xmap, ymap)
+    u8 = torch.empty((K, 2, H, W), dtype=torch.uint8, device=d.device) if want_u8 else None
+    view = torch.empty((2 * K, H, W), dtype=torch.float32, device=d.device) if want_view else None
+    ws = _workspace(desc.n, H, W, d.device)
+    flags = _lib.TAF_U8_FLIP_K if flip_k else 0
+    _lib.check(_lib.load().frlw_taf_encode(C.byref(desc), H, W, K, int(t_start), int(window_us), int(n_windows),
+                                           _ptr(state), _ptr(view), _ptr(u8), flags, _ptr(ws), ws.numel(), _stream()),
+               "encode_taf_dat")
+    if check:
+        _finish(ws, "encode_taf_dat")
+    return u8, view
+
+
+def encode_ev_dat(dat, shape, t_end, window_us, volume_bins=5, want_f32=True, want_u8=False, xmap=None, ymap=None,
+                  check=True):
+    """generate_eventvolume.py:139-157 on device -> (f32 (2*bins, H, W) or None, u8 or None)."""
+    H, W = int(shape[0]), int(shape[1])
+    d, desc = _events_dat(dat, xmap, ymap)
+    out = torch.empty((2 * volume_bins, H, W), dtype=torch.float32, device=d.device) if want_f32 else None
+    u8 = torch.empty((2 * volume_bins, H, W), dtype=torch.uint8, device=d.device) if want_u8 else None
+    ws = _workspace(desc.n, H, W, d.device)
+    _lib.check(_lib.load().frlw_ev_encode(C.byref(desc), H, W, int(volume_bins), int(t_end), int(window_us), _ptr(out),
+                                          _ptr(u8), _ptr(ws), ws.numel(), _stream()), "encode_ev_dat")
+    if check:
+        _finish(ws, "encode_ev_dat")
+    return out, u8
+
+
+def encode_eci_dat(dat, shape, want_f32=True, want_u8=False, xmap=None, ymap=None, check=True):
+    """generate_eventcountimage.py:155-180 on device (the caller has cut the last ``events_window`` records)."""
+    H, W = int(shape[0]), int(shape[1])
+    d, desc = _events_dat(dat, xmap, ymap)
+    out = torch.empty((2, H, W), dtype=torch.float32, device=d.device) if want_f32 else None
+    u8 = torch.empty((2, H, W), dtype=torch.uint8, device=d.device) if want_u8 else None
+    ws = _workspace(desc.n, H, W, d.device)
+    _lib.check(_lib.load().frlw_eci_encode(C.byref(desc), H, W, _ptr(out), _ptr(u8), _ptr(ws), ws.numel(), _stream()),
+               "encode_eci_dat")
+    if check:
+        _finish(ws, "encode_eci_dat")
+    return out, u8
+
+
+def encode_sae_dat(dat, shape, lamdas, memory, now, window_us, want_f32=True, want_u8=False, xmap=None, ymap=None,
+                   check=True):
+    """generate_surfaceofactiveevents.py:183-194 on device -> (f32 or None, u8 or None, new memory)."""
+    H, W = int(shape[0]), int(shape[1])
+    d, desc = _events_dat(dat, xmap, ymap)
+    lam = (C.c_double * len(lamdas))(*[float(l) for l in lamdas])
+    out = torch.empty((2 * len(lamdas), H, W), dtype=torch.float32, device=d.device) if want_f32 else None
+    u8 = torch.empty((2 * len(lamdas), H, W), dtype=torch.uint8, device=d.device) if want_u8 else None
+    mem_out = torch.empty((2, H, W), dtype=torch.float32, device=d.device)
+    mem_in = None if memory is None else memory.to(torch.float32).contiguous()
+    ws = _workspace(desc.n, H, W, d.device)
+    _lib.check(_lib.load().frlw_sae_encode(C.byref(desc), H, W, lam, len(lamdas), _ptr(mem_in), _ptr(mem_out), int(now),
+                                           int(window_us), _ptr(out), _ptr(u8), _ptr(ws), ws.numel(), _stream()),
+               "encode_sae_dat")
+    if check:
+        _finish(ws, "encode_sae_dat")
+    return out, u8, mem_out

@@ -1,0 +1,314 @@
+"""HIP encoders (through the C-ABI, via the reference-signature shims) against the CPU oracle, the
+reference-generated golden vectors, and size-independent properties at BASELINE sizes.
+
+Bars: bit-exact f32 for everything that is add / sub / mul / div / max in the
+reference; directly after expf / log1pf the f32 values agree within 2 ulp and the uint8 artefact may
+differ by exactly 1 LSB in at most 1e-5 of the elements (1e-4 on the small samples).
+"""
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from frlw_evd_amd import synth  # noqa: E402
+from golden_util import (GEN1, LAMDAS, MPX, assert_big, assert_bitexact, assert_u8_budget,  # noqa: E402
+                         downscale_maps, sha)
+
+pytestmark = pytest.mark.gpu
+
+U8_BUDGET = 1e-5
+
+
+@pytest.fixture(scope="module")
+def er():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from frlw_evd_amd import event_representation
+    return event_representation
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+    return oracle
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def dat_dev(ev):
+    return torch.from_numpy(synth.to_dat8(ev).view(np.uint8).reshape(-1, 8).copy()).cuda()
+
+
+def host(t):
+    return t.cpu().numpy()
+
+
+def assert_ulp(got, want, ulps, what):
+    a = np.ascontiguousarray(got).view(np.int32).astype(np.int64)
+    b = np.ascontiguousarray(want).view(np.int32).astype(np.int64)
+    assert np.abs(a - b).max() <= ulps, f"{what}: {np.abs(a - b).max()} ulp"
+
+
+# ------------------------------------------------------------------------------------------
+# tiny hand-checkable cases through the reference signatures, against the reference's goldens
+# ------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def tiny(golden_dir):
+    return np.load(os.path.join(golden_dir, "tiny.npz"))
+
+
+def test_tiny_eci_ev(er, tiny):
+    H, W = (int(v) for v in tiny["shape"])
+    ev = dev(tiny["events"])
+    out, dt = er.generate_eventframe(ev, (H, W))
+    assert_bitexact(host(out), tiny["eci"], "eci")
+    assert dt >= 0
+    out, _ = er.generate_agile_event_volume_cuda(ev, (H, W), 50000, 5)
+    assert_bitexact(host(out), tiny["ev"], "ev")
+    out, _ = er.generate_agile_event_volume_cuda(ev, (H, W), 50000, 3)
+    assert_bitexact(host(out), tiny["ev_bins3"], "ev bins=3")
+
+
+def test_tiny_sae(er, tiny):
+    H, W = (int(v) for v in tiny["shape"])
+    se, half, now = tiny["sae_events"], int(tiny["sae_half"]), tiny["sae_now"]
+    o1, m1, _ = er.generate_leaky_cuda(dev(se[:half]), (H, W), LAMDAS, None, now[0])
+    assert_bitexact(host(m1), tiny["sae_mem1"], "sae memory 1")
+    assert_ulp(host(o1), tiny["sae_out1"], 2, "sae out 1")
+    o2, m2, _ = er.generate_leaky_cuda(dev(se[half:]), (H, W), LAMDAS, m1, now[1])
+    assert_bitexact(host(m2), tiny["sae_mem2"], "sae memory 2")
+    assert_ulp(host(o2), tiny["sae_out2"], 2, "sae out 2")
+
+
+@pytest.mark.parametrize("K", [8, 4])
+def test_tiny_taf(er, tiny, K):
+    H, W = (int(v) for v in tiny["shape"])
+    ev, sp = tiny["events"], tiny["taf_splits"]
+    st = torch.full((H, W, 2, K), -6000.0, device="cuda")
+    for i in range(4):
+        w = ev[sp[i]:sp[i + 1]]
+        w5 = np.concatenate([w, np.zeros((len(w), 1))], axis=1)  # the z column, generate_taf.py:203
+        before = st.clone()
+        view, st2, _ = er.generate_taf_cuda(dev(w5), (H, W), st, K)
+        assert torch.equal(st, before), "past_volume must not be mutated"
+        st = st2
+        if K == 8:
+            assert_bitexact(host(view), tiny[f"taf_view{i}"], f"taf view {i}")
+            assert_bitexact(host(st), tiny[f"taf_state{i}"], f"taf state {i}")
+    if K == 8:
+        assert_ulp(host(er.leaky_transform(view)), tiny["taf_leaky"], 2, "leaky_transform")
+    else:
+        assert_bitexact(host(st), tiny["taf_k4_state"], "taf K=4 state")
+        assert_bitexact(host(view), tiny["taf_k4_view"], "taf K=4 view")
+
+
+def test_errors_like_torch(er):
+    oob = dev(np.array([[0.0, 8.0, 0.5, 1.0]]))  # flat index past the end
+    with pytest.raises(IndexError):
+        er.generate_eventframe(oob, (8, 12))
+    with pytest.raises(IndexError):
+        er.generate_agile_event_volume_cuda(oob, (8, 12))
+    with pytest.raises(IndexError):
+        er.generate_taf_cuda(oob, (8, 12), torch.zeros((8, 12, 2, 8), device="cuda"), 8)
+    # x >= W alone aliases into the next row, like the flat index of the reference
+    out, _ = er.generate_eventframe(dev(np.array([[13.0, 1.0, 0.5, 1.0]])), (8, 12))
+    out = host(out)
+    assert out[1, 2, 1] > 0 and np.count_nonzero(out) == 1
+    # SAE filters (generate_surfaceofactiveevents.py:72)
+    o, mem, _ = er.generate_leaky_cuda(oob, (8, 12), LAMDAS, None, 100)
+    assert np.all(host(mem) == np.float32(100) - np.float32(5000000))
+    with pytest.raises(RuntimeError):
+        er.generate_eventframe(torch.zeros((1, 4), dtype=torch.float64), (8, 12))  # CPU tensor: no fallback
+
+
+def test_empty_stream(er):
+    ev = torch.zeros((0, 4), dtype=torch.float64, device="cuda")
+    out, _ = er.generate_eventframe(ev, (8, 12))
+    assert torch.count_nonzero(out) == 0
+    out, _ = er.generate_agile_event_volume_cuda(ev, (8, 12))
+    assert torch.count_nonzero(out) == 0
+    st = torch.full((8, 12, 2, 8), -6000.0, device="cuda")
+    view, st2, _ = er.generate_taf_cuda(ev, (8, 12), st, 8)
+    assert torch.equal(st2, st)  # all(forward) -> unchanged (generate_taf.py:40-41)
+    assert torch.equal(view, st.permute(3, 2, 0, 1).reshape(16, 8, 12))
+
+
+# ------------------------------------------------------------------------------------------
+# random ragged shapes: HIP vs oracle on the same seeded inputs (f64-tensor path)
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("H,W,n,seed", [(8, 12, 500, 1), (37, 70, 20_000, 2), (240, 304, 200_000, 3),
+                                         (9, 33, 5_000, 4), (64, 64, 100_000, 5)])
+def test_random_vs_oracle_f64(er, orc, H, W, n, seed):
+    ev = synth.synth_events(seed, n, W, H, 100_000, hotspot=bool(seed & 1))
+    t = ev["t"] / 100_000.0
+    e = synth.to_xytp_f64(ev, t)
+    ed = dev(e)
+    assert_bitexact(host(er.generate_eventframe(ed, (H, W))[0]), orc.eventframe(e, (H, W)), "eci")
+    for bins in (5, 2):
+        assert_bitexact(host(er.generate_agile_event_volume_cuda(ed, (H, W), 0, bins)[0]),
+                        orc.event_volume(e, (H, W), bins), f"ev bins={bins}")
+    st0 = np.random.default_rng(seed).uniform(-50, 0, size=(H, W, 2, 6)).astype(np.float32)
+    view, st, _ = er.generate_taf_cuda(ed, (H, W), dev(st0), 6)
+    oview, ost = orc.taf_window(e, (H, W), st0, 6)
+    assert_bitexact(host(st), ost, "taf state")
+    assert_bitexact(host(view), oview, "taf view")
+    e_abs = synth.to_xytp_f64(ev, ev["t"] + 40_000_000)
+    o, mem, _ = er.generate_leaky_cuda(dev(e_abs), (H, W), LAMDAS, None, 40_100_000)
+    oo, omem = orc.sae(e_abs, (H, W), LAMDAS, None, 40_100_000)
+    assert_bitexact(host(mem), omem, "sae memory")
+    assert_ulp(host(o), oo, 2, "sae out")
+    assert_u8_budget(host(er.quantize_u8(o)), orc.quantize_u8(oo), 1e-4, "sae u8")
+
+
+def test_taf_unsorted_stream(er, orc):
+    """Stream order, not time order, defines the result: shuffle the records (windows interleave)."""
+    H, W, K = 40, 70, 8
+    ev = synth.synth_events(21, 60_000, W, H, 80_000, hotspot=True)
+    perm = np.random.default_rng(5).permutation(60_000)
+    ev = {k: v[perm] for k, v in ev.items()}
+    dat = synth.to_dat8(ev)
+    st0 = np.full((H, W, 2, K), -6000, np.float32)
+    oview, ost = orc.taf_stream_dat8(dat, (H, W), (H, W), K, 0, 10_000, 8, st0)
+    st = dev(st0)
+    u8, view = er.encode_taf_dat(dat_dev(ev), (H, W), st, 0, 10_000, 8, K, want_view=True)
+    assert_bitexact(host(st), ost, "unsorted taf state")
+    assert_bitexact(host(view), oview, "unsorted taf view")
+
+
+def test_taf_outside_window_span(er, orc):
+    """Events before t_start / after the last window fall into window 0 (generate_taf.py:197-203)."""
+    H, W, K = 16, 40, 8
+    ev = synth.synth_events(22, 20_000, W, H, 120_000)
+    dat = synth.to_dat8(ev)
+    st0 = np.full((H, W, 2, K), -6000, np.float32)
+    oview, ost = orc.taf_stream_dat8(dat, (H, W), (H, W), K, 20_000, 10_000, 8, st0)
+    st = dev(st0)
+    er.encode_taf_dat(dat_dev(ev), (H, W), st, 20_000, 10_000, 8, K)
+    assert_bitexact(host(st), ost, "taf with outsiders")
+
+
+# ------------------------------------------------------------------------------------------
+# GEN1-shaped goldens through the fused DAT path (SURVEY.md section 8d cfg 1, 2, 5)
+# ------------------------------------------------------------------------------------------
+def test_gen1_eci(er, golden_dir):
+    g = np.load(os.path.join(golden_dir, "gen1_eci.npz"))
+    shape, tshape = GEN1
+    for hot, nat_key, u8_key in ((False, "eci_native", "eci_u8"), (True, None, "eci_hot_u8")):
+        ev = synth.synth_events(1001, 100_000, shape[1], shape[0], 50_000, hotspot=hot)
+        out, u8 = er.encode_eci_dat(dat_dev(ev), shape, want_u8=True)
+        if nat_key:
+            assert_bitexact(host(out), g[nat_key], "eci native")
+        else:
+            assert sha(host(out)) == str(g["eci_hot_native_sha"])
+        assert_bitexact(host(er.resize_nearest(u8, tshape)), g[u8_key], "eci u8")
+        assert_bitexact(host(er.quantize_u8(er.resize_nearest(out, tshape))), g[u8_key], "eci u8 via f32")
+
+
+@pytest.mark.parametrize("tag,hot", [("", False), ("hot_", True)])
+def test_gen1_ev(er, golden_dir, tag, hot):
+    g = np.load(os.path.join(golden_dir, "gen1_ev.npz"))
+    shape, tshape = GEN1
+    ev = synth.synth_events(1002, 1_000_000, shape[1], shape[0], 250_000, hotspot=hot)
+    out, u8 = er.encode_ev_dat(dat_dev(ev), shape, 250_000, 250_000, 5, want_u8=True)
+    assert_big(host(out), g, tag + "native", "ev native")
+    assert_bitexact(host(er.resize_nearest(u8, tshape)), g[tag + "u8"], "ev u8")
+
+
+def test_gen1_sae(er, golden_dir):
+    g = np.load(os.path.join(golden_dir, "gen1_sae.npz"))
+    shape, tshape = GEN1
+    ev = synth.synth_events(1006, 1_000_000, shape[1], shape[0], 5_000_000, t_offset=30_000_000)
+    dat = dat_dev(ev)
+    cut, now = int(g["cut"]), g["now"]
+    o1, u1, m1 = er.encode_sae_dat(dat[:cut], shape, LAMDAS, None, now[0], 5541263, want_u8=True)
+    assert_big(host(m1), g, "mem1", "sae mem1")
+    assert_u8_budget(host(er.resize_nearest(u1, tshape)), g["u8_1"], U8_BUDGET, "sae u8 1")
+    o2, u2, m2 = er.encode_sae_dat(dat[cut:], shape, LAMDAS, m1, now[1], 5541263, want_u8=True)
+    assert_big(host(m2), g, "mem2", "sae mem2")
+    assert_u8_budget(host(er.resize_nearest(u2, tshape)), g["u8_2"], U8_BUDGET, "sae u8 2")
+
+
+@pytest.mark.parametrize("tag,hot", [("", False), ("hot_", True)])
+def test_gen1_taf(er, golden_dir, tag, hot):
+    g = np.load(os.path.join(golden_dir, "gen1_taf.npz"))
+    shape, tshape = GEN1
+    K = 8
+    ev = synth.synth_events(1005, 1_000_000, shape[1], shape[0], 80_000, hotspot=hot)
+    st = torch.full((*shape, 2, K), -6000.0, device="cuda")
+    u8, view = er.encode_taf_dat(dat_dev(ev), shape, st, 0, 10_000, 8, K, want_view=True)
+    assert_big(host(st), g, tag + "state", "taf state")
+    assert_big(host(view), g, tag + "native", "taf view")
+    u8r = er.resize_nearest(u8.reshape(2 * K, *shape), tshape).reshape(K, 2, *tshape)
+    assert_u8_budget(host(u8r), g[tag + "u8"], U8_BUDGET, "taf u8")
+    if not hot:  # second label with the state carried over (generate_taf.py:180-186)
+        ev2 = synth.synth_events(2005, 300_000, shape[1], shape[0], 30_000, t_offset=80_000)
+        u8, _ = er.encode_taf_dat(dat_dev(ev2), shape, st, 80_000, 10_000, 3, K)
+        assert_big(host(st), g, "carry_state", "taf carry state")
+        u8r = er.resize_nearest(u8.reshape(2 * K, *shape), tshape).reshape(K, 2, *tshape)
+        assert_u8_budget(host(u8r), g["carry_u8"], U8_BUDGET, "taf carry u8")
+
+
+# ------------------------------------------------------------------------------------------
+# BASELINE.json full sizes: 1 Mpx goldens + size-independent properties
+# ------------------------------------------------------------------------------------------
+def test_mpx_taf_native_golden(er, golden_dir):
+    """cfg 3: TAF K=8, 10 M events, 1280x720, 8 windows -- state sha256 equals the reference's."""
+    g = np.load(os.path.join(golden_dir, "mpx_taf_native.npz"))
+    shape = MPX[0]
+    K = 8
+    ev = synth.synth_events(1003, 10_000_000, shape[1], shape[0], 80_000)
+    st = torch.full((*shape, 2, K), -6000.0, device="cuda")
+    u8, _ = er.encode_taf_dat(dat_dev(ev), shape, st, 0, 10_000, 8, K)
+    assert_big(host(st), g, "state", "mpx taf state")
+    assert_u8_budget(host(u8).reshape(-1)[g["u8_idx"]], g["u8_val"], 1e-4, "mpx taf u8 sample")
+
+
+def test_mpx_downscale_golden(er, golden_dir):
+    g = np.load(os.path.join(golden_dir, "mpx_downscale.npz"))
+    shape, tshape = MPX
+    K = 8
+    ev = synth.synth_events(1013, 2_000_000, shape[1], shape[0], 80_000, hotspot=True)
+    dat = dat_dev(ev)
+    xm, ym = er.coordinate_maps(shape, tshape, "cuda")
+    xmap, ymap = downscale_maps(shape, tshape)
+    assert np.array_equal(host(xm).astype(np.uint16), xmap) and np.array_equal(host(ym).astype(np.uint16), ymap)
+    st = torch.full((*tshape, 2, K), -6000.0, device="cuda")
+    er.encode_taf_dat(dat, tshape, st, 0, 10_000, 8, K, xmap=xm, ymap=ym)
+    assert_big(host(st), g, "state", "downscale taf state")
+    out, _ = er.encode_ev_dat(dat, tshape, 80_000, 80_000, 5, xmap=xm, ymap=ym)
+    assert_big(host(out), g, "ev_native", "downscale ev")
+    out, _ = er.encode_eci_dat(dat[-200_000:], tshape, xmap=xm, ymap=ym)
+    assert_big(host(out), g, "eci_native", "downscale eci")
+
+
+def test_mpx_properties(er):
+    """Size-independent properties at the cfg-3 size (no oracle run needed)."""
+    shape = MPX[0]
+    K = 8
+    ev = synth.synth_events(77, 10_000_000, shape[1], shape[0], 80_000, hotspot=True)
+    dat = dat_dev(ev)
+    # (1) one 8-window call == a 5-window call followed by a 3-window call on the carried state
+    st_a = torch.full((*shape, 2, K), -6000.0, device="cuda")
+    er.encode_taf_dat(dat, shape, st_a, 0, 10_000, 8, K, want_u8=False)
+    cut = int(np.searchsorted(ev["t"], 50_000, side="left"))
+    st_b = torch.full((*shape, 2, K), -6000.0, device="cuda")
+    er.encode_taf_dat(dat[:cut], shape, st_b, 0, 10_000, 5, K, want_u8=False)
+    er.encode_taf_dat(dat[cut:], shape, st_b, 50_000, 10_000, 3, K, want_u8=False)
+    assert torch.equal(st_a, st_b)
+    # (2) deterministic run to run
+    st_c = torch.full((*shape, 2, K), -6000.0, device="cuda")
+    er.encode_taf_dat(dat, shape, st_c, 0, 10_000, 8, K, want_u8=False)
+    assert torch.equal(st_a, st_c)
+    # (3) ECI is a pure count: invariant under any permutation of the stream, and sums to the event count
+    out, _ = er.encode_eci_dat(dat[:2_000_000], shape)
+    perm = torch.randperm(2_000_000, device="cuda")
+    out_p, _ = er.encode_eci_dat(dat[:2_000_000][perm], shape)
+    assert torch.equal(out, out_p)
+    # (4) SAE memory is idempotent: feeding the memory back with no events returns it unchanged
+    o, _, mem = er.encode_sae_dat(dat[:2_000_000], shape, LAMDAS, None, 80_000, 0)
+    _, _, mem2 = er.encode_sae_dat(dat[:0], shape, LAMDAS, mem, 80_000, 0)
+    assert torch.equal(mem, mem2)
