@@ -1,0 +1,98 @@
+// elementwise.hip -- the harness' stand-alone elementwise steps: leaky_transform
+// (generate_taf.py:69-76), uint8 truncation (generate_taf.py:232), nearest resize
+// (generate_eventvolume.py:149).  HBM-bound streaming kernels, grid-stride.
+
+#include "frlw_common.h"
+
+using namespace frlw;
+
+namespace {
+
+__global__ void k_leaky(const float *in, long long n, float *out_f32, uint8_t *out_u8)
+{
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        float v = leaky_f(in[i]);
+        if (out_f32) out_f32[i] = v;
+        if (out_u8) out_u8[i] = (uint8_t)(int)v;
+    }
+}
+
+__global__ void k_quantize(const float *in, long long n, int clip255, uint8_t *out)
+{
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        float v = in[i];
+        if (clip255 && v > 255.0f) v = 255.0f;
+        out[i] = (uint8_t)(int)v;
+    }
+}
+
+template <typename T>
+__global__ void k_resize_nearest(const T *in, int C, int H, int W, int Ho, int Wo, float sh, float sw,
+                                 T *out)
+{
+    const long long total = (long long)C * Ho * Wo;
+    for (long long o = blockIdx.x * (long long)blockDim.x + threadIdx.x; o < total;
+         o += (long long)gridDim.x * blockDim.x) {
+        const int xo = (int)(o % Wo);
+        const int yo = (int)((o / Wo) % Ho);
+        const int c = (int)(o / ((long long)Wo * Ho));
+        int ys = (int)floorf((float)yo * sh);
+        int xs = (int)floorf((float)xo * sw);
+        if (ys > H - 1) ys = H - 1;
+        if (xs > W - 1) xs = W - 1;
+        out[o] = in[((long long)c * H + ys) * W + xs];
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+int frlw_leaky_transform(const float *in, int64_t n, float *out_f32, uint8_t *out_u8,
+                         frlw_stream_t stream)
+{
+    if (!in || (!out_f32 && !out_u8) || n < 0) return FRLW_ERR_ARG;
+    if (n == 0) return FRLW_OK;
+    hipLaunchKernelGGL(k_leaky, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, in,
+                       (long long)n, out_f32, out_u8);
+    HIP_TRY(hipGetLastError());
+    return FRLW_OK;
+}
+
+int frlw_quantize_u8(const float *in, int64_t n, int clip255, uint8_t *out, frlw_stream_t stream)
+{
+    if (!in || !out || n < 0) return FRLW_ERR_ARG;
+    if (n == 0) return FRLW_OK;
+    hipLaunchKernelGGL(k_quantize, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, in,
+                       (long long)n, clip255, out);
+    HIP_TRY(hipGetLastError());
+    return FRLW_OK;
+}
+
+int frlw_resize_nearest_f32(const float *in, int C, int H, int W, int Ho, int Wo, float *out,
+                            frlw_stream_t stream)
+{
+    if (!in || !out || C <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0) return FRLW_ERR_ARG;
+    const long long total = (long long)C * Ho * Wo;
+    hipLaunchKernelGGL(k_resize_nearest<float>, dim3(grid_for(total, 256)), dim3(256), 0,
+                       (hipStream_t)stream, in, C, H, W, Ho, Wo, (float)H / (float)Ho,
+                       (float)W / (float)Wo, out);
+    HIP_TRY(hipGetLastError());
+    return FRLW_OK;
+}
+
+int frlw_resize_nearest_u8(const uint8_t *in, int C, int H, int W, int Ho, int Wo, uint8_t *out,
+                           frlw_stream_t stream)
+{
+    if (!in || !out || C <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0) return FRLW_ERR_ARG;
+    const long long total = (long long)C * Ho * Wo;
+    hipLaunchKernelGGL(k_resize_nearest<uint8_t>, dim3(grid_for(total, 256)), dim3(256), 0,
+                       (hipStream_t)stream, in, C, H, W, Ho, Wo, (float)H / (float)Ho,
+                       (float)W / (float)Wo, out);
+    HIP_TRY(hipGetLastError());
+    return FRLW_OK;
+}
+
+} // extern "C"

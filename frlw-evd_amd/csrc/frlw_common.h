@@ -1,0 +1,226 @@
+// frlw_common.h -- shared device helpers of the event encoders (gfx950, wave64).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "frlw_evd.h"
+
+namespace frlw {
+
+constexpr int kWave = 64;
+// A tile is (1 << twl) pixels wide and 8 rows high; twl = 7 for frames wider than 512 px, else 6
+// (measured best on MI355X; FRLW_TWL overrides for experiments).
+// One tile = one workgroup of the tile kernels = NT = 4 << twl threads owning 4 cells each
+// (cell = (pixel, polarity)).  A tile row is a whole number of wavefronts of consecutive cells,
+// so the (H, W, 2, K) state and the (C, H, W) outputs are read / written in full lines.
+constexpr int kTileH = 8;
+constexpr int kTileHLog = 3;
+constexpr int kCellsPerThread = 4;
+constexpr int kMaxTiles = 2048;   // LDS of the scatter workgroup: 52 B per tile
+constexpr int kMaxTlut = 1 << 16; // longest TAF window (us) served by the value table
+constexpr int kPartThreads = 1024; // partition workgroup = 16 wavefronts
+constexpr int kPartWaves = kPartThreads / kWave;
+constexpr int kMaxBpw = 8;        // batches of 64 events per wavefront per workgroup chunk (registers!)
+constexpr int kSlabUnits = 32;    // workgroups per slab of the two-level column scan
+
+enum Kind : int { KIND_ECI = 0, KIND_EV = 1, KIND_SAE = 2, KIND_TAF = 3 };
+enum : int { ST_INDEX = 1, ST_POLARITY = 2 };
+
+// First kHeaderBytes of the workspace.
+struct WsHeader {
+    int32_t status; // ST_* flags
+    uint32_t pad;
+    unsigned long long wmask; // bit w set <=> TAF window w holds at least one encoded event
+};
+constexpr size_t kHeaderBytes = 1024;
+static_assert(sizeof(WsHeader) <= kHeaderBytes, "header");
+
+// How one event becomes (tile, cell, window, value).  Passed by value to the kernels.
+struct Decode {
+    const void *data;
+    long long n;
+    int row_stride;
+    const uint16_t *xmap;
+    const uint16_t *ymap;
+    int map_w, map_h;
+    int H, W;
+    int twl;            // log2 of the tile width
+    int tiles_x, n_tiles;
+    long long t0;       // EV: t_end - window; SAE: now - window; TAF: t_start
+    long long win;      // EV: window; TAF: window_us
+    int n_windows;      // TAF
+    int time_filter;    // DAT8 EV / SAE: drop t <= t0
+    uint32_t win_magic; // floor(2^32 / win), TAF DAT8
+    const float *tlut;  // TAF DAT8: tlut[r] = float(r / (win + 1e-8)) - 1 for r in [0, win], or NULL
+    int dbg;            // FRLW_DBG ablation switches (timing experiments only; results are wrong when set)
+};
+
+struct Pos {
+    int tile;      // < 0: not encoded
+    uint32_t cell; // ((ly << twl | lx) << 1) | p
+    int err;
+};
+
+// Bounds / polarity handling common to all layouts.
+template <int KIND>
+__device__ __forceinline__ Pos place(const Decode &P, int x, int y, int p)
+{
+    Pos r;
+    r.tile = -1; r.cell = 0; r.err = 0;
+    if ((unsigned)p > 1u) { r.err = ST_POLARITY; return r; }
+    if ((unsigned)x >= (unsigned)P.W || (unsigned)y >= (unsigned)P.H) {
+        // The reference indexes the FLAT pixel x + W*y (generate_eventvolume.py:32): x >= W aliases
+        // into the next row and only a flat index outside [0, H*W) raises.  index_put_ (SAE,
+        // generate_surfaceofactiveevents.py:49) checks each axis.
+        if (KIND == KIND_SAE) { r.err = ST_INDEX; return r; }
+        long long flat = (long long)x + (long long)P.W * y;
+        if (flat < 0 || flat >= (long long)P.H * P.W) { r.err = ST_INDEX; return r; }
+        y = (int)(flat / P.W);
+        x = (int)(flat - (long long)y * P.W);
+    }
+    r.tile = (y >> kTileHLog) * P.tiles_x + (x >> P.twl);
+    r.cell = (uint32_t)((((y & (kTileH - 1)) << P.twl) | (x & ((1 << P.twl) - 1))) << 1) | (uint32_t)p;
+    return r;
+}
+
+// Position of a raw DAT record (src/io/dat_events_tools.py:96-98) incl. the optional coordinate
+// maps and the time / range filters that drop an event without an error.
+template <int KIND>
+__device__ __forceinline__ Pos dat_pos(const Decode &P, uint2 r)
+{
+    int x = (int)(r.y & 16383u), y = (int)((r.y >> 14) & 16383u), p = (int)((r.y >> 28) & 1u);
+    Pos o;
+    o.tile = -1; o.cell = 0; o.err = 0;
+    if (P.xmap) {
+        if (x >= P.map_w || y >= P.map_h) { o.err = ST_INDEX; return o; }
+        x = P.xmap[x];
+        y = P.ymap[y];
+    }
+    if (KIND == KIND_SAE && (x >= P.W || y >= P.H)) return o; // generate_surfaceofactiveevents.py:72
+    if ((KIND == KIND_EV || KIND == KIND_SAE) && P.time_filter && !((long long)r.x > P.t0)) return o;
+    return place<KIND>(P, x, y, p);
+}
+
+// Window and f32 value of a raw DAT record.
+template <int KIND>
+__device__ __forceinline__ void dat_value(const Decode &P, uint2 r, int &window, float &val)
+{
+    window = 0;
+    val = 0.0f;
+    if (KIND == KIND_EV) {
+        val = (float)((double)((long long)r.x - P.t0) / (double)P.win); // generate_eventvolume.py:141
+    } else if (KIND == KIND_SAE) {
+        val = (float)r.x; // float(t), generate_surfaceofactiveevents.py:76
+    } else if (KIND == KIND_TAF) {
+        // generate_taf.py:197-203: z = the last window i with start + i*w <= t <= start + (i+1)*w, else 0
+        const long long rel = (long long)r.x - P.t0;
+        const uint32_t winu = (uint32_t)P.win;
+        double num;
+        if (rel >= 0 && rel <= (long long)P.n_windows * P.win) {
+            const uint32_t relu = (uint32_t)rel;
+            uint32_t z = __umulhi(relu, P.win_magic); // floor(rel / win) - {0, 1, 2}
+            uint32_t rem = relu - z * winu;
+            if (rem >= winu) { ++z; rem -= winu; }
+            if (rem >= winu) { ++z; rem -= winu; }
+            if (z >= (uint32_t)P.n_windows) { z = (uint32_t)P.n_windows - 1u; rem = winu; } // t == end of the last window
+            window = (int)z;
+            if (P.tlut) { val = P.tlut[rem]; return; } // same f64 division, done once per distinct value
+            num = (double)rem;
+        } else {
+            num = (double)rel; // outside the span: window 0, normalised time outside [0, 1]
+        }
+        const double tn = num / ((double)P.win + 1e-8); // generate_taf.py:215
+        val = (float)tn - 1.0f;                         // t - 1, generate_taf.py:26
+    }
+}
+
+// The reference's device tensor: (N, row_stride) float64 rows [x, y, t, p, ...].
+template <int KIND>
+__device__ __forceinline__ Pos f64_pos(const Decode &P, long long i, double &t)
+{
+    const double *r = (const double *)P.data + i * (long long)P.row_stride;
+    const double xd = r[0], yd = r[1], pd = r[3];
+    t = r[2];
+    Pos o;
+    o.tile = -1; o.cell = 0; o.err = 0;
+    if (KIND == KIND_SAE && !(xd < (double)P.W && yd < (double)P.H)) return o;
+    if (!(fabs(xd) < 1.0e9) || !(fabs(yd) < 1.0e9) || !(fabs(pd) < 1.0e9)) { o.err = ST_INDEX; return o; }
+    return place<KIND>(P, (int)xd, (int)yd, (int)pd); // .long(): truncation toward zero
+}
+
+template <int KIND>
+__device__ __forceinline__ float f64_value(double t)
+{
+    if (KIND == KIND_TAF) return (float)t - 1.0f; // generate_taf.py:26
+    if (KIND == KIND_ECI) return 0.0f;
+    return (float)t;
+}
+
+__device__ __forceinline__ uint64_t lanemask_lt()
+{
+    return (1ull << (threadIdx.x & 63)) - 1ull;
+}
+
+struct TileGeom {
+    int x0, y0, nx, ny; // nx, ny: valid pixels of this tile
+};
+
+__device__ __forceinline__ TileGeom tile_geom(int tile, int tiles_x, int twl, int H, int W)
+{
+    TileGeom g;
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int tw = 1 << twl;
+    g.x0 = tx << twl;
+    g.y0 = ty << kTileHLog;
+    g.nx = W - g.x0 < tw ? W - g.x0 : tw;
+    g.ny = H - g.y0 < kTileH ? H - g.y0 : kTileH;
+    return g;
+}
+
+__device__ __forceinline__ float leaky_f(float v)
+{
+    float l = log1pf(-v);   // generate_taf.py:72
+    l = 1.0f - l / 8.7f;    // :73
+    if (l < 0.0f) l = 0.0f; // :74
+    return l * 255.0f;      // :75
+}
+
+// ---- host side ---------------------------------------------------------------------------------
+struct Plan {
+    int twl, tiles_x, tiles_y, n_tiles;
+    int bpw;          // batches of 64 events per wavefront
+    long long chunk;  // events per partition workgroup = 1024 * bpw
+    int units, slabs; // partition workgroups, slabs of 32
+    size_t off_counts, off_slabtot, off_base, off_tlut, off_records, bytes;
+};
+
+struct Partitioned {
+    const uint2 *records;
+    const uint32_t *base;
+    WsHeader *hdr;
+    Plan plan;
+};
+
+bool make_plan(long long n, int H, int W, Plan &p);
+int env_int(const char *name, int dflt);
+int hip_fail(hipError_t e, const char *what, int line);
+
+// hist -> scans -> stable scatter: tile-major 8-byte records {window << (twl + 4) | cell, f32 bits}.
+int partition_events(const frlw_events_t *ev, int H, int W, int kind, long long t0, long long win,
+                     int n_windows, int time_filter, void *ws, size_t ws_bytes, hipStream_t s,
+                     Partitioned &out);
+
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return frlw::hip_fail(e_, #expr, __LINE__); } while (0)
+
+inline int grid_for(long long n, int block)
+{
+    long long g = (n + block - 1) / block;
+    if (g > 256 * 8) g = 256 * 8;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+} // namespace frlw

@@ -1,0 +1,421 @@
+// partition.hip -- stable tile partition of an event stream (steps 1-3 of every encoder).
+//
+// The reference's accumulators (torch index_add_, generate_eventvolume.py:32, generate_taf.py:24-26)
+// are defined by the single-thread result: f32 adds in STREAM ORDER.  To reproduce that on a GPU the
+// events are first partitioned by tile ((1 << twl) x 8 pixels) with a STABLE counting sort, so that
+// every tile's records are still in stream order and one workgroup can own the tile's accumulators.
+//
+//   k_hist      one workgroup (16 wavefronts) per contiguous chunk of 1024*bpw events; LDS histogram
+//               over tiles -> counts[wg][tile]          (events read once, bpw loads in flight / lane)
+//   k_slabscan  exclusive prefix over the 32 workgroups of a slab, in place + slabtot[slab][tile]
+//   k_tilescan  exclusive prefix over slabs (in place) and over tiles      -> base[tile]
+//   k_scatter   same chunks again.  Wavefront w of the workgroup owns the w-th run of 64*bpw events and
+//               walks it 64 events at a time in stream order; the rank of an event among the events
+//               of its batch that fall in the same tile comes from an LDS tag round (write the lane
+//               id, read it back: a mismatch marks a collision) plus one ballot per colliding tile.
+//               Per-wave running counts live in LDS; after a workgroup barrier they are prefix-summed
+//               over the 16 waves, and the whole workgroup writes its 8-byte records in ONE burst, so
+//               each tile's run (~chunk / n_tiles records) is completed in the L2 while it is hot.
+
+#include "frlw_common.h"
+
+namespace frlw {
+
+int env_int(const char *name, int dflt)
+{
+    const char *s = getenv(name);
+    return s && *s ? atoi(s) : dflt;
+}
+
+int hip_fail(hipError_t e, const char *what, int line)
+{
+    if (env_int("FRLW_DEBUG", 0))
+        fprintf(stderr, "frlw_evd: %s failed at line %d: %s\n", what, line, hipGetErrorString(e));
+    return FRLW_ERR_HIP;
+}
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+template <int LAYOUT, int KIND>
+__global__ __launch_bounds__(kPartThreads) void k_hist(Decode P, int bpw, uint32_t *counts,
+                                                        WsHeader *hdr, float *tlut_w)
+{
+    extern __shared__ uint32_t lds[];
+    uint32_t *hist = lds; // [n_tiles]
+    const int tid = threadIdx.x;
+    const long long wg = blockIdx.x;
+    for (int b = tid; b < P.n_tiles; b += kPartThreads) hist[b] = 0;
+    __syncthreads();
+    const long long begin = wg * (long long)kPartThreads * bpw;
+    int err = 0;
+    if (KIND == KIND_TAF && tlut_w) {
+        // value table for k_scatter: tlut[r] = float(r / (win + 1e-8)) - 1 (generate_taf.py:215, :26);
+        // one correctly rounded f64 division per distinct in-window time instead of one per event
+        const double den = (double)P.win + 1e-8;
+        for (long long r = wg * kPartThreads + tid; r <= P.win; r += (long long)gridDim.x * kPartThreads)
+            tlut_w[r] = (float)((double)r / den) - 1.0f;
+    }
+    if (LAYOUT == FRLW_LAYOUT_DAT8) {
+        const uint2 *src = (const uint2 *)P.data;
+        uint2 q[kMaxBpw];
+#pragma unroll
+        for (int j = 0; j < kMaxBpw; ++j) {
+            const long long i = begin + (long long)j * kPartThreads + tid;
+            q[j] = (j < bpw && i < P.n) ? src[i] : make_uint2(0u, 0xffffffffu);
+        }
+#pragma unroll
+        for (int j = 0; j < kMaxBpw; ++j) {
+            const long long i = begin + (long long)j * kPartThreads + tid;
+            if (j < bpw && i < P.n) {
+                const Pos o = dat_pos<KIND>(P, q[j]);
+                err |= o.err;
+                if (o.tile >= 0) atomicAdd(&hist[o.tile], 1u);
+            }
+        }
+    } else {
+        for (int j = 0; j < bpw; ++j) {
+            const long long i = begin + (long long)j * kPartThreads + tid;
+            if (i < P.n) {
+                double t;
+                const Pos o = f64_pos<KIND>(P, i, t);
+                err |= o.err;
+                if (o.tile >= 0) atomicAdd(&hist[o.tile], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t *row = counts + wg * (long long)P.n_tiles;
+    for (int b = tid; b < P.n_tiles; b += kPartThreads) row[b] = hist[b];
+    if (err) atomicOr(&hdr->status, err);
+}
+
+// counts[u][b], u in one slab of 32 workgroups -> exclusive prefix over u (in place), slabtot[slab][b]
+__global__ __launch_bounds__(kWave) void k_slabscan(uint32_t *counts, int units, int n_tiles,
+                                                     uint32_t *slabtot)
+{
+    const int b = blockIdx.x * kWave + threadIdx.x;
+    const int slab = blockIdx.y;
+    const int u0 = slab * kSlabUnits;
+    if (b >= n_tiles) return;
+    uint32_t v[kSlabUnits];
+#pragma unroll
+    for (int k = 0; k < kSlabUnits; ++k)
+        v[k] = (u0 + k < units) ? counts[(long long)(u0 + k) * n_tiles + b] : 0u;
+    uint32_t run = 0;
+#pragma unroll
+    for (int k = 0; k < kSlabUnits; ++k) {
+        const uint32_t t = v[k];
+        v[k] = run;
+        run += t;
+    }
+#pragma unroll
+    for (int k = 0; k < kSlabUnits; ++k)
+        if (u0 + k < units) counts[(long long)(u0 + k) * n_tiles + b] = v[k];
+    slabtot[(long long)slab * n_tiles + b] = run;
+}
+
+// slabtot[s][b] -> exclusive prefix over s (in place); then exclusive scan over tiles -> base[0..n]
+__global__ __launch_bounds__(1024) void k_tilescan(uint32_t *slabtot, int slabs, int n, uint32_t *base)
+{
+    __shared__ uint32_t tot[kMaxTiles];
+    __shared__ uint32_t wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int b = tid; b < n; b += 1024) {
+        uint32_t run = 0;
+        for (int s = 0; s < slabs; ++s) {
+            uint32_t *p = &slabtot[(long long)s * n + b];
+            const uint32_t v = *p;
+            *p = run;
+            run += v;
+        }
+        tot[b] = run;
+    }
+    __syncthreads();
+    const int per = (n + 1023) / 1024;
+    const int b0 = tid * per;
+    int b1 = b0 + per;
+    if (b1 > n) b1 = n;
+    uint32_t s = 0;
+    for (int b = b0; b < b1; ++b) s += tot[b];
+    uint32_t inc = s; // inclusive scan inside the wave
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        const uint32_t v = __shfl_up(inc, off);
+        if (lane >= off) inc += v;
+    }
+    if (lane == kWave - 1) wsum[wv] = inc;
+    __syncthreads();
+    uint32_t pre = 0;
+    for (int k = 0; k < wv; ++k) pre += wsum[k];
+    uint32_t run = pre + inc - s;
+    for (int b = b0; b < b1; ++b) {
+        base[b] = run;
+        run += tot[b];
+    }
+    if (tid == 1023) base[n] = pre + inc;
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int LAYOUT, int KIND>
+__global__ __launch_bounds__(kPartThreads, 8) void k_scatter(Decode P, int bpw, const uint32_t *counts,
+                                                           const uint32_t *slabtot,
+                                                           const uint32_t *base, uint2 *records,
+                                                           WsHeader *hdr)
+{
+    extern __shared__ uint32_t lds[];
+    // gs[n_tiles] u32 | wcnt[16][n_tiles] u16 | tag[16][n_tiles] u8
+    uint32_t *gs = lds;
+    uint16_t *wcnt_all = (uint16_t *)(lds + P.n_tiles);
+    const int nt2 = (P.n_tiles + 1) & ~1;
+    uint8_t *tag_all = (uint8_t *)(wcnt_all + (size_t)kPartWaves * nt2);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const long long wg = blockIdx.x;
+    // volatile: the tag write-then-read-back must reach LDS (another lane may have overwritten it)
+    volatile uint16_t *wcnt = wcnt_all + (size_t)wv * nt2;
+    volatile uint8_t *tag = tag_all + (size_t)wv * P.n_tiles;
+    for (int b = tid; b < kPartWaves * nt2; b += kPartThreads) wcnt_all[b] = 0;
+    __syncthreads();
+
+    const long long wave_begin = (wg * kPartWaves + wv) * (long long)kWave * bpw;
+    const uint64_t lt = lanemask_lt();
+    uint32_t where[kMaxBpw]; // tile << 16 | rank in (wave, tile); 0xffffffff = not encoded
+    uint2 q[kMaxBpw];
+    if (LAYOUT == FRLW_LAYOUT_DAT8) {
+        const uint2 *src = (const uint2 *)P.data;
+#pragma unroll
+        for (int j = 0; j < kMaxBpw; ++j) {
+            const long long i = wave_begin + j * kWave + lane;
+            q[j] = (j < bpw && i < P.n) ? src[i] : make_uint2(0u, 0xffffffffu);
+        }
+    }
+    // ---- phase A: ranks inside the wave's run, batch by batch in stream order (positions only;
+    //      windows and f32 values are computed in phase C so that few registers stay live)
+#pragma unroll
+    for (int j = 0; j < kMaxBpw; ++j) {
+        where[j] = 0xffffffffu;
+        if (j < bpw) { // wave-uniform
+            const long long i = wave_begin + j * kWave + lane;
+            Pos o;
+            o.tile = -1; o.cell = 0; o.err = 0;
+            if (i < P.n) {
+                if (LAYOUT == FRLW_LAYOUT_DAT8) {
+                    o = dat_pos<KIND>(P, q[j]);
+                } else {
+                    double t;
+                    o = f64_pos<KIND>(P, i, t);
+                }
+            }
+            const bool act = o.tile >= 0;
+            const uint64_t am = __ballot(act);
+            if (P.dbg & 512) { if (act) where[j] = (uint32_t)o.tile << 16; }
+            if (am != 0ull && !(P.dbg & 512)) {
+                if (act) tag[o.tile] = (uint8_t)lane;
+                const int seen = act ? (int)tag[o.tile] : lane; // LDS ops of a wave execute in order
+                uint64_t cm = __ballot(act && seen != lane);
+                uint32_t rank = 0, size = 1;
+                while (cm) {
+                    const int l0 = __ffsll((long long)cm) - 1;
+                    const int g = __builtin_amdgcn_readlane(o.tile, l0);
+                    const uint64_t mg = __ballot(act && o.tile == g);
+                    if (act && o.tile == g) {
+                        rank = (uint32_t)__popcll(mg & lt);
+                        size = (uint32_t)__popcll(mg);
+                    }
+                    cm &= ~mg;
+                }
+                if (act) {
+                    const uint32_t r = (uint32_t)wcnt[o.tile] + rank;
+                    where[j] = ((uint32_t)o.tile << 16) | r;
+                    if (rank + 1 == size) wcnt[o.tile] = (uint16_t)(r + 1); // after every member's read
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase B: per tile, exclusive prefix of the 16 wave counts; global start of this workgroup's run
+    {
+        const uint32_t *row = counts + wg * (long long)P.n_tiles;
+        const uint32_t *srow = slabtot + (wg / kSlabUnits) * (long long)P.n_tiles;
+        for (int b = tid; b < P.n_tiles; b += kPartThreads) {
+            uint32_t run = 0;
+#pragma unroll
+            for (int w = 0; w < kPartWaves; ++w) {
+                const uint32_t v = wcnt_all[(size_t)w * nt2 + b];
+                wcnt_all[(size_t)w * nt2 + b] = (uint16_t)run;
+                run += v;
+            }
+            gs[b] = base[b] + srow[b] + row[b];
+        }
+    }
+    __syncthreads();
+    // ---- phase C: window + value of every encoded event (all table loads first: vmcnt also counts
+    //      stores, so a load issued after a store would wait for that store), then the burst write
+    const int cb = P.twl + 4;
+    const uint16_t *woff = wcnt_all + (size_t)wv * nt2;
+    unsigned long long wseen = 0ull; // TAF: windows this lane has encoded an event for
+    uint32_t meta[kMaxBpw], valb[kMaxBpw];
+#pragma unroll
+    for (int j = 0; j < kMaxBpw; ++j) {
+        meta[j] = 0; valb[j] = 0;
+        if (j < bpw && where[j] != 0xffffffffu) {
+            int window = 0;
+            float val = 0.0f;
+            uint32_t cell;
+            if (LAYOUT == FRLW_LAYOUT_DAT8) {
+                cell = dat_pos<KIND>(P, q[j]).cell;
+                dat_value<KIND>(P, q[j], window, val);
+            } else {
+                double t;
+                cell = f64_pos<KIND>(P, wave_begin + j * kWave + lane, t).cell;
+                val = f64_value<KIND>(t);
+            }
+            meta[j] = ((uint32_t)window << cb) | cell;
+            valb[j] = __float_as_uint(val);
+            if (KIND == KIND_TAF) wseen |= 1ull << window;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kMaxBpw; ++j) {
+        if (j < bpw && where[j] != 0xffffffffu) {
+            const uint32_t b = where[j] >> 16;
+            const uint32_t pos = gs[b] + (uint32_t)woff[b] + (where[j] & 0xffffu);
+            if (!(P.dbg & 256)) records[pos] = make_uint2(meta[j], valb[j]);
+        }
+    }
+    if (KIND == KIND_TAF) { // which windows hold events at all: decides "all(forward)", generate_taf.py:40
+        // one same-address global atomic costs ~10 ns at the L2: OR inside the wave, then inside the
+        // workgroup, and touch the global word only for bits it does not show yet
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const unsigned lo = __shfl_xor((unsigned)wseen, off), hi = __shfl_xor((unsigned)(wseen >> 32), off);
+            wseen |= ((unsigned long long)hi << 32) | lo;
+        }
+        __syncthreads(); // gs[] is dead now: reuse its first words
+        unsigned long long *wg_seen = (unsigned long long *)gs;
+        if (tid == 0) *wg_seen = 0ull;
+        __syncthreads();
+        if (lane == 0 && wseen) atomicOr(wg_seen, wseen);
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned long long mine = *wg_seen;
+            const unsigned long long have = __hip_atomic_load(&hdr->wmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (mine & ~have) atomicOr(&hdr->wmask, mine);
+        }
+    }
+}
+
+template <int LAYOUT, int KIND>
+void launch_partition(const Decode &d, const Plan &p, uint32_t *counts, uint32_t *slabtot,
+                      uint32_t *base, uint2 *records, WsHeader *hdr, float *tlut_w, hipStream_t s)
+{
+    const size_t lds_hist = (size_t)p.n_tiles * 4;
+    const int nt2 = (p.n_tiles + 1) & ~1;
+    const size_t lds_sc = (size_t)p.n_tiles * 4 + (size_t)kPartWaves * nt2 * 2 +
+                          (size_t)kPartWaves * p.n_tiles + 16;
+    hipLaunchKernelGGL((k_hist<LAYOUT, KIND>), dim3(p.units), dim3(kPartThreads), lds_hist, s, d, p.bpw, counts, hdr, tlut_w);
+    hipLaunchKernelGGL(k_slabscan, dim3((p.n_tiles + kWave - 1) / kWave, p.slabs), dim3(kWave), 0, s, counts,
+                       p.units, p.n_tiles, slabtot);
+    hipLaunchKernelGGL(k_tilescan, dim3(1), dim3(1024), 0, s, slabtot, p.slabs, p.n_tiles, base);
+    hipLaunchKernelGGL((k_scatter<LAYOUT, KIND>), dim3(p.units), dim3(kPartThreads), lds_sc, s, d, p.bpw, counts,
+                       slabtot, base, records, hdr);
+}
+
+template <int LAYOUT>
+void launch_partition_kind(int kind, const Decode &d, const Plan &p, uint32_t *counts, uint32_t *slabtot,
+                           uint32_t *base, uint2 *records, WsHeader *hdr, float *tlut_w, hipStream_t s)
+{
+    switch (kind) {
+    case KIND_ECI: launch_partition<LAYOUT, KIND_ECI>(d, p, counts, slabtot, base, records, hdr, tlut_w, s); break;
+    case KIND_EV: launch_partition<LAYOUT, KIND_EV>(d, p, counts, slabtot, base, records, hdr, tlut_w, s); break;
+    case KIND_SAE: launch_partition<LAYOUT, KIND_SAE>(d, p, counts, slabtot, base, records, hdr, tlut_w, s); break;
+    default: launch_partition<LAYOUT, KIND_TAF>(d, p, counts, slabtot, base, records, hdr, tlut_w, s); break;
+    }
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+} // namespace
+
+bool make_plan(long long n, int H, int W, Plan &p)
+{
+    if (H <= 0 || W <= 0 || n < 0) return false;
+    p.twl = env_int("FRLW_TWL", W > 512 ? 7 : 6);
+    if (p.twl < 6 || p.twl > 8) return false;
+    const int tw = 1 << p.twl;
+    p.tiles_x = (W + tw - 1) / tw;
+    p.tiles_y = (H + kTileH - 1) / kTileH;
+    p.n_tiles = p.tiles_x * p.tiles_y;
+    if (p.n_tiles > kMaxTiles) return false;
+    // Workgroup chunk = 1024 * bpw events.  Two partition workgroups fit on a CU (2 x 16 waves), i.e.
+    // 512 at a time on the chip: pick bpw so that the workgroup count lands just under a multiple of 512
+    // (whole rounds) with the longest chunk (= longest contiguous run per tile) that allows.
+    int bpw = kMaxBpw;
+    for (int rounds = 1; rounds <= 64; ++rounds) {
+        const long long want = (n + 512ll * rounds * kPartThreads - 1) / (512ll * rounds * kPartThreads);
+        if (want <= kMaxBpw) { bpw = (int)(want < 1 ? 1 : want); break; }
+    }
+    p.bpw = env_int("FRLW_BPW", bpw);
+    if (p.bpw < 1 || p.bpw > kMaxBpw) return false;
+    p.chunk = (long long)kPartThreads * p.bpw;
+    p.units = (int)((n + p.chunk - 1) / p.chunk);
+    if (p.units < 1) p.units = 1;
+    p.slabs = (p.units + kSlabUnits - 1) / kSlabUnits;
+    size_t off = kHeaderBytes;
+    p.off_counts = off;  off = align_up(off + (size_t)p.units * p.n_tiles * 4, 256);
+    p.off_slabtot = off; off = align_up(off + (size_t)p.slabs * p.n_tiles * 4, 256);
+    p.off_base = off;    off = align_up(off + (size_t)(p.n_tiles + 1) * 4, 256);
+    p.off_tlut = off;    off = align_up(off + (size_t)(kMaxTlut + 1) * 4, 256);
+    p.off_records = off; off = align_up(off + (size_t)(n > 0 ? n : 1) * 8, 256);
+    p.bytes = off;
+    return true;
+}
+
+int partition_events(const frlw_events_t *ev, int H, int W, int kind, long long t0, long long win,
+                     int n_windows, int time_filter, void *ws, size_t ws_bytes, hipStream_t s,
+                     Partitioned &out)
+{
+    if (!ev || !ws || (ev->n > 0 && !ev->data)) return FRLW_ERR_ARG;
+    if (ev->layout != FRLW_LAYOUT_XYTP_F64 && ev->layout != FRLW_LAYOUT_DAT8) return FRLW_ERR_ARG;
+    if (ev->layout == FRLW_LAYOUT_XYTP_F64 && ev->row_stride < 4) return FRLW_ERR_ARG;
+    if ((ev->xmap == nullptr) != (ev->ymap == nullptr)) return FRLW_ERR_ARG;
+    if (ev->n >= (1ll << 32)) return FRLW_ERR_UNSUPPORTED;
+    if (win < 1) win = 1;
+    if (kind == KIND_TAF && ev->layout == FRLW_LAYOUT_DAT8 &&
+        ((long long)n_windows * win >= (1ll << 32) || win >= (1ll << 31)))
+        return FRLW_ERR_UNSUPPORTED;
+    Plan p;
+    if (!make_plan(ev->n, H, W, p)) return FRLW_ERR_UNSUPPORTED;
+    if (ws_bytes < p.bytes) return FRLW_ERR_WORKSPACE;
+    char *w8 = (char *)ws;
+    WsHeader *hdr = (WsHeader *)w8;
+    uint32_t *counts = (uint32_t *)(w8 + p.off_counts);
+    uint32_t *slabtot = (uint32_t *)(w8 + p.off_slabtot);
+    uint32_t *base = (uint32_t *)(w8 + p.off_base);
+    uint2 *records = (uint2 *)(w8 + p.off_records);
+
+    Decode d;
+    d.data = ev->data; d.n = ev->n; d.row_stride = ev->row_stride;
+    d.xmap = ev->layout == FRLW_LAYOUT_DAT8 ? ev->xmap : nullptr;
+    d.ymap = ev->layout == FRLW_LAYOUT_DAT8 ? ev->ymap : nullptr;
+    d.map_w = ev->map_w; d.map_h = ev->map_h;
+    d.H = H; d.W = W; d.twl = p.twl; d.tiles_x = p.tiles_x; d.n_tiles = p.n_tiles;
+    d.t0 = t0; d.win = win; d.n_windows = n_windows; d.time_filter = time_filter;
+    const unsigned long long magic = (1ull << 32) / (unsigned long long)win;
+    d.win_magic = magic > 0xffffffffull ? 0xffffffffu : (uint32_t)magic;
+    float *tlut_w = nullptr;
+    if (kind == KIND_TAF && ev->layout == FRLW_LAYOUT_DAT8 && win <= kMaxTlut && !env_int("FRLW_NOLUT", 0)) tlut_w = (float *)(w8 + p.off_tlut);
+    d.tlut = tlut_w;
+    d.dbg = env_int("FRLW_DBG", 0);
+
+    HIP_TRY(hipMemsetAsync(hdr, 0, kHeaderBytes, s));
+    if (ev->layout == FRLW_LAYOUT_DAT8)
+        launch_partition_kind<FRLW_LAYOUT_DAT8>(kind, d, p, counts, slabtot, base, records, hdr, tlut_w, s);
+    else
+        launch_partition_kind<FRLW_LAYOUT_XYTP_F64>(kind, d, p, counts, slabtot, base, records, hdr, tlut_w, s);
+    HIP_TRY(hipGetLastError());
+    out.records = records; out.base = base; out.hdr = hdr; out.plan = p;
+    return FRLW_OK;
+}
+
+} // namespace frlw

@@ -72,7 +72,7 @@ typedef struct frlw_events {
 
 #define FRLW_MAX_WINDOWS 64
 #define FRLW_MAX_LAMDAS 8
-#define FRLW_MAX_BINS 16
+#define FRLW_MAX_BINS 8 /* Event Volume bins and TAF K: register-resident per cell */
 
 /* frlw_taf_encode flags */
 #define FRLW_TAF_U8_FLIP_K 1 /* write out_u8 newest slot first (np.flip(axis=0), generate_taf.py:229) */
