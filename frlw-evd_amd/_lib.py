@@ -53,6 +53,16 @@ SYMBOLS = {
     "frlw_resize_nearest_f32": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     "frlw_resize_nearest_u8": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     "frlw_quantize_u8": (_I, [_P, _I64, _I, _P, _P]),
+    "frlw_det_create": (_P, []),
+    "frlw_det_destroy": (None, [_P]),
+    "frlw_det_num_ops": (_I, [_P]),
+    "frlw_det_add_focus": (_I, [_P, _I, _I, _I, _I, _I]),
+    "frlw_det_add_upsample": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I]),
+    "frlw_det_add_spp_pool": (_I, [_P, _I, _I, _I, _I, _I]),
+    "frlw_det_add_conv": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I64, _I, _I, _I, _I, _I]),
+    "frlw_det_add_decode_nms": (_I, [_P, _I, _I, _I, _I, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                     C.c_float, C.c_float, _I, _I, _I]),
+    "frlw_det_run": (_I, [_P, _I, C.POINTER(C.c_void_p), _I, _I, _I, _P]),
 }
 
 _lib = None

@@ -1,0 +1,266 @@
+"""YOLOX detector eval forward on MI355X: the plan builder over the gfx950 kernels of csrc/detector.hip.
+
+``DetectorEngine(model)`` walks the reference-named module tree (``frlw_evd_amd.yolox.model.model`` =
+core/model.py, backbone CSPDarknet, neck YOLOPAFPN, head YOLOXHead), folds every BatchNorm into its
+convolution, re-lays the weights as (k*k*Cin, Cout) GEMM operands and records one launch per layer in a
+native plan (``frlw_det_*`` in include/frlw_evd.h).  ``torch.cat`` never happens: producers write into
+channel slices of the consumer's NHWC buffer.  There is no fallback: a missing library raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+ACT_NONE, ACT_SILU, ACT_SIGMOID = 0, 1, 2
+
+
+class View:
+    """A channel slice of an NHWC buffer: (buffer index, pixel stride, channel offset, C, H, W)."""
+
+    def __init__(self, buf, cs, co, c, h, w):
+        self.buf, self.cs, self.co, self.c, self.h, self.w = buf, cs, co, c, h, w
+
+    def slice(self, co, c):
+        return View(self.buf, self.cs, self.co + co, c, self.h, self.w)
+
+
+def fold_bn(conv, bn):
+    """Conv2d(bias=False) + BatchNorm2d(eval) -> (weight, bias) of one biased convolution."""
+    w = conv.weight.detach().double()
+    scale = bn.weight.detach().double() / torch.sqrt(bn.running_var.detach().double() + bn.eps)
+    b = bn.bias.detach().double() - bn.running_mean.detach().double() * scale
+    return (w * scale[:, None, None, None]).float(), b.float()
+
+
+def gemm_weight(w):
+    """(Cout, Cin, k, k) -> (k*k*Cin, Npad) row-major, row (ky*k + kx)*Cin + ci, Npad = Cout rounded up to 32."""
+    cout, cin, k, _ = w.shape
+    npad = (cout + 31) // 32 * 32
+    m = torch.zeros((k * k * cin, npad), dtype=torch.float32)
+    m[:, :cout] = w.permute(2, 3, 1, 0).reshape(k * k * cin, cout)
+    return m.contiguous(), npad
+
+
+class DetectorEngine:
+    def __init__(self, net, device=None):
+        self.lib = _lib.load()
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.net = net
+        self.handle = self.lib.frlw_det_create()
+        self._keep = []      # device weights referenced by the plan
+        self._shapes = []    # per buffer: floats per image (index 0 = the NCHW input, set per call)
+        self._bufs = {}      # batch size -> list of tensors
+        self._built_for = None
+        self.n_conv = 0
+        self.flops_per_image = 0
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self.lib.frlw_det_destroy(self.handle)
+        except Exception:
+            pass
+
+    # ---- plan construction ---------------------------------------------------------------------
+    def _new_buf(self, h, w, c):
+        self._shapes.append(h * w * c)
+        return View(len(self._shapes) - 1, c, 0, c, h, w)
+
+    def _dev(self, t):
+        t = t.to(self.device).contiguous()
+        self._keep.append(t)
+        return C.c_void_p(t.data_ptr())
+
+    def _conv_raw(self, weight, bias, src, dst, k, stride, act, res=None, dst_bs=0, sig_from=0):
+        wm, npad = gemm_weight(weight)
+        cout, cin = weight.shape[0], weight.shape[1]
+        assert cin == src.c and cout == dst.c, (cin, src.c, cout, dst.c)
+        rb, rcs, rco = (res.buf, res.cs, res.co) if res is not None else (-1, 0, 0)
+        rc = self.lib.frlw_det_add_conv(self.handle, src.buf, src.cs, src.co, cin, src.h, src.w, self._dev(wm),
+                                        self._dev(bias) if bias is not None else None, cout, npad, k, stride,
+                                        dst.buf, dst.cs, dst.co, dst_bs, rb, rcs, rco, act, sig_from)
+        _lib.check(rc, "frlw_det_add_conv")
+        pad = (k - 1) // 2
+        ho, wo = (src.h + 2 * pad - k) // stride + 1, (src.w + 2 * pad - k) // stride + 1
+        assert (ho, wo) == (dst.h, dst.w), ((ho, wo), (dst.h, dst.w))
+        self.n_conv += 1
+        self.flops_per_image += 2 * ho * wo * cout * cin * k * k
+
+    def _baseconv(self, bc, src, dst, res=None):
+        w, b = fold_bn(bc.conv, bc.bn)
+        if not isinstance(bc.act, torch.nn.SiLU):
+            raise NotImplementedError("only SiLU BaseConv is on the hot path")
+        self._conv_raw(w, b, src, dst, bc.conv.kernel_size[0], bc.conv.stride[0], ACT_SILU, res)
+
+    def _csp(self, csp, src, dst):
+        """CSPLayer (network_blocks.py:156-194): conv1 -> n bottlenecks || conv2, concat, conv3."""
+        hidden = csp.conv1.conv.out_channels
+        cat = self._new_buf(src.h, src.w, 2 * hidden)
+        self._baseconv(csp.conv2, src, cat.slice(hidden, hidden))
+        n = len(csp.m)
+        cur = cat.slice(0, hidden) if n == 0 else self._new_buf(src.h, src.w, hidden)
+        self._baseconv(csp.conv1, src, cur)
+        for i, bott in enumerate(csp.m):
+            mid = self._new_buf(src.h, src.w, bott.conv1.conv.out_channels)
+            self._baseconv(bott.conv1, cur, mid)
+            nxt = cat.slice(0, hidden) if i == n - 1 else self._new_buf(src.h, src.w, hidden)
+            self._baseconv(bott.conv2, mid, nxt, res=cur if bott.use_add else None)
+            cur = nxt
+        self._baseconv(csp.conv3, cat, dst)
+
+    def build(self, in_shape):
+        """in_shape = (C, H, W) of one image (the network input without the trailing singleton dims)."""
+        net = self.net
+        bb, neck, head = net.backbone, net.neck, net.head
+        cin, H, W = in_shape
+        assert H % 32 == 0 and W % 32 == 0, "the detector needs H, W multiples of 32 (settings.py:22-25)"
+        lib = self.lib
+        self._shapes = [cin * H * W]
+        x_in = 0
+        # ---- backbone (darknet.py:270-354)
+        f = self._new_buf(H // 2, W // 2, 4 * cin)
+        _lib.check(lib.frlw_det_add_focus(self.handle, x_in, cin, H, W, f.buf), "focus")
+        c = bb.stem.conv.conv.out_channels
+        stem = self._new_buf(H // 2, W // 2, c)
+        self._baseconv(bb.stem.conv, f, stem)
+        h2, w2 = H // 4, W // 4
+        d2a = self._new_buf(h2, w2, 2 * c)
+        self._baseconv(bb.dark2[0], stem, d2a)
+        d2 = self._new_buf(h2, w2, 2 * c)
+        self._csp(bb.dark2[1], d2a, d2)
+        # the three backbone outputs are written straight into the neck's concat buffers
+        c3, c4, c5 = 4 * c, 8 * c, 16 * c
+        h3, w3, h4, w4, h5, w5 = H // 8, W // 8, H // 16, W // 16, H // 32, W // 32
+        cat_p3 = self._new_buf(h3, w3, 2 * c3)   # [upsample(fpn_out1) | dark3]
+        cat_p4 = self._new_buf(h4, w4, 2 * c4)   # [upsample(fpn_out0) | dark4]
+        cat_n3 = self._new_buf(h4, w4, 2 * c3)   # [bu_conv2(pan_out2) | fpn_out1]
+        cat_n4 = self._new_buf(h5, w5, 2 * c4)   # [bu_conv1(pan_out1) | fpn_out0]
+        d3a = self._new_buf(h3, w3, c3)
+        self._baseconv(bb.dark3[0], d2, d3a)
+        d3 = cat_p3.slice(c3, c3)
+        self._csp(bb.dark3[1], d3a, d3)
+        d4a = self._new_buf(h4, w4, c4)
+        self._baseconv(bb.dark4[0], d3, d4a)
+        d4 = cat_p4.slice(c4, c4)
+        self._csp(bb.dark4[1], d4a, d4)
+        d5a = self._new_buf(h5, w5, c5)
+        self._baseconv(bb.dark5[0], d4, d5a)
+        spp = bb.dark5[1]
+        hid = spp.conv1.conv.out_channels
+        assert [m.kernel_size for m in spp.m] == [5, 9, 13]
+        sppcat = self._new_buf(h5, w5, 4 * hid)
+        self._baseconv(spp.conv1, d5a, sppcat.slice(0, hid))
+        _lib.check(lib.frlw_det_add_spp_pool(self.handle, sppcat.buf, sppcat.cs, hid, h5, w5), "spp")
+        d5b = self._new_buf(h5, w5, c5)
+        self._baseconv(spp.conv2, sppcat, d5b)
+        d5 = self._new_buf(h5, w5, c5)
+        self._csp(bb.dark5[2], d5b, d5)
+        # ---- neck (yolo_pafpn.py:77-113)
+        fpn_out0 = cat_n4.slice(c4, c4)
+        self._baseconv(neck.lateral_conv0, d5, fpn_out0)
+        _lib.check(lib.frlw_det_add_upsample(self.handle, fpn_out0.buf, fpn_out0.cs, fpn_out0.co, c4, h5, w5,
+                                             cat_p4.buf, cat_p4.cs, 0), "upsample")
+        f_out0 = self._new_buf(h4, w4, c4)
+        self._csp(neck.C3_p4, cat_p4, f_out0)
+        fpn_out1 = cat_n3.slice(c3, c3)
+        self._baseconv(neck.reduce_conv1, f_out0, fpn_out1)
+        _lib.check(lib.frlw_det_add_upsample(self.handle, fpn_out1.buf, fpn_out1.cs, fpn_out1.co, c3, h4, w4,
+                                             cat_p3.buf, cat_p3.cs, 0), "upsample")
+        pan_out2 = self._new_buf(h3, w3, c3)
+        self._csp(neck.C3_p3, cat_p3, pan_out2)
+        self._baseconv(neck.bu_conv2, pan_out2, cat_n3.slice(0, c3))
+        pan_out1 = self._new_buf(h4, w4, c4)
+        self._csp(neck.C3_n3, cat_n3, pan_out1)
+        self._baseconv(neck.bu_conv1, pan_out1, cat_n4.slice(0, c4))
+        pan_out0 = self._new_buf(h5, w5, c5)
+        self._csp(neck.C3_n4, cat_n4, pan_out0)
+        # ---- head (yolo_head.py:162-231): the prediction convs write straight into (B, A, 5 + nc)
+        nc = head.num_classes
+        F = 5 + nc
+        levels = [pan_out2, pan_out1, pan_out0]
+        A = sum(v.h * v.w for v in levels)
+        raw = self._new_buf(1, A, F)
+        self.raw_buf, self.A, self.F = raw.buf, A, F
+        off = 0
+        for k, v in enumerate(levels):
+            hs = self._new_buf(v.h, v.w, 256)
+            self._baseconv(head.stems[k], v, hs)
+            feats = []
+            for tower in (head.cls_convs[k], head.reg_convs[k]):
+                t1 = self._new_buf(v.h, v.w, 256)
+                self._baseconv(tower[0], hs, t1)
+                t2 = self._new_buf(v.h, v.w, 256)
+                self._baseconv(tower[1], t1, t2)
+                feats.append(t2)
+            cls_feat, reg_feat = feats
+            w_ro = torch.cat([head.reg_preds[k].weight.detach(), head.obj_preds[k].weight.detach()], 0).float()
+            b_ro = torch.cat([head.reg_preds[k].bias.detach(), head.obj_preds[k].bias.detach()], 0).float()
+            dst = View(raw.buf, F, off * F, 5, v.h, v.w)
+            self._conv_raw(w_ro, b_ro, reg_feat, dst, 1, 1, ACT_SIGMOID, dst_bs=A * F, sig_from=4)
+            dst = View(raw.buf, F, off * F + 5, nc, v.h, v.w)
+            self._conv_raw(head.cls_preds[k].weight.detach().float(), head.cls_preds[k].bias.detach().float(), cls_feat,
+                           dst, 1, 1, ACT_SIGMOID, dst_bs=A * F, sig_from=0)
+            off += v.h * v.w
+        self.n_forward_ops = lib.frlw_det_num_ops(self.handle)
+        # ---- decode + NMS (yolo_head.py:258-303)
+        self.dec_buf = self._new_buf(1, A, F).buf
+        self.dets_buf = self._new_buf(1, A, 6).buf
+        self.counts_buf = self._new_buf(1, 1, 1).buf
+        n = len(levels)
+        arr = C.c_int * n
+        _lib.check(lib.frlw_det_add_decode_nms(self.handle, raw.buf, A, nc, n, arr(*[v.h for v in levels]),
+                                               arr(*[v.w for v in levels]), arr(*[int(s) for s in head.strides]),
+                                               C.c_float(head.obj_threshold), C.c_float(head.nms_threshold),
+                                               self.dec_buf, self.dets_buf, self.counts_buf), "decode")
+        head.hw = [(v.h, v.w) for v in levels]
+        self._built_for = tuple(in_shape)
+
+    # ---- execution -----------------------------------------------------------------------------
+    def _buffers(self, B):
+        bufs = self._bufs.get(B)
+        if bufs is None:
+            bufs = [None] + [torch.empty(B * n, dtype=torch.float32, device=self.device) for n in self._shapes[1:]]
+            bufs[self.counts_buf] = torch.zeros(B, dtype=torch.int32, device=self.device)
+            self._bufs[B] = bufs
+        return bufs
+
+    def _run(self, x, first, last):
+        if not x.is_cuda:
+            raise RuntimeError("DetectorEngine needs a ROCm tensor: there is no CPU path in the engine")
+        if x.dim() == 5:  # (B, C, H, W, 1): the singleton Focus drops (network_blocks.py:221)
+            x = x[..., 0]
+        x = x.contiguous().float()
+        B = x.shape[0]
+        if self._built_for is None:
+            self.build(tuple(x.shape[1:]))
+        assert tuple(x.shape[1:]) == self._built_for, "input shape differs from the one the plan was built for"
+        bufs = self._buffers(B)
+        ptrs = (C.c_void_p * len(bufs))(*[C.c_void_p(x.data_ptr())] + [C.c_void_p(t.data_ptr()) for t in bufs[1:]])
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(self.lib.frlw_det_run(self.handle, B, ptrs, len(bufs), first, last, stream), "frlw_det_run")
+        self._last_input = x  # keep alive until the stream has consumed it
+        return bufs, B
+
+    def raw_outputs(self, x):
+        """(B, A, 5 + nc) = cat[reg, sigmoid(obj), sigmoid(cls)] per anchor (the pre-NMS tensor)."""
+        if self._built_for is None:
+            self.build(tuple((x[..., 0] if x.dim() == 5 else x).shape[1:]))
+        bufs, B = self._run(x, 0, self.n_forward_ops)
+        return bufs[self.raw_buf].view(B, self.A, self.F)
+
+    def detect(self, x, return_decoded=False):
+        """Full eval forward: list of (n_i, 6) [cx, cy, w, h, cls, obj * max cls] per image."""
+        bufs, B = self._run(x, 0, -1)
+        counts = bufs[self.counts_buf].cpu().tolist()  # the reference loops over images on the host too
+        dets = bufs[self.dets_buf].view(B, self.A, 6)
+        out = []
+        for b, n in enumerate(counts):
+            if n < 0:
+                raise RuntimeError("more than 2048 NMS candidates in one image: not handled on device yet")
+            out.append(dets[b, :n].clone() if n > 0 else torch.zeros((1, 6), device=self.device))
+        if return_decoded:
+            return out, bufs[self.dec_buf].view(B, self.A, self.F)
+        return out

@@ -1,0 +1,113 @@
+"""``model(backbone, neck, memory, head)`` wrapper (reference: core/model.py:10-70) and the ``yolox``
+experiment's constructor arguments (core/exp.py:372,377-384,582)."""
+import time
+
+import torch
+import torch.nn as nn
+
+from .darknet import CSPDarknet
+from .network_blocks import Focus
+from .yolo_head import YOLOXHead
+from .yolo_pafpn import YOLOPAFPN
+
+
+class model(nn.Module):
+    """``xs``: (B, C, H, W, 1, T) -- one trailing singleton is dropped here (core/model.py:40) and one by
+    ``Focus`` (network_blocks.py:221); T = 1 in every shipped experiment (settings.py:45).
+
+    Eval mode on a ROCm tensor runs the gfx950 engine (:class:`frlw_evd_amd.detector.DetectorEngine`);
+    there is no silent fallback: a missing HIP library raises.
+    """
+
+    def __init__(self, backbone, neck, memory, head):
+        super().__init__()
+        self.backbone = backbone
+        self.neck = neck
+        self.memory = memory
+        self.head = head
+        self._engine = None
+
+    def reference_outputs(self, x):
+        """Plain-PyTorch eval forward up to the pre-NMS tensor (B, A, 5 + nc); x: (B, C, H, W, 1)."""
+        outs = self.head.raw_outputs(self.neck(self.backbone(x)))
+        self.head.hw = [o.shape[-2:] for o in outs]
+        return torch.cat([o.flatten(start_dim=2) for o in outs], dim=2).permute(0, 2, 1)
+
+    def engine(self):
+        if self._engine is None:
+            from ..detector import DetectorEngine
+            self._engine = DetectorEngine(self)
+        return self._engine
+
+    def detect(self, x):
+        """Eval forward of one time step: list of (n_i, 6) detections per image."""
+        if x.is_cuda:
+            return self.engine().detect(x)
+        return self.head(self.neck(self.backbone(x)))
+
+    def forward(self, xs, targets=None, filenames=None, timestamps=None, evaluator=None):
+        if self.memory is not None:
+            raise NotImplementedError("recurrent memory is disabled in every shipped experiment (core/exp.py:374-375)")
+        outputs_tol = None
+        for i in range(xs.shape[-1]):
+            start = time.time()
+            if i < xs.shape[-1] - 1:
+                continue  # earlier time steps only feed memory / seq-NMS, both disabled
+            if self.training:
+                losses = self.head(self.neck(self.backbone(xs[..., i])), targets, xs[..., i])
+                outputs_tol = losses[0] if outputs_tol is None else outputs_tol + losses[0]
+            else:
+                outputs = self.detect(xs[..., i])
+                if xs.is_cuda:
+                    torch.cuda.synchronize()
+                infer_time = time.time() - start
+                if evaluator is not None:
+                    evaluator.add_result(outputs, timestamps, targets, filenames, infer_time, 0)
+        if self.head.seq_nms:
+            self.head.clean_seqnms()
+        if self.training:
+            return outputs_tol
+        if evaluator is not None:
+            evaluator.end_a_batch()
+            return evaluator
+        return outputs
+
+
+def build_yolox(in_channels=10, num_classes=2, radius=5.0):
+    """The ``yolox`` experiment: CSPDarknet(C, 0.33, 0.5, Focus) + YOLOPAFPN(0.33, [128, 256, 512]) +
+    YOLOXHead(nc, strides [8, 16, 32], in_channels [128, 256, 512]) (core/exp.py:372,377-384,580-586)."""
+    chans = [128, 256, 512]
+    backbone = CSPDarknet(in_channels, 0.33, 0.5, stem=Focus)
+    neck = YOLOPAFPN(0.33, in_features=["dark3", "dark4", "dark5"], in_channels=chans, act="silu")
+    head = YOLOXHead(num_classes, in_channels=chans, act="silu", strides=[8, 16, 32], radius=radius)
+    return model(backbone, neck, None, head)
+
+
+def recipe_state_dict(module, seed=1004):
+    """Deterministic random weights by recipe: every tensor is drawn from its own
+    PCG64 stream keyed by (seed, crc32(name)), so any model with the same parameter names and shapes gets
+    the same values without shipping a 57 MB weight file.
+    conv weights N(0, sqrt(2 / fan_in)); BN gamma U(0.5, 1.5), beta N(0, 0.1), running_mean N(0, 0.1),
+    running_var U(0.5, 1.5); prediction biases N(0, 0.1)."""
+    import zlib
+
+    import numpy as np
+    out = {}
+    for name, t in module.state_dict().items():
+        rng = np.random.default_rng([seed, zlib.crc32(name.encode())])
+        shape = tuple(t.shape)
+        if name.endswith("num_batches_tracked"):
+            v = np.zeros(shape, np.int64)
+        elif name.endswith("running_var"):
+            v = rng.uniform(0.5, 1.5, shape)
+        elif name.endswith("running_mean"):
+            v = rng.normal(0.0, 0.1, shape)
+        elif ".bn." in name and name.endswith("weight"):
+            v = rng.uniform(0.5, 1.5, shape)
+        elif name.endswith("bias"):
+            v = rng.normal(0.0, 0.1, shape)
+        else:  # conv weight (Cout, Cin, kh, kw)
+            fan_in = int(np.prod(shape[1:]))
+            v = rng.normal(0.0, np.sqrt(2.0 / fan_in), shape)
+        out[name] = torch.from_numpy(np.asarray(v)).to(t.dtype)
+    return out

@@ -152,6 +152,65 @@ int frlw_resize_nearest_u8(const uint8_t *in, int C, int H, int W, int Ho, int W
 /* np.where(v > 255, 255, v).astype(uint8) (clip255 != 0) or plain .astype(uint8) truncation. */
 int frlw_quantize_u8(const float *in, int64_t n, int clip255, uint8_t *out, frlw_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * YOLOX detector forward (eval): replaces the forward of the reference's nn.Modules
+ * CSPDarknet / YOLOPAFPN / YOLOXHead (core/yolox/models/, all files) called from core/model.py:40-58.
+ *
+ * The network is a plan of kernel launches built once from the module tree (frlw-evd_amd/detector.py
+ * walks the reference-named modules, folds BatchNorm into the weights and uploads them) and replayed
+ * natively by frlw_det_run.  Tensors are NHWC f32; a tensor argument is (buffer index, pixel stride
+ * in floats, channel offset), so a concat is just several producers writing disjoint channel slices
+ * of one buffer.  Buffer indices refer to the `bufs` array passed to frlw_det_run.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct frlw_detector frlw_detector_t;
+
+enum { FRLW_ACT_NONE = 0, FRLW_ACT_SILU = 1, FRLW_ACT_SIGMOID = 2 };
+
+frlw_detector_t *frlw_det_create(void);
+void frlw_det_destroy(frlw_detector_t *d);
+int frlw_det_num_ops(const frlw_detector_t *d);
+
+/* Focus space-to-depth (network_blocks.py:205-217): NCHW (B, C, H, W) -> NHWC (B, H/2, W/2, 4C). */
+int frlw_det_add_focus(frlw_detector_t *d, int src_buf, int C, int H, int W, int dst_buf);
+
+/* nn.Upsample(scale_factor=2, mode="nearest") of a channel slice (yolo_pafpn.py:29). */
+int frlw_det_add_upsample(frlw_detector_t *d, int src_buf, int cs_src, int co_src, int C, int H, int W,
+                          int dst_buf, int cs_dst, int co_dst);
+
+/* SPPBottleneck pools (network_blocks.py:139-151): channels [0, C) -> max-pool 5 / 9 / 13 into [C, 4C). */
+int frlw_det_add_spp_pool(frlw_detector_t *d, int buf, int cs, int C, int H, int W);
+
+/*
+ * BaseConv (network_blocks.py:33-65) with BatchNorm folded: y = act(conv(x, w) + bias) [+ res].
+ *   w_dev   : device, (k*k*Cin, Npad) row-major, row (ky*k + kx)*Cin + ci, Npad = Cout rounded up to 32
+ *   bias_dev: device, Cout floats (or NULL)
+ *   k in {1, 3}, stride in {1, 2}, padding (k-1)/2; Cin, src_cs, src_co multiples of 4
+ *   dst_bs  : floats between images in the destination (0 = dense Ho*Wo*dst_cs); lets the prediction
+ *             convs write straight into the (B, A, 5 + nc) head tensor (yolo_head.py:229-231)
+ *   res_buf : < 0 for none; Bottleneck shortcut added AFTER the activation (network_blocks.py:108-110)
+ *   act     : FRLW_ACT_*; with FRLW_ACT_SIGMOID only channels >= sig_from are squashed (yolo_head.py:209-211)
+ */
+int frlw_det_add_conv(frlw_detector_t *d, int src_buf, int src_cs, int src_co, int Cin, int H, int W,
+                      const float *w_dev, const float *bias_dev, int Cout, int Npad, int k, int stride,
+                      int dst_buf, int dst_cs, int dst_co, int64_t dst_bs, int res_buf, int res_cs,
+                      int res_co, int act, int sig_from);
+
+/*
+ * decode_outputs (yolo_head.py:258-303): xy = (xy + grid) * stride, wh = square(wh) * stride, keep
+ * obj > obj_thr, class-agnostic NMS at iou_thr (the documented torchvision.ops.nms semantics: descending
+ * score, suppress IoU > thr), emit [cx, cy, w, h, argmax cls, obj * max cls] in descending-score order.
+ *   raw_buf    : (B, A, 5 + nc) f32     decoded_buf: optional (B, A, 5 + nc), < 0 for none
+ *   dets_buf   : (B, A, 6) f32          counts_buf : (B) int32; 0 = nothing passed (the reference then
+ *                returns one all-zero row), -1 = more than 2048 candidates (not handled on device)
+ */
+int frlw_det_add_decode_nms(frlw_detector_t *d, int raw_buf, int A, int nc, int n_levels, const int *lvl_h,
+                            const int *lvl_w, const int *lvl_stride, float obj_thr, float iou_thr,
+                            int decoded_buf, int dets_buf, int counts_buf);
+
+/* Launch ops [first, last) (last < 0: to the end) for B images on `stream`; bufs: n_bufs device pointers. */
+int frlw_det_run(const frlw_detector_t *d, int B, void *const *bufs, int n_bufs, int first, int last,
+                 frlw_stream_t stream);
+
 /* Library identification: "frlw_evd <version> gfx950". */
 const char *frlw_version(void);
 

@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""Golden vectors of the YOLOX detector, produced by the REFERENCE's own modules
+(core/yolox/models/*, core/model.py imported from /root/reference, torch-CPU fp32) with recipe weights.
+
+Runs only in the build container.  Weights are not stored: frlw_evd_amd.yolox.model.recipe_state_dict
+regenerates them from (seed, parameter name) on both sides; the input is regenerated from its seed.
+
+    python tests/golden/make_golden_detector.py     # rewrites tests/golden/detector.npz
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("FRLW_REFERENCE", "/root/reference")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+
+def stub(name, **attrs):
+    if name in sys.modules:
+        return sys.modules[name]
+    m = types.ModuleType(name)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+    return m
+
+
+# modules the reference imports but this image lacks
+stub("turtle", forward=None)
+stub("loguru", logger=types.SimpleNamespace(info=print, warning=print, error=print))
+tv = stub("torchvision")
+tv.ops = stub("torchvision.ops", nms=None, batched_nms=None)
+stub("cv2")
+stub("thop", profile=None)
+timm = stub("timm")
+timm.models = stub("timm.models")
+timm.models.layers = stub("timm.models.layers", DropPath=torch.nn.Identity, trunc_normal_=lambda *a, **k: None)
+torch.cuda.synchronize = lambda *a, **k: None
+torch.set_num_threads(8)
+
+from core.yolox.models.darknet import CSPDarknet  # noqa: E402
+from core.yolox.models.network_blocks import Focus  # noqa: E402
+from core.yolox.models.yolo_head import YOLOXHead  # noqa: E402
+from core.yolox.models.yolo_pafpn import YOLOPAFPN  # noqa: E402
+from core.model import model as RefModel  # noqa: E402
+
+from frlw_evd_amd.yolox.model import build_yolox, recipe_state_dict  # noqa: E402
+
+
+def detector_input(seed, B, C=10, H=256, W=320):
+    """uint8-quantised U{0..255} / 255 as (B, C, H, W, 1, 1) f32 (SURVEY.md section 8d cfg 4)."""
+    rng = np.random.default_rng(seed)
+    return torch.from_numpy((rng.integers(0, 256, size=(B, C, H, W, 1, 1)).astype(np.float32) / np.float32(255)))
+
+
+def main():
+    out = {}
+    for tag, C, nc in (("ev10", 10, 2), ("taf16", 16, 2)):
+        chans = [128, 256, 512]
+        ref = RefModel(CSPDarknet(C, 0.33, 0.5, stem=Focus),
+                       YOLOPAFPN(0.33, in_features=["dark3", "dark4", "dark5"], in_channels=chans, act="silu"), None,
+                       YOLOXHead(nc, in_channels=chans, act="silu", strides=[8, 16, 32], radius=5))
+        mine = build_yolox(C, nc)
+        sd = recipe_state_dict(mine, seed=1004)
+        assert list(sd.keys()) == list(ref.state_dict().keys()), "parameter names differ from the reference"
+        for (k, a), (_, b) in zip(sd.items(), ref.state_dict().items()):
+            assert a.shape == b.shape, k
+        ref.load_state_dict(sd)
+        ref.eval()
+        x = detector_input(1004, 2, C)
+        with torch.no_grad():
+            feats = ref.backbone(x[..., 0])
+            fpn = ref.neck(feats)
+            head = ref.head
+            head.decode_in_inference = False
+            raw = head(fpn)  # (B, 1680, 5 + nc) pre-decode
+        out[f"{tag}_raw"] = raw.numpy()
+        for name, t in zip(("dark3", "dark4", "dark5"), feats):
+            out[f"{tag}_{name}_stats"] = np.array([t.mean().item(), t.norm().item(), t.abs().max().item()])
+        for name, t in zip(("pan2", "pan1", "pan0"), fpn):
+            out[f"{tag}_{name}_stats"] = np.array([t.mean().item(), t.norm().item(), t.abs().max().item()])
+        out[f"{tag}_params"] = np.array(sum(p.numel() for p in ref.parameters()))
+        # decoded (pre-NMS) boxes with the reference's own arithmetic (yolo_head.py:258-272)
+        grids, strides = [], []
+        for (h, w), s in zip(head.hw, head.strides):
+            yv, xv = torch.meshgrid([torch.arange(h), torch.arange(w)])
+            grids.append(torch.stack((xv, yv), 2).view(1, -1, 2))
+            strides.append(torch.full((1, h * w, 1), s))
+        grids = torch.cat(grids, 1).float()
+        strides = torch.cat(strides, 1).float()
+        dec = raw.clone()
+        dec[..., :2] = (dec[..., :2] + grids) * strides
+        dec[..., 2:4] = torch.square(dec[..., 2:4]) * strides
+        out[f"{tag}_decoded"] = dec.numpy()
+    np.savez_compressed(os.path.join(HERE, "detector.npz"), **out)
+    print("detector.npz", os.path.getsize(os.path.join(HERE, "detector.npz")) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()

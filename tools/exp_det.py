@@ -1,0 +1,26 @@
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from frlw_evd_amd.yolox import build_yolox
+from frlw_evd_amd.yolox.model import recipe_state_dict
+def timeit(fn, n=20, warm=3):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+B = int(os.environ.get("B", "32"))
+m = build_yolox(10, 2); m.load_state_dict(recipe_state_dict(m)); m.eval().cuda()
+x = torch.rand(B, 10, 256, 320, device="cuda")
+eng = m.engine()
+t = timeit(lambda: eng.raw_outputs(x))
+gf = eng.flops_per_image * B / 1e9
+print(f"engine fwd  B={B}: {t:.3f} ms  {B/t*1e3:.0f} frames/s  {gf/t:.1f} TFLOP/s ({gf/t/157.3*100:.1f}% of fp32 MFMA peak)")
+t2 = timeit(lambda: eng.detect(x), n=10)
+print(f"engine fwd+decode+nms (incl. host list): {t2:.3f} ms")
+with torch.no_grad():
+    x5 = x[..., None]
+    t3 = timeit(lambda: m.reference_outputs(x5), n=10)
+print(f"torch (MIOpen) fwd: {t3:.3f} ms  {B/t3*1e3:.0f} frames/s")
