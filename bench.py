@@ -50,6 +50,8 @@ def main():
     ap.add_argument("--workload", default="taf_mpx", choices=sorted(WORKLOADS))
     ap.add_argument("--hotspot", action="store_true", help="25 %% of the events in a sigma-8px blob")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-detector", action="store_true", help="skip the detector forward leg")
+    ap.add_argument("--det-batch", type=int, default=32)
     ap.add_argument("--local_rank", "--local-rank", type=int, default=None)
     args = ap.parse_args()
 
@@ -149,12 +151,85 @@ def main():
         with open(traffic_file) as f:
             result["roofline"]["traffic"] = json.load(f).get("hbm_bytes_per_encode")
 
+    if not args.no_detector:
+        result["detector"] = bench_detector(args, torch, dist, world, rank, sync_all)
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(dat_h, n, H, W, K, n_win, win_us)
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
+
+
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, f32 in / f32 accumulate
+
+
+def bench_detector(args, torch, dist, world, rank, sync_all):
+    """Second half of BASELINE.json's metric: YOLOX forward frames/s (SURVEY.md section 8d cfg 4):
+    B = 32, (10, 256, 320) f32 input (the detector shape of a 304x240 sensor), recipe weights, eval mode,
+    forward to the pre-NMS tensor (B, 1680, 7); decode + NMS timed separately."""
+    from frlw_evd_amd.yolox import build_yolox
+    from frlw_evd_amd.yolox.model import recipe_state_dict
+    B = args.det_batch
+    net = build_yolox(10, 2)
+    net.load_state_dict(recipe_state_dict(net, seed=1004))
+    net.eval()
+    rng = np.random.default_rng(1004 + rank)
+    x_h = torch.from_numpy(rng.integers(0, 256, size=(B, 10, 256, 320)).astype(np.float32) / np.float32(255))
+    x = x_h.cuda()
+    eng = net.engine()
+    steps = max(5, min(args.steps, 30))
+    for _ in range(3):
+        eng.raw_outputs(x)
+    sync_all()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(steps):
+        eng.raw_outputs(x)
+    e1.record()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    dev_ms = e0.elapsed_time(e1) / steps
+    for _ in range(2):
+        eng.detect(x)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(5):
+        eng.detect(x)
+    torch.cuda.synchronize()
+    full_ms = (time.perf_counter() - t1) / 5 * 1e3
+    if world > 1:
+        t = torch.tensor([elapsed, dev_ms], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, dev_ms = float(t[0]), float(t[1])
+    tflops = eng.flops_per_image * B / (dev_ms * 1e-3) / 1e12
+    out = {
+        "metric": "YOLOX-S (CSPDarknet + PAFPN + decoupled head) eval forward to the pre-NMS tensor",
+        "value": round(world * B / (elapsed / steps), 1), "unit": "frames/s", "batch_per_gpu": B,
+        "input": "(B, 10, 256, 320) f32, recipe weights", "steps": steps, "ms_per_batch": round(elapsed / steps * 1e3, 3),
+        "dtype": "f32", "fwd_plus_decode_nms_ms": round(full_ms, 3),
+        "roofline": {"bound": "mfma", "kernel": "k_conv_mfma (80 launches per forward)", "achieved": round(tflops, 2),
+                     "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / FP32_MFMA_PEAK_TFLOPS, 4),
+                     "flops_per_image": eng.flops_per_image, "device_ms_per_batch": round(dev_ms, 3),
+                     "mfma": "v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate)"},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # PyTorch-CPU forward of the same module definition (BASELINE.md section 3 item 2)
+        nthreads = min(os.cpu_count() or 1, 64)
+        torch.set_num_threads(nthreads)
+        xb = x_h[:8, ..., None]
+        with torch.no_grad():
+            net.reference_outputs(xb)
+            best = None
+            for _ in range(3):
+                t2 = time.perf_counter()
+                net.reference_outputs(xb)
+                dt = time.perf_counter() - t2
+                best = dt if best is None else min(best, dt)
+        out["cpu_baseline"] = {"value": round(8 / best, 1), "unit": "frames/s", "cores": nthreads, "kind": "port",
+                               "sample": f"PyTorch-CPU fp32 forward of the same modules, batch 8, best of 3 ({best:.3f} s)"}
+    return out
 
 
 def cpu_baseline(dat_h, n, H, W, K, n_win, win_us, budget_s=20.0):

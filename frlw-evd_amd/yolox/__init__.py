@@ -6,7 +6,7 @@ plain-PyTorch fp32 definition of the network (used for training and as the numer
 eval mode on a ROCm device :class:`frlw_evd_amd.detector.DetectorEngine` runs the same network with the
 hand-written gfx950 kernels.
 """
-from .network_blocks import BaseConv, Bottleneck, CSPLayer, Focus, SPPBottleneck, SiLU, get_activation
+from .network_blocks import BaseConv, Bottleneck, CSPLayer, Focus, SPPBottleneck, SiLU, get_activation  # noqa: F401
 from .darknet import CSPDarknet
 from .yolo_pafpn import YOLOPAFPN
 from .yolo_head import YOLOXHead
