@@ -58,19 +58,14 @@ def main():
     import torch
     import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", args.local_rank if args.local_rank is not None else 0))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", init_method="env://", device_id=torch.device("cuda", local_rank))
-    n_gpus = world
-
     from frlw_evd_amd import _lib, synth
+    from frlw_evd_amd import dist as fd
     from frlw_evd_amd import event_representation as er
+    rank, world, local_rank = fd.init_from_env("nccl", args.local_rank)  # one process per GPU, RCCL
+    torch.cuda.set_device(local_rank)
+    n_gpus = world
     _lib.load()
 
     seed, n, H, W, t_span, n_win, win_us, K = WORKLOADS[args.workload]
@@ -83,11 +78,7 @@ def main():
         return er.encode_taf_dat(dat, (H, W), state, 0, win_us, n_win, K, want_view=False, want_u8=True,
                                  flip_k=True, check=False)
 
-    def sync_all():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
+    sync_all = fd.barrier_sync
 
     # correctness guard: data-dependent status of the first encode must be clean
     u8, _ = er.encode_taf_dat(dat, (H, W), state, 0, win_us, n_win, K, check=True)
@@ -104,10 +95,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     dev_ms = e0.elapsed_time(e1) / args.steps  # HIP events on the launch stream (torch's current stream)
-    if world > 1:
-        t = torch.tensor([elapsed, dev_ms], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, dev_ms = float(t[0]), float(t[1])
+    elapsed, dev_ms = fd.max_over_ranks([elapsed, dev_ms])
 
     ms_per_step = elapsed / args.steps * 1e3
     value = n_gpus * n / (elapsed / args.steps) / 1e6
@@ -199,10 +187,8 @@ def bench_detector(args, torch, dist, world, rank, sync_all):
         eng.detect(x)
     torch.cuda.synchronize()
     full_ms = (time.perf_counter() - t1) / 5 * 1e3
-    if world > 1:
-        t = torch.tensor([elapsed, dev_ms], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, dev_ms = float(t[0]), float(t[1])
+    from frlw_evd_amd import dist as fd
+    elapsed, dev_ms = fd.max_over_ranks([elapsed, dev_ms])
     tflops = eng.flops_per_image * B / (dev_ms * 1e-3) / 1e12
     out = {
         "metric": "YOLOX-S (CSPDarknet + PAFPN + decoupled head) eval forward to the pre-NMS tensor",

@@ -1,0 +1,56 @@
+"""The N > 1 path on CPU: two processes, gloo backend, 127.0.0.1 rendezvous.  Covers the sharding rules and the
+reductions bench.py uses (barrier-bracketed timing, MAX over ranks, whole-job throughput)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from frlw_evd_amd import dist as fd
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    r, w, lr = fd.init_from_env(backend="gloo")
+    assert (r, w, lr) == (rank, world, rank)
+    seqs = list(range(11))  # 11 sequences, every rank encodes its own (stand-in "encode" = a checksum)
+    mine = fd.shard_round_robin(seqs, r, w)
+    lo, hi = fd.shard_range(1001, r, w)
+    fd.barrier_sync()
+    seconds = 0.5 + 0.25 * r  # rank 1 is the slow one
+    tmax, = fd.max_over_ranks([seconds])
+    rate = fd.job_throughput(len(mine) * 1000, seconds)
+    checksum = fd.sum_over_ranks([sum(s * s for s in mine)])[0]
+    fd.barrier_sync()
+    np.save(os.path.join(out_dir, f"r{rank}.npy"), np.array([len(mine), lo, hi, tmax, rate, checksum]))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_process_gloo(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = (np.load(tmp_path / f"r{i}.npy") for i in range(world))
+    assert r0[0] + r1[0] == 11 and abs(r0[0] - r1[0]) <= 1           # every sequence exactly once
+    assert (r0[1], r0[2], r1[1], r1[2]) == (0, 501, 501, 1001)       # contiguous, balanced, no gap
+    assert r0[3] == r1[3] == 0.75                                    # MAX over ranks
+    assert r0[4] == r1[4] == pytest.approx(11000 / 0.75)             # whole-job units / slowest rank
+    assert r0[5] == r1[5] == sum(s * s for s in range(11))           # nothing lost, nothing twice
+
+
+def test_single_process_helpers():
+    assert fd.shard_round_robin(range(5), 0, 1) == [0, 1, 2, 3, 4]
+    assert fd.shard_range(10, 0, 1) == (0, 10)
+    assert [fd.shard_range(10, r, 3) for r in range(3)] == [(0, 4), (4, 7), (7, 10)]
+    assert fd.max_over_ranks([1.5, 2.0]) == [1.5, 2.0]
+    assert fd.job_throughput(100, 2.0) == 50.0
