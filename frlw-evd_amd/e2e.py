@@ -1,0 +1,61 @@
+"""End-to-end synthetic harness of BASELINE.json config 5: TAF encode (HIP) -> detector input -> YOLOX train /
+eval step, one process per GPU (SURVEY.md section 8d cfg 5).
+
+Per sample: a 304x240 stream of 8 windows x 125 000 events -> TAF K=8 (16 channels) -> leaky transform ->
+uint8 (the file the reference would write, generate_taf.py:228-235) -> /255 (data/dataset.py:294-308) ->
+nearest resize to 256x320 -> YOLOX(16-channel Focus stem) with 2 GT boxes.  Real datasets, augmentation and
+the evaluator are out of scope.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import event_representation as er
+from . import synth
+from .yolox import build_yolox
+from .yolox.model import recipe_state_dict
+
+GEN1_SENSOR = (240, 304)
+GEN1_DETECTOR = (256, 320)
+
+
+class SyntheticTafSource:
+    """Independent per-sample event streams (one sequence each), resident on the GPU as raw DAT records."""
+
+    def __init__(self, n_samples, seed=1005, events_per_window=125_000, n_windows=8, device="cuda"):
+        H, W = GEN1_SENSOR
+        self.n_windows, self.K = n_windows, 8
+        self.streams = []
+        for i in range(n_samples):
+            ev = synth.synth_events(seed + i, events_per_window * n_windows, W, H, 10_000 * n_windows)
+            self.streams.append(torch.from_numpy(synth.to_dat8(ev).view(np.uint8).reshape(-1, 8)).to(device))
+        self.device = device
+
+    def labels(self, n):
+        """(n, 80, 5) float64 [cls, cx, cy, w, h] with 2 boxes per sample, zero-padded (data/dataset.py:211-217)."""
+        rng = np.random.default_rng(99)
+        lab = torch.zeros((n, 80, 5), dtype=torch.float64)
+        for i in range(n):
+            for j in range(2):
+                lab[i, j] = torch.tensor([rng.integers(0, 2), rng.uniform(60, 260), rng.uniform(50, 200),
+                                          rng.uniform(20, 80), rng.uniform(20, 80)])
+        return lab.to(self.device)
+
+    def encode_batch(self, idx):
+        """-> (B, 16, 256, 320, 1, 1) f32 in [0, 1]: what propheseeTafDataset hands to the model."""
+        H, W = GEN1_SENSOR
+        out = []
+        for i in idx:
+            state = torch.full((H, W, 2, self.K), -6000.0, device=self.device)
+            u8, _ = er.encode_taf_dat(self.streams[i], (H, W), state, 0, 10_000, self.n_windows, self.K, check=False)
+            u8 = er.resize_nearest(u8.reshape(2 * self.K, H, W), GEN1_DETECTOR)
+            out.append(u8)
+        x = torch.stack(out).float() / 255.0
+        return x[..., None, None]
+
+
+def build_model(in_channels=16, num_classes=2, device="cuda", seed=1004):
+    net = build_yolox(in_channels, num_classes)
+    net.load_state_dict(recipe_state_dict(net, seed=seed))
+    return net.to(device)

@@ -1,0 +1,156 @@
+"""Training branch of the YOLOX head: SimOTA label assignment and the losses
+(reference: core/yolox/models/yolo_head.py:237-256,305-707, core/yolox/models/losses.py:9-53,
+core/yolox/utils/boxes.py:79-102).
+
+Host logic on ROCm tensors with plain torch ops (the assignment is per-image
+Python with ``.item()`` syncs in the reference too).  Dtype behaviour is kept: labels arrive as float64
+(data/dataset.py:216), so IoUs, costs and the total loss are float64 while predictions stay float32.
+"""
+import torch
+import torch.nn.functional as F
+
+
+def bboxes_iou_cxcywh(a, b):
+    """Pairwise IoU of (N, 4) and (M, 4) boxes in cxcywh (boxes.py:79-102 with xyxy=False)."""
+    tl = torch.max(a[:, None, :2] - a[:, None, 2:] / 2, b[:, :2] - b[:, 2:] / 2)
+    br = torch.min(a[:, None, :2] + a[:, None, 2:] / 2, b[:, :2] + b[:, 2:] / 2)
+    area_a = torch.prod(a[:, 2:], 1)
+    area_b = torch.prod(b[:, 2:], 1)
+    en = (tl < br).type(tl.type()).prod(dim=2)
+    area_i = torch.prod(br - tl, 2) * en
+    return area_i / (area_a[:, None] + area_b - area_i)
+
+
+def iou_loss(pred, target):
+    """1 - IoU^2 per box, cxcywh (losses.py:16-36, loss_type "iou")."""
+    pred = pred.view(-1, 4)
+    target = target.view(-1, 4)
+    tl = torch.max(pred[:, :2] - pred[:, 2:] / 2, target[:, :2] - target[:, 2:] / 2)
+    br = torch.min(pred[:, :2] + pred[:, 2:] / 2, target[:, :2] + target[:, 2:] / 2)
+    area_p = torch.prod(pred[:, 2:], 1)
+    area_g = torch.prod(target[:, 2:], 1)
+    en = (tl < br).type(tl.type()).prod(dim=1)
+    area_i = torch.prod(br - tl, 1) * en
+    iou = area_i / (area_p + area_g - area_i + 1e-16)
+    return 1 - iou ** 2
+
+
+def output_and_grid(output, stride):
+    """(B, 5 + nc, h, w) raw level output -> decoded (B, h*w, 5 + nc) and its (1, h*w, 2) grid
+    (yolo_head.py:237-256): xy = (xy + grid) * stride, wh = square(wh) * stride."""
+    B, n_ch, h, w = output.shape
+    yv, xv = torch.meshgrid([torch.arange(h), torch.arange(w)], indexing="ij")
+    grid = torch.stack((xv, yv), 2).view(1, h * w, 2).to(device=output.device, dtype=output.dtype)
+    out = output.view(B, 1, n_ch, h, w).permute(0, 1, 3, 4, 2).reshape(B, h * w, n_ch)
+    xy = (out[..., :2] + grid) * stride
+    wh = torch.square(out[..., 2:4]) * stride
+    return torch.cat([xy, wh, out[..., 4:]], dim=-1), grid
+
+
+def in_boxes_info(gt, strides, x_shifts, y_shifts, radius):
+    """Candidate anchors = centre inside a GT box OR inside the radius*stride square around its centre
+    (yolo_head.py:586-669).  Returns (candidate mask (A,), in-box-AND-in-centre (G, n_candidates))."""
+    s = strides[0]
+    xc = (x_shifts[0] * s + 0.5 * s).unsqueeze(0)  # (1, A)
+    yc = (y_shifts[0] * s + 0.5 * s).unsqueeze(0)
+    cx, cy, w, h = (gt[:, i].unsqueeze(1) for i in range(4))  # (G, 1)
+    deltas = torch.stack([xc - (cx - 0.5 * w), yc - (cy - 0.5 * h), (cx + 0.5 * w) - xc, (cy + 0.5 * h) - yc], 2)
+    is_in_boxes = deltas.min(dim=-1).values > 0.0
+    r = radius * s.unsqueeze(0)
+    cdeltas = torch.stack([xc - (cx - r), yc - (cy - r), (cx + r) - xc, (cy + r) - yc], 2)
+    is_in_centers = cdeltas.min(dim=-1).values > 0.0
+    anchor = (is_in_boxes.sum(dim=0) > 0) | (is_in_centers.sum(dim=0) > 0)
+    return anchor, is_in_boxes[:, anchor] & is_in_centers[:, anchor]
+
+
+def dynamic_k_matching(cost, ious, gt_classes, fg_mask):
+    """SimOTA (yolo_head.py:671-707): per GT k = clamp(floor(sum of its top-10 IoUs), 1) lowest-cost anchors;
+    an anchor claimed by several GTs goes to the cheapest.  Updates fg_mask in place."""
+    num_gt = cost.shape[0]
+    matching = torch.zeros_like(cost)
+    topk_ious, _ = torch.topk(ious, min(10, ious.size(1)), dim=1)
+    dynamic_ks = torch.clamp(topk_ious.sum(1).int(), min=1)
+    for g in range(num_gt):
+        _, pos = torch.topk(cost[g], k=dynamic_ks[g].item(), largest=False)
+        matching[g][pos] = 1.0
+    multi = matching.sum(0) > 1
+    if multi.sum() > 0:
+        _, argmin = torch.min(cost[:, multi], dim=0)
+        matching[:, multi] *= 0.0
+        matching[argmin, multi] = 1.0
+    fg_in = matching.sum(0) > 0.0
+    num_fg = fg_in.sum().item()
+    fg_mask[fg_mask.clone()] = fg_in
+    matched_gt = matching[:, fg_in].argmax(0)
+    return num_fg, gt_classes[matched_gt], (matching * ious).sum(0)[fg_in], matched_gt
+
+
+@torch.no_grad()
+def get_assignments(b, gt_boxes, gt_classes, preds_b, strides, x_shifts, y_shifts, cls_preds, obj_preds,
+                    num_classes, radius):
+    """yolo_head.py:482-584."""
+    num_gt = gt_boxes.shape[0]
+    fg_mask, in_box_and_center = in_boxes_info(gt_boxes, strides, x_shifts, y_shifts, radius)
+    boxes = preds_b[fg_mask]
+    cls_ = cls_preds[b][fg_mask]
+    obj_ = obj_preds[b][fg_mask]
+    n_in = boxes.shape[0]
+    ious = bboxes_iou_cxcywh(gt_boxes, boxes)
+    gt_onehot = F.one_hot(gt_classes.to(torch.int64), num_classes).float().unsqueeze(1).repeat(1, n_in, 1)
+    iou_cost = -torch.log(ious + 1e-8)
+    joint = (cls_.float().unsqueeze(0).repeat(num_gt, 1, 1).sigmoid_()
+             * obj_.float().unsqueeze(0).repeat(num_gt, 1, 1).sigmoid_())
+    cls_cost = F.binary_cross_entropy(joint.sqrt_(), gt_onehot, reduction="none").sum(-1)
+    cost = cls_cost + 3.0 * iou_cost + 100000.0 * (~in_box_and_center)
+    num_fg, matched_classes, matched_ious, matched_gt = dynamic_k_matching(cost, ious, gt_classes, fg_mask)
+    return matched_classes, fg_mask, matched_ious, matched_gt, num_fg
+
+
+def yolox_losses(level_outputs, strides, labels, num_classes, radius):
+    """``get_losses`` (yolo_head.py:305-473) on the raw per-level outputs cat[reg, obj, cls] (B, 5 + nc, h, w).
+
+    Returns (loss, 5 * loss_iou, loss_obj, loss_cls, loss_l1 = 0.0, num_fg / num_gt)."""
+    outs, xs, ys, ss = [], [], [], []
+    for o, stride in zip(level_outputs, strides):
+        dec, grid = output_and_grid(o, stride)
+        outs.append(dec)
+        xs.append(grid[:, :, 0])
+        ys.append(grid[:, :, 1])
+        ss.append(torch.zeros(1, grid.shape[1]).fill_(stride).type_as(o))
+    outputs = torch.cat(outs, 1)
+    x_shifts, y_shifts, strides_all = torch.cat(xs, 1), torch.cat(ys, 1), torch.cat(ss, 1)
+    bbox_preds = outputs[:, :, :4]
+    obj_preds = outputs[:, :, 4].unsqueeze(-1)
+    cls_preds = outputs[:, :, 5:]
+    nlabel = (labels.sum(dim=2) > 0).sum(dim=1)
+    A = outputs.shape[1]
+    cls_t, reg_t, obj_t, fg_masks = [], [], [], []
+    num_fg, num_gts = 0.0, 0.0
+    for b in range(outputs.shape[0]):
+        num_gt = int(nlabel[b])
+        num_gts += num_gt
+        if num_gt == 0:
+            cls_t.append(outputs.new_zeros((0, num_classes)))
+            reg_t.append(outputs.new_zeros((0, 4)))
+            obj_t.append(outputs.new_zeros((A, 1)))
+            fg_masks.append(outputs.new_zeros(A).bool())
+            continue
+        gt_boxes = labels[b, :num_gt, 1:5]
+        gt_classes = labels[b, :num_gt, 0]
+        matched_classes, fg_mask, matched_ious, matched_gt, n_fg = get_assignments(
+            b, gt_boxes, gt_classes, bbox_preds[b], strides_all, x_shifts, y_shifts, cls_preds, obj_preds,
+            num_classes, radius)
+        num_fg += n_fg
+        cls_t.append(F.one_hot(matched_classes.to(torch.int64), num_classes) * matched_ious.unsqueeze(-1))
+        obj_t.append(fg_mask.unsqueeze(-1).to(outputs.dtype))
+        reg_t.append(gt_boxes[matched_gt])
+        fg_masks.append(fg_mask)
+    cls_t, reg_t, obj_t, fg_masks = torch.cat(cls_t, 0), torch.cat(reg_t, 0), torch.cat(obj_t, 0), torch.cat(fg_masks, 0)
+    num_fg = max(num_fg, 1)
+    bce = torch.nn.BCEWithLogitsLoss(reduction="none")
+    loss_iou = iou_loss(bbox_preds.reshape(-1, 4)[fg_masks], reg_t).sum() / num_fg
+    loss_obj = bce(obj_preds.reshape(-1, 1), obj_t).sum() / num_fg
+    loss_cls = bce(cls_preds.reshape(-1, num_classes)[fg_masks], cls_t).sum() / num_fg
+    reg_weight = 5.0
+    loss = reg_weight * loss_iou + loss_obj + loss_cls + 0.0
+    return loss, reg_weight * loss_iou, loss_obj, loss_cls, 0.0, num_fg / max(num_gts, 1)

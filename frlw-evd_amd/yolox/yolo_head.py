@@ -4,8 +4,8 @@ Per level: 1x1 stem -> 256 (fixed, no width multiplier), cls and reg towers of t
 BaseConv, biased 1x1 predictions (num_classes / 4 / 1).  Eval: ``cat[reg, sigmoid(obj), sigmoid(cls)]``,
 flatten, permute -> (B, A, 5 + nc), then :meth:`decode_outputs`.
 
-The training branch (SimOTA assignment + losses, yolo_head.py:305-707) is not part of this module yet;
-``forward`` raises in training mode.
+Training: the raw per-level outputs go to :func:`frlw_evd_amd.yolox.losses.yolox_losses` (SimOTA assignment +
+losses, yolo_head.py:305-707) and the 6-tuple (loss, 5*iou, obj, cls, l1, fg/gt) is returned.
 """
 import math
 
@@ -87,9 +87,20 @@ class YOLOXHead(nn.Module):
                                    self.cls_preds[k](cls_feat).sigmoid()], 1))
         return outs
 
+    def train_outputs(self, xin):
+        """Per level ``cat[reg, obj, cls]`` without sigmoid (yolo_head.py:186, training branch)."""
+        outs = []
+        for k, x in enumerate(xin):
+            x = self.stems[k](x)
+            cls_feat = self.cls_convs[k](x)
+            reg_feat = self.reg_convs[k](x)
+            outs.append(torch.cat([self.reg_preds[k](reg_feat), self.obj_preds[k](reg_feat), self.cls_preds[k](cls_feat)], 1))
+        return outs
+
     def forward(self, xin, labels=None, imgs=None):
         if self.training:
-            raise NotImplementedError("the SimOTA training branch (yolo_head.py:305-707) is not built yet")
+            from .losses import yolox_losses
+            return yolox_losses(self.train_outputs(xin), self.strides, labels, self.num_classes, self.radius)
         outs = self.raw_outputs(xin)
         self.hw = [o.shape[-2:] for o in outs]
         outputs = torch.cat([o.flatten(start_dim=2) for o in outs], dim=2).permute(0, 2, 1)

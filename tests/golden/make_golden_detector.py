@@ -59,6 +59,18 @@ def detector_input(seed, B, C=10, H=256, W=320):
     return torch.from_numpy((rng.integers(0, 256, size=(B, C, H, W, 1, 1)).astype(np.float32) / np.float32(255)))
 
 
+def train_labels():
+    """(4, 80, 5) float64 [cls, cx, cy, w, h] in detector pixels, zero-padded (data/dataset.py:211-217)."""
+    lab = torch.zeros((4, 80, 5), dtype=torch.float64)
+    lab[0, 0] = torch.tensor([1, 100.0, 120.0, 40.0, 60.0])
+    lab[0, 1] = torch.tensor([0, 200.0, 80.0, 30.0, 30.0])
+    lab[1, 0] = torch.tensor([0, 160.0, 128.0, 80.0, 50.0])
+    lab[2, 0] = torch.tensor([1, 30.5, 40.25, 21.0, 33.0])
+    lab[2, 1] = torch.tensor([1, 36.0, 44.0, 25.0, 30.0])   # overlapping pair: anchors claimed twice
+    lab[2, 2] = torch.tensor([0, 290.0, 230.0, 50.0, 40.0])
+    return lab                                              # image 3 has no box
+
+
 def main():
     out = {}
     for tag, C, nc in (("ev10", 10, 2), ("taf16", 16, 2)):
@@ -98,6 +110,22 @@ def main():
         dec[..., :2] = (dec[..., :2] + grids) * strides
         dec[..., 2:4] = torch.square(dec[..., 2:4]) * strides
         out[f"{tag}_decoded"] = dec.numpy()
+        if tag == "ev10":
+            # train branch: SimOTA + losses + backward on a fixed label set (yolo_head.py:305-473)
+            ref.load_state_dict(sd)
+            ref.train()
+            ref.head.decode_in_inference = True
+            xt = detector_input(1005, 4, C)
+            labels = train_labels()
+            loss = ref(xt, labels, None, None)          # core/model.py:50-56 returns losses[0]
+            out["train_loss"] = np.array(loss.item())
+            ref.zero_grad()
+            loss.backward()
+            for grp in ("backbone", "neck", "head"):
+                out[f"train_gradnorm_{grp}"] = np.array(float(torch.sqrt(sum((p.grad.double() ** 2).sum() for n, p in ref.named_parameters() if n.startswith(grp) and p.grad is not None))))
+            feats = ref.neck(ref.backbone(xt[..., 0, 0][..., None]))
+            tup = ref.head(feats, labels, xt[..., 0])
+            out["train_tuple"] = np.array([float(v) for v in tup])
     np.savez_compressed(os.path.join(HERE, "detector.npz"), **out)
     print("detector.npz", os.path.getsize(os.path.join(HERE, "detector.npz")) // 1024, "KiB")
 

@@ -54,3 +54,40 @@ def test_single_process_helpers():
     assert [fd.shard_range(10, r, 3) for r in range(3)] == [(0, 4), (4, 7), (7, 10)]
     assert fd.max_over_ranks([1.5, 2.0]) == [1.5, 2.0]
     assert fd.job_throughput(100, 2.0) == 50.0
+
+
+def _ddp_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(3)
+    fd.init_from_env(backend="gloo")
+    from frlw_evd_amd.trainer import Trainer
+    from frlw_evd_amd.yolox import build_yolox
+    from frlw_evd_amd.yolox.model import recipe_state_dict
+    from test_detector_cpu import detector_input, train_labels
+    m = build_yolox(10, 2)
+    m.load_state_dict(recipe_state_dict(m, seed=1004 + rank))  # different init: DDP broadcasts rank 0's weights
+    tr = Trainer(m, global_batch=4, nodes=world, iters_per_epoch=10, ddp=True)   # per-GPU batch = 4 / 2
+    assert tr.per_gpu_batch == 2
+    x, lab = detector_input(1005, 4, H=128, W=160), train_labels()
+    lab[..., 1:] *= 0.5  # boxes for the 128 x 160 input
+    lo, hi = fd.shard_range(4, rank, world)
+    losses = [tr.train_step(x[lo:hi], lab[lo:hi], i)[0] for i in range(2)]
+    w = m.head.cls_preds[0].bias.detach().double()
+    rm = m.backbone.stem.conv.bn.running_mean.detach().double()
+    np.save(os.path.join(out_dir, f"d{rank}.npy"), np.array(losses + [float(w.sum()), float(w.abs().sum()), float(rm.sum())]))
+    torch.distributed.destroy_process_group()
+
+
+def test_ddp_train_step_two_ranks(tmp_path):
+    """core/exp.py:386-391 + 292-303 with world_size 2: weights stay identical across ranks (broadcast at wrap,
+    all-reduced gradients), BatchNorm statistics stay per rank (broadcast_buffers=False)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    world = 2
+    mp.spawn(_ddp_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    d0, d1 = (np.load(tmp_path / f"d{i}.npy") for i in range(world))
+    assert np.all(np.isfinite(d0)) and np.all(np.isfinite(d1))
+    assert d0[2] == d1[2] and d0[3] == d1[3]      # parameters identical after two steps
+    assert d0[4] != d1[4]                         # running_mean differs: each rank saw its own shard
+    assert d0[0] != d1[0]                         # per-rank losses differ (different images)

@@ -1,0 +1,27 @@
+"""BASELINE.json config 5 in miniature on one GPU: TAF encode (HIP) -> YOLOX train step and eval forward."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+def test_encode_then_train_and_eval_step():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from frlw_evd_amd import e2e
+    from frlw_evd_amd.trainer import Trainer
+    src = e2e.SyntheticTafSource(2, events_per_window=20_000)
+    x = src.encode_batch([0, 1])
+    assert x.shape == (2, 16, 256, 320, 1, 1) and float(x.min()) >= 0.0 and float(x.max()) <= 1.0
+    q = (x * 255).round()
+    assert torch.equal(q / 255, x)  # values are exactly the uint8 artefact / 255 (data/dataset.py:294-308)
+    net = e2e.build_model(16, 2)
+    tr = Trainer(net, global_batch=2, nodes=1, iters_per_epoch=10)
+    l0, _ = tr.train_step(x, src.labels(2), 0)
+    l1, lr = tr.train_step(x, src.labels(2), 1)
+    assert np.isfinite(l0) and np.isfinite(l1) and lr > 0
+    net.eval()
+    with torch.no_grad():
+        dets = net(x)
+    assert len(dets) == 2 and dets[0].shape[1] == 6
