@@ -42,6 +42,8 @@ struct ConvArgs {
     const float *res; int r_cs, r_co; long long r_bs;
     int act, sig_from; // sigmoid applies to channels >= sig_from when act == ACT_SIGMOID
     int M, K;
+    int splits;        // split-K: blockIdx.z owns a slice of the k-tiles and writes raw partial sums
+    float *partial;    // [splits][M][Npad] when splits > 1
 };
 
 constexpr int BK = 16;
@@ -87,17 +89,19 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
     constexpr int BN4 = BN / 4;
     float4 ra[A_F4], rb[B_F4];
 
+    // (ky, kx, ci) of this thread's float4 in the CURRENT k-tile to be loaded; advanced by BK per tile
+    int t_ci = 0, t_ky = 0, t_kx = 0;
     auto load_tiles = [&](int kt) {
         const int k = kt * BK + a_k4;
-        const int tap = k / a.Cin, ci = k - tap * a.Cin; // Cin % 4 == 0: a float4 never straddles taps
-        const int ky = tap / a.k, kx = tap - ky * a.k;
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) {
-            const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
+            const int iy = a_iy0[i] + t_ky, ix = a_ix0[i] + t_kx;
             const bool ok = a_ok[i] && k < a.K && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            ra[i] = ok ? *(const float4 *)(a.x + a_base[i] + ((long long)iy * a.W + ix) * a.x_cs + ci)
+            ra[i] = ok ? *(const float4 *)(a.x + a_base[i] + ((long long)iy * a.W + ix) * a.x_cs + t_ci)
                        : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        t_ci += BK; // Cin % 4 == 0: a float4 never straddles taps
+        while (t_ci >= a.Cin) { t_ci -= a.Cin; if (++t_kx == a.k) { t_kx = 0; ++t_ky; } }
 #pragma unroll
         for (int i = 0; i < B_F4; ++i) {
             const int e = tid + 256 * i;
@@ -132,14 +136,23 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    const int nk = (a.K + BK - 1) / BK;
-    load_tiles(0);
+    const int nk_all = (a.K + BK - 1) / BK;
+    const int kt0 = (int)((long long)nk_all * blockIdx.z / a.splits), kt1 = (int)((long long)nk_all * (blockIdx.z + 1) / a.splits);
+    const int nk = kt1 - kt0;
+    {   // position the tap tracker on this split's first k-tile
+        const int k = kt0 * BK + a_k4;
+        const int tap = k / a.Cin;
+        t_ci = k - tap * a.Cin;
+        t_ky = tap / a.k;
+        t_kx = tap - t_ky * a.k;
+    }
+    load_tiles(kt0);
     store_tiles(0);
     __syncthreads();
     const int fm = wr * TM * 32 + (lane & 31), fn = wc * TN * 32 + (lane & 31), fk = lane >> 5;
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) load_tiles(kt + 1);
+        if (kt + 1 < nk) load_tiles(kt0 + kt + 1);
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
             float fa[TM], fb[TN];
@@ -158,25 +171,62 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
     }
 
     // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    if (a.splits > 1) { // raw partial sums; k_splitk_reduce applies bias / activation / residual
+        float *dst = a.partial + (long long)blockIdx.z * a.M * a.Npad;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wc * TN * 32 + 32 * j + (lane & 31);
-        if (n >= a.Cout) continue;
-        const float bias = a.bias ? a.bias[n] : 0.0f;
-        const int act = (a.act == ACT_SIGMOID && n < a.sig_from) ? ACT_NONE : a.act;
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wc * TN * 32 + 32 * j + (lane & 31);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wr * TM * 32 + 32 * i + 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2);
+                    if (m < a.M && n < a.Npad) dst[(long long)m * a.Npad + n] = acc[i][j][r];
+                }
+            }
+        return;
+    }
+    const int howo = a.Ho * a.Wo;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int mrow0 = m0 + wr * TM * 32 + 32 * i + 4 * (lane >> 5); // first row of this lane in the tile
+        const int b0 = mrow0 / howo, pix0 = mrow0 - b0 * howo;          // one division per 32x32 tile
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wc * TN * 32 + 32 * j + (lane & 31);
+            if (n >= a.Cout) continue;
+            const float bias = a.bias ? a.bias[n] : 0.0f;
+            const int act = (a.act == ACT_SIGMOID && n < a.sig_from) ? ACT_NONE : a.act;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wr * TM * 32 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (m < a.M) {
-                    const int b = m / (a.Ho * a.Wo), pix = m - b * (a.Ho * a.Wo);
+                const int dr = (r & 3) + 8 * (r >> 2);
+                if (mrow0 + dr < a.M) {
+                    int b = b0, pix = pix0 + dr;
+                    while (pix >= howo) { pix -= howo; ++b; }
                     float v = act_apply(acc[i][j][r] + bias, act);
                     if (a.res) v = v + a.res[(long long)b * a.r_bs + (long long)pix * a.r_cs + a.r_co + n];
                     a.y[(long long)b * a.y_bs + (long long)pix * a.y_cs + a.y_co + n] = v;
                 }
             }
         }
+    }
+}
+
+// y = act(sum over splits of partial + bias) [+ res]
+__global__ void k_splitk_reduce(ConvArgs a)
+{
+    const long long total = (long long)a.M * a.Cout;
+    const int howo = a.Ho * a.Wo;
+    for (long long o = blockIdx.x * (long long)blockDim.x + threadIdx.x; o < total; o += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(o % a.Cout);
+        const int m = (int)(o / a.Cout);
+        float v = 0.0f;
+        for (int z = 0; z < a.splits; ++z) v += a.partial[((long long)z * a.M + m) * a.Npad + n];
+        const int act = (a.act == ACT_SIGMOID && n < a.sig_from) ? ACT_NONE : a.act;
+        v = act_apply(v + (a.bias ? a.bias[n] : 0.0f), act);
+        const int b = m / howo, pix = m - b * howo;
+        if (a.res) v = v + a.res[(long long)b * a.r_bs + (long long)pix * a.r_cs + a.r_co + n];
+        a.y[(long long)b * a.y_bs + (long long)pix * a.y_cs + a.y_co + n] = v;
     }
 }
 
@@ -390,6 +440,8 @@ int grid_1d(long long n) { long long g = (n + 255) / 256; if (g > 4096) g = 4096
 
 struct frlw_detector {
     std::vector<Op> ops;
+    int scratch_buf = -1;        // split-K partial sums
+    long long scratch_floats = 0;
 };
 
 extern "C" {
@@ -397,6 +449,14 @@ extern "C" {
 frlw_detector_t *frlw_det_create(void) { return new frlw_detector(); }
 void frlw_det_destroy(frlw_detector_t *d) { delete d; }
 int frlw_det_num_ops(const frlw_detector_t *d) { return d ? (int)d->ops.size() : 0; }
+
+int frlw_det_set_scratch(frlw_detector_t *d, int buf, int64_t n_floats)
+{
+    if (!d) return FRLW_ERR_ARG;
+    d->scratch_buf = buf;
+    d->scratch_floats = n_floats;
+    return FRLW_OK;
+}
 
 int frlw_det_add_focus(frlw_detector_t *d, int src_buf, int C, int H, int W, int dst_buf)
 {
@@ -495,6 +555,8 @@ int frlw_det_run(const frlw_detector_t *d, int B, void *const *bufs, int n_bufs,
             c.x = buf(op.src); c.y = buf(op.dst); c.res = buf(op.res);
             if (!c.x || !c.y) return FRLW_ERR_ARG;
             c.M = B * c.Ho * c.Wo;
+            c.splits = 1;
+            c.partial = nullptr;
             // tile choice: the big tile when it still fills the chip, small N for the prediction convs
             const long long big = (long long)((c.M + 127) / 128) * ((c.Npad + 127) / 128);
             if (c.Npad <= 32) {
@@ -502,7 +564,18 @@ int frlw_det_run(const frlw_detector_t *d, int B, void *const *bufs, int n_bufs,
             } else if (big >= 384 && c.Npad >= 128) {
                 hipLaunchKernelGGL((k_conv_mfma<128, 128, 2, 2>), dim3((c.M + 127) / 128, (c.Npad + 127) / 128), dim3(256), 0, s, c);
             } else {
-                hipLaunchKernelGGL((k_conv_mfma<64, 64, 2, 2>), dim3((c.M + 63) / 64, (c.Npad + 63) / 64), dim3(256), 0, s, c);
+                const long long wgs = (long long)((c.M + 63) / 64) * ((c.Npad + 63) / 64);
+                const int nk = (c.K + BK - 1) / BK;
+                // small feature maps leave most CUs idle: split the contraction over blockIdx.z
+                if (wgs < 256 && nk >= 32 && d->scratch_buf >= 0) {
+                    int sp = (int)((768 + wgs - 1) / wgs);
+                    if (sp > 8) sp = 8;
+                    if (sp > nk / 8) sp = nk / 8;
+                    if (sp > 1 && (long long)sp * c.M * c.Npad <= d->scratch_floats) { c.splits = sp; c.partial = buf(d->scratch_buf); }
+                }
+                hipLaunchKernelGGL((k_conv_mfma<64, 64, 2, 2>), dim3((c.M + 63) / 64, (c.Npad + 63) / 64, c.splits), dim3(256), 0, s, c);
+                if (c.splits > 1)
+                    hipLaunchKernelGGL(k_splitk_reduce, dim3(grid_1d((long long)c.M * c.Cout)), dim3(256), 0, s, c);
             }
             break;
         }

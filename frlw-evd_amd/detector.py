@@ -56,6 +56,7 @@ class DetectorEngine:
         self._built_for = None
         self.n_conv = 0
         self.flops_per_image = 0
+        self.ops_meta = []   # one entry per plan op, in launch order (profiling aid)
 
     def __del__(self):
         try:
@@ -88,6 +89,7 @@ class DetectorEngine:
         assert (ho, wo) == (dst.h, dst.w), ((ho, wo), (dst.h, dst.w))
         self.n_conv += 1
         self.flops_per_image += 2 * ho * wo * cout * cin * k * k
+        self.ops_meta.append(("conv", ho * wo, cout, k * k * cin, 2 * ho * wo * cout * cin * k * k))
 
     def _baseconv(self, bc, src, dst, res=None):
         w, b = fold_bn(bc.conv, bc.bn)
@@ -123,6 +125,7 @@ class DetectorEngine:
         # ---- backbone (darknet.py:270-354)
         f = self._new_buf(H // 2, W // 2, 4 * cin)
         _lib.check(lib.frlw_det_add_focus(self.handle, x_in, cin, H, W, f.buf), "focus")
+        self.ops_meta.append(("focus", H * W // 4, 4 * cin, 0, 0))
         c = bb.stem.conv.conv.out_channels
         stem = self._new_buf(H // 2, W // 2, c)
         self._baseconv(bb.stem.conv, f, stem)
@@ -154,6 +157,7 @@ class DetectorEngine:
         sppcat = self._new_buf(h5, w5, 4 * hid)
         self._baseconv(spp.conv1, d5a, sppcat.slice(0, hid))
         _lib.check(lib.frlw_det_add_spp_pool(self.handle, sppcat.buf, sppcat.cs, hid, h5, w5), "spp")
+        self.ops_meta.append(("spp", h5 * w5, hid, 0, 0))
         d5b = self._new_buf(h5, w5, c5)
         self._baseconv(spp.conv2, sppcat, d5b)
         d5 = self._new_buf(h5, w5, c5)
@@ -163,12 +167,14 @@ class DetectorEngine:
         self._baseconv(neck.lateral_conv0, d5, fpn_out0)
         _lib.check(lib.frlw_det_add_upsample(self.handle, fpn_out0.buf, fpn_out0.cs, fpn_out0.co, c4, h5, w5,
                                              cat_p4.buf, cat_p4.cs, 0), "upsample")
+        self.ops_meta.append(("upsample", h4 * w4, c4, 0, 0))
         f_out0 = self._new_buf(h4, w4, c4)
         self._csp(neck.C3_p4, cat_p4, f_out0)
         fpn_out1 = cat_n3.slice(c3, c3)
         self._baseconv(neck.reduce_conv1, f_out0, fpn_out1)
         _lib.check(lib.frlw_det_add_upsample(self.handle, fpn_out1.buf, fpn_out1.cs, fpn_out1.co, c3, h4, w4,
                                              cat_p3.buf, cat_p3.cs, 0), "upsample")
+        self.ops_meta.append(("upsample", h3 * w3, c3, 0, 0))
         pan_out2 = self._new_buf(h3, w3, c3)
         self._csp(neck.C3_p3, cat_p3, pan_out2)
         self._baseconv(neck.bu_conv2, pan_out2, cat_n3.slice(0, c3))
@@ -216,6 +222,11 @@ class DetectorEngine:
                                                C.c_float(head.obj_threshold), C.c_float(head.nms_threshold),
                                                self.dec_buf, self.dets_buf, self.counts_buf), "decode")
         head.hw = [(v.h, v.w) for v in levels]
+        # split-K scratch: 8 splits x (< 256 tiles of 64 x 64), independent of the batch size
+        self.scratch_floats = 8 * 256 * 64 * 64
+        self._shapes.append(0)
+        self.scratch_buf = len(self._shapes) - 1
+        _lib.check(lib.frlw_det_set_scratch(self.handle, self.scratch_buf, self.scratch_floats), "scratch")
         self._built_for = tuple(in_shape)
 
     # ---- execution -----------------------------------------------------------------------------
@@ -224,6 +235,7 @@ class DetectorEngine:
         if bufs is None:
             bufs = [None] + [torch.empty(B * n, dtype=torch.float32, device=self.device) for n in self._shapes[1:]]
             bufs[self.counts_buf] = torch.zeros(B, dtype=torch.int32, device=self.device)
+            bufs[self.scratch_buf] = torch.empty(self.scratch_floats, dtype=torch.float32, device=self.device)
             self._bufs[B] = bufs
         return bufs
 

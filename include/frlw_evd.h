@@ -170,6 +170,10 @@ frlw_detector_t *frlw_det_create(void);
 void frlw_det_destroy(frlw_detector_t *d);
 int frlw_det_num_ops(const frlw_detector_t *d);
 
+/* Optional scratch buffer (index into bufs, size in floats for the batch) for split-K partial sums of the
+ * convolutions whose output grid would leave most CUs idle (8x10 feature maps). */
+int frlw_det_set_scratch(frlw_detector_t *d, int buf, int64_t n_floats);
+
 /* Focus space-to-depth (network_blocks.py:205-217): NCHW (B, C, H, W) -> NHWC (B, H/2, W/2, 4C). */
 int frlw_det_add_focus(frlw_detector_t *d, int src_buf, int C, int H, int W, int dst_buf);
 

@@ -64,10 +64,13 @@ def test_batch_32_vs_torch_gpu(gpu):
         torch.backends.cudnn.allow_tf32 = False
         ref = m.reference_outputs(x[..., 0])
     assert rel_err(raw, ref) <= TOL, rel_err(raw, ref)
-    # batch independence: image 7 alone gives the same numbers as inside the batch
+    # batch independence: image 7 alone gives the same numbers as inside the batch (up to the summation
+    # order: the split-K factor of the small feature maps depends on the batch size)
     one = m.engine().raw_outputs(x[7:8, ..., 0]).clone()
     raw = m.engine().raw_outputs(x[..., 0])
-    assert torch.equal(one[0], raw[7])
+    assert rel_err(one[0], raw[7]) <= 1e-5
+    again = m.engine().raw_outputs(x[..., 0]).clone()
+    assert torch.equal(again, m.engine().raw_outputs(x[..., 0]))  # deterministic run to run
 
 
 def test_other_resolution(gpu):
