@@ -385,42 +385,79 @@ __global__ __launch_bounds__(1024) void k_decode_nms(DecodeArgs a)
     }
     for (int i = tid; i < n; i += nt) { sarea[i] = (sx2[i] - sx1[i]) * (sy2[i] - sy1[i]); ssup[i] = 0; }
     __syncthreads();
-    // ---- greedy suppression in score order: IoU = inter / (area_i + area_j - inter) > thr
-    for (int i = 0; i < n; ++i) {
-        if (ssup[i]) continue; // block-uniform (read after the barrier below)
-        const float x1 = sx1[i], y1 = sy1[i], x2 = sx2[i], y2 = sy2[i], ar = sarea[i];
-        for (int j = i + 1 + tid; j < n; j += nt) {
-            const float xx1 = fmaxf(x1, sx1[j]), yy1 = fmaxf(y1, sy1[j]);
-            const float xx2 = fminf(x2, sx2[j]), yy2 = fminf(y2, sy2[j]);
-            const float iw = fmaxf(xx2 - xx1, 0.0f), ih = fmaxf(yy2 - yy1, 0.0f);
-            const float inter = iw * ih;
-            const float ovr = inter / (ar + sarea[j] - inter);
-            if (ovr > a.iou_thr) ssup[j] = 1;
+    // ---- greedy suppression in score order, IoU = inter / (area_i + area_j - inter) > thr, resolved 64
+    // boxes at a time: (a) the chunk's 64 x 64 "i suppresses j" bit matrix in parallel, (b) one thread walks
+    // the chunk's 64 rows sequentially on bitmasks, (c) the chunk's kept boxes suppress all later boxes in
+    // parallel.  Same result as the box-by-box loop, ~3 barriers per 64 boxes instead of one per box.
+    __shared__ unsigned long long rowmask[64];
+    __shared__ unsigned long long keptmask;
+    auto iou_gt = [&](int i, int j) {
+        const float xx1 = fmaxf(sx1[i], sx1[j]), yy1 = fmaxf(sy1[i], sy1[j]);
+        const float xx2 = fminf(sx2[i], sx2[j]), yy2 = fminf(sy2[i], sy2[j]);
+        const float iw = fmaxf(xx2 - xx1, 0.0f), ih = fmaxf(yy2 - yy1, 0.0f);
+        const float inter = iw * ih;
+        return inter / (sarea[i] + sarea[j] - inter) > a.iou_thr;
+    };
+    for (int c0 = 0; c0 < n; c0 += 64) {
+        const int nb = n - c0 < 64 ? n - c0 : 64;
+        if (tid < 64) rowmask[tid] = 0ull;
+        __syncthreads();
+        for (int p = tid; p < 64 * 64; p += nt) {
+            const int i = p >> 6, j = p & 63;
+            if (i < j && j < nb && iou_gt(c0 + i, c0 + j)) atomicOr(&rowmask[i], 1ull << j);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long sup = 0ull, kept = 0ull;
+            for (int i = 0; i < nb; ++i) sup |= (unsigned long long)(ssup[c0 + i] != 0) << i;
+            for (int i = 0; i < nb; ++i)
+                if (!((sup >> i) & 1ull)) { kept |= 1ull << i; sup |= rowmask[i]; }
+            keptmask = kept;
+        }
+        __syncthreads();
+        const unsigned long long kept = keptmask;
+        if (tid < nb) ssup[c0 + tid] = ((kept >> tid) & 1ull) ? 0 : 1;
+        for (int j = c0 + 64 + tid; j < n; j += nt) {
+            if (ssup[j]) continue;
+            unsigned long long k = kept;
+            while (k) {
+                const int i = __ffsll((long long)k) - 1;
+                k &= k - 1ull;
+                if (iou_gt(c0 + i, j)) { ssup[j] = 1; break; }
+            }
         }
         __syncthreads();
     }
-    // ---- emit kept boxes in score order (stable compaction by one thread: n <= 2048)
-    if (tid == 0) {
-        int cnt = 0;
-        for (int i = 0; i < n; ++i) {
-            if (ssup[i]) continue;
+    // ---- emit kept boxes in score order: exclusive scan of the kept flags gives the output row
+    __shared__ int wtot[16];
+    int run = 0;
+    for (int base = 0; base < n; base += nt) {
+        const int i = base + tid;
+        const bool keep = i < n && !ssup[i];
+        const unsigned long long bal = __ballot(keep);
+        const int lane = tid & 63, wv = tid >> 6;
+        if (lane == 0) wtot[wv] = __popcll(bal);
+        __syncthreads();
+        int pre = run;
+        for (int k = 0; k < wv; ++k) pre += wtot[k];
+        const int row = pre + __popcll(bal & ((1ull << lane) - 1ull));
+        if (keep) {
             const float *r = a.raw + ((long long)b * a.A + sidx[i]) * F;
-            const float w = sx2[i] - sx1[i], h = sy2[i] - sy1[i];
-            (void)w; (void)h;
             int lvl = 0, off = sidx[i];
             while (lvl + 1 < a.n_levels && off >= a.lvl_h[lvl] * a.lvl_w[lvl]) { off -= a.lvl_h[lvl] * a.lvl_w[lvl]; ++lvl; }
             const float gx = (float)(off % a.lvl_w[lvl]), gy = (float)(off / a.lvl_w[lvl]), s = (float)a.lvl_stride[lvl];
             int best = 0;
             float bv = r[5];
             for (int c = 1; c < a.nc; ++c) if (r[5 + c] > bv) { bv = r[5 + c]; best = c; } // first max, like argmax
-            float *d = a.dets + ((long long)b * a.A + cnt) * 6;
+            float *d = a.dets + ((long long)b * a.A + row) * 6;
             d[0] = (r[0] + gx) * s; d[1] = (r[1] + gy) * s; d[2] = (r[2] * r[2]) * s; d[3] = (r[3] * r[3]) * s;
             d[4] = (float)best;
             d[5] = r[4] * bv; // obj * max cls, yolo_head.py:301
-            ++cnt;
         }
-        a.counts[b] = cnt;
+        for (int k = 0; k < (nt + 63) / 64; ++k) run += wtot[k];
+        __syncthreads();
     }
+    if (tid == 0) a.counts[b] = run;
 }
 
 // ---- plan ------------------------------------------------------------------------------------------
