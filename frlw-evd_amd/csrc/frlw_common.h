@@ -188,19 +188,49 @@ __device__ __forceinline__ float leaky_f(float v)
     return l * 255.0f;      // :75
 }
 
+// uint8(leaky_transform(v)) is a non-increasing step function of x = -v >= 0 with at most 256 levels.
+// thr[k] (k = 1..255) = bit pattern of the largest x with uint8(leaky_f(-x)) >= k, found by bisection on the
+// SAME f32 pipeline (k_hist builds the table once per encode); thr[0] = +inf.  The lookup below returns
+// exactly what evaluating leaky_f would, for ~10 instructions instead of a log1pf per value.
+constexpr int kLeakyLevels = 256;
+
+__device__ __forceinline__ uint32_t leaky_threshold_bits(int k)
+{
+    uint32_t lo = 0u, hi = 0x7f000000u; // f(0) = 255 >= k always; f(huge) = 0
+    while (hi - lo > 1u) {
+        const uint32_t mid = lo + (hi - lo) / 2u;
+        if ((int)leaky_f(-__uint_as_float(mid)) >= k) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ uint8_t leaky_u8_lookup(float v, const uint32_t *thr)
+{
+    if (!(v <= 0.0f)) return (uint8_t)(int)leaky_f(v); // outside the table's domain (never for a TAF state)
+    const float x = -v;
+    const uint32_t xb = __float_as_uint(x);
+    // first guess from the hardware log2 (1 ulp-ish), then walk to the exact level
+    float g = 255.0f * (1.0f - (__log2f(1.0f + x) * 0.69314718f) / 8.7f);
+    int k = g < 0.0f ? 0 : (g > 255.0f ? 255 : (int)g);
+    while (k < 255 && xb <= thr[k + 1]) ++k;
+    while (k > 0 && xb > thr[k]) --k;
+    return (uint8_t)k;
+}
+
 // ---- host side ---------------------------------------------------------------------------------
 struct Plan {
     int twl, tiles_x, tiles_y, n_tiles;
     int bpw;          // batches of 64 events per wavefront
     long long chunk;  // events per partition workgroup = 1024 * bpw
     int units, slabs; // partition workgroups, slabs of 32
-    size_t off_counts, off_slabtot, off_base, off_tlut, off_records, bytes;
+    size_t off_counts, off_slabtot, off_base, off_tlut, off_leaky, off_records, bytes;
 };
 
 struct Partitioned {
     const uint2 *records;
     const uint32_t *base;
     WsHeader *hdr;
+    const uint32_t *leaky_thr; // TAF: threshold table built by k_hist
     Plan plan;
 };
 

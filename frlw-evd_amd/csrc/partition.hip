@@ -39,7 +39,7 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 template <int LAYOUT, int KIND>
 __global__ __launch_bounds__(kPartThreads) void k_hist(Decode P, int bpw, uint32_t *counts,
-                                                        WsHeader *hdr, float *tlut_w)
+                                                        WsHeader *hdr, float *tlut_w, uint32_t *leaky_w)
 {
     extern __shared__ uint32_t lds[];
     uint32_t *hist = lds; // [n_tiles]
@@ -49,6 +49,10 @@ __global__ __launch_bounds__(kPartThreads) void k_hist(Decode P, int bpw, uint32
     __syncthreads();
     const long long begin = wg * (long long)kPartThreads * bpw;
     int err = 0;
+    if (KIND == KIND_TAF && leaky_w && wg == gridDim.x - 1 && tid < kLeakyLevels) {
+        // level thresholds of uint8(leaky_transform(.)) for the tile kernel's epilogue (generate_taf.py:69-76)
+        leaky_w[tid] = tid == 0 ? 0x7f800000u : leaky_threshold_bits(tid);
+    }
     if (KIND == KIND_TAF && tlut_w) {
         // value table for k_scatter: tlut[r] = float(r / (win + 1e-8)) - 1 (generate_taf.py:215, :26);
         // one correctly rounded f64 division per distinct in-window time instead of one per event
@@ -307,13 +311,13 @@ __global__ __launch_bounds__(kPartThreads, 8) void k_scatter(Decode P, int bpw, 
 
 template <int LAYOUT, int KIND>
 void launch_partition(const Decode &d, const Plan &p, uint32_t *counts, uint32_t *slabtot,
-                      uint32_t *base, uint2 *records, WsHeader *hdr, float *tlut_w, hipStream_t s)
+                      uint32_t *base, uint2 *records, WsHeader *hdr, float *tlut_w, uint32_t *leaky_w, hipStream_t s)
 {
     const size_t lds_hist = (size_t)p.n_tiles * 4;
     const int nt2 = (p.n_tiles + 1) & ~1;
     const size_t lds_sc = (size_t)p.n_tiles * 4 + (size_t)kPartWaves * nt2 * 2 +
                           (size_t)kPartWaves * p.n_tiles + 16;
-    hipLaunchKernelGGL((k_hist<LAYOUT, KIND>), dim3(p.units), dim3(kPartThreads), lds_hist, s, d, p.bpw, counts, hdr, tlut_w);
+    hipLaunchKernelGGL((k_hist<LAYOUT, KIND>), dim3(p.units), dim3(kPartThreads), lds_hist, s, d, p.bpw, counts, hdr, tlut_w, leaky_w);
     hipLaunchKernelGGL(k_slabscan, dim3((p.n_tiles + kWave - 1) / kWave, p.slabs), dim3(kWave), 0, s, counts,
                        p.units, p.n_tiles, slabtot);
     hipLaunchKernelGGL(k_tilescan, dim3(1), dim3(1024), 0, s, slabtot, p.slabs, p.n_tiles, base);
@@ -323,13 +327,13 @@ void launch_partition(const Decode &d, const Plan &p, uint32_t *counts, uint32_t
 
 template <int LAYOUT>
 void launch_partition_kind(int kind, const Decode &d, const Plan &p, uint32_t *counts, uint32_t *slabtot,
-                           uint32_t *base, uint2 *records, WsHeader *hdr, float *tlut_w, hipStream_t s)
+                           uint32_t *base, uint2 *records, WsHeader *hdr, float *tlut_w, uint32_t *leaky_w, hipStream_t s)
 {
     switch (kind) {
-    case KIND_ECI: launch_partition<LAYOUT, KIND_ECI>(d, p, counts, slabtot, base, records, hdr, tlut_w, s); break;
-    case KIND_EV: launch_partition<LAYOUT, KIND_EV>(d, p, counts, slabtot, base, records, hdr, tlut_w, s); break;
-    case KIND_SAE: launch_partition<LAYOUT, KIND_SAE>(d, p, counts, slabtot, base, records, hdr, tlut_w, s); break;
-    default: launch_partition<LAYOUT, KIND_TAF>(d, p, counts, slabtot, base, records, hdr, tlut_w, s); break;
+    case KIND_ECI: launch_partition<LAYOUT, KIND_ECI>(d, p, counts, slabtot, base, records, hdr, tlut_w, leaky_w, s); break;
+    case KIND_EV: launch_partition<LAYOUT, KIND_EV>(d, p, counts, slabtot, base, records, hdr, tlut_w, leaky_w, s); break;
+    case KIND_SAE: launch_partition<LAYOUT, KIND_SAE>(d, p, counts, slabtot, base, records, hdr, tlut_w, leaky_w, s); break;
+    default: launch_partition<LAYOUT, KIND_TAF>(d, p, counts, slabtot, base, records, hdr, tlut_w, leaky_w, s); break;
     }
 }
 
@@ -347,12 +351,13 @@ bool make_plan(long long n, int H, int W, Plan &p)
     p.tiles_y = (H + kTileH - 1) / kTileH;
     p.n_tiles = p.tiles_x * p.tiles_y;
     if (p.n_tiles > kMaxTiles) return false;
-    // Workgroup chunk = 1024 * bpw events.  Two partition workgroups fit on a CU (2 x 16 waves), i.e.
-    // 512 at a time on the chip: pick bpw so that the workgroup count lands just under a multiple of 512
-    // (whole rounds) with the longest chunk (= longest contiguous run per tile) that allows.
+    // Workgroup chunk = kPartThreads * bpw events.  32 / kPartWaves partition workgroups fit on a CU, i.e.
+    // `slots` at a time on the chip: pick bpw so that the workgroup count lands just under a multiple of
+    // `slots` (whole rounds) with the longest chunk (= longest contiguous run per tile) that allows.
+    const long long slots = 256ll * (32 / kPartWaves);
     int bpw = kMaxBpw;
     for (int rounds = 1; rounds <= 64; ++rounds) {
-        const long long want = (n + 512ll * rounds * kPartThreads - 1) / (512ll * rounds * kPartThreads);
+        const long long want = (n + slots * rounds * kPartThreads - 1) / (slots * rounds * kPartThreads);
         if (want <= kMaxBpw) { bpw = (int)(want < 1 ? 1 : want); break; }
     }
     p.bpw = env_int("FRLW_BPW", bpw);
@@ -366,6 +371,7 @@ bool make_plan(long long n, int H, int W, Plan &p)
     p.off_slabtot = off; off = align_up(off + (size_t)p.slabs * p.n_tiles * 4, 256);
     p.off_base = off;    off = align_up(off + (size_t)(p.n_tiles + 1) * 4, 256);
     p.off_tlut = off;    off = align_up(off + (size_t)(kMaxTlut + 1) * 4, 256);
+    p.off_leaky = off;   off = align_up(off + (size_t)kLeakyLevels * 4, 256);
     p.off_records = off; off = align_up(off + (size_t)(n > 0 ? n : 1) * 8, 256);
     p.bytes = off;
     return true;
@@ -406,15 +412,16 @@ int partition_events(const frlw_events_t *ev, int H, int W, int kind, long long 
     float *tlut_w = nullptr;
     if (kind == KIND_TAF && ev->layout == FRLW_LAYOUT_DAT8 && win <= kMaxTlut && !env_int("FRLW_NOLUT", 0)) tlut_w = (float *)(w8 + p.off_tlut);
     d.tlut = tlut_w;
+    uint32_t *leaky_w = kind == KIND_TAF ? (uint32_t *)(w8 + p.off_leaky) : nullptr;
     d.dbg = env_int("FRLW_DBG", 0);
 
     HIP_TRY(hipMemsetAsync(hdr, 0, kHeaderBytes, s));
     if (ev->layout == FRLW_LAYOUT_DAT8)
-        launch_partition_kind<FRLW_LAYOUT_DAT8>(kind, d, p, counts, slabtot, base, records, hdr, tlut_w, s);
+        launch_partition_kind<FRLW_LAYOUT_DAT8>(kind, d, p, counts, slabtot, base, records, hdr, tlut_w, leaky_w, s);
     else
-        launch_partition_kind<FRLW_LAYOUT_XYTP_F64>(kind, d, p, counts, slabtot, base, records, hdr, tlut_w, s);
+        launch_partition_kind<FRLW_LAYOUT_XYTP_F64>(kind, d, p, counts, slabtot, base, records, hdr, tlut_w, leaky_w, s);
     HIP_TRY(hipGetLastError());
-    out.records = records; out.base = base; out.hdr = hdr; out.plan = p;
+    out.records = records; out.base = base; out.hdr = hdr; out.plan = p; out.leaky_thr = leaky_w;
     return FRLW_OK;
 }
 
