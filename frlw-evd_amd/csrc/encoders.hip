@@ -467,206 +467,6 @@ __global__ __launch_bounds__(NT) void k_taf_tile(const uint2 *rec, const uint32_
     }
 }
 
-// ---- TAF, wave-per-strip version ---------------------------------------------------------------
-// One wavefront owns a 32-pixel x 8-row strip of the tile (512 cells, 8 per lane, their K-deep FIFO in 64
-// registers) and never synchronises with the other wavefronts of the workgroup: every wave scans the tile's
-// record list, keeps the records of its own strip, and counting-sorts them by cell 256 at a time in its
-// private 6 KiB of LDS.  No workgroup barrier anywhere; LDS operations of one wave execute in order.
-constexpr int kStripChunk = 256;
-
-__device__ __forceinline__ void wave_fence()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-template <int NSTRIPS>
-__global__ __launch_bounds__(64 * NSTRIPS) void k_taf_strip(const uint2 *rec, const uint32_t *base, TafParams q)
-{
-    constexpr int SC = 512; // strip cells
-    __shared__ uint32_t lds_cnt[NSTRIPS][SC];
-    __shared__ uint2 lds_stage[NSTRIPS][kStripChunk];  // {val bits, window << 9 | strip cell}, arrival = stream order
-    __shared__ uint2 lds_sorted[NSTRIPS][kStripChunk]; // {val bits, stage index << 8 | window}
-    __shared__ uint32_t thr[kLeakyLevels];
-    for (int i = threadIdx.x; i < kLeakyLevels; i += 64 * NSTRIPS) thr[i] = q.leaky_thr[i];
-    __syncthreads();
-    const int lane = threadIdx.x & 63, strip = threadIdx.x >> 6;
-    uint32_t *cnt = lds_cnt[strip];
-    uint2 *stage = lds_stage[strip];
-    uint2 *sorted = lds_sorted[strip];
-    const int tile = blockIdx.x;
-    const int K = q.K;
-    const int cb = q.twl + 4; // cell bits of a record
-    const TileGeom g = tile_geom(tile, q.tiles_x, q.twl, q.H, q.W);
-    const uint32_t beg = base[tile], end = base[tile + 1];
-    const unsigned long long wmask = q.hdr->wmask;
-    const uint64_t lt = lanemask_lt();
-    // lane owns strip cells lane + 64 j: row j, pixel 32*strip + (lane >> 1), polarity lane & 1
-    const int px = 32 * strip + (lane >> 1), pol = lane & 1;
-    const bool colok = px < g.nx;
-    float st[8][kMaxK], sum[8];
-    uint32_t num[8];
-
-    // mode 0: one pass, the strip's records are window-sorted (always true for a time-sorted stream);
-    // mode 1 (only after mode 0 found a window running backwards; nothing has been written yet): one pass
-    // per window over the whole list.  Every piece of code below has a single call site on purpose (the
-    // FIFO lives in 64 registers; duplicated code would blow the register budget).
-    for (int mode = 0; mode < 2; ++mode) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            cnt[lane + 64 * j] = 0u;
-#pragma unroll
-            for (int k = 0; k < kMaxK; ++k) st[j][k] = 0.0f;
-            if (colok && j < g.ny) {
-                const float *src = q.state + ((((long long)(g.y0 + j) * q.W + g.x0 + px) * 2) + pol) * K;
-                if (K == 8) {
-                    const float4 a = ((const float4 *)src)[0], b = ((const float4 *)src)[1];
-                    st[j][0] = a.x; st[j][1] = a.y; st[j][2] = a.z; st[j][3] = a.w;
-                    st[j][4] = b.x; st[j][5] = b.y; st[j][6] = b.z; st[j][7] = b.w;
-                } else {
-#pragma unroll
-                    for (int k = 0; k < kMaxK; ++k) if (k < K) st[j][k] = src[k];
-                }
-            }
-            sum[j] = 0.0f;
-            num[j] = 0u;
-        }
-        wave_fence();
-        bool bad = false;
-        const int n_pass = mode == 0 ? 1 : q.n_windows;
-        for (int pass = 0; pass < n_pass && !bad; ++pass) {
-            const int only_w = mode == 0 ? -1 : pass;          // keep the records of this window only
-            int cur_w = mode == 0 ? 0 : pass;                   // wave-uniform: windows < cur_w are closed
-            const int final_target = mode == 0 ? q.n_windows : pass + 1;
-            uint32_t pending = 0;
-            for (uint32_t i0 = beg;; i0 += 64) {
-                const bool last = i0 >= end;
-                const uint32_t i = i0 + lane;
-                uint2 r = make_uint2(0xffffffffu, 0u);
-                if (!last && i < end) r = rec[i];
-                const uint32_t cell = r.x & ((1u << cb) - 1u);
-                const int win = (int)(r.x >> cb);
-                const bool mine = !last && i < end && (int)((cell >> 6) & (uint32_t)(NSTRIPS - 1)) == strip &&
-                                  (only_w < 0 || win == only_w);
-                const uint64_t mm = __ballot(mine);
-                const uint32_t k = (uint32_t)__popcll(mm);
-                if (last || pending + k > (uint32_t)kStripChunk) {
-                    // ---- sort the staged records by cell, add them to the window sums in stream order
-                    wave_fence();
-                    int wlo = cur_w, whi = cur_w;
-                    if (pending) {
-                        wlo = (int)(stage[0].y >> 9);
-                        whi = (int)(stage[pending - 1].y >> 9);
-                        if (wlo < cur_w || whi < wlo || whi >= q.n_windows) bad = true;
-                    }
-                    uint32_t c[8], o[8], a[8];
-                    uint32_t tot = 0;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) { c[j] = cnt[lane + 64 * j]; tot += c[j]; }
-                    uint32_t inc = tot;
-#pragma unroll
-                    for (int off = 1; off < 64; off <<= 1) {
-                        const uint32_t v = __shfl_up(inc, off);
-                        if (lane >= off) inc += v;
-                    }
-                    uint32_t run = inc - tot;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) { o[j] = run; cnt[lane + 64 * j] = run; run += c[j]; a[j] = 0; }
-                    wave_fence();
-                    for (uint32_t p0 = 0; p0 < pending; p0 += 64) {
-                        const uint32_t p = p0 + lane;
-                        if (p < pending) {
-                            const uint2 e = stage[p];
-                            const uint32_t slot = atomicAdd(&cnt[e.y & (SC - 1)], 1u);
-                            sorted[slot] = make_uint2(e.x, (p << 8) | (e.y >> 9));
-                        }
-                        wave_fence(); // slots of a later batch always follow those of an earlier one
-                    }
-                    if (!bad) {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) { // stream order inside my segments (almost always already true)
-                            for (uint32_t x = 1; x < c[j]; ++x) {
-                                const uint2 e = sorted[o[j] + x];
-                                if (sorted[o[j] + x - 1].y <= e.y) continue;
-                                uint32_t y = x;
-                                while (y > 0 && sorted[o[j] + y - 1].y > e.y) { sorted[o[j] + y] = sorted[o[j] + y - 1]; --y; }
-                                sorted[o[j] + y] = e;
-                            }
-                        }
-                        const int w_last = last ? final_target - 1 : whi;
-                        for (int w = cur_w; w <= w_last; ++w) {
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) {
-                                while (a[j] < c[j]) {
-                                    const uint2 e = sorted[o[j] + a[j]];
-                                    if ((int)(e.y & 255u) != w) break;
-                                    sum[j] = sum[j] + __uint_as_float(e.x); // sum += t - 1 in stream order, generate_taf.py:26
-                                    num[j] += 1u;
-                                    ++a[j];
-                                }
-                            }
-                            if (last || w < whi) { // close window w: FIFO step, skipped when it is empty frame-wide (:40-41)
-                                const bool has = (wmask >> w) & 1ull;
-#pragma unroll
-                                for (int j = 0; j < 8; ++j) {
-                                    if (has) taf_fifo(st[j], K, num[j], sum[j]);
-                                    sum[j] = 0.0f;
-                                    num[j] = 0u;
-                                }
-                            }
-                        }
-                        cur_w = last ? final_target : whi;
-                        bool viol = false; // a record whose window runs backwards inside its cell's segment
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) viol |= a[j] != c[j];
-                        if (__ballot(viol)) bad = true;
-                    }
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) cnt[lane + 64 * j] = 0u;
-                    wave_fence();
-                    pending = 0;
-                }
-                if (last || bad) break;
-                if (mine) {
-                    const uint32_t sc = ((cell >> (q.twl + 1)) << 6) | (cell & 63u);
-                    stage[pending + (uint32_t)__popcll(mm & lt)] = make_uint2(r.y, ((uint32_t)win << 9) | sc);
-                    atomicAdd(&cnt[sc], 1u);
-                }
-                pending += k;
-            }
-        }
-        if (!bad) break;
-        if (lane == 0) atomicAdd(const_cast<uint32_t *>(&q.hdr->pad), 1u); // diagnostic: strips on the general path
-    }
-
-    // ---- write-out: state, optional f32 view (2K, H, W), optional uint8 leaky transform
-    const long long plane = (long long)q.H * q.W;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        if (!(colok && j < g.ny)) continue;
-        const long long pix = (long long)(g.y0 + j) * q.W + g.x0 + px;
-        float *dst = q.state + (pix * 2 + pol) * K;
-        if (K == 8) {
-            ((float4 *)dst)[0] = make_float4(st[j][0], st[j][1], st[j][2], st[j][3]);
-            ((float4 *)dst)[1] = make_float4(st[j][4], st[j][5], st[j][6], st[j][7]);
-        } else {
-#pragma unroll
-            for (int k = 0; k < kMaxK; ++k) if (k < K) dst[k] = st[j][k];
-        }
-#pragma unroll
-        for (int k = 0; k < kMaxK; ++k) {
-            if (k < K) {
-                if (q.view_f32) q.view_f32[(long long)(2 * k + pol) * plane + pix] = st[j][k]; // channel 2k + p, :55
-                if (q.out_u8) {
-                    const int ko = q.flip ? (K - 1 - k) : k;
-                    q.out_u8[(long long)(2 * ko + pol) * plane + pix] = leaky_u8_lookup(st[j][k], thr);
-                }
-            }
-        }
-    }
-}
-
 #define LAUNCH_TILE(KERNEL, PLAN, STREAM, ...)                                                          \
     do {                                                                                                \
         if ((PLAN).twl == 8)                                                                            \
@@ -788,15 +588,7 @@ int frlw_taf_encode(const frlw_events_t *ev, int H, int W, int K, int64_t t_star
     q.flip = (flags & FRLW_TAF_U8_FLIP_K) ? 1 : 0;
     q.hdr = pt.hdr; q.state = state; q.view_f32 = view_f32; q.out_u8 = out_u8; q.leaky_thr = pt.leaky_thr;
     q.dbg = frlw::env_int("FRLW_DBG", 0);
-    if (!frlw::env_int("FRLW_TAF_STRIP", 0)) {
-        LAUNCH_TILE(k_taf_tile, pt.plan, s, pt.records, pt.base, q);
-    } else if (pt.plan.twl == 8) {
-        hipLaunchKernelGGL(k_taf_strip<8>, dim3(pt.plan.n_tiles), dim3(512), 0, s, pt.records, pt.base, q);
-    } else if (pt.plan.twl == 7) {
-        hipLaunchKernelGGL(k_taf_strip<4>, dim3(pt.plan.n_tiles), dim3(256), 0, s, pt.records, pt.base, q);
-    } else {
-        hipLaunchKernelGGL(k_taf_strip<2>, dim3(pt.plan.n_tiles), dim3(128), 0, s, pt.records, pt.base, q);
-    }
+    LAUNCH_TILE(k_taf_tile, pt.plan, s, pt.records, pt.base, q);
     HIP_TRY(hipGetLastError());
     return FRLW_OK;
 }

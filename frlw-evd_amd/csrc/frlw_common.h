@@ -88,13 +88,13 @@ __device__ __forceinline__ Pos place(const Decode &P, int x, int y, int p)
 
 // Position of a raw DAT record (src/io/dat_events_tools.py:96-98) incl. the optional coordinate
 // maps and the time / range filters that drop an event without an error.
-template <int KIND>
+template <int KIND, bool HAS_MAP = true>
 __device__ __forceinline__ Pos dat_pos(const Decode &P, uint2 r)
 {
     int x = (int)(r.y & 16383u), y = (int)((r.y >> 14) & 16383u), p = (int)((r.y >> 28) & 1u);
     Pos o;
     o.tile = -1; o.cell = 0; o.err = 0;
-    if (P.xmap) {
+    if (HAS_MAP && P.xmap) {
         if (x >= P.map_w || y >= P.map_h) { o.err = ST_INDEX; return o; }
         x = P.xmap[x];
         y = P.ymap[y];

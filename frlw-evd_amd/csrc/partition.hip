@@ -37,7 +37,7 @@ int hip_fail(hipError_t e, const char *what, int line)
 namespace {
 
 // ---------------------------------------------------------------------------------------------
-template <int LAYOUT, int KIND>
+template <int LAYOUT, int KIND, bool HAS_MAP>
 __global__ __launch_bounds__(kPartThreads) void k_hist(Decode P, int bpw, uint32_t *counts,
                                                         WsHeader *hdr, float *tlut_w, uint32_t *leaky_w)
 {
@@ -61,18 +61,20 @@ __global__ __launch_bounds__(kPartThreads) void k_hist(Decode P, int bpw, uint32
             tlut_w[r] = (float)((double)r / den) - 1.0f;
     }
     if (LAYOUT == FRLW_LAYOUT_DAT8) {
-        const uint2 *src = (const uint2 *)P.data;
+        const uint2 *src = (const uint2 *)P.data + begin;
+        const long long left = P.n - begin;
+        const uint32_t nloc = left < (long long)kPartThreads * bpw ? (uint32_t)(left < 0 ? 0 : left) : (uint32_t)(kPartThreads * bpw);
         uint2 q[kMaxBpw];
 #pragma unroll
         for (int j = 0; j < kMaxBpw; ++j) {
-            const long long i = begin + (long long)j * kPartThreads + tid;
-            q[j] = (j < bpw && i < P.n) ? src[i] : make_uint2(0u, 0xffffffffu);
+            const uint32_t i = (uint32_t)(j * kPartThreads + tid);
+            q[j] = i < nloc ? src[i] : make_uint2(0u, 0xffffffffu);
         }
 #pragma unroll
         for (int j = 0; j < kMaxBpw; ++j) {
-            const long long i = begin + (long long)j * kPartThreads + tid;
-            if (j < bpw && i < P.n) {
-                const Pos o = dat_pos<KIND>(P, q[j]);
+            const uint32_t i = (uint32_t)(j * kPartThreads + tid);
+            if (i < nloc) {
+                const Pos o = dat_pos<KIND, HAS_MAP>(P, q[j]);
                 err |= o.err;
                 if (o.tile >= 0) atomicAdd(&hist[o.tile], 1u);
             }
@@ -127,11 +129,15 @@ __global__ __launch_bounds__(1024) void k_tilescan(uint32_t *slabtot, int slabs,
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     for (int b = tid; b < n; b += 1024) {
         uint32_t run = 0;
-        for (int s = 0; s < slabs; ++s) {
-            uint32_t *p = &slabtot[(long long)s * n + b];
-            const uint32_t v = *p;
-            *p = run;
-            run += v;
+        for (int s0 = 0; s0 < slabs; s0 += 8) { // 8 independent loads in flight, then the 8 prefix stores
+            uint32_t v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = s0 + k < slabs ? slabtot[(long long)(s0 + k) * n + b] : 0u;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (s0 + k < slabs) slabtot[(long long)(s0 + k) * n + b] = run;
+                run += v[k];
+            }
         }
         tot[b] = run;
     }
@@ -161,7 +167,7 @@ __global__ __launch_bounds__(1024) void k_tilescan(uint32_t *slabtot, int slabs,
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int LAYOUT, int KIND>
+template <int LAYOUT, int KIND, bool HAS_MAP>
 __global__ __launch_bounds__(kPartThreads, 8) void k_scatter(Decode P, int bpw, const uint32_t *counts,
                                                            const uint32_t *slabtot,
                                                            const uint32_t *base, uint2 *records,
@@ -183,34 +189,44 @@ __global__ __launch_bounds__(kPartThreads, 8) void k_scatter(Decode P, int bpw, 
 
     const long long wave_begin = (wg * kPartWaves + wv) * (long long)kWave * bpw;
     const uint64_t lt = lanemask_lt();
+    // this workgroup's first record slot of tile `tid` (needed only in phase B: issue the loads now)
+    uint32_t gs_pre = 0;
+    if (tid < P.n_tiles)
+        gs_pre = base[tid] + slabtot[(wg / kSlabUnits) * (long long)P.n_tiles + tid] + counts[wg * (long long)P.n_tiles + tid];
     uint32_t where[kMaxBpw]; // tile << 16 | rank in (wave, tile); 0xffffffff = not encoded
+    uint32_t cells[kMaxBpw / 2]; // strip-free cell of every event, two 16-bit values per register
     uint2 q[kMaxBpw];
+    const long long left = P.n - wave_begin;
+    const uint32_t nloc = left < (long long)kWave * bpw ? (uint32_t)(left < 0 ? 0 : left) : (uint32_t)(kWave * bpw);
     if (LAYOUT == FRLW_LAYOUT_DAT8) {
-        const uint2 *src = (const uint2 *)P.data;
+        const uint2 *src = (const uint2 *)P.data + wave_begin;
 #pragma unroll
         for (int j = 0; j < kMaxBpw; ++j) {
-            const long long i = wave_begin + j * kWave + lane;
-            q[j] = (j < bpw && i < P.n) ? src[i] : make_uint2(0u, 0xffffffffu);
+            const uint32_t i = (uint32_t)(j * kWave + lane);
+            q[j] = i < nloc ? src[i] : make_uint2(0u, 0xffffffffu);
         }
     }
+#pragma unroll
+    for (int j = 0; j < kMaxBpw / 2; ++j) cells[j] = 0u;
     // ---- phase A: ranks inside the wave's run, batch by batch in stream order (positions only;
     //      windows and f32 values are computed in phase C so that few registers stay live)
 #pragma unroll
     for (int j = 0; j < kMaxBpw; ++j) {
         where[j] = 0xffffffffu;
         if (j < bpw) { // wave-uniform
-            const long long i = wave_begin + j * kWave + lane;
+            const uint32_t i = (uint32_t)(j * kWave + lane);
             Pos o;
             o.tile = -1; o.cell = 0; o.err = 0;
-            if (i < P.n) {
+            if (i < nloc) {
                 if (LAYOUT == FRLW_LAYOUT_DAT8) {
-                    o = dat_pos<KIND>(P, q[j]);
+                    o = dat_pos<KIND, HAS_MAP>(P, q[j]);
                 } else {
                     double t;
-                    o = f64_pos<KIND>(P, i, t);
+                    o = f64_pos<KIND>(P, wave_begin + i, t);
                 }
             }
             const bool act = o.tile >= 0;
+            cells[j >> 1] |= (o.cell & 0xffffu) << (16 * (j & 1));
             const uint64_t am = __ballot(act);
             if (P.dbg & 512) { if (act) where[j] = (uint32_t)o.tile << 16; }
             if (am != 0ull && !(P.dbg & 512)) {
@@ -245,11 +261,11 @@ __global__ __launch_bounds__(kPartThreads, 8) void k_scatter(Decode P, int bpw, 
             uint32_t run = 0;
 #pragma unroll
             for (int w = 0; w < kPartWaves; ++w) {
-                const uint32_t v = wcnt_all[(size_t)w * nt2 + b];
-                wcnt_all[(size_t)w * nt2 + b] = (uint16_t)run;
+                const uint32_t v = wcnt_all[w * nt2 + b];
+                wcnt_all[w * nt2 + b] = (uint16_t)run;
                 run += v;
             }
-            gs[b] = base[b] + srow[b] + row[b];
+            gs[b] = b == tid ? gs_pre : base[b] + srow[b] + row[b];
         }
     }
     __syncthreads();
@@ -265,13 +281,11 @@ __global__ __launch_bounds__(kPartThreads, 8) void k_scatter(Decode P, int bpw, 
         if (j < bpw && where[j] != 0xffffffffu) {
             int window = 0;
             float val = 0.0f;
-            uint32_t cell;
+            const uint32_t cell = (cells[j >> 1] >> (16 * (j & 1))) & 0xffffu;
             if (LAYOUT == FRLW_LAYOUT_DAT8) {
-                cell = dat_pos<KIND>(P, q[j]).cell;
                 dat_value<KIND>(P, q[j], window, val);
             } else {
-                double t;
-                cell = f64_pos<KIND>(P, wave_begin + j * kWave + lane, t).cell;
+                const double t = ((const double *)P.data + (wave_begin + j * kWave + lane) * (long long)P.row_stride)[2];
                 val = f64_value<KIND>(t);
             }
             meta[j] = ((uint32_t)window << cb) | cell;
@@ -309,20 +323,30 @@ __global__ __launch_bounds__(kPartThreads, 8) void k_scatter(Decode P, int bpw, 
     }
 }
 
-template <int LAYOUT, int KIND>
-void launch_partition(const Decode &d, const Plan &p, uint32_t *counts, uint32_t *slabtot,
+template <int LAYOUT, int KIND, bool HAS_MAP>
+void launch_partition_m(const Decode &d, const Plan &p, uint32_t *counts, uint32_t *slabtot,
                       uint32_t *base, uint2 *records, WsHeader *hdr, float *tlut_w, uint32_t *leaky_w, hipStream_t s)
 {
     const size_t lds_hist = (size_t)p.n_tiles * 4;
     const int nt2 = (p.n_tiles + 1) & ~1;
     const size_t lds_sc = (size_t)p.n_tiles * 4 + (size_t)kPartWaves * nt2 * 2 +
                           (size_t)kPartWaves * p.n_tiles + 16;
-    hipLaunchKernelGGL((k_hist<LAYOUT, KIND>), dim3(p.units), dim3(kPartThreads), lds_hist, s, d, p.bpw, counts, hdr, tlut_w, leaky_w);
+    hipLaunchKernelGGL((k_hist<LAYOUT, KIND, HAS_MAP>), dim3(p.units), dim3(kPartThreads), lds_hist, s, d, p.bpw, counts, hdr, tlut_w, leaky_w);
     hipLaunchKernelGGL(k_slabscan, dim3((p.n_tiles + kWave - 1) / kWave, p.slabs), dim3(kWave), 0, s, counts,
                        p.units, p.n_tiles, slabtot);
     hipLaunchKernelGGL(k_tilescan, dim3(1), dim3(1024), 0, s, slabtot, p.slabs, p.n_tiles, base);
-    hipLaunchKernelGGL((k_scatter<LAYOUT, KIND>), dim3(p.units), dim3(kPartThreads), lds_sc, s, d, p.bpw, counts,
+    hipLaunchKernelGGL((k_scatter<LAYOUT, KIND, HAS_MAP>), dim3(p.units), dim3(kPartThreads), lds_sc, s, d, p.bpw, counts,
                        slabtot, base, records, hdr);
+}
+
+template <int LAYOUT, int KIND>
+void launch_partition(const Decode &d, const Plan &p, uint32_t *counts, uint32_t *slabtot, uint32_t *base,
+                      uint2 *records, WsHeader *hdr, float *tlut_w, uint32_t *leaky_w, hipStream_t s)
+{
+    if (LAYOUT == FRLW_LAYOUT_DAT8 && d.xmap)
+        launch_partition_m<LAYOUT, KIND, true>(d, p, counts, slabtot, base, records, hdr, tlut_w, leaky_w, s);
+    else
+        launch_partition_m<LAYOUT, KIND, false>(d, p, counts, slabtot, base, records, hdr, tlut_w, leaky_w, s);
 }
 
 template <int LAYOUT>
