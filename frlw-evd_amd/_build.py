@@ -38,7 +38,8 @@ def needs_build():
 
 def build(force: bool = False, verbose: bool = False) -> str:
     if force or needs_build():
-        cmd = [hipcc()] + HIPCC_FLAGS + ["-I", INCLUDE, "-I", CSRC] + sources() + ["-o", LIB]
+        extra = os.environ.get("FRLW_EXTRA_HIPCC_FLAGS", "").split()  # experiments only (e.g. -DCONV_BK_BIG=32)
+        cmd = [hipcc()] + HIPCC_FLAGS + extra + ["-I", INCLUDE, "-I", CSRC] + sources() + ["-o", LIB]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

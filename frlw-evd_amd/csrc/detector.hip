@@ -46,7 +46,13 @@ struct ConvArgs {
     float *partial;    // [splits][M][Npad] when splits > 1
 };
 
-constexpr int BK = 16;
+#ifndef CONV_BK_BIG
+#define CONV_BK_BIG 16
+#endif
+#ifndef CONV_BK_SMALL
+#define CONV_BK_SMALL 16
+#endif
+constexpr int kSplitBK = 16; // granularity the split-K heuristics count k-tiles in
 
 __device__ __forceinline__ float act_apply(float v, int act)
 {
@@ -56,10 +62,12 @@ __device__ __forceinline__ float act_apply(float v, int act)
 }
 
 // BM x BN output tile, 4 wavefronts arranged WROWS x WCOLS, each owning TM x TN MFMA tiles of 32 x 32.
-template <int BM, int BN, int WROWS, int WCOLS>
+template <int BM, int BN, int WROWS, int WCOLS, int BK>
 __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
 {
     constexpr int TM = BM / (32 * WROWS), TN = BN / (32 * WCOLS);
+    constexpr int KQ = BK / 4;        // float4 per A row of the k-tile
+    constexpr int RPP = 256 / KQ;     // A rows staged per pass of the 256 threads
     constexpr int LDA = BM + 4, LDB = BN + 4; // +4 floats: k rows land on different banks for the staging writes
     constexpr int A_F4 = BM * BK / 4 / 256;   // float4 loads per thread for the A tile
     constexpr int B_F4 = (BN * BK / 4 + 255) / 256;
@@ -70,13 +78,13 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
 
     // ---- A staging: thread -> A_F4 rows m, one float4 of 4 consecutive k
-    const int a_k4 = (tid & 3) * 4;
+    const int a_k4 = (tid % KQ) * 4;
     int a_iy0[A_F4], a_ix0[A_F4];
     long long a_base[A_F4];
     bool a_ok[A_F4];
 #pragma unroll
     for (int i = 0; i < A_F4; ++i) {
-        const int m = m0 + (tid >> 2) + 64 * i;
+        const int m = m0 + tid / KQ + RPP * i;
         a_ok[i] = m < a.M;
         const int mm = a_ok[i] ? m : 0;
         const int b = mm / (a.Ho * a.Wo), pix = mm - b * (a.Ho * a.Wo);
@@ -114,7 +122,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
     auto store_tiles = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) {
-            const int ml = (tid >> 2) + 64 * i;
+            const int ml = tid / KQ + RPP * i;
             As[buf][a_k4 + 0][ml] = ra[i].x;
             As[buf][a_k4 + 1][ml] = ra[i].y;
             As[buf][a_k4 + 2][ml] = ra[i].z;
@@ -597,12 +605,12 @@ int frlw_det_run(const frlw_detector_t *d, int B, void *const *bufs, int n_bufs,
             // tile choice: the big tile when it still fills the chip, small N for the prediction convs
             const long long big = (long long)((c.M + 127) / 128) * ((c.Npad + 127) / 128);
             if (c.Npad <= 32) {
-                hipLaunchKernelGGL((k_conv_mfma<128, 32, 4, 1>), dim3((c.M + 127) / 128, 1), dim3(256), 0, s, c);
+                hipLaunchKernelGGL((k_conv_mfma<128, 32, 4, 1, 16>), dim3((c.M + 127) / 128, 1), dim3(256), 0, s, c);
             } else if (big >= 384 && c.Npad >= 128) {
-                hipLaunchKernelGGL((k_conv_mfma<128, 128, 2, 2>), dim3((c.M + 127) / 128, (c.Npad + 127) / 128), dim3(256), 0, s, c);
+                hipLaunchKernelGGL((k_conv_mfma<128, 128, 2, 2, CONV_BK_BIG>), dim3((c.M + 127) / 128, (c.Npad + 127) / 128), dim3(256), 0, s, c);
             } else {
                 const long long wgs = (long long)((c.M + 63) / 64) * ((c.Npad + 63) / 64);
-                const int nk = (c.K + BK - 1) / BK;
+                const int nk = (c.K + kSplitBK - 1) / kSplitBK;
                 // small feature maps leave most CUs idle: split the contraction over blockIdx.z
                 if (wgs < 256 && nk >= 32 && d->scratch_buf >= 0) {
                     int sp = (int)((768 + wgs - 1) / wgs);
@@ -610,7 +618,7 @@ int frlw_det_run(const frlw_detector_t *d, int B, void *const *bufs, int n_bufs,
                     if (sp > nk / 8) sp = nk / 8;
                     if (sp > 1 && (long long)sp * c.M * c.Npad <= d->scratch_floats) { c.splits = sp; c.partial = buf(d->scratch_buf); }
                 }
-                hipLaunchKernelGGL((k_conv_mfma<64, 64, 2, 2>), dim3((c.M + 63) / 64, (c.Npad + 63) / 64, c.splits), dim3(256), 0, s, c);
+                hipLaunchKernelGGL((k_conv_mfma<64, 64, 2, 2, CONV_BK_SMALL>), dim3((c.M + 63) / 64, (c.Npad + 63) / 64, c.splits), dim3(256), 0, s, c);
                 if (c.splits > 1)
                     hipLaunchKernelGGL(k_splitk_reduce, dim3(grid_1d((long long)c.M * c.Cout)), dim3(256), 0, s, c);
             }

@@ -11,7 +11,7 @@
 namespace frlw {
 
 constexpr int kWave = 64;
-// A tile is (1 << twl) pixels wide and 8 rows high; twl = 7 for frames wider than 512 px, else 6
+// A tile is (1 << twl) pixels wide and 8 rows high; twl = 8 for frames wider than 512 px, else 6
 // (measured best on MI355X; FRLW_TWL overrides for experiments).
 // One tile = one workgroup of the tile kernels = NT = 4 << twl threads owning 4 cells each
 // (cell = (pixel, polarity)).  A tile row is a whole number of wavefronts of consecutive cells,

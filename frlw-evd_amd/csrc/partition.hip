@@ -368,7 +368,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 bool make_plan(long long n, int H, int W, Plan &p)
 {
     if (H <= 0 || W <= 0 || n < 0) return false;
-    p.twl = env_int("FRLW_TWL", W > 512 ? 7 : 6);
+    p.twl = env_int("FRLW_TWL", W > 512 ? 8 : 6);
     if (p.twl < 6 || p.twl > 8) return false;
     const int tw = 1 << p.twl;
     p.tiles_x = (W + tw - 1) / tw;
