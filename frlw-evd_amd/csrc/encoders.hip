@@ -28,6 +28,9 @@ using namespace frlw;
 
 namespace {
 
+#ifndef FRLW_SLICE_MULT
+#define FRLW_SLICE_MULT 8
+#endif
 constexpr int CPT = kCellsPerThread;
 constexpr int kMaxK = 8;
 
@@ -138,7 +141,7 @@ __device__ __forceinline__ void segment_order(uint32_t n, uint32_t s, float *sva
 
 template <int NT> struct TileLds {
     static constexpr int NC = NT * CPT;
-    static constexpr int SLICE = NT == 1024 ? 4096 : 2048; // records counting-sorted per pass
+    static constexpr int SLICE = FRLW_SLICE_MULT * NT; // records counting-sorted per pass
 };
 
 // ---- ECI -------------------------------------------------------------------------------------
