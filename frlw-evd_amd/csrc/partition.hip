@@ -370,10 +370,13 @@ bool make_plan(long long n, int H, int W, Plan &p)
     if (H <= 0 || W <= 0 || n < 0) return false;
     p.twl = env_int("FRLW_TWL", W > 512 ? 8 : 6);
     if (p.twl < 6 || p.twl > 8) return false;
-    const int tw = 1 << p.twl;
-    p.tiles_x = (W + tw - 1) / tw;
-    p.tiles_y = (H + kTileH - 1) / kTileH;
-    p.n_tiles = p.tiles_x * p.tiles_y;
+    for (;; ++p.twl) { // tall frames (a batch of sequences stacked along y): widen the tiles to stay under kMaxTiles
+        const int tw = 1 << p.twl;
+        p.tiles_x = (W + tw - 1) / tw;
+        p.tiles_y = (H + kTileH - 1) / kTileH;
+        p.n_tiles = p.tiles_x * p.tiles_y;
+        if (p.n_tiles <= kMaxTiles || p.twl == 8) break;
+    }
     if (p.n_tiles > kMaxTiles) return false;
     // Workgroup chunk = kPartThreads * bpw events.  32 / kPartWaves partition workgroups fit on a CU, i.e.
     // `slots` at a time on the chip: pick bpw so that the workgroup count lands just under a multiple of

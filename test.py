@@ -31,7 +31,8 @@ def main():
     src = e2e.SyntheticTafSource(B, seed=1005 + 1000 * rank)
     idx = list(range(B))
     with torch.no_grad():
-        net(src.encode_batch(idx))
+        for _ in range(3):  # plan build, allocator warm-up
+            net(src.encode_batch(idx))
         fd.barrier_sync()
         t0 = time.perf_counter()
         for _ in range(args.steps):

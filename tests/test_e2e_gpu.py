@@ -13,6 +13,9 @@ def test_encode_then_train_and_eval_step():
     from frlw_evd_amd.trainer import Trainer
     src = e2e.SyntheticTafSource(2, events_per_window=20_000)
     x = src.encode_batch([0, 1])
+    assert src.batched
+    one = torch.cat([src.encode_batch([0]), src.encode_batch([1])])  # per-sample launches: same bytes
+    assert torch.equal(x, one)
     assert x.shape == (2, 16, 256, 320, 1, 1) and float(x.min()) >= 0.0 and float(x.max()) <= 1.0
     q = (x * 255).round()
     assert torch.equal(q / 255, x)  # values are exactly the uint8 artefact / 255 (data/dataset.py:294-308)

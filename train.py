@@ -48,7 +48,8 @@ def main():
     src = e2e.SyntheticTafSource(B, seed=1005 + 1000 * rank)
     labels = src.labels(B)
     idx = list(range(B))
-    tr.train_step(src.encode_batch(idx), labels, 0)  # warm-up
+    for _ in range(2):  # warm-up (allocator, MIOpen find)
+        tr.train_step(src.encode_batch(idx), labels, 0)
     fd.barrier_sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
