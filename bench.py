@@ -124,7 +124,7 @@ def main():
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "frlw_taf_encode = k_hist + k_colscan + k_tilescan + k_scatter + k_taf_tile",
+            "kernel": "frlw_taf_encode = k_hist + k_slabscan + k_tilescan + k_scatter + k_taf_tile (dominant: k_taf_tile)",
             "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
