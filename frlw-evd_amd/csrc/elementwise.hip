@@ -14,7 +14,7 @@ __global__ void k_leaky(const float *in, long long n, float *out_f32, uint8_t *o
          i += (long long)gridDim.x * blockDim.x) {
         float v = leaky_f(in[i]);
         if (out_f32) out_f32[i] = v;
-        if (out_u8) out_u8[i] = (uint8_t)(int)v;
+        if (out_u8) out_u8[i] = f32_to_u8(v);
     }
 }
 
@@ -24,7 +24,7 @@ __global__ void k_quantize(const float *in, long long n, int clip255, uint8_t *o
          i += (long long)gridDim.x * blockDim.x) {
         float v = in[i];
         if (clip255 && v > 255.0f) v = 255.0f;
-        out[i] = (uint8_t)(int)v;
+        out[i] = f32_to_u8(v);
     }
 }
 

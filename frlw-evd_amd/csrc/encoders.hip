@@ -174,7 +174,7 @@ __global__ __launch_bounds__(NT) void k_eci_tile(const uint2 *rec, const uint32_
             const float v = q.lut[n > 20u ? 20u : n];
             const long long idx = ow.p * plane + ow.pix[j];
             if (q.out_f32) q.out_f32[idx] = v;
-            if (q.out_u8) q.out_u8[idx] = (uint8_t)(int)v;
+            if (q.out_u8) q.out_u8[idx] = f32_to_u8(v);
         }
     }
 }
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(NT) void k_sae_tile(const uint2 *rec, const uint32_
                 const float v = expf(q.lam[l] * dt) * 255.0f;
                 const long long oi = (long long)l * 2 * plane + idx;
                 if (q.out_f32) q.out_f32[oi] = v;
-                if (q.out_u8) q.out_u8[oi] = (uint8_t)(int)v;
+                if (q.out_u8) q.out_u8[oi] = f32_to_u8(v);
             }
         }
     }
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(NT) void k_ev_tile(const uint2 *rec, const uint32_t
                     const float v = acc[j][k] / 5.0f * 255.0f; // generate_eventvolume.py:37
                     const long long idx = (long long)(2 * k + ch) * plane + ow.pix[j];
                     if (q.out_f32) q.out_f32[idx] = v;
-                    if (q.out_u8) q.out_u8[idx] = (uint8_t)(int)(v > 255.0f ? 255.0f : v);
+                    if (q.out_u8) q.out_u8[idx] = f32_to_u8(v > 255.0f ? 255.0f : v);
                 }
             }
         }

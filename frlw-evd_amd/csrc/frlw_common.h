@@ -180,6 +180,16 @@ __device__ __forceinline__ TileGeom tile_geom(int tile, int tiles_x, int twl, in
     return g;
 }
 
+// float -> uint8 the way numpy's .astype(np.uint8) does it on the reference's x86 hosts: truncate to int32
+// (cvttss2si: NaN / inf / out-of-range give INT_MIN), then keep the low byte.  v_cvt_i32_f32 saturates
+// instead, so the out-of-range case is made explicit.  (Only reachable with state values > 0, i.e. events
+// the harness placed after the last window.)
+__device__ __forceinline__ uint8_t f32_to_u8(float v)
+{
+    const int i = (v >= -2147483648.0f && v < 2147483648.0f) ? (int)v : (int)0x80000000;
+    return (uint8_t)i;
+}
+
 __device__ __forceinline__ float leaky_f(float v)
 {
     float l = log1pf(-v);   // generate_taf.py:72
@@ -206,8 +216,8 @@ __device__ __forceinline__ uint32_t leaky_threshold_bits(int k)
 
 __device__ __forceinline__ uint8_t leaky_u8_lookup(float v, const uint32_t *thr)
 {
-    if (!(v <= 0.0f)) return (uint8_t)(int)leaky_f(v); // outside the table's domain (never for a TAF state)
-    const float x = -v;
+    if (!(v <= 0.0f)) return f32_to_u8(leaky_f(v)); // outside the table's domain (events after the last window)
+    const float x = fabsf(v); // v <= 0 here; fabsf also maps +0 to +0 (-(+0) = -0 would compare as a huge bit pattern)
     const uint32_t xb = __float_as_uint(x);
     // first guess from the hardware log2 (1 ulp-ish), then walk to the exact level
     float g = 255.0f * (1.0f - (__log2f(1.0f + x) * 0.69314718f) / 8.7f);

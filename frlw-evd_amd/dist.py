@@ -22,6 +22,7 @@ def init_from_env(backend=None, local_rank_arg=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        backend = os.environ.get("FRLW_DIST_BACKEND", backend)  # e.g. gloo: several ranks on one GPU in tests
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         kw = {}
@@ -29,6 +30,8 @@ def init_from_env(backend=None, local_rank_arg=None):
             torch.cuda.set_device(local_rank)
             kw["device_id"] = torch.device("cuda", local_rank)
         dist.init_process_group(backend, init_method="env://", rank=rank, world_size=world, **kw)
+    if torch.cuda.is_available() and local_rank >= torch.cuda.device_count():
+        local_rank = local_rank % torch.cuda.device_count()  # only reachable with FRLW_DIST_BACKEND=gloo
     return rank, world, local_rank
 
 

@@ -312,3 +312,60 @@ def test_mpx_properties(er):
     o, _, mem = er.encode_sae_dat(dat[:2_000_000], shape, LAMDAS, None, 80_000, 0)
     _, _, mem2 = er.encode_sae_dat(dat[:0], shape, LAMDAS, mem, 80_000, 0)
     assert torch.equal(mem, mem2)
+
+
+# ------------------------------------------------------------------------------------------
+# parameter sweeps through the fused DAT path: HIP vs oracle, bit-exact
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("K,n_windows,window_us,H,W", [(4, 1, 10_000, 64, 96), (5, 13, 7_000, 40, 200),
+                                                      (8, 64, 1_250, 72, 130), (1, 3, 50_000, 16, 300),
+                                                      (7, 8, 10_000, 240, 304)])
+def test_taf_dat_parameter_sweep(er, orc, K, n_windows, window_us, H, W):
+    span = n_windows * window_us
+    ev = synth.synth_events(100 + K + n_windows, 150_000, W, H, span + window_us // 2, hotspot=True, t_offset=5_000)
+    dat = synth.to_dat8(ev)
+    st0 = np.random.default_rng(K).uniform(-100, 0, size=(H, W, 2, K)).astype(np.float32)
+    oview, ost = orc.taf_stream_dat8(dat, (H, W), (H, W), K, 4_000, window_us, n_windows, st0)
+    st = dev(st0)
+    u8, view = er.encode_taf_dat(dat_dev(ev), (H, W), st, 4_000, window_us, n_windows, K, want_view=True, flip_k=False)
+    assert_bitexact(host(st), ost, "taf state")
+    assert_bitexact(host(view), oview, "taf view")
+    want_u8 = orc.quantize_u8(orc.leaky_transform(oview.reshape(K, 2, H, W)))
+    assert_u8_budget(host(u8), want_u8, 1e-4, "taf u8")
+
+
+@pytest.mark.parametrize("bins", [1, 2, 5, 8])
+def test_ev_dat_bins_and_time_filter(er, orc, bins):
+    H, W = 48, 200
+    ev = synth.synth_events(300 + bins, 120_000, W, H, 400_000)
+    dat = synth.to_dat8(ev)
+    want = orc.ev_stream_dat8(dat, (H, W), (H, W), bins, 400_000, 250_000)  # drops t <= 150 000
+    out, u8 = er.encode_ev_dat(dat_dev(ev), (H, W), 400_000, 250_000, bins, want_u8=True)
+    assert_bitexact(host(out), want, f"ev bins={bins}")
+    assert_bitexact(host(u8), orc.quantize_u8(want, clip255=True), "ev u8")
+
+
+def test_sae_dat_window_filter_and_downscale(er, orc):
+    sensor, shape = (120, 200), (60, 100)
+    ev = synth.synth_events(41, 80_000, sensor[1], sensor[0], 3_000_000, t_offset=10_000_000)
+    dat = synth.to_dat8(ev)
+    xm, ym = er.coordinate_maps(sensor, shape, "cuda")
+    now = 13_000_000
+    want, wmem = orc.sae_stream_dat8(dat, sensor, shape, LAMDAS, None, now, 1_000_000)
+    out, _, mem = er.encode_sae_dat(dat_dev(ev), shape, LAMDAS, None, now, 1_000_000, xmap=xm, ymap=ym)
+    assert_bitexact(host(mem), wmem, "sae memory (filter + downscale)")
+    assert_ulp(host(out), want, 2, "sae out")
+
+
+def test_workspace_reuse_across_shapes_and_kinds(er, orc):
+    """One cached workspace serves calls of different kinds / sizes back to back (no stale state)."""
+    for H, W, n in ((240, 304, 50_000), (8, 12, 300), (720, 1280, 400_000), (240, 304, 50_000)):
+        ev = synth.synth_events(n, n, W, H, 80_000)
+        dat = synth.to_dat8(ev)
+        out, _ = er.encode_eci_dat(dat_dev(ev), (H, W))
+        assert_bitexact(host(out), orc.eci_stream_dat8(dat, (H, W), (H, W)), "eci")
+        st0 = np.full((H, W, 2, 8), -6000, np.float32)
+        _, ost = orc.taf_stream_dat8(dat, (H, W), (H, W), 8, 0, 10_000, 8, st0)
+        st = dev(st0)
+        er.encode_taf_dat(dat_dev(ev), (H, W), st, 0, 10_000, 8, 8)
+        assert_bitexact(host(st), ost, "taf")
