@@ -604,16 +604,19 @@ int frlw_det_run(const frlw_detector_t *d, int B, void *const *bufs, int n_bufs,
             c.partial = nullptr;
             // tile choice: the big tile when it still fills the chip, small N for the prediction convs
             const long long big = (long long)((c.M + 127) / 128) * ((c.Npad + 127) / 128);
+            static const long long split_below = [] { const char *e = getenv("FRLW_CONV_SPLIT_BELOW"); return e ? atoll(e) : 700ll; }();
+            static const long long split_target = [] { const char *e = getenv("FRLW_CONV_SPLIT_TARGET"); return e ? atoll(e) : 1024ll; }();
+            static const long long big_min = [] { const char *e = getenv("FRLW_CONV_BIG_MIN"); return e ? atoll(e) : 1000000ll; }();
             if (c.Npad <= 32) {
                 hipLaunchKernelGGL((k_conv_mfma<128, 32, 4, 1, 16>), dim3((c.M + 127) / 128, 1), dim3(256), 0, s, c);
-            } else if (big >= 384 && c.Npad >= 128) {
+            } else if (big >= big_min && c.Npad >= 128) {
                 hipLaunchKernelGGL((k_conv_mfma<128, 128, 2, 2, CONV_BK_BIG>), dim3((c.M + 127) / 128, (c.Npad + 127) / 128), dim3(256), 0, s, c);
             } else {
                 const long long wgs = (long long)((c.M + 63) / 64) * ((c.Npad + 63) / 64);
                 const int nk = (c.K + kSplitBK - 1) / kSplitBK;
                 // small feature maps leave most CUs idle: split the contraction over blockIdx.z
-                if (wgs < 256 && nk >= 32 && d->scratch_buf >= 0) {
-                    int sp = (int)((768 + wgs - 1) / wgs);
+                if (wgs < split_below && nk >= 32 && d->scratch_buf >= 0) {
+                    int sp = (int)((split_target + wgs - 1) / wgs);
                     if (sp > 8) sp = 8;
                     if (sp > nk / 8) sp = nk / 8;
                     if (sp > 1 && (long long)sp * c.M * c.Npad <= d->scratch_floats) { c.splits = sp; c.partial = buf(d->scratch_buf); }
