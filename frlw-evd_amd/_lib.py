@@ -57,6 +57,9 @@ SYMBOLS = {
     "frlw_det_destroy": (None, [_P]),
     "frlw_det_num_ops": (_I, [_P]),
     "frlw_det_set_scratch": (_I, [_P, _I, _I64]),
+    "frlw_det_set_lane": (_I, [_P, _I]),
+    "frlw_det_add_fork": (_I, [_P]),
+    "frlw_det_add_join": (_I, [_P]),
     "frlw_det_add_focus": (_I, [_P, _I, _I, _I, _I, _I]),
     "frlw_det_add_upsample": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I]),
     "frlw_det_add_spp_pool": (_I, [_P, _I, _I, _I, _I, _I]),

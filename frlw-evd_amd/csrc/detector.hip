@@ -469,10 +469,12 @@ __global__ __launch_bounds__(1024) void k_decode_nms(DecodeArgs a)
 }
 
 // ---- plan ------------------------------------------------------------------------------------------
-enum OpType : int { OP_CONV = 0, OP_FOCUS = 1, OP_UPSAMPLE = 2, OP_SPP = 3, OP_DECODE = 4 };
+enum OpType : int { OP_CONV = 0, OP_FOCUS = 1, OP_UPSAMPLE = 2, OP_SPP = 3, OP_DECODE = 4, OP_FORK = 5, OP_JOIN = 6 };
+constexpr int kSideLanes = 2; // independent sub-graphs (the head levels) run on side streams
 
 struct Op {
     int type;
+    int lane;               // 0 = the caller's stream, 1..kSideLanes = side streams
     int src, dst, res;      // buffer indices
     ConvArgs conv;          // pointers x / y / res filled at run time; w / bias are baked
     int C, H, W, cs_src, co_src, cs_dst, co_dst;
@@ -485,14 +487,50 @@ int grid_1d(long long n) { long long g = (n + 255) / 256; if (g > 4096) g = 4096
 
 struct frlw_detector {
     std::vector<Op> ops;
-    int scratch_buf = -1;        // split-K partial sums
+    int scratch_buf = -1;        // split-K partial sums: (1 + kSideLanes) regions of scratch_floats
     long long scratch_floats = 0;
+    int cur_lane = 0;
+    bool have_side = false;
+    hipStream_t side[kSideLanes] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[kSideLanes] = {};
 };
 
 extern "C" {
 
 frlw_detector_t *frlw_det_create(void) { return new frlw_detector(); }
-void frlw_det_destroy(frlw_detector_t *d) { delete d; }
+void frlw_det_destroy(frlw_detector_t *d)
+{
+    if (d && d->have_side) {
+        for (int i = 0; i < kSideLanes; ++i) { (void)hipStreamDestroy(d->side[i]); (void)hipEventDestroy(d->ev_join[i]); }
+        (void)hipEventDestroy(d->ev_fork);
+    }
+    delete d;
+}
+
+int frlw_det_set_lane(frlw_detector_t *d, int lane)
+{
+    if (!d || lane < 0 || lane > kSideLanes) return FRLW_ERR_ARG;
+    d->cur_lane = lane;
+    return FRLW_OK;
+}
+
+int frlw_det_add_fork(frlw_detector_t *d)
+{
+    if (!d) return FRLW_ERR_ARG;
+    Op op = {};
+    op.type = OP_FORK;
+    d->ops.push_back(op);
+    return FRLW_OK;
+}
+
+int frlw_det_add_join(frlw_detector_t *d)
+{
+    if (!d) return FRLW_ERR_ARG;
+    Op op = {};
+    op.type = OP_JOIN;
+    d->ops.push_back(op);
+    return FRLW_OK;
+}
 int frlw_det_num_ops(const frlw_detector_t *d) { return d ? (int)d->ops.size() : 0; }
 
 int frlw_det_set_scratch(frlw_detector_t *d, int buf, int64_t n_floats)
@@ -508,6 +546,7 @@ int frlw_det_add_focus(frlw_detector_t *d, int src_buf, int C, int H, int W, int
     if (!d || C < 1 || (H & 1) || (W & 1)) return FRLW_ERR_ARG;
     Op op = {};
     op.type = OP_FOCUS; op.src = src_buf; op.dst = dst_buf; op.C = C; op.H = H; op.W = W;
+    op.lane = d->cur_lane;
     d->ops.push_back(op);
     return FRLW_OK;
 }
@@ -519,6 +558,7 @@ int frlw_det_add_upsample(frlw_detector_t *d, int src_buf, int cs_src, int co_sr
     Op op = {};
     op.type = OP_UPSAMPLE; op.src = src_buf; op.dst = dst_buf; op.C = C; op.H = H; op.W = W;
     op.cs_src = cs_src; op.co_src = co_src; op.cs_dst = cs_dst; op.co_dst = co_dst;
+    op.lane = d->cur_lane;
     d->ops.push_back(op);
     return FRLW_OK;
 }
@@ -528,6 +568,7 @@ int frlw_det_add_spp_pool(frlw_detector_t *d, int buf, int cs, int C, int H, int
     if (!d || cs < 4 * C) return FRLW_ERR_ARG;
     Op op = {};
     op.type = OP_SPP; op.src = buf; op.dst = buf; op.C = C; op.H = H; op.W = W; op.cs_src = cs;
+    op.lane = d->cur_lane;
     d->ops.push_back(op);
     return FRLW_OK;
 }
@@ -549,6 +590,7 @@ int frlw_det_add_conv(frlw_detector_t *d, int src_buf, int src_cs, int src_co, i
     c.y_cs = dst_cs; c.y_co = dst_co; c.y_bs = dst_bs > 0 ? dst_bs : (long long)c.Ho * c.Wo * dst_cs;
     c.r_cs = res_cs; c.r_co = res_co; c.r_bs = (long long)c.Ho * c.Wo * res_cs;
     c.act = act; c.sig_from = sig_from; c.K = k * k * Cin;
+    op.lane = d->cur_lane;
     d->ops.push_back(op);
     return FRLW_OK;
 }
@@ -572,11 +614,34 @@ int frlw_det_run(const frlw_detector_t *d, int B, void *const *bufs, int n_bufs,
                  frlw_stream_t stream)
 {
     if (!d || B < 1 || !bufs) return FRLW_ERR_ARG;
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t s0 = (hipStream_t)stream;
     const int n_ops = (int)d->ops.size();
     if (last < 0 || last > n_ops) last = n_ops;
+    frlw_detector *dm = const_cast<frlw_detector *>(d);
     for (int oi = first; oi < last; ++oi) {
         const Op &op = d->ops[oi];
+        if (op.type == OP_FORK || op.type == OP_JOIN) {
+            if (!dm->have_side) { // created once, outside any graph capture
+                for (int i = 0; i < kSideLanes; ++i) {
+                    if (hipStreamCreateWithFlags(&dm->side[i], hipStreamNonBlocking) != hipSuccess) return FRLW_ERR_HIP;
+                    if (hipEventCreateWithFlags(&dm->ev_join[i], hipEventDisableTiming) != hipSuccess) return FRLW_ERR_HIP;
+                }
+                if (hipEventCreateWithFlags(&dm->ev_fork, hipEventDisableTiming) != hipSuccess) return FRLW_ERR_HIP;
+                dm->have_side = true;
+            }
+            if (op.type == OP_FORK) {
+                if (hipEventRecord(dm->ev_fork, s0) != hipSuccess) return FRLW_ERR_HIP;
+                for (int i = 0; i < kSideLanes; ++i)
+                    if (hipStreamWaitEvent(dm->side[i], dm->ev_fork, 0) != hipSuccess) return FRLW_ERR_HIP;
+            } else {
+                for (int i = 0; i < kSideLanes; ++i) {
+                    if (hipEventRecord(dm->ev_join[i], dm->side[i]) != hipSuccess) return FRLW_ERR_HIP;
+                    if (hipStreamWaitEvent(s0, dm->ev_join[i], 0) != hipSuccess) return FRLW_ERR_HIP;
+                }
+            }
+            continue;
+        }
+        hipStream_t s = (op.lane > 0 && dm->have_side) ? dm->side[op.lane - 1] : s0;
         auto buf = [&](int i) -> float * { return (i >= 0 && i < n_bufs) ? (float *)bufs[i] : nullptr; };
         switch (op.type) {
         case OP_FOCUS: {
@@ -619,7 +684,7 @@ int frlw_det_run(const frlw_detector_t *d, int B, void *const *bufs, int n_bufs,
                     int sp = (int)((split_target + wgs - 1) / wgs);
                     if (sp > 8) sp = 8;
                     if (sp > nk / 8) sp = nk / 8;
-                    if (sp > 1 && (long long)sp * c.M * c.Npad <= d->scratch_floats) { c.splits = sp; c.partial = buf(d->scratch_buf); }
+                    if (sp > 1 && (long long)sp * c.M * c.Npad <= d->scratch_floats) { c.splits = sp; c.partial = buf(d->scratch_buf) + (long long)op.lane * d->scratch_floats; }
                 }
                 hipLaunchKernelGGL((k_conv_mfma<64, 64, 2, 2, CONV_BK_SMALL>), dim3((c.M + 63) / 64, (c.Npad + 63) / 64, c.splits), dim3(256), 0, s, c);
                 if (c.splits > 1)

@@ -191,7 +191,12 @@ class DetectorEngine:
         raw = self._new_buf(1, A, F)
         self.raw_buf, self.A, self.F = raw.buf, A, F
         off = 0
+        import os
+        lanes = os.environ.get("FRLW_DET_LANES", "0") != "0"  # head levels on side streams: measured no gain (5.17 vs 5.08 ms), off
+        if lanes:
+            _lib.check(lib.frlw_det_add_fork(self.handle), "fork")
         for k, v in enumerate(levels):
+            _lib.check(lib.frlw_det_set_lane(self.handle, k if (lanes and k <= 2) else 0), "lane")
             hs = self._new_buf(v.h, v.w, 256)
             self._baseconv(head.stems[k], v, hs)
             feats = []
@@ -210,6 +215,9 @@ class DetectorEngine:
             self._conv_raw(head.cls_preds[k].weight.detach().float(), head.cls_preds[k].bias.detach().float(), cls_feat,
                            dst, 1, 1, ACT_SIGMOID, dst_bs=A * F, sig_from=0)
             off += v.h * v.w
+        _lib.check(lib.frlw_det_set_lane(self.handle, 0), "lane")
+        if lanes:
+            _lib.check(lib.frlw_det_add_join(self.handle), "join")
         self.n_forward_ops = lib.frlw_det_num_ops(self.handle)
         # ---- decode + NMS (yolo_head.py:258-303)
         self.dec_buf = self._new_buf(1, A, F).buf
@@ -235,7 +243,7 @@ class DetectorEngine:
         if bufs is None:
             bufs = [None] + [torch.empty(B * n, dtype=torch.float32, device=self.device) for n in self._shapes[1:]]
             bufs[self.counts_buf] = torch.zeros(B, dtype=torch.int32, device=self.device)
-            bufs[self.scratch_buf] = torch.empty(self.scratch_floats, dtype=torch.float32, device=self.device)
+            bufs[self.scratch_buf] = torch.empty(3 * self.scratch_floats, dtype=torch.float32, device=self.device)
             self._bufs[B] = bufs
         return bufs
 

@@ -170,7 +170,14 @@ frlw_detector_t *frlw_det_create(void);
 void frlw_det_destroy(frlw_detector_t *d);
 int frlw_det_num_ops(const frlw_detector_t *d);
 
-/* Optional scratch buffer (index into bufs, size in floats for the batch) for split-K partial sums of the
+/* Independent sub-graphs (the three head levels) can run concurrently: ops added after frlw_det_set_lane(d, l)
+ * with l in 1..2 are launched on library-owned side streams between a fork (side streams wait for everything
+ * launched so far on the caller's stream) and a join (the caller's stream waits for the side streams). */
+int frlw_det_set_lane(frlw_detector_t *d, int lane);
+int frlw_det_add_fork(frlw_detector_t *d);
+int frlw_det_add_join(frlw_detector_t *d);
+
+/* Optional scratch buffer (index into bufs; n_floats floats PER LANE, 3 lanes) for split-K partial sums of the
  * convolutions whose output grid would leave most CUs idle (8x10 feature maps). */
 int frlw_det_set_scratch(frlw_detector_t *d, int buf, int64_t n_floats);
 

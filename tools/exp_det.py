@@ -18,6 +18,15 @@ eng = m.engine()
 t = timeit(lambda: eng.raw_outputs(x))
 gf = eng.flops_per_image * B / 1e9
 print(f"engine fwd  B={B}: {t:.3f} ms  {B/t*1e3:.0f} frames/s  {gf/t:.1f} TFLOP/s ({gf/t/157.3*100:.1f}% of fp32 MFMA peak)")
+import time
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(50): eng.raw_outputs(x)
+torch.cuda.synchronize(); tw = (time.perf_counter() - t0) / 50 * 1e3
+print(f"engine fwd wall (50 back-to-back): {tw:.3f} ms  {B/tw*1e3:.0f} frames/s")
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(20): eng.raw_outputs(x); torch.cuda.synchronize()
+tw = (time.perf_counter() - t0) / 20 * 1e3
+print(f"engine fwd wall (sync each): {tw:.3f} ms")
 t2 = timeit(lambda: eng.detect(x), n=10)
 print(f"engine fwd+decode+nms (incl. host list): {t2:.3f} ms")
 with torch.no_grad():
