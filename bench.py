@@ -139,6 +139,24 @@ def main():
         with open(traffic_file) as f:
             result["roofline"]["traffic"] = json.load(f).get("hbm_bytes_per_encode")
 
+    if args.workload == "taf_mpx":
+        # the same encoder at the GEN1 sensor shape BASELINE.json's metric names (304x240, 1 M events): launch /
+        # latency bound at this size, reported next to the headline number
+        s2, n2, H2, W2, t2, nw2, wu2, K2 = WORKLOADS["taf_gen1"]
+        ev2 = synth.synth_events(s2 + 7919 * rank, n2, W2, H2, t2)
+        dat2 = torch.from_numpy(synth.to_dat8(ev2).view(np.uint8).reshape(-1, 8)).cuda()
+        st2 = torch.full((H2, W2, 2, K2), -6000.0, device="cuda")
+        for _ in range(3):
+            er.encode_taf_dat(dat2, (H2, W2), st2, 0, wu2, nw2, K2, check=False)
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            er.encode_taf_dat(dat2, (H2, W2), st2, 0, wu2, nw2, K2, check=False)
+        sync_all()
+        dt2, = fd.max_over_ranks([time.perf_counter() - t0])
+        result["also"] = [{"workload": "taf_gen1: TAF K=8 encode + leaky + uint8, 1000000 events, 304x240, 8 windows",
+                           "value": round(n_gpus * n2 / (dt2 / args.steps) / 1e6, 2), "unit": "Mevents/s",
+                           "ms_per_step": round(dt2 / args.steps * 1e3, 4)}]
     if not args.no_detector:
         result["detector"] = bench_detector(args, torch, dist, world, rank, sync_all)
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:

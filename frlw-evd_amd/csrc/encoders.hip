@@ -29,7 +29,7 @@ using namespace frlw;
 namespace {
 
 #ifndef FRLW_SLICE_MULT
-#define FRLW_SLICE_MULT 8
+#define FRLW_SLICE_MULT 16
 #endif
 constexpr int CPT = kCellsPerThread;
 constexpr int kMaxK = 8;
