@@ -39,7 +39,8 @@ def needs_build():
 def build(force: bool = False, verbose: bool = False) -> str:
     if force or needs_build():
         extra = os.environ.get("FRLW_EXTRA_HIPCC_FLAGS", "").split()  # experiments only (e.g. -DCONV_BK_BIG=32)
-        cmd = [hipcc()] + HIPCC_FLAGS + extra + ["-I", INCLUDE, "-I", CSRC] + sources() + ["-o", LIB]
+        out = os.environ.get("FRLW_LIB_OUT") or LIB  # experiments only: build a variant beside the product
+        cmd = [hipcc()] + HIPCC_FLAGS + extra + ["-I", INCLUDE, "-I", CSRC] + sources() + ["-o", out]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

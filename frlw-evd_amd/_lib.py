@@ -73,7 +73,8 @@ _lib = None
 
 
 def library_path() -> str:
-    return _build.LIB
+    # FRLW_LIB_PATH: developer knob to A/B a differently-built libfrlw_evd (tools/variants.sh)
+    return os.environ.get("FRLW_LIB_PATH") or _build.LIB
 
 
 def load():

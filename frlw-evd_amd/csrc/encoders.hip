@@ -60,27 +60,54 @@ __device__ __forceinline__ Owner make_owner(const TileGeom &g, int W)
     return o;
 }
 
+#ifdef FRLW_TILE_PROF
+// Developer build only (-DFRLW_TILE_PROF): per-phase cycle sums of the TAF tile kernel, thread 0 of each tile.
+__device__ unsigned long long g_prof[16];
+#define PROF_MARK(ph) do { const unsigned long long now_ = __builtin_readcyclecounter(); \
+        if (threadIdx.x == 0) atomicAdd(&g_prof[ph], now_ - prof_t_); prof_t_ = now_; } while (0)
+#define PROF_BEGIN unsigned long long prof_t_ = __builtin_readcyclecounter()
+#define PROF_RESET prof_t_ = __builtin_readcyclecounter()
+#else
+#define PROF_MARK(ph) do { } while (0)
+#define PROF_BEGIN do { } while (0)
+#define PROF_RESET do { } while (0)
+#endif
+
 // ---- slice counting sort shared by EV and TAF --------------------------------------------------
-// Sorts the records i in [s0, s0 + span) with pred(meta) by cell into (sval, sidx); returns through
+// Sorts the records i in [s0, s0 + span) with pred(meta) by cell into slot[]; returns through
 // (c[j], o[j]) the length and offset of the segments of this thread's four cells.  `cnt` has NC entries.
+#ifndef FRLW_KBATCH
+#define FRLW_KBATCH 8
+#endif
+constexpr int kBatch = FRLW_KBATCH; // global loads in flight per thread in the two passes of slice_sort
 template <int NT, typename Pred>
 __device__ __forceinline__ void slice_sort(const uint2 *rec, uint32_t s0, uint32_t span, uint32_t cell_mask,
-                                           Pred pred, uint32_t *cnt, float *sval, uint16_t *sidx,
+                                           Pred pred, uint32_t *cnt, uint2 *slot,
                                            uint32_t *red, bool counted, uint32_t (&c)[CPT], uint32_t (&o)[CPT],
-                                           uint8_t *swin = nullptr, int cb = 0)
+                                           int cb = 0)
 {
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     constexpr int NW = NT / kWave;
+    PROF_BEGIN;
     if (!counted) {
 #pragma unroll
         for (int j = 0; j < CPT; ++j) cnt[t + NT * j] = 0;
         __syncthreads();
-        for (uint32_t i = s0 + t; i < s0 + span; i += NT) {
-            const uint32_t m = rec[i].x;
-            if (pred(m)) atomicAdd(&cnt[m & cell_mask], 1u);
+        // batches of kBatch loads in flight per thread: the pass is bound by global-load latency
+        for (uint32_t i0 = s0 + t; i0 < s0 + span; i0 += kBatch * NT) {
+            uint32_t m[kBatch];
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u) {
+                const uint32_t i = i0 + u * NT;
+                m[u] = i < s0 + span ? rec[i].x : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u)
+                if (i0 + u * NT < s0 + span && pred(m[u])) atomicAdd(&cnt[m[u] & cell_mask], 1u);
         }
         __syncthreads();
     }
+    PROF_MARK(1);
     // exclusive scan in thread-major order: a thread's four segments are adjacent
     uint32_t tot = 0;
 #pragma unroll
@@ -98,44 +125,83 @@ __device__ __forceinline__ void slice_sort(const uint2 *rec, uint32_t s0, uint32
 #pragma unroll
     for (int j = 0; j < CPT; ++j) { o[j] = run; cnt[t + NT * j] = run; run += c[j]; }
     __syncthreads();
+    PROF_MARK(2);
     // Rounds of NT records with a barrier in between: slots of a later round always come after those
     // of an earlier one, so a cell's segment is out of order only among the few records of one round
     // (the per-segment insertion sort stays linear even for a hot pixel).
-    for (uint32_t i0 = s0; i0 < s0 + span; i0 += NT) {
-        const uint32_t i = i0 + t;
-        if (i < s0 + span) {
-            const uint2 r = rec[i];
-            if (pred(r.x)) {
-                const uint32_t slot = atomicAdd(&cnt[r.x & cell_mask], 1u);
-                sval[slot] = __uint_as_float(r.y);
-                sidx[slot] = (uint16_t)(i - s0);
-                if (swin) swin[slot] = (uint8_t)(r.x >> cb);
-            }
+    for (uint32_t g0 = s0; g0 < s0 + span; g0 += kBatch * NT) {
+        uint2 r[kBatch]; // the loads of kBatch rounds are issued together
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            const uint32_t i = g0 + u * NT + t;
+            r[u] = i < s0 + span ? rec[i] : make_uint2(0u, 0u);
         }
-        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            if (g0 + u * NT >= s0 + span) break; // block-uniform
+            const uint32_t i = g0 + u * NT + t;
+            if (i < s0 + span && pred(r[u].x)) {
+                const uint32_t sl = atomicAdd(&cnt[r[u].x & cell_mask], 1u);
+                // one 8-byte LDS entry per record: {value bits, position in the slice << 8 | window}
+                slot[sl] = make_uint2(r[u].y, ((i - s0) << 8) | ((r[u].x >> cb) & 255u));
+            }
+            __syncthreads();
+        }
     }
+    PROF_MARK(3);
 }
 
-// Slots were handed out by LDS atomics in arrival order; restore stream order inside one segment
-// (insertion sort on the position inside the slice -- segments are short and almost sorted).
-__device__ __forceinline__ void segment_order(uint32_t n, uint32_t s, float *sval, uint16_t *sidx,
-                                              uint8_t *swin = nullptr)
+// Slots were handed out by LDS atomics in arrival order; restore stream order inside the four segments
+// of this thread.  Only records of the same round (NT consecutive records) can be swapped, so a segment
+// is a run of tiny permuted blocks -- nearly always pairs.  One bubble pass, the four cells in lock-step
+// (four independent LDS reads in flight per step, no divergent loop), repairs every adjacent inversion;
+// a segment it cannot repair (an element that has to move two or more places: three or more records of
+// one pixel within NT events) is finished by an insertion sort afterwards.
+__device__ __forceinline__ void segments_order(const uint32_t (&c)[CPT], const uint32_t (&o)[CPT], uint2 *slot,
+                                               uint32_t last_slot)
 {
-    for (uint32_t a = 1; a < n; ++a) {
-        const uint16_t id = sidx[s + a];
-        if (sidx[s + a - 1] <= id) continue; // already in place (the common case)
-        const float v = sval[s + a];
-        const uint8_t w = swin ? swin[s + a] : (uint8_t)0;
-        uint32_t b = a;
-        while (b > 0 && sidx[s + b - 1] > id) {
-            sidx[s + b] = sidx[s + b - 1];
-            sval[s + b] = sval[s + b - 1];
-            if (swin) swin[s + b] = swin[s + b - 1];
-            --b;
+    uint32_t maxc = 0, below[CPT];
+    uint2 top[CPT]; // largest element so far = what slot[o + x - 1] holds
+    bool deep[CPT];
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        maxc = c[j] > maxc ? c[j] : maxc;
+        top[j] = make_uint2(0u, 0u);
+        below[j] = 0u;
+        deep[j] = false;
+    }
+    for (uint32_t x = 0; x < maxc; ++x) {
+        uint2 e[CPT];
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            const uint32_t at = o[j] + x;
+            e[j] = slot[at < last_slot ? at : last_slot];
         }
-        sidx[s + b] = id;
-        sval[s + b] = v;
-        if (swin) swin[s + b] = w;
+        // written with selects, not branches: the loop is bound by instruction issue
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            const bool live = x < c[j];
+            const bool inv = live && e[j].y < top[j].y; // .y orders by position in the slice
+            const bool fwd = live && !inv;
+            deep[j] |= inv && e[j].y < below[j];
+            if (inv) { // adjacent inversion: e goes under top
+                slot[o[j] + x - 1] = e[j];
+                slot[o[j] + x] = top[j];
+            }
+            below[j] = inv ? e[j].y : (fwd ? top[j].y : below[j]);
+            top[j].x = fwd ? e[j].x : top[j].x;
+            top[j].y = fwd ? e[j].y : top[j].y;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        if (!deep[j]) continue;
+        for (uint32_t x = 1; x < c[j]; ++x) {
+            const uint2 e = slot[o[j] + x];
+            uint32_t b = x;
+            while (b > 0 && slot[o[j] + b - 1].y > e.y) { slot[o[j] + b] = slot[o[j] + b - 1]; --b; }
+            slot[o[j] + b] = e;
+        }
     }
 }
 
@@ -246,8 +312,7 @@ __global__ __launch_bounds__(NT) void k_ev_tile(const uint2 *rec, const uint32_t
     constexpr int NC = NT * CPT;
     constexpr int SLICE = TileLds<NT>::SLICE;
     __shared__ uint32_t cnt[NC];
-    __shared__ float sval[SLICE];
-    __shared__ uint16_t sidx[SLICE];
+    __shared__ uint2 slot[SLICE];
     __shared__ uint32_t red[32];
     const int t = threadIdx.x, tile = blockIdx.x;
     const uint32_t beg = base[tile], end = base[tile + 1];
@@ -260,19 +325,28 @@ __global__ __launch_bounds__(NT) void k_ev_tile(const uint2 *rec, const uint32_t
     for (uint32_t s0 = beg; s0 < end; s0 += SLICE) {
         const uint32_t span = end - s0 < (uint32_t)SLICE ? end - s0 : (uint32_t)SLICE;
         uint32_t c[CPT], o[CPT];
-        slice_sort<NT>(rec, s0, span, NC - 1, [](uint32_t) { return true; }, cnt, sval, sidx, red, false, c, o);
+        slice_sort<NT>(rec, s0, span, NC - 1, [](uint32_t) { return true; }, cnt, slot, red, false, c, o);
+        segments_order(c, o, slot, SLICE - 1);
+        uint32_t maxc = 0;
 #pragma unroll
-        for (int j = 0; j < CPT; ++j) {
-            if (c[j] >= 2u) segment_order(c[j], o[j], sval, sidx);
-            for (uint32_t a = 0; a < c[j]; ++a) {
-                const float ts = binsf * sval[o[j] + a]; // t* = bins * float(t), generate_eventvolume.py:23
+        for (int j = 0; j < CPT; ++j) maxc = c[j] > maxc ? c[j] : maxc;
+        for (uint32_t a = 0; a < maxc; ++a) {
+            uint32_t tv[CPT];
 #pragma unroll
-                for (int k = 0; k < kMaxK; ++k) {
-                    if (k < q.bins) {
-                        const float d = (float)(k + 1) - ts;
-                        const float w = 1.0f - fabsf(d); // :28; negative weights -> 0 (:29) = skipped
-                        if (w > 0.0f) acc[j][k] = acc[j][k] + w;
-                    }
+            for (int j = 0; j < CPT; ++j) {
+                const uint32_t at = o[j] + a;
+                tv[j] = slot[at < SLICE - 1 ? at : SLICE - 1].x;
+            }
+#pragma unroll
+            for (int j = 0; j < CPT; ++j) {
+                const bool live = a < c[j];
+                const float ts = binsf * __uint_as_float(tv[j]); // t* = bins * float(t), generate_eventvolume.py:23
+#pragma unroll
+                for (int k = 0; k < kMaxK; ++k) { // bins beyond q.bins are accumulated but never stored
+                    const float d = (float)(k + 1) - ts;
+                    const float w = 1.0f - fabsf(d); // :28; negative weights -> 0 (:29) = skipped
+                    const float na = acc[j][k] + w;
+                    acc[j][k] = (live && w > 0.0f) ? na : acc[j][k];
                 }
             }
         }
@@ -311,16 +385,15 @@ struct TafParams {
 // One FIFO step of one cell, generate_taf.py:27,35-49 (K <= 8, unused slots are never stored).
 __device__ __forceinline__ void taf_fifo(float (&st)[kMaxK], int K, uint32_t n, float sum)
 {
-    if (n == 0u) {
+    // empty cell: every slot - 1; otherwise shift down (slot k+1 - 1) and the mean enters at K-1.  One
+    // select-only body for both cases (the cells of a wave take both).
+    const bool hit = n != 0u;
+    const float mean = sum / ((float)n + 1e-8f);
 #pragma unroll
-        for (int k = 0; k < kMaxK; ++k) st[k] = st[k] - 1.0f;
-    } else {
-        const float mean = sum / ((float)n + 1e-8f);
-#pragma unroll
-        for (int k = 0; k < kMaxK; ++k) {
-            const float nxt = k + 1 < kMaxK ? st[k + 1] : 0.0f;
-            st[k] = (k == K - 1) ? mean : (nxt - 1.0f);
-        }
+    for (int k = 0; k < kMaxK; ++k) {
+        const float nxt = k + 1 < kMaxK ? st[k + 1] : 0.0f;
+        const float v = (hit ? nxt : st[k]) - 1.0f;
+        st[k] = (hit && k == K - 1) ? mean : v;
     }
 }
 
@@ -331,9 +404,7 @@ __global__ __launch_bounds__(NT) void k_taf_tile(const uint2 *rec, const uint32_
     constexpr int SLICE = TileLds<NT>::SLICE;
     constexpr int NW = NT / kWave;
     __shared__ uint32_t cnt[NC];
-    __shared__ float sval[SLICE];
-    __shared__ uint16_t sidx[SLICE];
-    __shared__ uint8_t swin[SLICE];
+    __shared__ uint2 slot[SLICE];
     __shared__ uint32_t red[48];
     __shared__ uint32_t thr[kLeakyLevels];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -383,6 +454,7 @@ __global__ __launch_bounds__(NT) void k_taf_tile(const uint2 *rec, const uint32_
     // ---- fast path: the tile's records are window-sorted (always true for a time-sorted stream, the
     // partition being stable).  Slices of SLICE records, each counting-sorted by cell once, may span
     // several windows; the FIFO steps between them are block-uniform.
+    PROF_BEGIN;
     load_state();
     bool bad = false;
     int cur_w = 0; // block-uniform: windows < cur_w are closed
@@ -392,33 +464,49 @@ __global__ __launch_bounds__(NT) void k_taf_tile(const uint2 *rec, const uint32_
         if (wlo < cur_w || whi < wlo || whi >= q.n_windows) { bad = true; break; }
         for (; cur_w < wlo; ++cur_w) close_window(cur_w);
         uint32_t c[CPT], o[CPT], a[CPT];
+        PROF_MARK(0);
         if (q.dbg & 8) continue;
-        slice_sort<NT>(rec, s0, span, NC - 1, [](uint32_t) { return true; }, cnt, sval, sidx, red, false, c, o,
-                       swin, cb);
+        slice_sort<NT>(rec, s0, span, NC - 1, [](uint32_t) { return true; }, cnt, slot, red, false, c, o, cb);
         if (q.dbg & 4) continue;
+        PROF_RESET;
+        segments_order(c, o, slot, SLICE - 1);
+        PROF_MARK(4);
 #pragma unroll
-        for (int j = 0; j < CPT; ++j) {
-            if (c[j] >= 2u) segment_order(c[j], o[j], sval, sidx, swin);
-            a[j] = 0;
-        }
+        for (int j = 0; j < CPT; ++j) a[j] = 0;
         for (int w = wlo; w <= whi; ++w) {
+            // the four cells advance together: one LDS read each per step, until none of them has a
+            // record of window w next
+            for (;;) {
+                uint2 e[CPT];
 #pragma unroll
-            for (int j = 0; j < CPT; ++j) {
-                while (a[j] < c[j] && (int)swin[o[j] + a[j]] == w) {
-                    sum[j] = sum[j] + sval[o[j] + a[j]]; // sum += t - 1 in stream order, generate_taf.py:26
-                    num[j] += 1u;
-                    ++a[j];
+                for (int j = 0; j < CPT; ++j) {
+                    const uint32_t at = o[j] + a[j];
+                    e[j] = slot[at < SLICE - 1 ? at : SLICE - 1];
                 }
+                uint32_t any = 0u;
+#pragma unroll
+                for (int j = 0; j < CPT; ++j) {
+                    const bool take = a[j] < c[j] && (int)(e[j].y & 255u) == w;
+                    const float nsum = sum[j] + __uint_as_float(e[j].x); // sum += t - 1 in stream order, generate_taf.py:26
+                    sum[j] = take ? nsum : sum[j];
+                    num[j] += take ? 1u : 0u;
+                    a[j] += take ? 1u : 0u;
+                    any |= take ? 1u : 0u;
+                }
+                if (!any) break;
             }
             if (w < whi) { close_window(w); cur_w = w + 1; }
         }
+        PROF_MARK(5);
         bool viol = false; // a record whose window runs backwards inside its cell's segment
 #pragma unroll
         for (int j = 0; j < CPT; ++j) viol |= a[j] != c[j];
         if (__syncthreads_or(viol)) { bad = true; break; }
+        PROF_MARK(6);
     }
     if (!bad) {
         for (; cur_w < q.n_windows; ++cur_w) close_window(cur_w);
+        PROF_MARK(7);
     } else {
         // ---- general path (stream not time-sorted): nothing has been written yet.  One pass per window
         // over the whole list, slices in list order, records selected by window.
@@ -429,12 +517,12 @@ __global__ __launch_bounds__(NT) void k_taf_tile(const uint2 *rec, const uint32_
             for (uint32_t s0 = beg; s0 < end; s0 += SLICE) {
                 const uint32_t span = end - s0 < (uint32_t)SLICE ? end - s0 : (uint32_t)SLICE;
                 uint32_t c[CPT], o[CPT];
-                slice_sort<NT>(rec, s0, span, NC - 1, [=](uint32_t m) { return (int)(m >> cb) == w; }, cnt, sval,
-                               sidx, red, false, c, o);
+                slice_sort<NT>(rec, s0, span, NC - 1, [=](uint32_t m) { return (int)(m >> cb) == w; }, cnt, slot,
+                               red, false, c, o, cb);
+                segments_order(c, o, slot, SLICE - 1);
 #pragma unroll
                 for (int j = 0; j < CPT; ++j) {
-                    if (c[j] >= 2u) segment_order(c[j], o[j], sval, sidx);
-                    for (uint32_t x = 0; x < c[j]; ++x) sum[j] = sum[j] + sval[o[j] + x];
+                    for (uint32_t x = 0; x < c[j]; ++x) sum[j] = sum[j] + __uint_as_float(slot[o[j] + x].x);
                     num[j] += c[j];
                 }
                 __syncthreads();
@@ -457,17 +545,24 @@ __global__ __launch_bounds__(NT) void k_taf_tile(const uint2 *rec, const uint32_
 #pragma unroll
             for (int k = 0; k < kMaxK; ++k) if (k < K) dst[k] = st[j][k];
         }
+        if (q.view_f32) {
 #pragma unroll
-        for (int k = 0; k < kMaxK; ++k) {
-            if (k < K) {
-                if (q.view_f32) q.view_f32[(long long)(2 * k + ow.p) * plane + ow.pix[j]] = st[j][k]; // :55
-                if (q.out_u8) {
+            for (int k = 0; k < kMaxK; ++k)
+                if (k < K) q.view_f32[(long long)(2 * k + ow.p) * plane + ow.pix[j]] = st[j][k]; // :55
+        }
+        if (q.out_u8) {
+            uint8_t lv[kMaxK];
+            leaky_u8_lookup_n<kMaxK>(st[j], thr, lv); // the eight table look-ups in flight together
+#pragma unroll
+            for (int k = 0; k < kMaxK; ++k) {
+                if (k < K) {
                     const int ko = q.flip ? (K - 1 - k) : k;
-                    q.out_u8[(long long)(2 * ko + ow.p) * plane + ow.pix[j]] = leaky_u8_lookup(st[j][k], thr);
+                    q.out_u8[(long long)(2 * ko + ow.p) * plane + ow.pix[j]] = lv[k];
                 }
             }
         }
     }
+    PROF_MARK(8);
 }
 
 #define LAUNCH_TILE(KERNEL, PLAN, STREAM, ...)                                                          \
@@ -486,6 +581,15 @@ __global__ __launch_bounds__(NT) void k_taf_tile(const uint2 *rec, const uint32_
 // C-ABI
 // =============================================================================================
 extern "C" {
+
+#ifdef FRLW_TILE_PROF
+int frlw_debug_prof(unsigned long long *out, int reset)
+{
+    if (out) hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 16);
+    if (reset) { unsigned long long z[16] = {}; hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof z); }
+    return 0;
+}
+#endif
 
 const char *frlw_version(void) { return "frlw_evd 0.3.0 gfx950"; }
 

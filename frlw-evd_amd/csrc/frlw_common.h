@@ -227,6 +227,35 @@ __device__ __forceinline__ uint8_t leaky_u8_lookup(float v, const uint32_t *thr)
     return (uint8_t)k;
 }
 
+// Out-of-line on purpose: it is the rare path of the batched look-up below, which would otherwise inline
+// N copies of log1pf per cell.
+__device__ __noinline__ uint8_t leaky_u8_exact(float v, const uint32_t *thr) { return leaky_u8_lookup(v, thr); }
+
+// N look-ups at once: the first guess is off by at most one level, so thr[k] and thr[k + 1] decide it; both
+// are read for all N values before any is used.  The (rare) values the pair does not pin down, and those
+// outside the table's domain, take the exact scalar routine.
+template <int N>
+__device__ __forceinline__ void leaky_u8_lookup_n(const float (&v)[N], const uint32_t *thr, uint8_t (&out)[N])
+{
+    int k[N];
+    uint32_t t0[N], t1[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const float x = fabsf(v[i]);
+        const float g = 255.0f * (1.0f - (__log2f(1.0f + x) * 0.69314718f) / 8.7f);
+        k[i] = g > 0.0f ? (g > 254.0f ? 254 : (int)g) : 0; // k + 1 stays inside the table
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) { t0[i] = thr[k[i]]; t1[i] = thr[k[i] + 1]; }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const uint32_t xb = __float_as_uint(fabsf(v[i]));
+        // level k exactly: thr[k + 1] < x <= thr[k]  (thr[0] = +inf)
+        out[i] = (uint8_t)k[i];
+        if (!(v[i] <= 0.0f && xb > t1[i] && xb <= t0[i])) out[i] = leaky_u8_exact(v[i], thr);
+    }
+}
+
 // ---- host side ---------------------------------------------------------------------------------
 struct Plan {
     int twl, tiles_x, tiles_y, n_tiles;
