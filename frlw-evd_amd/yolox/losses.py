@@ -106,10 +106,81 @@ def get_assignments(b, gt_boxes, gt_classes, preds_b, strides, x_shifts, y_shift
     return matched_classes, fg_mask, matched_ious, matched_gt, num_fg
 
 
+_SIMOTA_WS = {}
+_FORCE_LOOP = False  # tests flip this to compare the batched path with the per-image procedure on the GPU
+
+
+@torch.no_grad()
+def simota_assign(outputs, labels, x_shifts, y_shifts, strides_all, num_classes, radius):
+    """Whole-batch SimOTA on the GPU (frlw_simota_assign, csrc/simota.hip): no per-image Python, no sync.
+
+    Returns fg (B, A) bool, matched_gt (B, A) int32 (-1 = background), matched_iou (B, A) float64,
+    num_fg (B) int32, nlabel (B) int32 -- all device tensors."""
+    import ctypes as C
+    from .. import _lib
+    lib = _lib.load()
+    B, A, P = outputs.shape
+    G = labels.shape[1]
+    dev = outputs.device
+    preds = outputs.detach().float().contiguous()
+    lab = labels.detach().to(device=dev, dtype=torch.float64).contiguous()
+    xs = x_shifts.reshape(-1).float().contiguous()
+    ys = y_shifts.reshape(-1).float().contiguous()
+    st = strides_all.reshape(-1).float().contiguous()
+    fg = torch.empty((B, A), dtype=torch.uint8, device=dev)
+    matched_gt = torch.empty((B, A), dtype=torch.int32, device=dev)
+    matched_iou = torch.empty((B, A), dtype=torch.float64, device=dev)
+    num_fg = torch.empty((B,), dtype=torch.int32, device=dev)
+    nlabel = torch.empty((B,), dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    need = lib.frlw_simota_workspace_bytes(B, A, G)
+    key = (dev.index, stream)
+    ws = _SIMOTA_WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        _SIMOTA_WS[key] = ws
+    _lib.check(lib.frlw_simota_assign(preds.data_ptr(), lab.data_ptr(), xs.data_ptr(), ys.data_ptr(), st.data_ptr(),
+                                      B, A, G, num_classes, C.c_float(radius), fg.data_ptr(), matched_gt.data_ptr(),
+                                      matched_iou.data_ptr(), num_fg.data_ptr(), nlabel.data_ptr(), ws.data_ptr(),
+                                      ws.numel(), stream), "frlw_simota_assign")
+    return fg.bool(), matched_gt, matched_iou, num_fg, nlabel
+
+
+def yolox_losses_batched(outputs, x_shifts, y_shifts, strides_all, labels, num_classes, radius):
+    """The loss of ``yolox_losses`` with the assignment done by ``simota_assign`` and the three terms summed
+    over all anchors under the foreground mask instead of over gathered rows: same value (up to the order of
+    the float sums), no host synchronisation.  ROCm tensors only."""
+    B, A, _ = outputs.shape
+    bbox_preds = outputs[:, :, :4]
+    obj_preds = outputs[:, :, 4:5]
+    cls_preds = outputs[:, :, 5:]
+    fg, matched_gt, matched_iou, num_fg_b, nlabel = simota_assign(outputs, labels, x_shifts, y_shifts, strides_all,
+                                                                  num_classes, radius)
+    labels = labels.to(device=outputs.device, dtype=torch.float64)
+    gi = matched_gt.clamp(min=0).long()
+    reg_t = torch.gather(labels[:, :, 1:5], 1, gi.unsqueeze(-1).expand(-1, -1, 4))            # (B, A, 4) f64
+    cls_id = torch.gather(labels[:, :, 0], 1, gi).to(torch.int64).clamp(0, num_classes - 1)  # (B, A)
+    cls_t = F.one_hot(cls_id, num_classes) * matched_iou.unsqueeze(-1)                        # f64, yolo_head.py:383-385
+    obj_t = fg.unsqueeze(-1).to(outputs.dtype)
+    num_fg = num_fg_b.sum().clamp(min=1).to(torch.float64)
+    bce = torch.nn.BCEWithLogitsLoss(reduction="none")
+    zero = torch.zeros((), dtype=torch.float64, device=outputs.device)
+    l_iou = iou_loss(bbox_preds.reshape(-1, 4), reg_t.reshape(-1, 4)).view(B, A)
+    loss_iou = torch.where(fg, l_iou, zero).sum() / num_fg
+    loss_obj = bce(obj_preds.reshape(-1, 1), obj_t.reshape(-1, 1)).sum() / num_fg
+    l_cls = bce(cls_preds, cls_t)
+    loss_cls = torch.where(fg.unsqueeze(-1), l_cls, zero.to(l_cls.dtype)).sum() / num_fg
+    reg_weight = 5.0
+    loss = reg_weight * loss_iou + loss_obj + loss_cls + 0.0
+    return loss, reg_weight * loss_iou, loss_obj, loss_cls, 0.0, num_fg / nlabel.sum().clamp(min=1)
+
+
 def yolox_losses(level_outputs, strides, labels, num_classes, radius):
     """``get_losses`` (yolo_head.py:305-473) on the raw per-level outputs cat[reg, obj, cls] (B, 5 + nc, h, w).
 
-    Returns (loss, 5 * loss_iou, loss_obj, loss_cls, loss_l1 = 0.0, num_fg / num_gt)."""
+    Returns (loss, 5 * loss_iou, loss_obj, loss_cls, loss_l1 = 0.0, num_fg / num_gt).  On ROCm tensors the
+    assignment runs in the HIP library (one launch sequence per batch); on CPU tensors -- the gloo tests and
+    the golden checks -- it is the reference's per-image procedure."""
     outs, xs, ys, ss = [], [], [], []
     for o, stride in zip(level_outputs, strides):
         dec, grid = output_and_grid(o, stride)
@@ -119,6 +190,8 @@ def yolox_losses(level_outputs, strides, labels, num_classes, radius):
         ss.append(torch.zeros(1, grid.shape[1]).fill_(stride).type_as(o))
     outputs = torch.cat(outs, 1)
     x_shifts, y_shifts, strides_all = torch.cat(xs, 1), torch.cat(ys, 1), torch.cat(ss, 1)
+    if outputs.is_cuda and not _FORCE_LOOP:
+        return yolox_losses_batched(outputs, x_shifts, y_shifts, strides_all, labels, num_classes, radius)
     bbox_preds = outputs[:, :, :4]
     obj_preds = outputs[:, :, 4].unsqueeze(-1)
     cls_preds = outputs[:, :, 5:]

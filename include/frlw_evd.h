@@ -222,6 +222,26 @@ int frlw_det_add_decode_nms(frlw_detector_t *d, int raw_buf, int A, int nc, int 
 int frlw_det_run(const frlw_detector_t *d, int B, void *const *bufs, int n_bufs, int first, int last,
                  frlw_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * SimOTA label assignment of the YOLOX training branch, whole batch, no host round trips.
+ * Replaces the per-image Python of core/yolox/models/yolo_head.py:482-584 (get_assignments),
+ * :586-669 (get_in_boxes_info), :671-707 (dynamic_k_matching) and core/yolox/utils/boxes.py:79-102.
+ *
+ *   preds     (B, A, 5 + num_classes) f32: decoded cx, cy, w, h (yolo_head.py:237-256), obj and class logits
+ *   labels    (B, G, 5) f64 rows [class, cx, cy, w, h]; an image's boxes are its first n rows, n = number of
+ *             rows with a positive field sum (yolo_head.py:330,349-350)
+ *   x_shifts, y_shifts, strides  (A) f32: grid coordinates and stride of every anchor (yolo_head.py:254-256)
+ *   radius    centre-sampling radius in strides (core/exp.py:377-384: 5 for GEN1, 2.5 for 1 Mpx)
+ * outputs (caller-allocated):
+ *   fg (B, A) u8, matched_gt (B, A) i32 (-1 = background), matched_iou (B, A) f64 (IoU of the prediction
+ *   with its matched box, the class target), num_fg (B) i32, nlabel (B) i32 (may be NULL).
+ * The losses proper stay autograd-side (frlw-evd_amd/yolox/losses.py). */
+size_t frlw_simota_workspace_bytes(int B, int A, int G);
+int frlw_simota_assign(const float *preds, const double *labels, const float *x_shifts, const float *y_shifts,
+                       const float *strides, int B, int A, int G, int num_classes, float radius, uint8_t *fg,
+                       int32_t *matched_gt, double *matched_iou, int32_t *num_fg, int32_t *nlabel, void *workspace,
+                       size_t workspace_bytes, frlw_stream_t stream);
+
 /* Library identification: "frlw_evd <version> gfx950". */
 const char *frlw_version(void);
 
