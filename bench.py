@@ -52,6 +52,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-detector", action="store_true", help="skip the detector forward leg")
     ap.add_argument("--det-batch", type=int, default=32)
+    ap.add_argument("--no-train", action="store_true", help="skip the train-step leg")
+    ap.add_argument("--no-also", action="store_true", help="skip the GEN1-shaped TAF leg (clean per-kernel profiles)")
+    ap.add_argument("--train-batch", type=int, default=64, help="per-GPU batch of the train-step leg")
     ap.add_argument("--local_rank", "--local-rank", type=int, default=None)
     args = ap.parse_args()
 
@@ -139,7 +142,7 @@ def main():
         with open(traffic_file) as f:
             result["roofline"]["traffic"] = json.load(f).get("hbm_bytes_per_encode")
 
-    if args.workload == "taf_mpx":
+    if args.workload == "taf_mpx" and not args.no_also:
         # the same encoder at the GEN1 sensor shape BASELINE.json's metric names (304x240, 1 M events): launch /
         # latency bound at this size, reported next to the headline number
         s2, n2, H2, W2, t2, nw2, wu2, K2 = WORKLOADS["taf_gen1"]
@@ -159,12 +162,47 @@ def main():
                            "ms_per_step": round(dt2 / args.steps * 1e3, 4)}]
     if not args.no_detector:
         result["detector"] = bench_detector(args, torch, dist, world, rank, sync_all)
+    if not args.no_train:
+        try:
+            result["train"] = bench_train(args, torch, world, rank, local_rank, sync_all)
+        except Exception as e:  # never lose the headline line to the extra leg
+            result["train"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(dat_h, n, H, W, K, n_win, win_us)
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
+
+
+def bench_train(args, torch, world, rank, local_rank, sync_all):
+    """SURVEY.md section 8d cfg 5 without the encode: YOLOX (16-channel TAF input) train step -- forward, batched
+    SimOTA assignment (frlw_simota_assign) + losses, backward, Adam -- under DDP over RCCL when N > 1, per-GPU batch
+    fixed (weak scaling).  Convolution forward/backward of this leg are torch/MIOpen autograd; the assignment is ours."""
+    from frlw_evd_amd import dist as fd
+    from frlw_evd_amd import e2e
+    from frlw_evd_amd.trainer import Trainer
+    B = args.train_batch
+    m = e2e.build_model(in_channels=16, num_classes=2)
+    tr = Trainer(m, global_batch=B * world, nodes=world, iters_per_epoch=100, local_rank=local_rank, ddp=world > 1)
+    rng = np.random.default_rng(1005 + rank)
+    x = torch.from_numpy(rng.integers(0, 256, size=(B, 16, 256, 320, 1, 1), dtype=np.uint8)).float().div(255).cuda()
+    lab = torch.zeros(B, 80, 5, dtype=torch.float64)
+    lab[:, 0] = torch.tensor([0, 100, 90, 60, 40.0])
+    lab[:, 1] = torch.tensor([1, 220, 150, 50, 80.0])
+    lab = lab.cuda()
+    steps = 5
+    for i in range(3):
+        tr.train_step(x, lab, i)
+    sync_all()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        loss, _ = tr.train_step(x, lab, 3 + i)
+    sync_all()
+    dt, = fd.max_over_ranks([time.perf_counter() - t0])
+    return {"metric": "YOLOX train step (frames/s)", "value": round(world * B * steps / dt, 1), "unit": "frames/s",
+            "ms_per_step": round(dt / steps * 1e3, 3), "per_gpu_batch": B, "steps": steps, "loss": round(loss, 4),
+            "parallelism": f"ddp{world}" if world > 1 else "single", "scaling": "weak"}
 
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, f32 in / f32 accumulate

@@ -4,8 +4,9 @@
 set -u
 TAG=${1:-r01}; shift || true
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/pmc_$TAG
-mkdir -p "$OUT"
+OUT=/tmp/frlw_pmc_$TAG   # raw counter dumps stay on the box
+KEEP=$R/gpurun_out/pmc_$TAG
+rm -rf "$OUT"; mkdir -p "$OUT" "$KEEP"
 cd /tmp && export TMPDIR=/tmp
 run() { # name counters...
   local name=$1; shift
@@ -18,4 +19,4 @@ run sq2 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_
 run fetch FETCH_SIZE
 run write WRITE_SIZE
 run tcc TCC_HIT_sum TCC_MISS_sum TCC_EA0_WRREQ_sum TCC_EA0_RDREQ_sum
-python3 "$R/tools/pmc_summary.py" "$OUT"
+python3 "$R/tools/pmc_summary.py" "$OUT" | tee "$KEEP/summary.txt"

@@ -6,12 +6,14 @@ set -u
 TAG=${1:-r01}
 shift || true
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/prof_$TAG
-mkdir -p "$OUT"
+OUT=/tmp/frlw_prof_$TAG   # raw traces stay on the box; only the summaries go to gpurun_out (64 MiB cap)
+KEEP=$R/gpurun_out/prof_$TAG
+rm -rf "$OUT"; mkdir -p "$OUT" "$KEEP"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o trace -- \
     python3 "$R/bench.py" --steps 20 --warmup 3 --no-cpu-baseline "$@" > "$OUT/bench.log" 2>&1
 echo "rc=$?"; tail -3 "$OUT/bench.log"
 find "$OUT" -name "*kernel_stats.csv" | head -3
 F=$(find "$OUT" -name "*kernel_stats.csv" | head -1)
-[ -n "$F" ] && column -s, -t < "$F" | cut -c1-200 | head -20
+[ -n "$F" ] && cp "$F" "$KEEP/kernel_stats.csv"; cp "$OUT/bench.log" "$KEEP/"
+[ -n "$F" ] && head -8 "$F" | cut -c1-200
