@@ -29,7 +29,7 @@ using namespace frlw;
 namespace {
 
 #ifndef FRLW_SLICE_MULT
-#define FRLW_SLICE_MULT 16
+#define FRLW_SLICE_MULT kSliceMult
 #endif
 constexpr int CPT = kCellsPerThread;
 constexpr int kMaxK = 8;
@@ -58,6 +58,42 @@ __device__ __forceinline__ Owner make_owner(const TileGeom &g, int W)
         o.pix[j] = (long long)(g.y0 + o.row[j]) * W + g.x0 + o.lx;
     }
     return o;
+}
+
+// ---- skew: sharing a hot tile --------------------------------------------------------------------
+// The EV / TAF kernels are launched with kMaxHot * (NT / kHotGroup) extra workgroups in front of the per-tile
+// ones.  Extra workgroup (h, g) takes share g -- the cells of threads [32 g, 32 g + 32), 128 cells -- of the
+// h-th tile listed by k_tilescan: it streams the tile's whole record list but sorts and sums only its own cells
+// (per-cell sums are sequential by contract; cells are independent).  The tile's own workgroup does nothing.
+struct Share {
+    int tile;
+    int group; // -1: the whole tile
+};
+
+template <int NT>
+__device__ __forceinline__ bool pick_share(const WsHeader *hdr, const uint32_t *base, Share &sh)
+{
+    constexpr int S = NT / kHotGroup;
+    const int b = blockIdx.x;
+    const uint32_t n_hot = hdr->n_hot < (uint32_t)kMaxHot ? hdr->n_hot : (uint32_t)kMaxHot;
+    if (b < kMaxHot * S) {
+        const int h = b / S;
+        if ((uint32_t)h >= n_hot) return false;
+        sh.tile = (int)hdr->hot[h];
+        sh.group = b - h * S;
+        return true;
+    }
+    sh.tile = b - kMaxHot * S;
+    sh.group = -1;
+    if (base[sh.tile + 1] - base[sh.tile] > hdr->hot_thr) // listed?  (more than kMaxHot hot tiles: the rest stay whole)
+        for (uint32_t h = 0; h < n_hot; ++h)
+            if ((int)hdr->hot[h] == sh.tile) return false;
+    return true;
+}
+
+__device__ __forceinline__ bool in_share(const Share &sh, uint32_t cell, uint32_t nt_mask)
+{
+    return sh.group < 0 || (int)((cell & nt_mask) / kHotGroup) == sh.group;
 }
 
 #ifdef FRLW_TILE_PROF
@@ -302,6 +338,7 @@ __global__ __launch_bounds__(NT) void k_sae_tile(const uint2 *rec, const uint32_
 // ---- Event Volume ----------------------------------------------------------------------------
 struct EvParams {
     int H, W, twl, tiles_x, bins;
+    const WsHeader *hdr;
     float *out_f32;
     uint8_t *out_u8;
 };
@@ -314,7 +351,10 @@ __global__ __launch_bounds__(NT) void k_ev_tile(const uint2 *rec, const uint32_t
     __shared__ uint32_t cnt[NC];
     __shared__ uint2 slot[SLICE];
     __shared__ uint32_t red[32];
-    const int t = threadIdx.x, tile = blockIdx.x;
+    Share sh;
+    if (!pick_share<NT>(q.hdr, base, sh)) return;
+    const int t = threadIdx.x, tile = sh.tile;
+    const bool mine = sh.group < 0 || t / kHotGroup == sh.group;
     const uint32_t beg = base[tile], end = base[tile + 1];
     float acc[CPT][kMaxK]; // cell (pixel, polarity) x time bin
 #pragma unroll
@@ -325,7 +365,8 @@ __global__ __launch_bounds__(NT) void k_ev_tile(const uint2 *rec, const uint32_t
     for (uint32_t s0 = beg; s0 < end; s0 += SLICE) {
         const uint32_t span = end - s0 < (uint32_t)SLICE ? end - s0 : (uint32_t)SLICE;
         uint32_t c[CPT], o[CPT];
-        slice_sort<NT>(rec, s0, span, NC - 1, [](uint32_t) { return true; }, cnt, slot, red, false, c, o);
+        slice_sort<NT>(rec, s0, span, NC - 1, [=](uint32_t m) { return in_share(sh, m, NT - 1); }, cnt, slot, red,
+                       false, c, o);
         segments_order(c, o, slot, SLICE - 1);
         uint32_t maxc = 0;
 #pragma unroll
@@ -358,7 +399,7 @@ __global__ __launch_bounds__(NT) void k_ev_tile(const uint2 *rec, const uint32_t
     const int ch = ow.p ? 0 : 1; // weights [p, 1 - p]: channel 0 = p == 1
 #pragma unroll
     for (int j = 0; j < CPT; ++j) {
-        if (ow.ok[j]) {
+        if (ow.ok[j] && mine) {
 #pragma unroll
             for (int k = 0; k < kMaxK; ++k) {
                 if (k < q.bins) {
@@ -407,13 +448,19 @@ __global__ __launch_bounds__(NT) void k_taf_tile(const uint2 *rec, const uint32_
     __shared__ uint2 slot[SLICE];
     __shared__ uint32_t red[48];
     __shared__ uint32_t thr[kLeakyLevels];
+    Share sh;
+    if (!pick_share<NT>(q.hdr, base, sh)) return;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const int tile = blockIdx.x;
+    const int tile = sh.tile;
     const int K = q.K;
     for (int i = t; i < kLeakyLevels; i += NT) thr[i] = q.leaky_thr[i];
     const int cb = q.twl + 4; // cell bits
     const TileGeom g = tile_geom(tile, q.tiles_x, q.twl, q.H, q.W);
-    const Owner ow = make_owner<NT>(g, q.W);
+    Owner ow = make_owner<NT>(g, q.W);
+    if (sh.group >= 0 && t / kHotGroup != sh.group) { // a share: the other threads own nothing
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) ow.ok[j] = false;
+    }
     const uint32_t beg = base[tile], end = base[tile + 1];
     const unsigned long long wmask = q.hdr->wmask; // windows that hold events (anywhere in the frame)
     float st[CPT][kMaxK], sum[CPT];
@@ -466,7 +513,8 @@ __global__ __launch_bounds__(NT) void k_taf_tile(const uint2 *rec, const uint32_
         uint32_t c[CPT], o[CPT], a[CPT];
         PROF_MARK(0);
         if (q.dbg & 8) continue;
-        slice_sort<NT>(rec, s0, span, NC - 1, [](uint32_t) { return true; }, cnt, slot, red, false, c, o, cb);
+        slice_sort<NT>(rec, s0, span, NC - 1, [=](uint32_t m) { return in_share(sh, m, NT - 1); }, cnt, slot, red,
+                       false, c, o, cb);
         if (q.dbg & 4) continue;
         PROF_RESET;
         segments_order(c, o, slot, SLICE - 1);
@@ -517,7 +565,8 @@ __global__ __launch_bounds__(NT) void k_taf_tile(const uint2 *rec, const uint32_
             for (uint32_t s0 = beg; s0 < end; s0 += SLICE) {
                 const uint32_t span = end - s0 < (uint32_t)SLICE ? end - s0 : (uint32_t)SLICE;
                 uint32_t c[CPT], o[CPT];
-                slice_sort<NT>(rec, s0, span, NC - 1, [=](uint32_t m) { return (int)(m >> cb) == w; }, cnt, slot,
+                slice_sort<NT>(rec, s0, span, NC - 1,
+                               [=](uint32_t m) { return (int)(m >> cb) == w && in_share(sh, m, NT - 1); }, cnt, slot,
                                red, false, c, o, cb);
                 segments_order(c, o, slot, SLICE - 1);
 #pragma unroll
@@ -565,14 +614,17 @@ __global__ __launch_bounds__(NT) void k_taf_tile(const uint2 *rec, const uint32_
     PROF_MARK(8);
 }
 
-#define LAUNCH_TILE(KERNEL, PLAN, STREAM, ...)                                                          \
+// SHARES = 1: kMaxHot * (NT / kHotGroup) workgroups in front of the per-tile ones take the shares of hot tiles
+#define LAUNCH_TILE(KERNEL, SHARES, PLAN, STREAM, ...)                                                  \
     do {                                                                                                \
+        const int nt_ = 4 << (PLAN).twl;                                                                \
+        const dim3 grid_((PLAN).n_tiles + ((SHARES) ? kMaxHot * (nt_ / kHotGroup) : 0));                \
         if ((PLAN).twl == 8)                                                                            \
-            hipLaunchKernelGGL(KERNEL<1024>, dim3((PLAN).n_tiles), dim3(1024), 0, STREAM, __VA_ARGS__); \
+            hipLaunchKernelGGL(KERNEL<1024>, grid_, dim3(1024), 0, STREAM, __VA_ARGS__);                \
         else if ((PLAN).twl == 7)                                                                       \
-            hipLaunchKernelGGL(KERNEL<512>, dim3((PLAN).n_tiles), dim3(512), 0, STREAM, __VA_ARGS__);   \
+            hipLaunchKernelGGL(KERNEL<512>, grid_, dim3(512), 0, STREAM, __VA_ARGS__);                  \
         else                                                                                            \
-            hipLaunchKernelGGL(KERNEL<256>, dim3((PLAN).n_tiles), dim3(256), 0, STREAM, __VA_ARGS__);   \
+            hipLaunchKernelGGL(KERNEL<256>, grid_, dim3(256), 0, STREAM, __VA_ARGS__);                  \
     } while (0)
 
 } // namespace
@@ -629,7 +681,7 @@ int frlw_eci_encode(const frlw_events_t *ev, int H, int W, float *out_f32, uint8
         float v = acc;
         q.lut[n] = (v > 1.0f ? 1.0f : v) * 255.0f;
     }
-    LAUNCH_TILE(k_eci_tile, pt.plan, s, pt.records, pt.base, q);
+    LAUNCH_TILE(k_eci_tile, 0, pt.plan, s, pt.records, pt.base, q);
     HIP_TRY(hipGetLastError());
     return FRLW_OK;
 }
@@ -647,8 +699,8 @@ int frlw_ev_encode(const frlw_events_t *ev, int H, int W, int bins, int64_t t_en
     if (rc != FRLW_OK) return rc;
     EvParams q;
     q.H = H; q.W = W; q.twl = pt.plan.twl; q.tiles_x = pt.plan.tiles_x; q.bins = bins;
-    q.out_f32 = out_f32; q.out_u8 = out_u8;
-    LAUNCH_TILE(k_ev_tile, pt.plan, s, pt.records, pt.base, q);
+    q.hdr = pt.hdr; q.out_f32 = out_f32; q.out_u8 = out_u8;
+    LAUNCH_TILE(k_ev_tile, 1, pt.plan, s, pt.records, pt.base, q);
     HIP_TRY(hipGetLastError());
     return FRLW_OK;
 }
@@ -670,7 +722,7 @@ int frlw_sae_encode(const frlw_events_t *ev, int H, int W, const double *lamdas,
     for (int l = 0; l < n_lamda; ++l) q.lam[l] = (float)lamdas[l];
     q.nowf = (float)now;
     q.mem_in = mem_in; q.mem_out = mem_out; q.out_f32 = out_f32; q.out_u8 = out_u8;
-    LAUNCH_TILE(k_sae_tile, pt.plan, s, pt.records, pt.base, q);
+    LAUNCH_TILE(k_sae_tile, 0, pt.plan, s, pt.records, pt.base, q);
     HIP_TRY(hipGetLastError());
     return FRLW_OK;
 }
@@ -695,7 +747,7 @@ int frlw_taf_encode(const frlw_events_t *ev, int H, int W, int K, int64_t t_star
     q.flip = (flags & FRLW_TAF_U8_FLIP_K) ? 1 : 0;
     q.hdr = pt.hdr; q.state = state; q.view_f32 = view_f32; q.out_u8 = out_u8; q.leaky_thr = pt.leaky_thr;
     q.dbg = frlw::env_int("FRLW_DBG", 0);
-    LAUNCH_TILE(k_taf_tile, pt.plan, s, pt.records, pt.base, q);
+    LAUNCH_TILE(k_taf_tile, 1, pt.plan, s, pt.records, pt.base, q);
     HIP_TRY(hipGetLastError());
     return FRLW_OK;
 }

@@ -30,10 +30,16 @@ enum Kind : int { KIND_ECI = 0, KIND_EV = 1, KIND_SAE = 2, KIND_TAF = 3 };
 enum : int { ST_INDEX = 1, ST_POLARITY = 2 };
 
 // First kHeaderBytes of the workspace.
+constexpr int kMaxHot = 32;     // tiles per encode whose cells are split over several workgroups (skew)
+constexpr int kHotGroup = 32;   // threads (= 128 cells) per share of a hot tile
+constexpr int kSliceMult = 16;  // records per thread in one LDS counting-sort slice of the EV / TAF tile kernels
 struct WsHeader {
     int32_t status; // ST_* flags
     uint32_t pad;
     unsigned long long wmask; // bit w set <=> TAF window w holds at least one encoded event
+    uint32_t n_hot;           // tiles with more than hot_thr records (may exceed kMaxHot; only the listed ones are split)
+    uint32_t hot_thr;
+    uint32_t hot[kMaxHot];
 };
 constexpr size_t kHeaderBytes = 1024;
 static_assert(sizeof(WsHeader) <= kHeaderBytes, "header");
@@ -262,6 +268,7 @@ struct Plan {
     int bpw;          // batches of 64 events per wavefront
     long long chunk;  // events per partition workgroup = 1024 * bpw
     int units, slabs; // partition workgroups, slabs of 32
+    unsigned hot_thr; // a tile with more records than this is shared by several workgroups (EV / TAF)
     size_t off_counts, off_slabtot, off_base, off_tlut, off_leaky, off_records, bytes;
 };
 

@@ -122,7 +122,8 @@ __global__ __launch_bounds__(kWave) void k_slabscan(uint32_t *counts, int units,
 }
 
 // slabtot[s][b] -> exclusive prefix over s (in place); then exclusive scan over tiles -> base[0..n]
-__global__ __launch_bounds__(1024) void k_tilescan(uint32_t *slabtot, int slabs, int n, uint32_t *base)
+__global__ __launch_bounds__(1024) void k_tilescan(uint32_t *slabtot, int slabs, int n, uint32_t *base,
+                                                   WsHeader *hdr, uint32_t hot_thr)
 {
     __shared__ uint32_t tot[kMaxTiles];
     __shared__ uint32_t wsum[16];
@@ -140,7 +141,12 @@ __global__ __launch_bounds__(1024) void k_tilescan(uint32_t *slabtot, int slabs,
             }
         }
         tot[b] = run;
+        if (run > hot_thr) { // skewed stream: list the tile, its cells will be shared by several workgroups
+            const uint32_t slot = atomicAdd(&hdr->n_hot, 1u);
+            if (slot < (uint32_t)kMaxHot) hdr->hot[slot] = (uint32_t)b;
+        }
     }
+    if (tid == 0) hdr->hot_thr = hot_thr;
     __syncthreads();
     const int per = (n + 1023) / 1024;
     const int b0 = tid * per;
@@ -334,7 +340,7 @@ void launch_partition_m(const Decode &d, const Plan &p, uint32_t *counts, uint32
     hipLaunchKernelGGL((k_hist<LAYOUT, KIND, HAS_MAP>), dim3(p.units), dim3(kPartThreads), lds_hist, s, d, p.bpw, counts, hdr, tlut_w, leaky_w);
     hipLaunchKernelGGL(k_slabscan, dim3((p.n_tiles + kWave - 1) / kWave, p.slabs), dim3(kWave), 0, s, counts,
                        p.units, p.n_tiles, slabtot);
-    hipLaunchKernelGGL(k_tilescan, dim3(1), dim3(1024), 0, s, slabtot, p.slabs, p.n_tiles, base);
+    hipLaunchKernelGGL(k_tilescan, dim3(1), dim3(1024), 0, s, slabtot, p.slabs, p.n_tiles, base, hdr, p.hot_thr);
     hipLaunchKernelGGL((k_scatter<LAYOUT, KIND, HAS_MAP>), dim3(p.units), dim3(kPartThreads), lds_sc, s, d, p.bpw, counts,
                        slabtot, base, records, hdr);
 }
@@ -401,6 +407,10 @@ bool make_plan(long long n, int H, int W, Plan &p)
     p.off_leaky = off;   off = align_up(off + (size_t)kLeakyLevels * 4, 256);
     p.off_records = off; off = align_up(off + (size_t)(n > 0 ? n : 1) * 8, 256);
     p.bytes = off;
+    // more than two slices and more than 4x the mean: worth sharing (FRLW_HOT_THR: tests force the shared path)
+    const long long slice2 = 2ll * kSliceMult * (4 << p.twl), mean4 = 4 * (n / p.n_tiles);
+    const long long thr = slice2 > mean4 ? slice2 : mean4;
+    p.hot_thr = (unsigned)env_int("FRLW_HOT_THR", thr > 0x7fffffffll ? 0x7fffffff : (int)thr);
     return true;
 }
 

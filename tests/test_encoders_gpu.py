@@ -179,6 +179,32 @@ def test_taf_unsorted_stream(er, orc):
     assert_bitexact(host(view), oview, "unsorted taf view")
 
 
+@pytest.mark.parametrize("thr", [0, 300, 3000])
+def test_hot_tile_sharing_forced(er, orc, monkeypatch, thr):
+    """Skew path: with FRLW_HOT_THR forced low, (up to 32) tiles are shared by several workgroups, each summing
+    only its own 128 cells; more than 32 hot tiles -> the rest stay whole.  Same bits either way, EV and TAF,
+    sorted and shuffled streams."""
+    monkeypatch.setenv("FRLW_HOT_THR", str(thr))
+    H, W, K = 100, 300, 8
+    ev = synth.synth_events(31 + thr, 300_000, W, H, 80_000, hotspot=True)
+    dat = synth.to_dat8(ev)
+    st0 = np.random.default_rng(thr).uniform(-50, 0, size=(H, W, 2, K)).astype(np.float32)
+    oview, ost = orc.taf_stream_dat8(dat, (H, W), (H, W), K, 0, 10_000, 8, st0)
+    st = dev(st0)
+    _, view = er.encode_taf_dat(dat_dev(ev), (H, W), st, 0, 10_000, 8, K, want_view=True)
+    assert_bitexact(host(st), ost, "shared taf state")
+    assert_bitexact(host(view), oview, "shared taf view")
+    f32 = er.encode_ev_dat(dat_dev(ev), (H, W), 80_000, 80_000, volume_bins=5)[0]
+    assert_bitexact(host(f32), orc.ev_stream_dat8(dat, (H, W), (H, W), 5, 80_000, 80_000), "shared ev")
+    perm = np.random.default_rng(6).permutation(len(ev["t"]))
+    evs = {k: v[perm] for k, v in ev.items()}
+    dats = synth.to_dat8(evs)
+    oview, ost = orc.taf_stream_dat8(dats, (H, W), (H, W), K, 0, 10_000, 8, st0)
+    st = dev(st0)
+    er.encode_taf_dat(dat_dev(evs), (H, W), st, 0, 10_000, 8, K)
+    assert_bitexact(host(st), ost, "shared taf state, shuffled stream")
+
+
 def test_taf_outside_window_span(er, orc):
     """Events before t_start / after the last window fall into window 0 (generate_taf.py:197-203)."""
     H, W, K = 16, 40, 8
