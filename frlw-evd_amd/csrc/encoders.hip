@@ -34,66 +34,55 @@ namespace {
 constexpr int CPT = kCellsPerThread;
 constexpr int kMaxK = 8;
 
-struct Owner { // the cells of thread t in a tile of NT threads
-    int row[CPT];  // tile row of cell j
-    int lx, p;     // pixel column inside the tile, polarity
-    bool ok[CPT];
-    long long pix[CPT]; // y * W + x
+template <int C> struct Owner { // the C cells of thread t in a tile of NT threads
+    int row[C];  // tile row of cell j
+    int lx, p;   // pixel column inside the tile, polarity
+    bool ok[C];
+    long long pix[C]; // y * W + x
 };
 
-template <int NT>
-__device__ __forceinline__ Owner make_owner(const TileGeom &g, int W)
+// Cell c = t + NT * j = (row << (twl + 1)) | (lx << 1) | p with a row of NT / 2 cells.  A whole-tile workgroup
+// owns j = 0..3 (C = 4, j0 = 0); a quarter workgroup of a hot tile owns the single j = j0 (C = 1).
+template <int NT, int C>
+__device__ __forceinline__ Owner<C> make_owner(const TileGeom &g, int W, int j0)
 {
-    // cell c = t + NT * j = (row << (twl + 1)) | (lx << 1) | p with a row of NT / 2 cells
     constexpr int RL = NT / 2;
-    Owner o;
+    Owner<C> o;
     const int t = threadIdx.x;
     const int within = t & (RL - 1);
     o.lx = within >> 1;
     o.p = within & 1;
 #pragma unroll
-    for (int j = 0; j < CPT; ++j) {
-        o.row[j] = 2 * j + (t >= RL ? 1 : 0);
+    for (int j = 0; j < C; ++j) {
+        o.row[j] = 2 * (j0 + j) + (t >= RL ? 1 : 0);
         o.ok[j] = o.lx < g.nx && o.row[j] < g.ny;
         o.pix[j] = (long long)(g.y0 + o.row[j]) * W + g.x0 + o.lx;
     }
     return o;
 }
 
-// ---- skew: sharing a hot tile --------------------------------------------------------------------
-// The EV / TAF kernels are launched with kMaxHot * (NT / kHotGroup) extra workgroups in front of the per-tile
-// ones.  Extra workgroup (h, g) takes share g -- the cells of threads [32 g, 32 g + 32), 128 cells -- of the
-// h-th tile listed by k_tilescan: it streams the tile's whole record list but sorts and sums only its own cells
-// (per-cell sums are sequential by contract; cells are independent).  The tile's own workgroup does nothing.
-struct Share {
-    int tile;
-    int group; // -1: the whole tile
-};
-
-template <int NT>
-__device__ __forceinline__ bool pick_share(const WsHeader *hdr, const uint32_t *base, Share &sh)
+// ---- skew: hot tiles ---------------------------------------------------------------------------------
+// k_tilescan lists up to kMaxHot tiles that hold more than hot_thr records.  Their per-tile workgroups do
+// nothing; 4 * kMaxHot workgroups in front of them in the grid give each listed tile to four workgroups of NT threads with ONE cell
+// per thread (quarter q = the cells t + NT * q), i.e. four times the lanes on the per-cell sequential sums.
+// Each quarter streams the tile's whole record list and keeps only its own cells.
+__device__ __forceinline__ bool tile_is_listed(const WsHeader *hdr, const uint32_t *base, int tile)
 {
-    constexpr int S = NT / kHotGroup;
-    const int b = blockIdx.x;
+    if (base[tile + 1] - base[tile] <= hdr->hot_thr) return false;
     const uint32_t n_hot = hdr->n_hot < (uint32_t)kMaxHot ? hdr->n_hot : (uint32_t)kMaxHot;
-    if (b < kMaxHot * S) {
-        const int h = b / S;
-        if ((uint32_t)h >= n_hot) return false;
-        sh.tile = (int)hdr->hot[h];
-        sh.group = b - h * S;
-        return true;
-    }
-    sh.tile = b - kMaxHot * S;
-    sh.group = -1;
-    if (base[sh.tile + 1] - base[sh.tile] > hdr->hot_thr) // listed?  (more than kMaxHot hot tiles: the rest stay whole)
-        for (uint32_t h = 0; h < n_hot; ++h)
-            if ((int)hdr->hot[h] == sh.tile) return false;
-    return true;
+    for (uint32_t h = 0; h < n_hot; ++h) // more than kMaxHot hot tiles: the unlisted ones stay whole
+        if ((int)hdr->hot[h] == tile) return true;
+    return false;
 }
 
-__device__ __forceinline__ bool in_share(const Share &sh, uint32_t cell, uint32_t nt_mask)
+__device__ __forceinline__ bool pick_quarter(const WsHeader *hdr, int idx, int &tile, int &quarter)
 {
-    return sh.group < 0 || (int)((cell & nt_mask) / kHotGroup) == sh.group;
+    const int h = idx >> 2;
+    const uint32_t n_hot = hdr->n_hot < (uint32_t)kMaxHot ? hdr->n_hot : (uint32_t)kMaxHot;
+    if ((uint32_t)h >= n_hot) return false;
+    tile = (int)hdr->hot[h];
+    quarter = idx & 3;
+    return true;
 }
 
 #ifdef FRLW_TILE_PROF
@@ -110,44 +99,43 @@ __device__ unsigned long long g_prof[16];
 #endif
 
 // ---- slice counting sort shared by EV and TAF --------------------------------------------------
-// Sorts the records i in [s0, s0 + span) with pred(meta) by cell into slot[]; returns through
-// (c[j], o[j]) the length and offset of the segments of this thread's four cells.  `cnt` has NC entries.
+// Sorts the records i in [s0, s0 + span) that `sel` maps to a local cell (sel(meta) >= 0; local cell =
+// t + NT * j, j < C) by cell into slot[]; returns through (c[j], o[j]) the length and offset of the segments of
+// this thread's C cells.  `cnt` has NT * C entries.
 #ifndef FRLW_KBATCH
 #define FRLW_KBATCH 8
 #endif
 constexpr int kBatch = FRLW_KBATCH; // global loads in flight per thread in the two passes of slice_sort
-template <int NT, typename Pred>
-__device__ __forceinline__ void slice_sort(const uint2 *rec, uint32_t s0, uint32_t span, uint32_t cell_mask,
-                                           Pred pred, uint32_t *cnt, uint2 *slot,
-                                           uint32_t *red, bool counted, uint32_t (&c)[CPT], uint32_t (&o)[CPT],
-                                           int cb = 0)
+template <int NT, int C, typename Sel>
+__device__ __forceinline__ void slice_sort(const uint2 *rec, uint32_t s0, uint32_t span, Sel sel, uint32_t *cnt,
+                                           uint2 *slot, uint32_t *red, uint32_t (&c)[C], uint32_t (&o)[C], int cb = 0)
 {
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     constexpr int NW = NT / kWave;
     PROF_BEGIN;
-    if (!counted) {
 #pragma unroll
-        for (int j = 0; j < CPT; ++j) cnt[t + NT * j] = 0;
-        __syncthreads();
-        // batches of kBatch loads in flight per thread: the pass is bound by global-load latency
-        for (uint32_t i0 = s0 + t; i0 < s0 + span; i0 += kBatch * NT) {
-            uint32_t m[kBatch];
+    for (int j = 0; j < C; ++j) cnt[t + NT * j] = 0;
+    __syncthreads();
+    // batches of kBatch loads in flight per thread
+    for (uint32_t i0 = s0 + t; i0 < s0 + span; i0 += kBatch * NT) {
+        uint32_t m[kBatch];
 #pragma unroll
-            for (int u = 0; u < kBatch; ++u) {
-                const uint32_t i = i0 + u * NT;
-                m[u] = i < s0 + span ? rec[i].x : 0u;
-            }
-#pragma unroll
-            for (int u = 0; u < kBatch; ++u)
-                if (i0 + u * NT < s0 + span && pred(m[u])) atomicAdd(&cnt[m[u] & cell_mask], 1u);
+        for (int u = 0; u < kBatch; ++u) {
+            const uint32_t i = i0 + u * NT;
+            m[u] = i < s0 + span ? rec[i].x : 0u;
         }
-        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            const int cell = sel(m[u]);
+            if (i0 + u * NT < s0 + span && cell >= 0) atomicAdd(&cnt[cell], 1u);
+        }
     }
+    __syncthreads();
     PROF_MARK(1);
-    // exclusive scan in thread-major order: a thread's four segments are adjacent
+    // exclusive scan in thread-major order: a thread's segments are adjacent
     uint32_t tot = 0;
 #pragma unroll
-    for (int j = 0; j < CPT; ++j) { c[j] = cnt[t + NT * j]; tot += c[j]; }
+    for (int j = 0; j < C; ++j) { c[j] = cnt[t + NT * j]; tot += c[j]; }
     uint32_t inc = tot;
 #pragma unroll
     for (int off = 1; off < kWave; off <<= 1) {
@@ -159,12 +147,11 @@ __device__ __forceinline__ void slice_sort(const uint2 *rec, uint32_t s0, uint32
     uint32_t run = inc - tot;
     for (int k = 0; k < wv && k < NW; ++k) run += red[16 + k];
 #pragma unroll
-    for (int j = 0; j < CPT; ++j) { o[j] = run; cnt[t + NT * j] = run; run += c[j]; }
+    for (int j = 0; j < C; ++j) { o[j] = run; cnt[t + NT * j] = run; run += c[j]; }
     __syncthreads();
     PROF_MARK(2);
     // Rounds of NT records with a barrier in between: slots of a later round always come after those
-    // of an earlier one, so a cell's segment is out of order only among the few records of one round
-    // (the per-segment insertion sort stays linear even for a hot pixel).
+    // of an earlier one, so a cell's segment is out of order only among the few records of one round.
     for (uint32_t g0 = s0; g0 < s0 + span; g0 += kBatch * NT) {
         uint2 r[kBatch]; // the loads of kBatch rounds are issued together
 #pragma unroll
@@ -176,8 +163,9 @@ __device__ __forceinline__ void slice_sort(const uint2 *rec, uint32_t s0, uint32
         for (int u = 0; u < kBatch; ++u) {
             if (g0 + u * NT >= s0 + span) break; // block-uniform
             const uint32_t i = g0 + u * NT + t;
-            if (i < s0 + span && pred(r[u].x)) {
-                const uint32_t sl = atomicAdd(&cnt[r[u].x & cell_mask], 1u);
+            const int cell = sel(r[u].x);
+            if (i < s0 + span && cell >= 0) {
+                const uint32_t sl = atomicAdd(&cnt[cell], 1u);
                 // one 8-byte LDS entry per record: {value bits, position in the slice << 8 | window}
                 slot[sl] = make_uint2(r[u].y, ((i - s0) << 8) | ((r[u].x >> cb) & 255u));
             }
@@ -187,35 +175,35 @@ __device__ __forceinline__ void slice_sort(const uint2 *rec, uint32_t s0, uint32
     PROF_MARK(3);
 }
 
-// Slots were handed out by LDS atomics in arrival order; restore stream order inside the four segments
+// Slots were handed out by LDS atomics in arrival order; restore stream order inside the C segments
 // of this thread.  Only records of the same round (NT consecutive records) can be swapped, so a segment
-// is a run of tiny permuted blocks -- nearly always pairs.  One bubble pass, the four cells in lock-step
-// (four independent LDS reads in flight per step, no divergent loop), repairs every adjacent inversion;
+// is a run of tiny permuted blocks -- nearly always pairs.  One bubble pass, the cells in lock-step
+// (independent LDS reads in flight per step, selects instead of branches), repairs every adjacent inversion;
 // a segment it cannot repair (an element that has to move two or more places: three or more records of
 // one pixel within NT events) is finished by an insertion sort afterwards.
-__device__ __forceinline__ void segments_order(const uint32_t (&c)[CPT], const uint32_t (&o)[CPT], uint2 *slot,
+template <int C>
+__device__ __forceinline__ void segments_order(const uint32_t (&c)[C], const uint32_t (&o)[C], uint2 *slot,
                                                uint32_t last_slot)
 {
-    uint32_t maxc = 0, below[CPT];
-    uint2 top[CPT]; // largest element so far = what slot[o + x - 1] holds
-    bool deep[CPT];
+    uint32_t maxc = 0, below[C];
+    uint2 top[C]; // largest element so far = what slot[o + x - 1] holds
+    bool deep[C];
 #pragma unroll
-    for (int j = 0; j < CPT; ++j) {
+    for (int j = 0; j < C; ++j) {
         maxc = c[j] > maxc ? c[j] : maxc;
         top[j] = make_uint2(0u, 0u);
         below[j] = 0u;
         deep[j] = false;
     }
     for (uint32_t x = 0; x < maxc; ++x) {
-        uint2 e[CPT];
+        uint2 e[C];
 #pragma unroll
-        for (int j = 0; j < CPT; ++j) {
+        for (int j = 0; j < C; ++j) {
             const uint32_t at = o[j] + x;
             e[j] = slot[at < last_slot ? at : last_slot];
         }
-        // written with selects, not branches: the loop is bound by instruction issue
 #pragma unroll
-        for (int j = 0; j < CPT; ++j) {
+        for (int j = 0; j < C; ++j) {
             const bool live = x < c[j];
             const bool inv = live && e[j].y < top[j].y; // .y orders by position in the slice
             const bool fwd = live && !inv;
@@ -230,7 +218,7 @@ __device__ __forceinline__ void segments_order(const uint32_t (&c)[CPT], const u
         }
     }
 #pragma unroll
-    for (int j = 0; j < CPT; ++j) {
+    for (int j = 0; j < C; ++j) {
         if (!deep[j]) continue;
         for (uint32_t x = 1; x < c[j]; ++x) {
             const uint2 e = slot[o[j] + x];
@@ -239,6 +227,15 @@ __device__ __forceinline__ void segments_order(const uint32_t (&c)[CPT], const u
             slot[o[j] + b] = e;
         }
     }
+}
+
+// local cell of a record for a workgroup that owns the cells j0 .. j0 + C - 1 of every thread (-1: not ours)
+template <int NT, int C>
+__device__ __forceinline__ int local_cell(uint32_t meta, int j0)
+{
+    const int cell = (int)(meta & (uint32_t)(NT * kCellsPerThread - 1));
+    if (C == kCellsPerThread) return cell;
+    return (cell / NT) == j0 ? (cell & (NT - 1)) : -1;
 }
 
 template <int NT> struct TileLds {
@@ -267,7 +264,7 @@ __global__ __launch_bounds__(NT) void k_eci_tile(const uint2 *rec, const uint32_
     for (uint32_t i = beg + t; i < end; i += NT) atomicAdd(&cnt[rec[i].x & (NC - 1)], 1u);
     __syncthreads();
     const TileGeom g = tile_geom(tile, q.tiles_x, q.twl, q.H, q.W);
-    const Owner ow = make_owner<NT>(g, q.W);
+    const Owner<CPT> ow = make_owner<NT, CPT>(g, q.W, 0);
     const long long plane = (long long)q.H * q.W;
 #pragma unroll
     for (int j = 0; j < CPT; ++j) {
@@ -310,7 +307,7 @@ __global__ __launch_bounds__(NT) void k_sae_tile(const uint2 *rec, const uint32_
     }
     __syncthreads();
     const TileGeom g = tile_geom(tile, q.tiles_x, q.twl, q.H, q.W);
-    const Owner ow = make_owner<NT>(g, q.W);
+    const Owner<CPT> ow = make_owner<NT, CPT>(g, q.W, 0);
     const long long plane = (long long)q.H * q.W;
     const float init = (0.0f + q.nowf) - 5000000.0f; // generate_surfaceofactiveevents.py:48
 #pragma unroll
@@ -343,43 +340,35 @@ struct EvParams {
     uint8_t *out_u8;
 };
 
-template <int NT>
-__global__ __launch_bounds__(NT) void k_ev_tile(const uint2 *rec, const uint32_t *base, EvParams q)
+template <int NT, int C>
+__device__ __forceinline__ void ev_tile_body(const uint2 *rec, const uint32_t *base, const EvParams &q, int tile, int j0,
+                                             uint32_t *cnt, uint2 *slot, uint32_t *red)
 {
-    constexpr int NC = NT * CPT;
     constexpr int SLICE = TileLds<NT>::SLICE;
-    __shared__ uint32_t cnt[NC];
-    __shared__ uint2 slot[SLICE];
-    __shared__ uint32_t red[32];
-    Share sh;
-    if (!pick_share<NT>(q.hdr, base, sh)) return;
-    const int t = threadIdx.x, tile = sh.tile;
-    const bool mine = sh.group < 0 || t / kHotGroup == sh.group;
     const uint32_t beg = base[tile], end = base[tile + 1];
-    float acc[CPT][kMaxK]; // cell (pixel, polarity) x time bin
+    float acc[C][kMaxK]; // cell (pixel, polarity) x time bin
 #pragma unroll
-    for (int j = 0; j < CPT; ++j)
+    for (int j = 0; j < C; ++j)
 #pragma unroll
         for (int k = 0; k < kMaxK; ++k) acc[j][k] = 0.0f;
     const float binsf = (float)q.bins;
     for (uint32_t s0 = beg; s0 < end; s0 += SLICE) {
         const uint32_t span = end - s0 < (uint32_t)SLICE ? end - s0 : (uint32_t)SLICE;
-        uint32_t c[CPT], o[CPT];
-        slice_sort<NT>(rec, s0, span, NC - 1, [=](uint32_t m) { return in_share(sh, m, NT - 1); }, cnt, slot, red,
-                       false, c, o);
-        segments_order(c, o, slot, SLICE - 1);
+        uint32_t c[C], o[C];
+        slice_sort<NT, C>(rec, s0, span, [=](uint32_t m) { return local_cell<NT, C>(m, j0); }, cnt, slot, red, c, o);
+        segments_order<C>(c, o, slot, SLICE - 1);
         uint32_t maxc = 0;
 #pragma unroll
-        for (int j = 0; j < CPT; ++j) maxc = c[j] > maxc ? c[j] : maxc;
+        for (int j = 0; j < C; ++j) maxc = c[j] > maxc ? c[j] : maxc;
         for (uint32_t a = 0; a < maxc; ++a) {
-            uint32_t tv[CPT];
+            uint32_t tv[C];
 #pragma unroll
-            for (int j = 0; j < CPT; ++j) {
+            for (int j = 0; j < C; ++j) {
                 const uint32_t at = o[j] + a;
                 tv[j] = slot[at < SLICE - 1 ? at : SLICE - 1].x;
             }
 #pragma unroll
-            for (int j = 0; j < CPT; ++j) {
+            for (int j = 0; j < C; ++j) {
                 const bool live = a < c[j];
                 const float ts = binsf * __uint_as_float(tv[j]); // t* = bins * float(t), generate_eventvolume.py:23
 #pragma unroll
@@ -394,12 +383,12 @@ __global__ __launch_bounds__(NT) void k_ev_tile(const uint2 *rec, const uint32_t
         __syncthreads();
     }
     const TileGeom g = tile_geom(tile, q.tiles_x, q.twl, q.H, q.W);
-    const Owner ow = make_owner<NT>(g, q.W);
+    const Owner<C> ow = make_owner<NT, C>(g, q.W, j0);
     const long long plane = (long long)q.H * q.W;
     const int ch = ow.p ? 0 : 1; // weights [p, 1 - p]: channel 0 = p == 1
 #pragma unroll
-    for (int j = 0; j < CPT; ++j) {
-        if (ow.ok[j] && mine) {
+    for (int j = 0; j < C; ++j) {
+        if (ow.ok[j]) {
 #pragma unroll
             for (int k = 0; k < kMaxK; ++k) {
                 if (k < q.bins) {
@@ -410,6 +399,25 @@ __global__ __launch_bounds__(NT) void k_ev_tile(const uint2 *rec, const uint32_t
                 }
             }
         }
+    }
+}
+
+// grid = 4 * kMaxHot + n_tiles: the four quarters of every listed hot tile, then one workgroup per tile
+template <int NT>
+__global__ __launch_bounds__(NT) void k_ev_tile(const uint2 *rec, const uint32_t *base, EvParams q, int n_tiles)
+{
+    __shared__ uint32_t cnt[NT * CPT];
+    __shared__ uint2 slot[TileLds<NT>::SLICE];
+    __shared__ uint32_t red[32];
+    (void)n_tiles;
+    if ((int)blockIdx.x >= 4 * kMaxHot) {
+        const int tile = (int)blockIdx.x - 4 * kMaxHot;
+        if (tile_is_listed(q.hdr, base, tile)) return; // hot: left to its quarters
+        ev_tile_body<NT, CPT>(rec, base, q, tile, 0, cnt, slot, red);
+    } else { // the long-running workgroups come first in the grid
+        int tile, quarter;
+        if (!pick_quarter(q.hdr, (int)blockIdx.x, tile, quarter)) return;
+        ev_tile_body<NT, 1>(rec, base, q, tile, quarter, cnt, slot, red);
     }
 }
 
@@ -438,37 +446,26 @@ __device__ __forceinline__ void taf_fifo(float (&st)[kMaxK], int K, uint32_t n, 
     }
 }
 
-template <int NT>
-__global__ __launch_bounds__(NT) void k_taf_tile(const uint2 *rec, const uint32_t *base, TafParams q)
+template <int NT, int C>
+__device__ __forceinline__ void taf_tile_body(const uint2 *rec, const uint32_t *base, const TafParams &q, int tile,
+                                              int j0, uint32_t *cnt, uint2 *slot, uint32_t *red, uint32_t *thr)
 {
-    constexpr int NC = NT * CPT;
     constexpr int SLICE = TileLds<NT>::SLICE;
-    constexpr int NW = NT / kWave;
-    __shared__ uint32_t cnt[NC];
-    __shared__ uint2 slot[SLICE];
-    __shared__ uint32_t red[48];
-    __shared__ uint32_t thr[kLeakyLevels];
-    Share sh;
-    if (!pick_share<NT>(q.hdr, base, sh)) return;
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const int tile = sh.tile;
+    const int t = threadIdx.x;
     const int K = q.K;
     for (int i = t; i < kLeakyLevels; i += NT) thr[i] = q.leaky_thr[i];
     const int cb = q.twl + 4; // cell bits
     const TileGeom g = tile_geom(tile, q.tiles_x, q.twl, q.H, q.W);
-    Owner ow = make_owner<NT>(g, q.W);
-    if (sh.group >= 0 && t / kHotGroup != sh.group) { // a share: the other threads own nothing
-#pragma unroll
-        for (int j = 0; j < CPT; ++j) ow.ok[j] = false;
-    }
+    const Owner<C> ow = make_owner<NT, C>(g, q.W, j0);
     const uint32_t beg = base[tile], end = base[tile + 1];
     const unsigned long long wmask = q.hdr->wmask; // windows that hold events (anywhere in the frame)
-    float st[CPT][kMaxK], sum[CPT];
-    uint32_t num[CPT];
+    float st[C][kMaxK], sum[C];
+    uint32_t num[C];
+    const auto sel = [=](uint32_t m) { return local_cell<NT, C>(m, j0); };
 
     auto load_state = [&]() {
 #pragma unroll
-        for (int j = 0; j < CPT; ++j) {
+        for (int j = 0; j < C; ++j) {
             const float *src = q.state + (ow.pix[j] * 2 + ow.p) * K;
 #pragma unroll
             for (int k = 0; k < kMaxK; ++k) st[j][k] = 0.0f;
@@ -486,12 +483,12 @@ __global__ __launch_bounds__(NT) void k_taf_tile(const uint2 *rec, const uint32_
             num[j] = 0u;
         }
     };
-    // closes window w for the four cells: FIFO step (skipped when the window is empty in the whole
+    // closes window w for the thread's cells: FIFO step (skipped when the window is empty in the whole
     // frame, generate_taf.py:40-41), accumulators back to zero
     auto close_window = [&](int w) {
         const bool has = ((wmask >> w) & 1ull) && !(q.dbg & 2);
 #pragma unroll
-        for (int j = 0; j < CPT; ++j) {
+        for (int j = 0; j < C; ++j) {
             if (has) taf_fifo(st[j], K, num[j], sum[j]);
             sum[j] = 0.0f;
             num[j] = 0u;
@@ -510,30 +507,29 @@ __global__ __launch_bounds__(NT) void k_taf_tile(const uint2 *rec, const uint32_
         const int wlo = (int)(rec[s0].x >> cb), whi = (int)(rec[s0 + span - 1].x >> cb);
         if (wlo < cur_w || whi < wlo || whi >= q.n_windows) { bad = true; break; }
         for (; cur_w < wlo; ++cur_w) close_window(cur_w);
-        uint32_t c[CPT], o[CPT], a[CPT];
+        uint32_t c[C], o[C], a[C];
         PROF_MARK(0);
         if (q.dbg & 8) continue;
-        slice_sort<NT>(rec, s0, span, NC - 1, [=](uint32_t m) { return in_share(sh, m, NT - 1); }, cnt, slot, red,
-                       false, c, o, cb);
+        slice_sort<NT, C>(rec, s0, span, sel, cnt, slot, red, c, o, cb);
         if (q.dbg & 4) continue;
         PROF_RESET;
-        segments_order(c, o, slot, SLICE - 1);
+        segments_order<C>(c, o, slot, SLICE - 1);
         PROF_MARK(4);
 #pragma unroll
-        for (int j = 0; j < CPT; ++j) a[j] = 0;
+        for (int j = 0; j < C; ++j) a[j] = 0;
         for (int w = wlo; w <= whi; ++w) {
-            // the four cells advance together: one LDS read each per step, until none of them has a
+            // the cells advance together: one LDS read each per step, until none of them has a
             // record of window w next
             for (;;) {
-                uint2 e[CPT];
+                uint2 e[C];
 #pragma unroll
-                for (int j = 0; j < CPT; ++j) {
+                for (int j = 0; j < C; ++j) {
                     const uint32_t at = o[j] + a[j];
                     e[j] = slot[at < SLICE - 1 ? at : SLICE - 1];
                 }
                 uint32_t any = 0u;
 #pragma unroll
-                for (int j = 0; j < CPT; ++j) {
+                for (int j = 0; j < C; ++j) {
                     const bool take = a[j] < c[j] && (int)(e[j].y & 255u) == w;
                     const float nsum = sum[j] + __uint_as_float(e[j].x); // sum += t - 1 in stream order, generate_taf.py:26
                     sum[j] = take ? nsum : sum[j];
@@ -548,7 +544,7 @@ __global__ __launch_bounds__(NT) void k_taf_tile(const uint2 *rec, const uint32_
         PROF_MARK(5);
         bool viol = false; // a record whose window runs backwards inside its cell's segment
 #pragma unroll
-        for (int j = 0; j < CPT; ++j) viol |= a[j] != c[j];
+        for (int j = 0; j < C; ++j) viol |= a[j] != c[j];
         if (__syncthreads_or(viol)) { bad = true; break; }
         PROF_MARK(6);
     }
@@ -564,13 +560,12 @@ __global__ __launch_bounds__(NT) void k_taf_tile(const uint2 *rec, const uint32_
         for (int w = 0; w < q.n_windows; ++w) {
             for (uint32_t s0 = beg; s0 < end; s0 += SLICE) {
                 const uint32_t span = end - s0 < (uint32_t)SLICE ? end - s0 : (uint32_t)SLICE;
-                uint32_t c[CPT], o[CPT];
-                slice_sort<NT>(rec, s0, span, NC - 1,
-                               [=](uint32_t m) { return (int)(m >> cb) == w && in_share(sh, m, NT - 1); }, cnt, slot,
-                               red, false, c, o, cb);
-                segments_order(c, o, slot, SLICE - 1);
+                uint32_t c[C], o[C];
+                slice_sort<NT, C>(rec, s0, span, [=](uint32_t m) { return (int)(m >> cb) == w ? sel(m) : -1; }, cnt, slot,
+                                  red, c, o, cb);
+                segments_order<C>(c, o, slot, SLICE - 1);
 #pragma unroll
-                for (int j = 0; j < CPT; ++j) {
+                for (int j = 0; j < C; ++j) {
                     for (uint32_t x = 0; x < c[j]; ++x) sum[j] = sum[j] + __uint_as_float(slot[o[j] + x].x);
                     num[j] += c[j];
                 }
@@ -579,12 +574,11 @@ __global__ __launch_bounds__(NT) void k_taf_tile(const uint2 *rec, const uint32_
             close_window(w);
         }
     }
-    (void)lane; (void)wv; (void)NW;
 
     // ---- write-out: state, optional f32 view (2K, H, W), optional uint8 leaky transform
     const long long plane = (long long)q.H * q.W;
 #pragma unroll
-    for (int j = 0; j < CPT; ++j) {
+    for (int j = 0; j < C; ++j) {
         if (!ow.ok[j]) continue;
         float *dst = q.state + (ow.pix[j] * 2 + ow.p) * K;
         if (K == 8) {
@@ -614,18 +608,39 @@ __global__ __launch_bounds__(NT) void k_taf_tile(const uint2 *rec, const uint32_
     PROF_MARK(8);
 }
 
-// SHARES = 1: kMaxHot * (NT / kHotGroup) workgroups in front of the per-tile ones take the shares of hot tiles
-#define LAUNCH_TILE(KERNEL, SHARES, PLAN, STREAM, ...)                                                  \
+// grid = 4 * kMaxHot + n_tiles: the four quarters of every listed hot tile, then one workgroup per tile
+template <int NT>
+__global__ __launch_bounds__(NT) void k_taf_tile(const uint2 *rec, const uint32_t *base, TafParams q, int n_tiles)
+{
+    __shared__ uint32_t cnt[NT * CPT];
+    __shared__ uint2 slot[TileLds<NT>::SLICE];
+    __shared__ uint32_t red[48];
+    __shared__ uint32_t thr[kLeakyLevels];
+    (void)n_tiles;
+    if ((int)blockIdx.x >= 4 * kMaxHot) {
+        const int tile = (int)blockIdx.x - 4 * kMaxHot;
+        if (tile_is_listed(q.hdr, base, tile)) return; // hot: left to its quarters
+        taf_tile_body<NT, CPT>(rec, base, q, tile, 0, cnt, slot, red, thr);
+    } else { // the long-running workgroups come first in the grid
+        int tile, quarter;
+        if (!pick_quarter(q.hdr, (int)blockIdx.x, tile, quarter)) return;
+        taf_tile_body<NT, 1>(rec, base, q, tile, quarter, cnt, slot, red, thr);
+    }
+}
+
+#define LAUNCH_TILE_GRID(KERNEL, GRID, PLAN, STREAM, ...)                                               \
     do {                                                                                                \
-        const int nt_ = 4 << (PLAN).twl;                                                                \
-        const dim3 grid_((PLAN).n_tiles + ((SHARES) ? kMaxHot * (nt_ / kHotGroup) : 0));                \
         if ((PLAN).twl == 8)                                                                            \
-            hipLaunchKernelGGL(KERNEL<1024>, grid_, dim3(1024), 0, STREAM, __VA_ARGS__);                \
+            hipLaunchKernelGGL(KERNEL<1024>, dim3(GRID), dim3(1024), 0, STREAM, __VA_ARGS__);           \
         else if ((PLAN).twl == 7)                                                                       \
-            hipLaunchKernelGGL(KERNEL<512>, grid_, dim3(512), 0, STREAM, __VA_ARGS__);                  \
+            hipLaunchKernelGGL(KERNEL<512>, dim3(GRID), dim3(512), 0, STREAM, __VA_ARGS__);             \
         else                                                                                            \
-            hipLaunchKernelGGL(KERNEL<256>, grid_, dim3(256), 0, STREAM, __VA_ARGS__);                  \
+            hipLaunchKernelGGL(KERNEL<256>, dim3(GRID), dim3(256), 0, STREAM, __VA_ARGS__);             \
     } while (0)
+#define LAUNCH_TILE(KERNEL, PLAN, STREAM, ...) LAUNCH_TILE_GRID(KERNEL, (PLAN).n_tiles, PLAN, STREAM, __VA_ARGS__)
+// with the four quarters of every listed hot tile in front of the per-tile workgroups (skew)
+#define LAUNCH_TILE_Q(KERNEL, PLAN, STREAM, ...) \
+    LAUNCH_TILE_GRID(KERNEL, (PLAN).n_tiles + kMaxHot * 4, PLAN, STREAM, __VA_ARGS__, (PLAN).n_tiles)
 
 } // namespace
 
@@ -681,7 +696,7 @@ int frlw_eci_encode(const frlw_events_t *ev, int H, int W, float *out_f32, uint8
         float v = acc;
         q.lut[n] = (v > 1.0f ? 1.0f : v) * 255.0f;
     }
-    LAUNCH_TILE(k_eci_tile, 0, pt.plan, s, pt.records, pt.base, q);
+    LAUNCH_TILE(k_eci_tile, pt.plan, s, pt.records, pt.base, q);
     HIP_TRY(hipGetLastError());
     return FRLW_OK;
 }
@@ -700,7 +715,7 @@ int frlw_ev_encode(const frlw_events_t *ev, int H, int W, int bins, int64_t t_en
     EvParams q;
     q.H = H; q.W = W; q.twl = pt.plan.twl; q.tiles_x = pt.plan.tiles_x; q.bins = bins;
     q.hdr = pt.hdr; q.out_f32 = out_f32; q.out_u8 = out_u8;
-    LAUNCH_TILE(k_ev_tile, 1, pt.plan, s, pt.records, pt.base, q);
+    LAUNCH_TILE_Q(k_ev_tile, pt.plan, s, pt.records, pt.base, q);
     HIP_TRY(hipGetLastError());
     return FRLW_OK;
 }
@@ -722,7 +737,7 @@ int frlw_sae_encode(const frlw_events_t *ev, int H, int W, const double *lamdas,
     for (int l = 0; l < n_lamda; ++l) q.lam[l] = (float)lamdas[l];
     q.nowf = (float)now;
     q.mem_in = mem_in; q.mem_out = mem_out; q.out_f32 = out_f32; q.out_u8 = out_u8;
-    LAUNCH_TILE(k_sae_tile, 0, pt.plan, s, pt.records, pt.base, q);
+    LAUNCH_TILE(k_sae_tile, pt.plan, s, pt.records, pt.base, q);
     HIP_TRY(hipGetLastError());
     return FRLW_OK;
 }
@@ -747,7 +762,7 @@ int frlw_taf_encode(const frlw_events_t *ev, int H, int W, int K, int64_t t_star
     q.flip = (flags & FRLW_TAF_U8_FLIP_K) ? 1 : 0;
     q.hdr = pt.hdr; q.state = state; q.view_f32 = view_f32; q.out_u8 = out_u8; q.leaky_thr = pt.leaky_thr;
     q.dbg = frlw::env_int("FRLW_DBG", 0);
-    LAUNCH_TILE(k_taf_tile, 1, pt.plan, s, pt.records, pt.base, q);
+    LAUNCH_TILE_Q(k_taf_tile, pt.plan, s, pt.records, pt.base, q);
     HIP_TRY(hipGetLastError());
     return FRLW_OK;
 }

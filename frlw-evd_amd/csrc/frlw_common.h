@@ -31,7 +31,6 @@ enum : int { ST_INDEX = 1, ST_POLARITY = 2 };
 
 // First kHeaderBytes of the workspace.
 constexpr int kMaxHot = 32;     // tiles per encode whose cells are split over several workgroups (skew)
-constexpr int kHotGroup = 32;   // threads (= 128 cells) per share of a hot tile
 constexpr int kSliceMult = 16;  // records per thread in one LDS counting-sort slice of the EV / TAF tile kernels
 struct WsHeader {
     int32_t status; // ST_* flags
