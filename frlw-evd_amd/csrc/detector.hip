@@ -254,6 +254,83 @@ __global__ void k_focus(const float *x, int B, int C, int H, int W, float *y)
     }
 }
 
+// BFM stem, per-pixel part (core/Others/Temporal_Active_Focus.py:62-127, Temporal_Active_Focus_connect.forward
+// up to `self.patch`): log2(TC) grouped 1x1 convolutions (weight norm already applied) + ReLU, the first 4
+// channels of every stage concatenated (ER = 4 log2(TC) channels), residual MLP ER -> 4 ER -> ER with SiLU
+// (Dropout2d = identity in eval), written straight in the Focus layout NHWC (B, H/2, W/2, 4 ER), channel blocks
+// TL, BL, TR, BR.  One thread per input pixel, everything in registers, weights broadcast from LDS.
+// Stage i: tc = TC >> i time groups; inputs per group 2 * (i == 0 ? 2 : 4), outputs per group 4, tc / 2 groups.
+template <int TC> struct BfmDims {
+    static constexpr int R = TC == 2 ? 1 : (TC == 4 ? 2 : 3);
+    static constexpr int ER = 4 * R;
+    static constexpr int stage_in(int i) { return (i == 0 ? 2 : 4) * (TC >> i); }
+    static constexpr int stage_out(int i) { return 2 * (TC >> i); }
+    static constexpr int stage_ing(int i) { return 2 * (i == 0 ? 2 : 4); }
+    static constexpr int stage_off(int i) { return i == 0 ? 0 : stage_off(i - 1) + stage_out(i - 1) * stage_ing(i - 1) + stage_out(i - 1); }
+    static constexpr int up_off = stage_off(R);
+    static constexpr int down_off = up_off + 4 * ER * ER + 4 * ER;
+    static constexpr int total = down_off + ER * 4 * ER + ER;
+};
+
+// stage I of the grouped 1x1 stack: v[0 .. n_in) -> ReLU(W v + b) in v[0 .. n_out), first four outputs to cat
+template <int TC, int I>
+__device__ __forceinline__ void bfm_stage(float (&v)[2 * TC], float (&cat)[4 * BfmDims<TC>::R], const float *w)
+{
+    using D = BfmDims<TC>;
+    if constexpr (I < D::R) {
+        constexpr int n_out = D::stage_out(I), in_g = D::stage_ing(I);
+        const float *wi = w + D::stage_off(I), *bi = wi + n_out * in_g;
+        float nxt[n_out];
+#pragma unroll
+        for (int oc = 0; oc < n_out; ++oc) {
+            float acc = bi[oc];
+#pragma unroll
+            for (int k = 0; k < in_g; ++k) acc += wi[oc * in_g + k] * v[(oc >> 2) * in_g + k];
+            nxt[oc] = acc > 0.0f ? acc : 0.0f;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) cat[4 * I + c] = nxt[c];
+#pragma unroll
+        for (int c = 0; c < n_out; ++c) v[c] = nxt[c];
+        bfm_stage<TC, I + 1>(v, cat, w);
+    }
+}
+
+template <int TC>
+__global__ __launch_bounds__(256) void k_bfm_stem(const float *x, int B, int H, int W, const float *wts, float *y)
+{
+    using D = BfmDims<TC>;
+    constexpr int C = 2 * TC, ER = D::ER;
+    __shared__ float w[D::total];
+    for (int i = threadIdx.x; i < D::total; i += 256) w[i] = wts[i];
+    __syncthreads();
+    const long long total = (long long)B * H * W;
+    for (long long o = blockIdx.x * 256ll + threadIdx.x; o < total; o += (long long)gridDim.x * 256) {
+        const int ix = (int)(o % W), iy = (int)((o / W) % H), b = (int)(o / ((long long)W * H));
+        float v[C], cat[ER], out[ER];
+#pragma unroll
+        for (int c = 0; c < C; ++c) v[c] = x[(((long long)b * C + c) * H + iy) * W + ix];
+        bfm_stage<TC, 0>(v, cat, w);
+        const float *wu = w + D::up_off, *bu = wu + 4 * ER * ER;
+        const float *wd = w + D::down_off, *bd = wd + ER * 4 * ER;
+#pragma unroll
+        for (int c = 0; c < ER; ++c) out[c] = bd[c];
+#pragma unroll 4
+        for (int h = 0; h < 4 * ER; ++h) { // one hidden unit at a time: trans_up row, SiLU, trans_down column
+            float acc = bu[h];
+#pragma unroll
+            for (int c = 0; c < ER; ++c) acc += wu[h * ER + c] * cat[c];
+            const float hv = acc / (1.0f + expf(-acc));
+#pragma unroll
+            for (int c = 0; c < ER; ++c) out[c] += wd[c * 4 * ER + h] * hv;
+        }
+        const int q = (iy & 1) + 2 * (ix & 1); // 0 TL, 1 BL, 2 TR, 3 BR
+        float *dst = y + ((((long long)b * (H / 2) + (iy >> 1)) * (W / 2) + (ix >> 1)) * 4 + q) * ER;
+#pragma unroll
+        for (int c = 0; c < ER; ++c) dst[c] = cat[c] + out[c];
+    }
+}
+
 // nearest x2 upsample of an NHWC channel slice into another slice
 __global__ void k_upsample2x(const float *x, int B, int H, int W, int C, int x_cs, int x_co, float *y, int y_cs, int y_co)
 {
@@ -469,7 +546,7 @@ __global__ __launch_bounds__(1024) void k_decode_nms(DecodeArgs a)
 }
 
 // ---- plan ------------------------------------------------------------------------------------------
-enum OpType : int { OP_CONV = 0, OP_FOCUS = 1, OP_UPSAMPLE = 2, OP_SPP = 3, OP_DECODE = 4, OP_FORK = 5, OP_JOIN = 6 };
+enum OpType : int { OP_CONV = 0, OP_FOCUS = 1, OP_UPSAMPLE = 2, OP_SPP = 3, OP_DECODE = 4, OP_FORK = 5, OP_JOIN = 6, OP_BFM = 7 };
 constexpr int kSideLanes = 2; // independent sub-graphs (the head levels) run on side streams
 
 struct Op {
@@ -479,6 +556,7 @@ struct Op {
     ConvArgs conv;          // pointers x / y / res filled at run time; w / bias are baked
     int C, H, W, cs_src, co_src, cs_dst, co_dst;
     DecodeArgs dec; int decoded_buf, dets_buf, counts_buf;
+    const float *bfm_w;     // OP_BFM: packed weights (device)
 };
 
 int grid_1d(long long n) { long long g = (n + 255) / 256; if (g > 4096) g = 4096; if (g < 1) g = 1; return (int)g; }
@@ -546,6 +624,30 @@ int frlw_det_add_focus(frlw_detector_t *d, int src_buf, int C, int H, int W, int
     if (!d || C < 1 || (H & 1) || (W & 1)) return FRLW_ERR_ARG;
     Op op = {};
     op.type = OP_FOCUS; op.src = src_buf; op.dst = dst_buf; op.C = C; op.H = H; op.W = W;
+    op.lane = d->cur_lane;
+    d->ops.push_back(op);
+    return FRLW_OK;
+}
+
+int frlw_det_bfm_weight_count(int C)
+{
+    switch (C) {
+    case 4: return BfmDims<2>::total;
+    case 8: return BfmDims<4>::total;
+    case 16: return BfmDims<8>::total;
+    default: return 0;
+    }
+}
+
+int frlw_det_add_bfm_stem(frlw_detector_t *d, int src_buf, int C, int H, int W, const float *weights, int n_weights,
+                          int dst_buf)
+{
+    if (!d || !weights || (H & 1) || (W & 1)) return FRLW_ERR_ARG;
+    const int want = frlw_det_bfm_weight_count(C);
+    if (want == 0) return FRLW_ERR_UNSUPPORTED; // TAF with K = 2, 4 or 8 FIFO slots
+    if (n_weights != want) return FRLW_ERR_ARG;
+    Op op = {};
+    op.type = OP_BFM; op.src = src_buf; op.dst = dst_buf; op.C = C; op.H = H; op.W = W; op.bfm_w = weights;
     op.lane = d->cur_lane;
     d->ops.push_back(op);
     return FRLW_OK;
@@ -647,6 +749,13 @@ int frlw_det_run(const frlw_detector_t *d, int B, void *const *bufs, int n_bufs,
         case OP_FOCUS: {
             const long long total = (long long)B * (op.H / 2) * (op.W / 2) * 4 * op.C;
             hipLaunchKernelGGL(k_focus, dim3(grid_1d(total)), dim3(256), 0, s, buf(op.src), B, op.C, op.H, op.W, buf(op.dst));
+            break;
+        }
+        case OP_BFM: {
+            const int grid = grid_1d((long long)B * op.H * op.W);
+            if (op.C == 4) hipLaunchKernelGGL(k_bfm_stem<2>, dim3(grid), dim3(256), 0, s, buf(op.src), B, op.H, op.W, op.bfm_w, buf(op.dst));
+            else if (op.C == 8) hipLaunchKernelGGL(k_bfm_stem<4>, dim3(grid), dim3(256), 0, s, buf(op.src), B, op.H, op.W, op.bfm_w, buf(op.dst));
+            else hipLaunchKernelGGL(k_bfm_stem<8>, dim3(grid), dim3(256), 0, s, buf(op.src), B, op.H, op.W, op.bfm_w, buf(op.dst));
             break;
         }
         case OP_UPSAMPLE: {

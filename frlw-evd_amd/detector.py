@@ -113,6 +113,30 @@ class DetectorEngine:
             cur = nxt
         self._baseconv(csp.conv3, cat, dst)
 
+    def _bfm_front(self, stem, x_in, cin, H, W):
+        """Temporal_Active_Focus_connect up to its BaseConv (core/Others/Temporal_Active_Focus.py:62-127):
+        weight norm applied here, all 1x1 layers packed for k_bfm_stem."""
+        if not isinstance(stem.act, torch.nn.SiLU):
+            raise NotImplementedError("the fused BFM stem kernel implements the SiLU MLP of the shipped recipes")
+        parts = []
+        for conv in stem.convs:
+            w = torch._weight_norm(conv.weight_v.detach(), conv.weight_g.detach(), 0)  # g * v / |v| per output channel
+            parts += [w.reshape(w.shape[0], -1).float().flatten(), conv.bias.detach().float().flatten()]
+        for lin in (stem.trans_up, stem.trans_down):
+            parts += [lin.weight.detach().reshape(lin.weight.shape[0], -1).float().flatten(),
+                      lin.bias.detach().float().flatten()]
+        packed = torch.cat([p.cpu() for p in parts]).contiguous()
+        want = self.lib.frlw_det_bfm_weight_count(cin)
+        if want == 0:
+            raise NotImplementedError(f"BFM stem with {cin} input channels (TAF K = {cin // 2}) is not supported")
+        assert packed.numel() == want, (packed.numel(), want)
+        er = stem.trans_down.out_channels
+        f = self._new_buf(H // 2, W // 2, 4 * er)
+        _lib.check(self.lib.frlw_det_add_bfm_stem(self.handle, x_in, cin, H, W, self._dev(packed), packed.numel(), f.buf),
+                   "bfm stem")
+        self.ops_meta.append(("bfm", H * W, 4 * er, 0, 0))
+        return f
+
     def build(self, in_shape):
         """in_shape = (C, H, W) of one image (the network input without the trailing singleton dims)."""
         net = self.net
@@ -123,9 +147,12 @@ class DetectorEngine:
         self._shapes = [cin * H * W]
         x_in = 0
         # ---- backbone (darknet.py:270-354)
-        f = self._new_buf(H // 2, W // 2, 4 * cin)
-        _lib.check(lib.frlw_det_add_focus(self.handle, x_in, cin, H, W, f.buf), "focus")
-        self.ops_meta.append(("focus", H * W // 4, 4 * cin, 0, 0))
+        if hasattr(bb.stem, "trans_up"):  # BFM stem (yolox_taf_bfm): fused per-pixel mix, Focus layout out
+            f = self._bfm_front(bb.stem, x_in, cin, H, W)
+        else:
+            f = self._new_buf(H // 2, W // 2, 4 * cin)
+            _lib.check(lib.frlw_det_add_focus(self.handle, x_in, cin, H, W, f.buf), "focus")
+            self.ops_meta.append(("focus", H * W // 4, 4 * cin, 0, 0))
         c = bb.stem.conv.conv.out_channels
         stem = self._new_buf(H // 2, W // 2, c)
         self._baseconv(bb.stem.conv, f, stem)

@@ -11,6 +11,7 @@ from .darknet import CSPDarknet
 from .yolo_pafpn import YOLOPAFPN
 from .yolo_head import YOLOXHead
 from .model import model, build_yolox
+from .bfm import Temporal_Active_Focus_connect
 
 __all__ = ["BaseConv", "Bottleneck", "CSPLayer", "Focus", "SPPBottleneck", "SiLU", "get_activation",
-           "CSPDarknet", "YOLOPAFPN", "YOLOXHead", "model", "build_yolox"]
+           "CSPDarknet", "YOLOPAFPN", "YOLOXHead", "model", "build_yolox", "Temporal_Active_Focus_connect"]

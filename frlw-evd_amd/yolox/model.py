@@ -73,11 +73,16 @@ class model(nn.Module):
         return outputs
 
 
-def build_yolox(in_channels=10, num_classes=2, radius=5.0):
+def build_yolox(in_channels=10, num_classes=2, radius=5.0, stem="focus"):
     """The ``yolox`` experiment: CSPDarknet(C, 0.33, 0.5, Focus) + YOLOPAFPN(0.33, [128, 256, 512]) +
-    YOLOXHead(nc, strides [8, 16, 32], in_channels [128, 256, 512]) (core/exp.py:372,377-384,580-586)."""
+    YOLOXHead(nc, strides [8, 16, 32], in_channels [128, 256, 512]) (core/exp.py:372,377-384,580-586).
+    ``stem="bfm"``: the ``yolox_taf_bfm`` experiment (core/exp.py:588-591), ``Temporal_Active_Focus_connect``."""
     chans = [128, 256, 512]
-    backbone = CSPDarknet(in_channels, 0.33, 0.5, stem=Focus)
+    if stem == "bfm":
+        from .bfm import Temporal_Active_Focus_connect
+        backbone = CSPDarknet(in_channels, 0.33, 0.5, stem=Temporal_Active_Focus_connect)
+    else:
+        backbone = CSPDarknet(in_channels, 0.33, 0.5, stem=Focus)
     neck = YOLOPAFPN(0.33, in_features=["dark3", "dark4", "dark5"], in_channels=chans, act="silu")
     head = YOLOXHead(num_classes, in_channels=chans, act="silu", strides=[8, 16, 32], radius=radius)
     return model(backbone, neck, None, head)
@@ -106,6 +111,8 @@ def recipe_state_dict(module, seed=1004):
             v = rng.uniform(0.5, 1.5, shape)
         elif name.endswith("bias"):
             v = rng.normal(0.0, 0.1, shape)
+        elif name.endswith("weight_g"):  # weight-normed convs of the BFM stem: per-output-channel gain
+            v = rng.uniform(0.5, 1.5, shape)
         else:  # conv weight (Cout, Cin, kh, kw)
             fan_in = int(np.prod(shape[1:]))
             v = rng.normal(0.0, np.sqrt(2.0 / fan_in), shape)

@@ -184,6 +184,16 @@ int frlw_det_set_scratch(frlw_detector_t *d, int buf, int64_t n_floats);
 /* Focus space-to-depth (network_blocks.py:205-217): NCHW (B, C, H, W) -> NHWC (B, H/2, W/2, 4C). */
 int frlw_det_add_focus(frlw_detector_t *d, int src_buf, int C, int H, int W, int dst_buf);
 
+/* BFM stem of the yolox_taf_bfm recipes, per-pixel part + Focus layout in one kernel
+ * (core/Others/Temporal_Active_Focus.py:62-127 Temporal_Active_Focus_connect.forward up to self.conv; eval mode):
+ * NCHW (B, C, H, W) with C = 2 T in {4, 8, 16} -> NHWC (B, H/2, W/2, 4 * 4 log2(T)).
+ * `weights` (device, kept by reference): for every stage i its effective grouped 1x1 weight g * v / |v| as
+ * (out_channels_i, in_channels_per_group_i) row-major then its bias; then trans_up weight (4E, E) + bias and
+ * trans_down weight (E, 4E) + bias, E = 4 log2(T).  frlw_det_bfm_weight_count(C) floats (0: unsupported C). */
+int frlw_det_bfm_weight_count(int C);
+int frlw_det_add_bfm_stem(frlw_detector_t *d, int src_buf, int C, int H, int W, const float *weights, int n_weights,
+                          int dst_buf);
+
 /* nn.Upsample(scale_factor=2, mode="nearest") of a channel slice (yolo_pafpn.py:29). */
 int frlw_det_add_upsample(frlw_detector_t *d, int src_buf, int cs_src, int co_src, int C, int H, int W,
                           int dst_buf, int cs_dst, int co_dst);

@@ -130,5 +130,38 @@ def main():
     print("detector.npz", os.path.getsize(os.path.join(HERE, "detector.npz")) // 1024, "KiB")
 
 
+def main_bfm():
+    """The ``yolox_taf_bfm`` recipes (core/exp.py:588-591): the reference's Temporal_Active_Focus_connect stem."""
+    from core.Others.Temporal_Active_Focus import Temporal_Active_Focus_connect
+    out = {}
+    for tag, C, nc in (("bfm8", 8, 2), ("bfm16", 16, 2)):
+        chans = [128, 256, 512]
+        ref = RefModel(CSPDarknet(C, 0.33, 0.5, stem=Temporal_Active_Focus_connect),
+                       YOLOPAFPN(0.33, in_features=["dark3", "dark4", "dark5"], in_channels=chans, act="silu"), None,
+                       YOLOXHead(nc, in_channels=chans, act="silu", strides=[8, 16, 32], radius=5))
+        mine = build_yolox(C, nc, stem="bfm")
+        sd = recipe_state_dict(mine, seed=1004)
+        assert list(sd.keys()) == list(ref.state_dict().keys()), "parameter names differ from the reference"
+        for (k, a), (_, b) in zip(sd.items(), ref.state_dict().items()):
+            assert a.shape == b.shape, k
+        ref.load_state_dict(sd)
+        ref.eval()
+        x = detector_input(1006, 2, C)
+        with torch.no_grad():
+            stem = ref.backbone.stem(x[..., 0])
+            feats = ref.backbone(x[..., 0])
+            head = ref.head
+            head.decode_in_inference = False
+            raw = head(ref.neck(feats))
+        out[f"{tag}_raw"] = raw.numpy()
+        out[f"{tag}_stem_stats"] = np.array([stem.mean().item(), stem.norm().item(), stem.abs().max().item()])
+        out[f"{tag}_stem_crop"] = stem[:, :, 40:48, 100:108].numpy()   # (2, 32, 8, 8)
+        out[f"{tag}_params"] = np.array(sum(p.numel() for p in ref.parameters()))
+    np.savez_compressed(os.path.join(HERE, "detector_bfm.npz"), **out)
+    print("detector_bfm.npz", os.path.getsize(os.path.join(HERE, "detector_bfm.npz")) // 1024, "KiB")
+
+
 if __name__ == "__main__":
-    main()
+    if "--bfm-only" not in sys.argv:
+        main()
+    main_bfm()

@@ -118,3 +118,25 @@ def test_trainer_step_quirks():
     l1, _ = tr.train_step(x, train_labels(), 1)
     assert not torch.equal(m.head.cls_preds[0].bias, before) and np.isfinite(l1)
     assert float(tr.scaler.get_scale()) == 65536.0  # never updated (no scaler.step / scaler.update)
+
+
+@pytest.mark.parametrize("tag,C", [("bfm8", 8), ("bfm16", 16)])
+def test_bfm_stem_matches_reference(golden_dir, tag, C):
+    """``yolox_taf_bfm`` (core/exp.py:588-591): Temporal_Active_Focus_connect stem, reference-generated goldens."""
+    g = np.load(os.path.join(golden_dir, "detector_bfm.npz"))
+    torch.set_num_threads(8)
+    m = build_yolox(C, 2, stem="bfm")
+    keys = list(m.state_dict().keys())
+    assert "backbone.stem.convs.0.weight_g" in keys and "backbone.stem.trans_down.bias" in keys
+    assert sum(p.numel() for p in m.parameters()) == int(g[f"{tag}_params"])
+    m.load_state_dict(recipe_state_dict(m, seed=1004))
+    m.eval()
+    x = detector_input(1006, 2, C)
+    with torch.no_grad():
+        stem = m.backbone.stem(x[..., 0])
+        raw = m.reference_outputs(x[..., 0])
+    assert np.abs(stem[:, :, 40:48, 100:108].numpy() - g[f"{tag}_stem_crop"]).max() <= 1e-5 * np.abs(g[f"{tag}_stem_crop"]).max()
+    st = np.array([stem.mean().item(), stem.norm().item(), stem.abs().max().item()])
+    assert st == pytest.approx(g[f"{tag}_stem_stats"], rel=1e-5)
+    want = g[f"{tag}_raw"]
+    assert np.abs(raw.numpy() - want).max() <= 1e-5 * np.abs(want).max()

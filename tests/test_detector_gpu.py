@@ -226,3 +226,24 @@ def test_simota_batched_equals_per_image_procedure(gpu, seed, B):
         losses._FORCE_LOOP = False
     got = m(x, labels, None, None)
     assert float(got.detach()) == pytest.approx(float(want.detach()), rel=1e-6)  # float32 sum of the objectness term in another order
+
+
+@pytest.mark.parametrize("tag,C", [("bfm8", 8), ("bfm16", 16)])
+def test_bfm_stem_engine_vs_golden_and_torch(gpu, golden_dir, tag, C):
+    """yolox_taf_bfm (core/exp.py:588-591): fused BFM stem kernel + the usual plan against the reference-generated
+    head tensor and the torch fp32 forward of the same modules."""
+    g = np.load(os.path.join(golden_dir, "detector_bfm.npz"))
+    m = build_yolox(C, 2, stem="bfm")
+    m.load_state_dict(recipe_state_dict(m, seed=1004))
+    m = m.to(gpu).eval()
+    x = detector_input(1006, 2, C).to(gpu)
+    with torch.no_grad():
+        got = m.engine().raw_outputs(x[..., 0])
+        ref = m.reference_outputs(x[..., 0])
+    want = torch.from_numpy(g[f"{tag}_raw"]).to(gpu)
+    assert rel_err(got, want) <= TOL
+    assert rel_err(got, ref) <= TOL
+    assert rel_err(got, want) <= 2e-5  # observed: exact-f32 MFMA
+    with torch.no_grad():
+        dets = m(x)
+    assert isinstance(dets, list) and len(dets) == 2 and dets[0].shape[1] == 6
