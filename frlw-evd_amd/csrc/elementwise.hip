@@ -46,9 +46,43 @@ __global__ void k_resize_nearest(const T *in, int C, int H, int W, int Ho, int W
     }
 }
 
+// Sample transform of the training loader (data/dataset.py:217-231): nearest resize of the (C, H, W) uint8 volume to
+// (Hr, Wr) -- torch's nearest: src = min(floor(dst * float(in) / out), in - 1) -- then / 255, crop at (y0, x0), flip.
+// par[b] = {Hr, Wr, y0, x0, flip}.  One thread per output element, x fastest.
+__global__ void k_sample_transform(const uint8_t *in, int B, int C, int H, int W, const int *par, float *out)
+{
+    const long long total = (long long)B * C * H * W;
+    for (long long o = blockIdx.x * (long long)blockDim.x + threadIdx.x; o < total;
+         o += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(o % W), y = (int)((o / W) % H);
+        const long long bc = o / ((long long)W * H);
+        const int b = (int)(bc / C);
+        const int *p = par + 5 * b;
+        const int Hr = p[0], Wr = p[1], y0 = p[2], x0 = p[3], flip = p[4];
+        const int xs = flip ? W - 1 - x : x; // img[:, :, ::-1] after the crop
+        const float sh = (float)H / (float)Hr, sw = (float)W / (float)Wr;
+        int sy = (int)floorf((float)(y + y0) * sh), sx = (int)floorf((float)(xs + x0) * sw);
+        if (sy > H - 1) sy = H - 1;
+        if (sx > W - 1) sx = W - 1;
+        out[o] = (float)in[(bc * H + sy) * W + sx] / 255.0f;
+    }
+}
+
 } // namespace
 
 extern "C" {
+
+int frlw_sample_transform_u8(const uint8_t *in, int B, int C, int H, int W, const int32_t *params, float *out,
+                             frlw_stream_t stream)
+{
+    if (!in || !params || !out || B < 0 || C < 1 || H < 1 || W < 1) return FRLW_ERR_ARG;
+    const long long n = (long long)B * C * H * W;
+    if (n == 0) return FRLW_OK;
+    hipLaunchKernelGGL(k_sample_transform, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, in, B, C, H, W,
+                       params, out);
+    HIP_TRY(hipGetLastError());
+    return FRLW_OK;
+}
 
 int frlw_leaky_transform(const float *in, int64_t n, float *out_f32, uint8_t *out_u8,
                          frlw_stream_t stream)

@@ -252,6 +252,12 @@ int frlw_simota_assign(const float *preds, const double *labels, const float *x_
                        int32_t *matched_gt, double *matched_iou, int32_t *num_fg, int32_t *nlabel, void *workspace,
                        size_t workspace_bytes, frlw_stream_t stream);
 
+/* Sample transform of the training loader for a batch (data/dataset.py:217-231 in propheseeDataset.__getitem__):
+ * (B, C, H, W) uint8 -> (B, C, H, W) f32 = flip(crop(nearest_resize(x, (Hr, Wr)) / 255)).
+ * params (device): B rows of five int32 {Hr = int(H * sr), Wr = int(W * sr), y0 = -cy, x0 = -cx, flip}. */
+int frlw_sample_transform_u8(const uint8_t *in, int B, int C, int H, int W, const int32_t *params, float *out,
+                             frlw_stream_t stream);
+
 /* Library identification: "frlw_evd <version> gfx950". */
 const char *frlw_version(void);
 

@@ -172,3 +172,18 @@ def sae_stream_dat8(dat, sensor_shape, shape, lamdas, memory, now, window_us):
                                      C.c_int64(int(window_us)), _p(out, C.c_float),
                                      _p(mem_out, C.c_float)))
     return out, mem_out
+
+
+def sample_transform(vol_u8, hr, wr, y0, x0, flip):
+    """Image half of the training loader's sample transform (data/dataset.py:217-231), numpy restatement:
+    nearest resize (torch: src = min(floor(dst * float32(in / out)), in - 1)) to (hr, wr), / 255, crop at (y0, x0)
+    to the input size, horizontal flip.  ``vol_u8`` (C, H, W) uint8 -> (C, H, W, 1, 1) float32."""
+    Cc, H, W = vol_u8.shape
+    sh = np.float32(H) / np.float32(hr)
+    sw = np.float32(W) / np.float32(wr)
+    ys = np.minimum(np.floor((np.arange(H) + y0).astype(np.float32) * sh).astype(np.int64), H - 1)
+    xs = np.minimum(np.floor((np.arange(W) + x0).astype(np.float32) * sw).astype(np.int64), W - 1)
+    out = vol_u8[:, ys][:, :, xs].astype(np.float32) / np.float32(255)
+    if flip:
+        out = out[:, :, ::-1]
+    return np.ascontiguousarray(out)[:, :, :, None, None]
