@@ -70,6 +70,8 @@ SYMBOLS = {
     "frlw_det_bfm_weight_count": (_I, [_I]),
     "frlw_det_add_bfm_stem": (_I, [_P, _I, _I, _I, _I, _P, _I, _I]),
     "frlw_sample_transform_u8": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
+    "frlw_eval_transform_dt": (_I, [_P, _P, _P, _I64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                   _P, _P, _P]),
     "frlw_simota_workspace_bytes": (_SZ, [_I, _I, _I]),
     "frlw_simota_assign": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, C.c_float, _P, _P, _P, _P, _P, _P, _SZ, _P]),
 }

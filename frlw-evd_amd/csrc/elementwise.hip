@@ -68,9 +68,39 @@ __global__ void k_sample_transform(const uint8_t *in, int B, int C, int H, int W
     }
 }
 
+// Evaluator hand-off (evaluate/evaluator.py:56-63 transform_dt + evaluate/src/io/box_filtering.py:17-39): detection
+// rows [cx, cy, w, h, class, score] in detector pixels -> [t, x, y, w, h, class, score, 0] in sensor pixels (float32
+// like the reference's tensors) and the Prophesee filter mask ts > skip, w^2 + h^2 >= diag^2, w >= min_w, h >= min_h.
+__global__ void k_eval_transform_dt(const float *dets, const int *img_of_row, const long long *ts, long long n, float rw,
+                                    float rh, float skip_ts, float diag2, float min_w, float min_h, float *out,
+                                    uint8_t *keep)
+{
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *d = dets + 6 * i;
+    const float t = (float)ts[img_of_row[i]];
+    const float x = (d[0] - d[2] / 2.0f) * rw, y = (d[1] - d[3] / 2.0f) * rh, w = d[2] * rw, h = d[3] * rh;
+    float *o = out + 8 * i;
+    o[0] = t; o[1] = x; o[2] = y; o[3] = w; o[4] = h; o[5] = d[4]; o[6] = d[5]; o[7] = 0.0f;
+    keep[i] = (t > skip_ts && w * w + h * h >= diag2 && w >= min_w && h >= min_h) ? 1 : 0;
+}
+
 } // namespace
 
 extern "C" {
+
+int frlw_eval_transform_dt(const float *dets, const int32_t *img_of_row, const int64_t *timestamps, int64_t n, float rw,
+                           float rh, float skip_ts, float min_diag_sq, float min_w, float min_h, float *out,
+                           uint8_t *keep, frlw_stream_t stream)
+{
+    if (n < 0 || (n > 0 && (!dets || !img_of_row || !timestamps || !out || !keep))) return FRLW_ERR_ARG;
+    if (n == 0) return FRLW_OK;
+    hipLaunchKernelGGL(k_eval_transform_dt, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dets,
+                       img_of_row, (const long long *)timestamps, (long long)n, rw, rh, skip_ts, min_diag_sq, min_w,
+                       min_h, out, keep);
+    HIP_TRY(hipGetLastError());
+    return FRLW_OK;
+}
 
 int frlw_sample_transform_u8(const uint8_t *in, int B, int C, int H, int W, const int32_t *params, float *out,
                              frlw_stream_t stream)

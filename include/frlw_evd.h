@@ -258,6 +258,14 @@ int frlw_simota_assign(const float *preds, const double *labels, const float *x_
 int frlw_sample_transform_u8(const uint8_t *in, int B, int C, int H, int W, const int32_t *params, float *out,
                              frlw_stream_t stream);
 
+/* Evaluator hand-off for the detections of a batch (evaluate/evaluator.py:56-63 transform_dt, and the mask of
+ * evaluate/src/io/box_filtering.py:17-39): n packed rows [cx, cy, w, h, class, score] (detector pixels) ->
+ * out (n, 8) f32 [t, x, y, w, h, class, score, 0] (sensor pixels; t = timestamps[img_of_row[i]]) and
+ * keep[i] = t > skip_ts && w^2 + h^2 >= min_diag_sq && w >= min_w && h >= min_h. */
+int frlw_eval_transform_dt(const float *dets, const int32_t *img_of_row, const int64_t *timestamps, int64_t n, float rw,
+                           float rh, float skip_ts, float min_diag_sq, float min_w, float min_h, float *out,
+                           uint8_t *keep, frlw_stream_t stream);
+
 /* Library identification: "frlw_evd <version> gfx950". */
 const char *frlw_version(void);
 
