@@ -192,17 +192,33 @@ def bench_train(args, torch, world, rank, local_rank, sync_all):
     lab[:, 1] = torch.tensor([1, 220, 150, 50, 80.0])
     lab = lab.cuda()
     steps = 5
-    for i in range(3):
-        tr.train_step(x, lab, i)
-    sync_all()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        loss, _ = tr.train_step(x, lab, 3 + i)
-    sync_all()
-    dt, = fd.max_over_ranks([time.perf_counter() - t0])
+
+    def timed():
+        for i in range(3):
+            tr.train_step(x, lab, i)
+        sync_all()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            loss, _ = tr.train_step(x, lab, 3 + i)
+        sync_all()
+        dt, = fd.max_over_ranks([time.perf_counter() - t0])
+        return dt, loss
+
+    dt, loss = timed()  # BaseConv forward / backward in the gfx950 kernels of csrc/train_ops.hip (the default)
+    prev = os.environ.get("FRLW_NATIVE_TRAIN")
+    os.environ["FRLW_NATIVE_TRAIN"] = "0"  # the same step with torch autograd / MIOpen convolutions, for comparison
+    try:
+        dt_t, _ = timed()
+    finally:
+        if prev is None:
+            os.environ.pop("FRLW_NATIVE_TRAIN", None)
+        else:
+            os.environ["FRLW_NATIVE_TRAIN"] = prev
     return {"metric": "YOLOX train step (frames/s)", "value": round(world * B * steps / dt, 1), "unit": "frames/s",
             "ms_per_step": round(dt / steps * 1e3, 3), "per_gpu_batch": B, "steps": steps, "loss": round(loss, 4),
-            "parallelism": f"ddp{world}" if world > 1 else "single", "scaling": "weak"}
+            "parallelism": f"ddp{world}" if world > 1 else "single", "scaling": "weak",
+            "convolutions": "csrc/train_ops.hip (fp32 MFMA fwd / dgrad / wgrad, BatchNorm + SiLU fwd / bwd), SimOTA csrc/simota.hip",
+            "same_step_with_miopen_convs": {"value": round(world * B * steps / dt_t, 1), "ms_per_step": round(dt_t / steps * 1e3, 3)}}
 
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, f32 in / f32 accumulate

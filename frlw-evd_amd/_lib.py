@@ -72,6 +72,19 @@ SYMBOLS = {
     "frlw_sample_transform_u8": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
     "frlw_eval_transform_dt": (_I, [_P, _P, _P, _I64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                    _P, _P, _P]),
+    "frlw_conv_weight_layouts": (_I, [_P, _I, _I, _I, _P, _P, _P]),
+    "frlw_conv2d_fwd": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _P, _P, _I64, _P]),
+    "frlw_conv2d_dgrad": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _P, _P, _I64, _P]),
+    "frlw_conv2d_wgrad_scratch_floats": (_I64, [_I, _I, _I, _I, _I, _I]),
+    "frlw_conv2d_wgrad": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _P, _P, _I64, _P]),
+    "frlw_bn_scratch_doubles": (_I64, [_I64, _I]),
+    "frlw_bn_stats": (_I, [_P, _I64, _I, C.c_float, _P, _P, _P, _P, _P]),
+    "frlw_bn_silu_fwd": (_I, [_P, _I64, _I, _P, _P, _P, _P, _P, _P]),
+    "frlw_bn_silu_bwd": (_I, [_P, _P, _I64, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "frlw_baseconv_train_scratch_bytes": (_I64, [_I, _I, _I, _I, _I, _I, _I]),
+    "frlw_baseconv_train_fwd": (_I, [_P, _P, _P, _P, C.c_float, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I64, _P]),
+    "frlw_baseconv_train_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P,
+                                    _I64, _P]),
     "frlw_simota_workspace_bytes": (_SZ, [_I, _I, _I]),
     "frlw_simota_assign": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, C.c_float, _P, _P, _P, _P, _P, _P, _SZ, _P]),
 }

@@ -95,6 +95,7 @@ int frlw_eval_transform_dt(const float *dets, const int32_t *img_of_row, const i
 {
     if (n < 0 || (n > 0 && (!dets || !img_of_row || !timestamps || !out || !keep))) return FRLW_ERR_ARG;
     if (n == 0) return FRLW_OK;
+    (void)hipGetLastError(); // stale errors of other libraries
     hipLaunchKernelGGL(k_eval_transform_dt, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dets,
                        img_of_row, (const long long *)timestamps, (long long)n, rw, rh, skip_ts, min_diag_sq, min_w,
                        min_h, out, keep);
@@ -108,6 +109,7 @@ int frlw_sample_transform_u8(const uint8_t *in, int B, int C, int H, int W, cons
     if (!in || !params || !out || B < 0 || C < 1 || H < 1 || W < 1) return FRLW_ERR_ARG;
     const long long n = (long long)B * C * H * W;
     if (n == 0) return FRLW_OK;
+    (void)hipGetLastError(); // stale errors of other libraries
     hipLaunchKernelGGL(k_sample_transform, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, in, B, C, H, W,
                        params, out);
     HIP_TRY(hipGetLastError());
@@ -119,6 +121,7 @@ int frlw_leaky_transform(const float *in, int64_t n, float *out_f32, uint8_t *ou
 {
     if (!in || (!out_f32 && !out_u8) || n < 0) return FRLW_ERR_ARG;
     if (n == 0) return FRLW_OK;
+    (void)hipGetLastError(); // stale errors of other libraries
     hipLaunchKernelGGL(k_leaky, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, in,
                        (long long)n, out_f32, out_u8);
     HIP_TRY(hipGetLastError());
@@ -129,6 +132,7 @@ int frlw_quantize_u8(const float *in, int64_t n, int clip255, uint8_t *out, frlw
 {
     if (!in || !out || n < 0) return FRLW_ERR_ARG;
     if (n == 0) return FRLW_OK;
+    (void)hipGetLastError(); // stale errors of other libraries
     hipLaunchKernelGGL(k_quantize, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, in,
                        (long long)n, clip255, out);
     HIP_TRY(hipGetLastError());
@@ -140,6 +144,7 @@ int frlw_resize_nearest_f32(const float *in, int C, int H, int W, int Ho, int Wo
 {
     if (!in || !out || C <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0) return FRLW_ERR_ARG;
     const long long total = (long long)C * Ho * Wo;
+    (void)hipGetLastError(); // stale errors of other libraries
     hipLaunchKernelGGL(k_resize_nearest<float>, dim3(grid_for(total, 256)), dim3(256), 0,
                        (hipStream_t)stream, in, C, H, W, Ho, Wo, (float)H / (float)Ho,
                        (float)W / (float)Wo, out);
@@ -152,6 +157,7 @@ int frlw_resize_nearest_u8(const uint8_t *in, int C, int H, int W, int Ho, int W
 {
     if (!in || !out || C <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0) return FRLW_ERR_ARG;
     const long long total = (long long)C * Ho * Wo;
+    (void)hipGetLastError(); // stale errors of other libraries
     hipLaunchKernelGGL(k_resize_nearest<uint8_t>, dim3(grid_for(total, 256)), dim3(256), 0,
                        (hipStream_t)stream, in, C, H, W, Ho, Wo, (float)H / (float)Ho,
                        (float)W / (float)Wo, out);

@@ -452,6 +452,7 @@ int partition_events(const frlw_events_t *ev, int H, int W, int kind, long long 
     uint32_t *leaky_w = kind == KIND_TAF ? (uint32_t *)(w8 + p.off_leaky) : nullptr;
     d.dbg = env_int("FRLW_DBG", 0);
 
+    (void)hipGetLastError(); // stale errors of other libraries in the process
     HIP_TRY(hipMemsetAsync(hdr, 0, kHeaderBytes, s));
     if (ev->layout == FRLW_LAYOUT_DAT8)
         launch_partition_kind<FRLW_LAYOUT_DAT8>(kind, d, p, counts, slabtot, base, records, hdr, tlut_w, leaky_w, s);

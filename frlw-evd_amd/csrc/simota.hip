@@ -260,6 +260,7 @@ int frlw_simota_assign(const float *preds, const double *labels, const float *x_
                        int32_t *matched_gt, double *matched_iou, int32_t *num_fg, int32_t *nlabel, void *workspace,
                        size_t workspace_bytes, frlw_stream_t stream)
 {
+    (void)hipGetLastError(); // clear stale errors of other libraries in the process
     if (!preds || !labels || !x_shifts || !y_shifts || !strides || !fg || !matched_gt || !matched_iou || !num_fg ||
         !workspace || B <= 0 || A <= 0 || G <= 0 || num_classes <= 0)
         return FRLW_ERR_ARG;

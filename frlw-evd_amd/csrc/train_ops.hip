@@ -1,0 +1,612 @@
+// train_ops.hip -- training-mode operators of BaseConv = Conv2d(bias=False) + BatchNorm2d (batch statistics) + SiLU
+// (core/yolox/models/network_blocks.py:33-65) for the train step of core/exp.py:283-315, on NHWC float32 tensors
+// (torch channels_last storage, so the autograd wrapper in frlw-evd_amd/yolox/train_ops.py passes pointers as is):
+//
+//   frlw_conv_weight_layouts   torch (Cout, Cin, k, k) -> the two GEMM operands: forward (k*k*Cin, Npad(Cout)) and
+//                              data-gradient (k*k*Cout, Npad(Cin)) with the taps flipped
+//   frlw_conv2d_fwd            z = conv(x, w)                    k_conv_mfma (conv_mfma.h), fp32 MFMA
+//   frlw_conv2d_dgrad          dx = conv^T(dz, w)                the same kernel on the flipped operand; stride 2 through
+//                              the transposed gather (tstride = 2)
+//   frlw_conv2d_wgrad          dw = x^T * dz                     k_wgrad_mfma: M = k*k*Cin, N = Cout, contraction over
+//                              the B*Ho*Wo output pixels split over blockIdx.z, deterministic two-stage reduction
+//                              straight into torch's (Cout, Cin, k, k) layout
+//   frlw_bn_stats              per-channel mean / biased variance (float64 accumulation, two-stage, deterministic)
+//   frlw_bn_silu_fwd           y = silu(gamma * (z - mean) * invstd + beta)
+//   frlw_bn_silu_bwd           dz, dgamma, dbeta from dy and z (u recomputed, nothing but z saved)
+//
+// MI355X: every contraction runs on the matrix cores with v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate), like
+// the forward; the elementwise passes are HBM-bound float4 streams over the (M, C) view of the tensor.
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "frlw_evd.h"
+
+namespace {
+
+#include "conv_mfma.h"
+
+#define TRY_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
+        if (getenv("FRLW_DEBUG")) fprintf(stderr, "frlw_evd train_ops: %s -> %s\n", #expr, hipGetErrorString(e_)); \
+        return FRLW_ERR_HIP; } } while (0)
+
+// ---- weight layouts -----------------------------------------------------------------------------
+// fwd[(ky*k + kx)*Cin + ci][co] = w[co][ci][ky][kx];  dgr[((k-1-ky)*k + (k-1-kx))*Cout + co][ci] = w[co][ci][ky][kx]
+// One thread per element of the padded forward operand (rows (ky, kx, ci), np_f columns) and of the padded
+// data-gradient operand: every element, padding included, is written, so no memset is needed.
+__global__ void k_weight_layouts(const float *w, int Cout, int Cin, int k, float *fwd, int np_f, float *dgr, int np_d)
+{
+    const int kk = k * k;
+    const long long nf = fwd ? (long long)kk * Cin * np_f : 0, nd = dgr ? (long long)kk * Cout * np_d : 0;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nf + nd; i += (long long)gridDim.x * blockDim.x) {
+        if (i < nf) {
+            const int co = (int)(i % np_f);
+            const long long row = i / np_f;
+            const int ci = (int)(row % Cin), tap = (int)(row / Cin);
+            fwd[i] = co < Cout ? w[((long long)co * Cin + ci) * kk + tap] : 0.0f;
+        } else {
+            const long long e = i - nf;
+            const int ci = (int)(e % np_d);
+            const long long row = e / np_d;
+            const int co = (int)(row % Cout), tapf = (int)(row / Cout); // tapf = flipped tap index
+            dgr[e] = ci < Cin ? w[((long long)co * Cin + ci) * kk + (kk - 1 - tapf)] : 0.0f;
+        }
+    }
+}
+
+// ---- weight gradient ------------------------------------------------------------------------------
+// dW[r = (ky, kx, ci)][co] = sum over pixels m of x[m shifted by the tap][ci] * dz[m][co].
+// 64 x 64 tile of (r, co) per workgroup, 4 wavefronts 2 x 2, k-tiles of 16 pixels, blockIdx.z owns a slice of the
+// pixels and writes a partial tile (always: the reduction kernel also converts to torch's layout).
+struct WgradArgs {
+    const float *x; int H, W, Cin; long long x_bs; int x_cs;     // input NHWC
+    const float *dz; int Ho, Wo, Cout; long long dz_bs; int dz_cs;
+    int k, stride, pad;
+    int R;          // k * k * Cin
+    int M;          // B * Ho * Wo
+    int splits;
+    float *partial; // [splits][R][Cout]
+};
+
+// BM = 64 or 128 rows (r) x 64 columns (co) per workgroup; the 4 wavefronts are 2 x 2, each TM = BM / 64 MFMA tiles tall.
+template <int BM>
+__global__ __launch_bounds__(256) void k_wgrad_mfma(WgradArgs a)
+{
+    constexpr int BN = 64, BK = 16, LDA = BM + 4, LDB = BN + 4, TM = BM / 64;
+    __shared__ float As[2][BK][LDA]; // [pixel][r]
+    __shared__ float Bs[2][BK][LDB]; // [pixel][co]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wr = wv >> 1, wc = wv & 1;
+    const int r0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    // staging: thread -> pixel (tid / 16) of the k-tile, float4 #(tid % 16) of each 64-wide group of r / co columns
+    const int pk = tid >> 4, q4 = (tid & 15) * 4;
+    bool r_ok[TM];
+    int ci[TM], ky[TM], kx[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) { // the (tap, ci) of this thread's float4 in r-group i (Cin % 4 == 0: one tap per float4)
+        const int r = r0 + 64 * i + q4;
+        r_ok[i] = r < a.R;
+        const int tap = r_ok[i] ? r / a.Cin : 0;
+        ci[i] = r_ok[i] ? r - tap * a.Cin : 0;
+        ky[i] = tap / a.k;
+        kx[i] = tap - ky[i] * a.k;
+    }
+    const bool n_ok = n0 + q4 < a.Cout;
+    const int howo = a.Ho * a.Wo;
+    const int nk_all = (a.M + BK - 1) / BK;
+    const int kt0 = (int)((long long)nk_all * blockIdx.z / a.splits), kt1 = (int)((long long)nk_all * (blockIdx.z + 1) / a.splits);
+    // this thread's pixel of the current k-tile as (image, oy, ox); advanced by BK pixels per tile without divisions
+    int pb, poy, pox;
+    {
+        const long long m = (long long)kt0 * BK + pk;
+        pb = (int)(m / howo);
+        const int pix = (int)(m - (long long)pb * howo);
+        poy = pix / a.Wo;
+        pox = pix - poy * a.Wo;
+    }
+    float4 ra[TM], rb;
+    auto load_tiles = [&]() {
+        rb = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) ra[i] = rb;
+        if (pb * howo + poy * a.Wo + pox < a.M) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int iy = poy * a.stride - a.pad + ky[i], ix = pox * a.stride - a.pad + kx[i];
+                if (r_ok[i] && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+                    ra[i] = *(const float4 *)(a.x + (long long)pb * a.x_bs + ((long long)iy * a.W + ix) * a.x_cs + ci[i]);
+            }
+            if (n_ok) rb = *(const float4 *)(a.dz + (long long)pb * a.dz_bs + ((long long)poy * a.Wo + pox) * a.dz_cs + n0 + q4);
+        }
+        pox += BK;
+        while (pox >= a.Wo) { pox -= a.Wo; if (++poy == a.Ho) { poy = 0; ++pb; } }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) *(float4 *)&As[buf][pk][64 * i + q4] = ra[i];
+        *(float4 *)&Bs[buf][pk][q4] = rb;
+    };
+    f32x16 acc[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.0f;
+    const int nk = kt1 - kt0;
+    if (nk > 0) {
+        load_tiles();
+        store_tiles(0);
+    }
+    __syncthreads();
+    const int fm = wr * 32 * TM + (lane & 31), fn = wc * 32 + (lane & 31), fk = lane >> 5;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tiles();
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const float fb = Bs[buf][kk + fk][fn];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(As[buf][kk + fk][fm + 32 * i], fb, acc[i], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+    float *dst = a.partial + (long long)blockIdx.z * a.R * a.Cout;
+    const int n = n0 + wc * 32 + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int rr = r0 + wr * 32 * TM + 32 * i + 4 * (lane >> 5) + (e & 3) + 8 * (e >> 2);
+            if (rr < a.R && n < a.Cout) dst[(long long)rr * a.Cout + n] = acc[i][e];
+        }
+}
+
+// dw[co][ci][ky][kx] = sum over splits of partial[z][(ky*k + kx)*Cin + ci][co].  32 x 32 tiles through LDS: the
+// partials are read along co (coalesced), the gradient is written along ci (contiguous for 1x1, stride k*k else).
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float *partial, int splits, int R, int Cout, int Cin, int k,
+                                                      float *dw)
+{
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const long long per = (long long)R * Cout;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = r0 + ty + 8 * j, co = c0 + tx;
+        float v = 0.0f;
+        if (r < R && co < Cout) {
+            const float *src = partial + (long long)r * Cout + co;
+            int z = 0;
+            for (; z + 8 <= splits; z += 8) { // eight independent loads in flight, fixed summation order
+                float t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = src[(long long)(z + u) * per];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v += t[u];
+            }
+            for (; z < splits; ++z) v += src[(long long)z * per];
+        }
+        tile[ty + 8 * j][tx] = v;
+    }
+    __syncthreads();
+    const int kk = k * k;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = r0 + tx, co = c0 + ty + 8 * j;
+        if (r < R && co < Cout) {
+            const int tap = r / Cin, ci = r - tap * Cin;
+            dw[((long long)co * Cin + ci) * kk + tap] = tile[tx][ty + 8 * j];
+        }
+    }
+}
+
+// ---- BatchNorm (batch statistics) + SiLU ------------------------------------------------------------
+// The tensor is an (M, C) row-major matrix (NHWC), C % 4 == 0.  Reductions over M are two-stage and deterministic:
+// a workgroup of 256 threads = C4 = min(C / 4, 256) float4 columns x 256 / C4 row lanes takes bn_rows_per_wg(M) rows (column
+// chunks of 1024 channels), every thread keeps float64 sums of its four channels with four rows in flight, the row
+// lanes are combined through LDS and the workgroup writes partial[wg][c][2]; a second kernel adds the partials of a
+// channel with 16 lanes in parallel.
+// rows per workgroup: enough workgroups to fill the chip on the mid-size layers, at most 512 rows
+__host__ __device__ inline int bn_rows_per_wg(long long M)
+{
+    long long r = M / 1024;
+    r = (r + 31) / 32 * 32;
+    if (r < 32) r = 32;
+    if (r > 512) r = 512;
+    return (int)r;
+}
+
+template <typename F>
+__device__ __forceinline__ void bn_reduce_rows(long long M, int C, double *partial, F f)
+{
+    __shared__ double red[256][8];
+    const int tid = threadIdx.x;
+    const int rows = bn_rows_per_wg(M);
+    const long long row0 = (long long)blockIdx.x * rows;
+    long long row1 = row0 + rows;
+    if (row1 > M) row1 = M;
+    for (int c0 = 0; c0 < C; c0 += 1024) {
+        const int c4n = (C - c0) / 4 < 256 ? (C - c0) / 4 : 256; // float4 columns in this chunk
+        const int lanes = 256 / c4n;                              // row lanes (>= 1)
+        const int q = tid % c4n, rl = tid / c4n;
+        const int c = c0 + 4 * q;
+        double acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = 0.0;
+        if (rl < lanes) {
+            long long r = row0 + rl;
+            for (; r + 3ll * lanes < row1; r += 4ll * lanes) { // four independent rows in flight
+                float a0[8], a1[8], a2[8], a3[8];
+                f(r, c, a0); f(r + lanes, c, a1); f(r + 2ll * lanes, c, a2); f(r + 3ll * lanes, c, a3);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] += ((double)a0[i] + (double)a1[i]) + ((double)a2[i] + (double)a3[i]);
+            }
+            for (; r < row1; r += lanes) {
+                float a0[8];
+                f(r, c, a0);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] += (double)a0[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) red[tid][i] = acc[i];
+        __syncthreads();
+        if (tid < c4n) {
+            for (int l = 1; l < lanes; ++l)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] += red[tid + l * c4n][i];
+            double *dst = partial + ((long long)blockIdx.x * C + c) * 2;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { dst[2 * j] = acc[j]; dst[2 * j + 1] = acc[4 + j]; }
+        }
+        __syncthreads();
+    }
+}
+
+// partial[wg][c] = {sum, sum of squares} in float64
+__global__ __launch_bounds__(256) void k_bn_stats_partial(const float *z, long long M, int C, double *partial)
+{
+    bn_reduce_rows(M, C, partial, [=](long long r, int c, float (&o)[8]) {
+        const float4 v = *(const float4 *)(z + r * C + c);
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+        o[4] = v.x * v.x; o[5] = v.y * v.y; o[6] = v.z * v.z; o[7] = v.w * v.w;
+    });
+}
+
+// adds the partials of 16 channels per workgroup, 16 lanes per channel -> tot[c] = {sum a, sum b}
+__device__ __forceinline__ void bn_sum_partials(const double *partial, int n_wg, int C, double &s0, double &s1, int &c_out)
+{
+    __shared__ double red2[256][2];
+    const int tid = threadIdx.x, cl = tid & 15, lane = tid >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    double a = 0.0, b = 0.0;
+    if (c < C)
+        for (int w = lane; w < n_wg; w += 16) { a += partial[((long long)w * C + c) * 2]; b += partial[((long long)w * C + c) * 2 + 1]; }
+    red2[tid][0] = a;
+    red2[tid][1] = b;
+    __syncthreads();
+    if (lane == 0)
+        for (int l = 1; l < 16; ++l) { a += red2[cl + 16 * l][0]; b += red2[cl + 16 * l][1]; }
+    s0 = a; s1 = b; c_out = (lane == 0 && c < C) ? c : -1;
+}
+
+// mean, biased variance, invstd = 1 / sqrt(var + eps) in float32 (what BatchNorm2d normalises with)
+__global__ __launch_bounds__(256) void k_bn_stats_final(const double *partial, int n_wg, int C, long long M, float eps,
+                                                        float *mean, float *var, float *invstd)
+{
+    double s, ss;
+    int c;
+    bn_sum_partials(partial, n_wg, C, s, ss, c);
+    if (c < 0) return;
+    const double mu = s / (double)M;
+    double v = ss / (double)M - mu * mu;
+    if (v < 0.0) v = 0.0;
+    mean[c] = (float)mu;
+    var[c] = (float)v;
+    invstd[c] = (float)(1.0 / sqrt(v + (double)eps));
+}
+
+__device__ __forceinline__ float silu_f(float u) { return u / (1.0f + expf(-u)); }
+
+// y = silu(gamma * (z - mean) * invstd + beta)
+__global__ void k_bn_silu_fwd(const float *z, long long n4, int C, const float *gamma, const float *beta, const float *mean,
+                              const float *invstd, float *y)
+{
+    const int C4 = C >> 2;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        const float4 v = ((const float4 *)z)[i];
+        float4 o;
+        o.x = silu_f(gamma[c + 0] * ((v.x - mean[c + 0]) * invstd[c + 0]) + beta[c + 0]);
+        o.y = silu_f(gamma[c + 1] * ((v.y - mean[c + 1]) * invstd[c + 1]) + beta[c + 1]);
+        o.z = silu_f(gamma[c + 2] * ((v.z - mean[c + 2]) * invstd[c + 2]) + beta[c + 2]);
+        o.w = silu_f(gamma[c + 3] * ((v.w - mean[c + 3]) * invstd[c + 3]) + beta[c + 3]);
+        ((float4 *)y)[i] = o;
+    }
+}
+
+// du = dy * d silu(u) / du with u = gamma * zhat + beta
+__device__ __forceinline__ float dsilu_times(float dy, float u)
+{
+    const float s = 1.0f / (1.0f + expf(-u));
+    return dy * (s * (1.0f + u * (1.0f - s)));
+}
+
+// partial[wg][c] = {sum du, sum du * zhat} in float64
+__global__ __launch_bounds__(256) void k_bn_silu_bwd_partial(const float *dy, const float *z, long long M, int C,
+                                                             const float *gamma, const float *beta, const float *mean,
+                                                             const float *invstd, double *partial)
+{
+    bn_reduce_rows(M, C, partial, [=](long long r, int c, float (&o)[8]) {
+        const float4 zv = *(const float4 *)(z + r * C + c), gv = *(const float4 *)(dy + r * C + c);
+        const float zz[4] = {zv.x, zv.y, zv.z, zv.w}, gg[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float zh = (zz[j] - mean[c + j]) * invstd[c + j];
+            const float du = dsilu_times(gg[j], gamma[c + j] * zh + beta[c + j]);
+            o[j] = du;
+            o[4 + j] = du * zh;
+        }
+    });
+}
+
+// dbeta = sum du, dgamma = sum du * zhat (float32 outputs); sums[c] = {dbeta / M, dgamma / M} for the apply pass
+__global__ __launch_bounds__(256) void k_bn_silu_bwd_final(const double *partial, int n_wg, int C, long long M,
+                                                           float *dgamma, float *dbeta, float *sums)
+{
+    double s, sz;
+    int c;
+    bn_sum_partials(partial, n_wg, C, s, sz, c);
+    if (c < 0) return;
+    dbeta[c] = (float)s;
+    dgamma[c] = (float)sz;
+    sums[2 * c + 0] = (float)(s / (double)M);
+    sums[2 * c + 1] = (float)(sz / (double)M);
+}
+
+// dz = gamma * invstd * (du - mean(du) - zhat * mean(du * zhat))
+__global__ void k_bn_silu_bwd_apply(const float *dy, const float *z, long long n4, int C, const float *gamma,
+                                    const float *beta, const float *mean, const float *invstd, const float *sums, float *dz)
+{
+    const int C4 = C >> 2;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        const float4 zv = ((const float4 *)z)[i], gv = ((const float4 *)dy)[i];
+        const float zz[4] = {zv.x, zv.y, zv.z, zv.w}, gg[4] = {gv.x, gv.y, gv.z, gv.w};
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float g = gamma[c + j], is = invstd[c + j];
+            const float zh = (zz[j] - mean[c + j]) * is;
+            const float du = dsilu_times(gg[j], g * zh + beta[c + j]);
+            o[j] = g * is * (du - sums[2 * (c + j)] - zh * sums[2 * (c + j) + 1]);
+        }
+        ((float4 *)dz)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+inline int npad32(int n) { return (n + 31) / 32 * 32; }
+
+} // namespace
+
+extern "C" {
+
+int frlw_conv_weight_layouts(const float *w, int Cout, int Cin, int k, float *w_fwd, float *w_dgrad, frlw_stream_t stream)
+{
+    (void)hipGetLastError(); // other libraries in the process (torch's BLAS look-ups) leave stale errors behind
+    if (!w || Cout < 1 || Cin < 1 || k < 1 || (!w_fwd && !w_dgrad)) return FRLW_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const long long total = (w_fwd ? (long long)k * k * Cin * npad32(Cout) : 0) + (w_dgrad ? (long long)k * k * Cout * npad32(Cin) : 0);
+    hipLaunchKernelGGL(k_weight_layouts, dim3(conv_grid_1d(total)), dim3(256), 0, s, w, Cout, Cin, k, w_fwd, npad32(Cout),
+                       w_dgrad, npad32(Cin));
+    TRY_HIP(hipGetLastError());
+    return FRLW_OK;
+}
+
+static int conv_common(const float *x, int B, int H, int W, int Cin, const float *w_gemm, int Cout, int k, int stride,
+                       int tstride, int Ho, int Wo, float *y, float *scratch, int64_t scratch_floats, hipStream_t s)
+{
+    (void)hipGetLastError(); // other libraries in the process (torch's BLAS look-ups) leave stale errors behind
+    if (!x || !w_gemm || !y || B < 1 || H < 1 || W < 1 || Cin < 4 || (Cin & 3) || Cout < 1 || k < 1) return FRLW_ERR_ARG;
+    ConvArgs c = {};
+    c.x = x; c.H = H; c.W = W; c.Cin = Cin; c.x_cs = Cin; c.x_co = 0; c.x_bs = (long long)H * W * Cin;
+    c.w = w_gemm; c.bias = nullptr; c.Cout = Cout; c.Npad = npad32(Cout); c.k = k; c.stride = stride; c.pad = (k - 1) / 2;
+    c.y = y; c.Ho = Ho; c.Wo = Wo; c.y_cs = Cout; c.y_co = 0; c.y_bs = (long long)Ho * Wo * Cout;
+    c.res = nullptr; c.act = ACT_NONE; c.sig_from = 0;
+    c.M = B * Ho * Wo; c.K = k * k * Cin;
+    c.tstride = tstride;
+    launch_conv(c, scratch, scratch ? scratch_floats : 0, s);
+    if (hipGetLastError() != hipSuccess) return FRLW_ERR_HIP;
+    return FRLW_OK;
+}
+
+int frlw_conv2d_fwd(const float *x, int B, int H, int W, int Cin, const float *w_fwd, int Cout, int k, int stride, float *z,
+                    float *scratch, int64_t scratch_floats, frlw_stream_t stream)
+{
+    if (stride != 1 && stride != 2) return FRLW_ERR_UNSUPPORTED;
+    const int pad = (k - 1) / 2;
+    const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+    return conv_common(x, B, H, W, Cin, w_fwd, Cout, k, stride, 0, Ho, Wo, z, scratch, scratch_floats, (hipStream_t)stream);
+}
+
+int frlw_conv2d_dgrad(const float *dz, int B, int Ho, int Wo, int Cout, const float *w_dgrad, int Cin, int k, int stride,
+                      int H, int W, float *dx, float *scratch, int64_t scratch_floats, frlw_stream_t stream)
+{
+    // dx[iy][ix][ci] = sum dz[(iy + pad - ky) / s][(ix + pad - kx) / s][co] * w[co][ci][ky][kx]: a stride-1 convolution of
+    // dz (transposed gather for s = 2) with the flipped operand and padding k - 1 - pad = pad (odd k)
+    if (stride != 1 && stride != 2) return FRLW_ERR_UNSUPPORTED;
+    if (!(k & 1)) return FRLW_ERR_UNSUPPORTED;
+    return conv_common(dz, B, Ho, Wo, Cout, w_dgrad, Cin, k, 1, stride == 2 ? 2 : 0, H, W, dx, scratch, scratch_floats,
+                       (hipStream_t)stream);
+}
+
+int64_t frlw_conv2d_wgrad_scratch_floats(int B, int Ho, int Wo, int Cin, int Cout, int k)
+{
+    const long long R = (long long)k * k * Cin, bm = R > 64 ? 128 : 64, tiles = ((R + bm - 1) / bm) * ((Cout + 63) / 64);
+    const long long nk = ((long long)B * Ho * Wo + 15) / 16;
+    long long sp = (1024 + tiles - 1) / tiles; // ~1024 workgroups, at most 64 partial tiles per output tile
+    if (sp > 64) sp = 64;
+    if (sp > nk / 4) sp = nk / 4;
+    if (sp < 1) sp = 1;
+    return sp * R * Cout;
+}
+
+int frlw_conv2d_wgrad(const float *x, int B, int H, int W, int Cin, const float *dz, int Ho, int Wo, int Cout, int k,
+                      int stride, float *dw, float *scratch, int64_t scratch_floats, frlw_stream_t stream)
+{
+    (void)hipGetLastError(); // other libraries in the process (torch's BLAS look-ups) leave stale errors behind
+    if (!x || !dz || !dw || !scratch || B < 1 || (Cin & 3) || (Cout & 3) || Cin < 4 || Cout < 4) return FRLW_ERR_ARG;
+    WgradArgs a = {};
+    a.x = x; a.H = H; a.W = W; a.Cin = Cin; a.x_bs = (long long)H * W * Cin; a.x_cs = Cin;
+    a.dz = dz; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.dz_bs = (long long)Ho * Wo * Cout; a.dz_cs = Cout;
+    a.k = k; a.stride = stride; a.pad = (k - 1) / 2;
+    a.R = k * k * Cin; a.M = B * Ho * Wo;
+    const long long per = (long long)a.R * Cout;
+    const long long want = frlw_conv2d_wgrad_scratch_floats(B, Ho, Wo, Cin, Cout, k) / per;
+    long long sp = scratch_floats / per;
+    if (sp > want) sp = want;
+    if (sp < 1) return FRLW_ERR_WORKSPACE;
+    a.splits = (int)sp;
+    a.partial = scratch;
+    hipStream_t s = (hipStream_t)stream;
+    if (a.R > 64)
+        hipLaunchKernelGGL(k_wgrad_mfma<128>, dim3((a.R + 127) / 128, (Cout + 63) / 64, a.splits), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL(k_wgrad_mfma<64>, dim3((a.R + 63) / 64, (Cout + 63) / 64, a.splits), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((a.R + 31) / 32, (Cout + 31) / 32), dim3(256), 0, s, scratch, a.splits, a.R, Cout, Cin, k, dw);
+    TRY_HIP(hipGetLastError());
+    return FRLW_OK;
+}
+
+int64_t frlw_bn_scratch_doubles(int64_t M, int C)
+{
+    const int rows = bn_rows_per_wg(M);
+    return ((M + rows - 1) / rows) * (int64_t)C * 2;
+}
+
+int frlw_bn_stats(const float *z, int64_t M, int C, float eps, float *mean, float *var, float *invstd, double *scratch,
+                  frlw_stream_t stream)
+{
+    (void)hipGetLastError(); // other libraries in the process (torch's BLAS look-ups) leave stale errors behind
+    if (!z || !mean || !var || !invstd || !scratch || M < 1 || C < 4 || (C & 3)) return FRLW_ERR_ARG;
+    const int n_wg = (int)((M + bn_rows_per_wg(M) - 1) / bn_rows_per_wg(M));
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_bn_stats_partial, dim3(n_wg), dim3(256), 0, s, z, (long long)M, C, scratch);
+    hipLaunchKernelGGL(k_bn_stats_final, dim3((C + 15) / 16), dim3(256), 0, s, scratch, n_wg, C, (long long)M, eps, mean,
+                       var, invstd);
+    TRY_HIP(hipGetLastError());
+    return FRLW_OK;
+}
+
+int frlw_bn_silu_fwd(const float *z, int64_t M, int C, const float *gamma, const float *beta, const float *mean,
+                     const float *invstd, float *y, frlw_stream_t stream)
+{
+    (void)hipGetLastError(); // other libraries in the process (torch's BLAS look-ups) leave stale errors behind
+    if (!z || !y || !gamma || !beta || !mean || !invstd || M < 1 || C < 4 || (C & 3)) return FRLW_ERR_ARG;
+    const long long n4 = (long long)M * C / 4;
+    hipLaunchKernelGGL(k_bn_silu_fwd, dim3(conv_grid_1d(n4)), dim3(256), 0, (hipStream_t)stream, z, n4, C, gamma, beta, mean,
+                       invstd, y);
+    TRY_HIP(hipGetLastError());
+    return FRLW_OK;
+}
+
+int frlw_bn_silu_bwd(const float *dy, const float *z, int64_t M, int C, const float *gamma, const float *beta,
+                     const float *mean, const float *invstd, float *dz, float *dgamma, float *dbeta, double *scratch,
+                     float *sums, frlw_stream_t stream)
+{
+    (void)hipGetLastError(); // other libraries in the process (torch's BLAS look-ups) leave stale errors behind
+    if (!dy || !z || !dz || !dgamma || !dbeta || !scratch || !sums || M < 1 || C < 4 || (C & 3)) return FRLW_ERR_ARG;
+    const int n_wg = (int)((M + bn_rows_per_wg(M) - 1) / bn_rows_per_wg(M));
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_bn_silu_bwd_partial, dim3(n_wg), dim3(256), 0, s, dy, z, (long long)M, C, gamma, beta, mean, invstd,
+                       scratch);
+    hipLaunchKernelGGL(k_bn_silu_bwd_final, dim3((C + 15) / 16), dim3(256), 0, s, scratch, n_wg, C, (long long)M, dgamma,
+                       dbeta, sums);
+    const long long n4 = (long long)M * C / 4;
+    hipLaunchKernelGGL(k_bn_silu_bwd_apply, dim3(conv_grid_1d(n4)), dim3(256), 0, s, dy, z, n4, C, gamma, beta, mean, invstd,
+                       sums, dz);
+    TRY_HIP(hipGetLastError());
+    return FRLW_OK;
+}
+
+/* ---- one call per BaseConv and direction (the per-operator entry points above stay for tests / other callers) ---- */
+int64_t frlw_baseconv_train_scratch_bytes(int B, int H, int W, int Cin, int Cout, int k, int stride)
+{
+    const int pad = (k - 1) / 2;
+    const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+    const int64_t M = (int64_t)B * Ho * Wo;
+    int64_t bytes = 0;
+    bytes += sizeof(float) * (int64_t)k * k * Cin * npad32(Cout);   // forward operand
+    bytes += sizeof(float) * (int64_t)k * k * Cout * npad32(Cin);   // data-gradient operand
+    bytes += sizeof(double) * frlw_bn_scratch_doubles(M, Cout);     // reduction partials
+    bytes += sizeof(float) * 2 * Cout;                              // sums
+    bytes += sizeof(float) * frlw_conv2d_wgrad_scratch_floats(B, Ho, Wo, Cin, Cout, k);
+    bytes += sizeof(float) * 8ll * 1024 * 1024;                     // split-K partials of forward / data gradient
+    return bytes + 6 * 256;
+}
+
+namespace {
+struct TrainScratch { float *w_fwd, *w_dg, *sums, *wgrad, *splitk; double *red; int64_t wgrad_floats, splitk_floats; };
+inline TrainScratch carve(void *scratch, int B, int Ho, int Wo, int Cin, int Cout, int k)
+{
+    char *p = (char *)scratch;
+    auto take = [&](int64_t bytes) { char *r = p; p += (bytes + 255) / 256 * 256; return r; };
+    TrainScratch t;
+    t.w_fwd = (float *)take(sizeof(float) * (int64_t)k * k * Cin * npad32(Cout));
+    t.w_dg = (float *)take(sizeof(float) * (int64_t)k * k * Cout * npad32(Cin));
+    t.red = (double *)take(sizeof(double) * frlw_bn_scratch_doubles((int64_t)B * Ho * Wo, Cout));
+    t.sums = (float *)take(sizeof(float) * 2 * Cout);
+    t.wgrad_floats = frlw_conv2d_wgrad_scratch_floats(B, Ho, Wo, Cin, Cout, k);
+    t.wgrad = (float *)take(sizeof(float) * t.wgrad_floats);
+    t.splitk_floats = 8ll * 1024 * 1024;
+    t.splitk = (float *)take(sizeof(float) * t.splitk_floats);
+    return t;
+}
+} // namespace
+
+/* y = silu(bn(conv(x, w))) with batch statistics; z (the convolution output), mean, var (biased), invstd are outputs
+ * the backward needs.  scratch: frlw_baseconv_train_scratch_bytes bytes, contents not needed afterwards. */
+int frlw_baseconv_train_fwd(const float *x, const float *w, const float *gamma, const float *beta, float eps, int B, int H,
+                            int W, int Cin, int Cout, int k, int stride, float *z, float *y, float *mean, float *var,
+                            float *invstd, void *scratch, int64_t scratch_bytes, frlw_stream_t stream)
+{
+    if (!x || !w || !gamma || !beta || !z || !y || !mean || !var || !invstd || !scratch) return FRLW_ERR_ARG;
+    if (scratch_bytes < frlw_baseconv_train_scratch_bytes(B, H, W, Cin, Cout, k, stride)) return FRLW_ERR_WORKSPACE;
+    const int pad = (k - 1) / 2;
+    const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+    const int64_t M = (int64_t)B * Ho * Wo;
+    TrainScratch t = carve(scratch, B, Ho, Wo, Cin, Cout, k);
+    int rc;
+    if ((rc = frlw_conv_weight_layouts(w, Cout, Cin, k, t.w_fwd, nullptr, stream)) != FRLW_OK) return rc;
+    if ((rc = frlw_conv2d_fwd(x, B, H, W, Cin, t.w_fwd, Cout, k, stride, z, t.splitk, t.splitk_floats, stream)) != FRLW_OK) return rc;
+    if ((rc = frlw_bn_stats(z, M, Cout, eps, mean, var, invstd, t.red, stream)) != FRLW_OK) return rc;
+    return frlw_bn_silu_fwd(z, M, Cout, gamma, beta, mean, invstd, y, stream);
+}
+
+/* Gradients of the block: dx (NULL: not needed), dw (Cout, Cin, k, k), dgamma, dbeta.  dz: (B, Ho, Wo, Cout) work buffer. */
+int frlw_baseconv_train_bwd(const float *dy, const float *x, const float *z, const float *w, const float *gamma,
+                            const float *beta, const float *mean, const float *invstd, int B, int H, int W, int Cin,
+                            int Cout, int k, int stride, float *dz, float *dx, float *dw, float *dgamma, float *dbeta,
+                            void *scratch, int64_t scratch_bytes, frlw_stream_t stream)
+{
+    if (!dy || !x || !z || !w || !gamma || !beta || !mean || !invstd || !dz || !dw || !dgamma || !dbeta || !scratch)
+        return FRLW_ERR_ARG;
+    if (scratch_bytes < frlw_baseconv_train_scratch_bytes(B, H, W, Cin, Cout, k, stride)) return FRLW_ERR_WORKSPACE;
+    const int pad = (k - 1) / 2;
+    const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+    const int64_t M = (int64_t)B * Ho * Wo;
+    TrainScratch t = carve(scratch, B, Ho, Wo, Cin, Cout, k);
+    int rc;
+    if ((rc = frlw_bn_silu_bwd(dy, z, M, Cout, gamma, beta, mean, invstd, dz, dgamma, dbeta, t.red, t.sums, stream)) != FRLW_OK) return rc;
+    if (dx) {
+        if ((rc = frlw_conv_weight_layouts(w, Cout, Cin, k, nullptr, t.w_dg, stream)) != FRLW_OK) return rc;
+        if ((rc = frlw_conv2d_dgrad(dz, B, Ho, Wo, Cout, t.w_dg, Cin, k, stride, H, W, dx, t.splitk, t.splitk_floats, stream)) != FRLW_OK) return rc;
+    }
+    return frlw_conv2d_wgrad(x, B, H, W, Cin, dz, Ho, Wo, Cout, k, stride, dw, t.wgrad, t.wgrad_floats, stream);
+}
+
+} // extern "C"

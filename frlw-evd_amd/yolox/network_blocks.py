@@ -38,6 +38,12 @@ class BaseConv(nn.Module):
         self.act = get_activation(act, inplace=True)
 
     def forward(self, x):
+        if self.training and x.is_cuda:
+            # train step on the GPU: forward, data / weight gradients and BatchNorm + SiLU run in the gfx950 kernels of
+            # csrc/train_ops.hip (FRLW_NATIVE_TRAIN=0: torch autograd / MIOpen, for A/B timing)
+            from . import train_ops
+            if train_ops.eligible(x, self.conv, self.bn, self.act):
+                return train_ops.base_conv_train(x, self.conv, self.bn)
         return self.act(self.bn(self.conv(x)))
 
 
@@ -70,6 +76,8 @@ class SPPBottleneck(nn.Module):
 
     def forward(self, x):
         x = self.conv1(x)
+        if self.training and x.is_cuda:
+            x = x.contiguous()  # ATen's channels_last max-pool backward is 0.5 ms per pool (measured); NCHW is not
         return self.conv2(torch.cat([x] + [m(x) for m in self.m], dim=1))
 
 

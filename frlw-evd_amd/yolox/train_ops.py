@@ -1,0 +1,114 @@
+"""Autograd wrapper of the training-mode BaseConv kernels (csrc/train_ops.hip): Conv2d(bias=False) +
+BatchNorm2d(batch statistics) + SiLU as ONE ``torch.autograd.Function`` on channels_last tensors
+(reference: core/yolox/models/network_blocks.py:33-65; the train step of core/exp.py:283-315).
+
+``base_conv_train(x, conv, bn)`` is what ``BaseConv.forward`` calls in training mode on a ROCm tensor
+(FRLW_NATIVE_TRAIN=0 switches back to torch autograd / MIOpen for A/B timing).  The function saves only the
+convolution input and output; ``u = gamma * zhat + beta`` is recomputed in the backward.  Running statistics
+are updated like ``nn.BatchNorm2d`` (momentum, unbiased variance, num_batches_tracked).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+from .. import _lib
+
+_SCRATCH = {}
+
+
+def _scratch(dev, key, numel, dtype):
+    k = (dev.index, key, dtype)
+    t = _SCRATCH.get(k)
+    if t is None or t.numel() < numel:
+        t = torch.empty(max(int(numel), 1), dtype=dtype, device=dev)
+        _SCRATCH[k] = t
+    return t
+
+
+def _stream(dev):
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def _nhwc(x):
+    """(B, C, H, W) logical tensor with NHWC storage (no copy when it already is channels_last)."""
+    return x.contiguous(memory_format=torch.channels_last)
+
+
+def pad32(n):
+    return (n + 31) // 32 * 32
+
+
+def native_enabled():
+    return os.environ.get("FRLW_NATIVE_TRAIN", "1") != "0"
+
+
+class _BaseConvTrain(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, stride, eps):
+        lib = _lib.load()
+        dev = x.device
+        x = _nhwc(x.float())
+        B, Cin, H, W = x.shape
+        Cout, _, k, _ = weight.shape
+        pad = (k - 1) // 2
+        Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+        w = weight.detach().float().contiguous()
+        g = gamma.detach().float().contiguous()
+        b = beta.detach().float().contiguous()
+        z = torch.empty((B, Cout, Ho, Wo), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
+        y = torch.empty_like(z)
+        stats = torch.empty((3, Cout), dtype=torch.float32, device=dev)  # mean, biased variance, invstd
+        sc = _scratch(dev, "block", lib.frlw_baseconv_train_scratch_bytes(B, H, W, Cin, Cout, k, stride), torch.uint8)
+        _lib.check(lib.frlw_baseconv_train_fwd(x.data_ptr(), w.data_ptr(), g.data_ptr(), b.data_ptr(), C.c_float(eps), B, H, W,
+                                               Cin, Cout, k, stride, z.data_ptr(), y.data_ptr(), stats[0].data_ptr(),
+                                               stats[1].data_ptr(), stats[2].data_ptr(), sc.data_ptr(), sc.numel(),
+                                               _stream(dev)), "baseconv_train_fwd")
+        ctx.save_for_backward(x, z, w, g, b, stats)
+        ctx.geom = (B, Cin, H, W, Cout, k, stride)
+        mean, var = stats[0], stats[1]
+        ctx.mark_non_differentiable(mean, var)
+        return y, mean, var
+
+    @staticmethod
+    def backward(ctx, dy, _dmean, _dvar):
+        lib = _lib.load()
+        x, z, w, g, b, stats = ctx.saved_tensors
+        B, Cin, H, W, Cout, k, stride = ctx.geom
+        dev = dy.device
+        dy = _nhwc(dy.float())
+        dz = torch.empty_like(z)
+        dx = (torch.empty((B, Cin, H, W), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
+              if ctx.needs_input_grad[0] else None)
+        dw = torch.empty((Cout, Cin, k, k), dtype=torch.float32, device=dev)
+        dgb = torch.empty((2, Cout), dtype=torch.float32, device=dev)
+        sc = _scratch(dev, "block", lib.frlw_baseconv_train_scratch_bytes(B, H, W, Cin, Cout, k, stride), torch.uint8)
+        _lib.check(lib.frlw_baseconv_train_bwd(dy.data_ptr(), x.data_ptr(), z.data_ptr(), w.data_ptr(), g.data_ptr(),
+                                               b.data_ptr(), stats[0].data_ptr(), stats[2].data_ptr(), B, H, W, Cin, Cout, k,
+                                               stride, dz.data_ptr(), dx.data_ptr() if dx is not None else None,
+                                               dw.data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(), sc.data_ptr(),
+                                               sc.numel(), _stream(dev)), "baseconv_train_bwd")
+        return dx, dw, dgb[0], dgb[1], None, None
+
+
+def base_conv_train(x, conv, bn):
+    """silu(bn(conv(x))) with batch statistics, running statistics updated like nn.BatchNorm2d.forward."""
+    y, mean, var = _BaseConvTrain.apply(x, conv.weight, bn.weight, bn.bias, conv.stride[0], bn.eps)
+    if bn.track_running_stats:
+        with torch.no_grad():
+            n = y.numel() // y.shape[1]
+            bn.num_batches_tracked += 1
+            m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+            bn.running_mean.mul_(1 - m).add_(mean, alpha=m)
+            bn.running_var.mul_(1 - m).add_(var * (n / max(n - 1, 1)), alpha=m)
+    return y
+
+
+def eligible(x, conv, bn, act):
+    return (native_enabled() and x.is_cuda and isinstance(act, torch.nn.SiLU) and conv.bias is None
+            and conv.groups == 1 and conv.in_channels % 4 == 0 and conv.out_channels % 4 == 0
+            and conv.kernel_size[0] == conv.kernel_size[1] and conv.kernel_size[0] % 2 == 1
+            and conv.stride[0] == conv.stride[1] and conv.stride[0] in (1, 2)
+            and conv.padding[0] == (conv.kernel_size[0] - 1) // 2 and conv.dilation[0] == 1)

@@ -94,8 +94,22 @@ class YOLOXHead(nn.Module):
             x = self.stems[k](x)
             cls_feat = self.cls_convs[k](x)
             reg_feat = self.reg_convs[k](x)
-            outs.append(torch.cat([self.reg_preds[k](reg_feat), self.obj_preds[k](reg_feat), self.cls_preds[k](cls_feat)], 1))
+            outs.append(torch.cat([self._pred(self.reg_preds[k], reg_feat), self._pred(self.obj_preds[k], reg_feat),
+                                   self._pred(self.cls_preds[k], cls_feat)], 1))
         return outs
+
+    @staticmethod
+    def _pred(conv, feat):
+        """The biased 1x1 prediction convolution.  On channels_last tensors (what the native BaseConv kernels produce)
+        it is a plain (B*H*W, C) x (C, n) GEMM on the NHWC view -- MIOpen would pick a naive NHWC weight-gradient
+        kernel for these 1-, 2- and 4-channel outputs (5.5 ms each, measured)."""
+        if feat.is_cuda and feat.dim() == 4 and feat.is_contiguous(memory_format=torch.channels_last) \
+                and not feat.is_contiguous():
+            B, C, H, W = feat.shape
+            out = torch.nn.functional.linear(feat.permute(0, 2, 3, 1).reshape(B * H * W, C),
+                                             conv.weight.view(conv.out_channels, C), conv.bias)
+            return out.view(B, H, W, conv.out_channels).permute(0, 3, 1, 2)
+        return conv(feat)
 
     def forward(self, xin, labels=None, imgs=None):
         if self.training:

@@ -266,6 +266,53 @@ int frlw_eval_transform_dt(const float *dets, const int32_t *img_of_row, const i
                            float rh, float skip_ts, float min_diag_sq, float min_w, float min_h, float *out,
                            uint8_t *keep, frlw_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Training-mode BaseConv = Conv2d(bias=False) + BatchNorm2d(batch statistics) + SiLU
+ * (core/yolox/models/network_blocks.py:33-65) for the train step of core/exp.py:283-315: forward, data gradient,
+ * weight gradient, BatchNorm + SiLU forward / backward.  All tensors NHWC float32 (= torch channels_last storage),
+ * dense (pixel stride = channels).  Cin % 4 == 0 and Cout % 4 == 0.  `scratch` buffers are caller-owned.
+ * ------------------------------------------------------------------------------------------- */
+/* torch weight (Cout, Cin, k, k) -> forward operand (k*k*Cin, pad32(Cout)) and / or data-gradient operand
+ * (k*k*Cout, pad32(Cin)) with flipped taps; pad32(n) = n rounded up to 32.  Either output may be NULL. */
+int frlw_conv_weight_layouts(const float *w, int Cout, int Cin, int k, float *w_fwd, float *w_dgrad, frlw_stream_t stream);
+/* z (B, Ho, Wo, Cout) = conv2d(x (B, H, W, Cin), w), padding (k - 1) / 2, stride 1 or 2.  scratch: optional split-K
+ * partial sums (scratch_floats floats; NULL = never split). */
+int frlw_conv2d_fwd(const float *x, int B, int H, int W, int Cin, const float *w_fwd, int Cout, int k, int stride, float *z,
+                    float *scratch, int64_t scratch_floats, frlw_stream_t stream);
+/* dx (B, H, W, Cin) = gradient of the convolution above with respect to x, from dz (B, Ho, Wo, Cout). */
+int frlw_conv2d_dgrad(const float *dz, int B, int Ho, int Wo, int Cout, const float *w_dgrad, int Cin, int k, int stride,
+                      int H, int W, float *dx, float *scratch, int64_t scratch_floats, frlw_stream_t stream);
+/* dw in torch's (Cout, Cin, k, k) layout = gradient with respect to the weight; scratch is REQUIRED
+ * (frlw_conv2d_wgrad_scratch_floats floats for full parallelism; fewer = fewer splits). */
+int64_t frlw_conv2d_wgrad_scratch_floats(int B, int Ho, int Wo, int Cin, int Cout, int k);
+int frlw_conv2d_wgrad(const float *x, int B, int H, int W, int Cin, const float *dz, int Ho, int Wo, int Cout, int k,
+                      int stride, float *dw, float *scratch, int64_t scratch_floats, frlw_stream_t stream);
+/* Per-channel batch statistics of z viewed as (M, C): mean, biased variance, invstd = 1 / sqrt(var + eps).
+ * scratch: frlw_bn_scratch_doubles(M, C) doubles. */
+int64_t frlw_bn_scratch_doubles(int64_t M, int C);
+int frlw_bn_stats(const float *z, int64_t M, int C, float eps, float *mean, float *var, float *invstd, double *scratch,
+                  frlw_stream_t stream);
+/* y = silu(gamma * (z - mean) * invstd + beta) */
+int frlw_bn_silu_fwd(const float *z, int64_t M, int C, const float *gamma, const float *beta, const float *mean,
+                     const float *invstd, float *y, frlw_stream_t stream);
+/* dz, dgamma (C), dbeta (C) from dy and the saved z; sums: 2 C floats of scratch. */
+int frlw_bn_silu_bwd(const float *dy, const float *z, int64_t M, int C, const float *gamma, const float *beta,
+                     const float *mean, const float *invstd, float *dz, float *dgamma, float *dbeta, double *scratch,
+                     float *sums, frlw_stream_t stream);
+
+/* The whole block in one call per direction (what frlw-evd_amd/yolox/train_ops.py uses): forward = weight layout +
+ * convolution + batch statistics + BatchNorm/SiLU; backward = BatchNorm/SiLU backward + data gradient (dx may be NULL)
+ * + weight gradient.  x (B, H, W, Cin), z / y / dy / dz (B, Ho, Wo, Cout) NHWC; w and dw in torch's (Cout, Cin, k, k).
+ * mean / var (biased) / invstd: (Cout).  scratch: frlw_baseconv_train_scratch_bytes(...) bytes, reusable between calls. */
+int64_t frlw_baseconv_train_scratch_bytes(int B, int H, int W, int Cin, int Cout, int k, int stride);
+int frlw_baseconv_train_fwd(const float *x, const float *w, const float *gamma, const float *beta, float eps, int B, int H,
+                            int W, int Cin, int Cout, int k, int stride, float *z, float *y, float *mean, float *var,
+                            float *invstd, void *scratch, int64_t scratch_bytes, frlw_stream_t stream);
+int frlw_baseconv_train_bwd(const float *dy, const float *x, const float *z, const float *w, const float *gamma,
+                            const float *beta, const float *mean, const float *invstd, int B, int H, int W, int Cin,
+                            int Cout, int k, int stride, float *dz, float *dx, float *dw, float *dgamma, float *dbeta,
+                            void *scratch, int64_t scratch_bytes, frlw_stream_t stream);
+
 /* Library identification: "frlw_evd <version> gfx950". */
 const char *frlw_version(void);
 
