@@ -20,6 +20,8 @@ struct ConvArgs {
     int splits;        // split-K: blockIdx.z owns a slice of the k-tiles and writes raw partial sums
     float *partial;    // [splits][M][Npad] when splits > 1
     int tstride;       // 0 / 1: ordinary gather; 2: transposed gather (dgrad of a stride-2 convolution)
+    int kw;            // taps per tap row when the window is not square (0: k); K = rows * kw * Cin
+    int y_rp;          // output row pitch in floats (0: dense, pixel p at p * y_cs); else pixel (oy, ox) at oy * y_rp + ox * y_cs
 };
 
 #ifndef CONV_BK_BIG
@@ -75,6 +77,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
 
     // (ky, kx, ci) of this thread's float4 in the CURRENT k-tile to be loaded; advanced by BK per tile
     int t_ci = 0, t_ky = 0, t_kx = 0;
+    const int kw = a.kw ? a.kw : a.k;
     auto load_tiles = [&](int kt) {
         const int k = kt * BK + a_k4;
 #pragma unroll
@@ -87,7 +90,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
                        : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         t_ci += BK; // Cin % 4 == 0: a float4 never straddles taps
-        while (t_ci >= a.Cin) { t_ci -= a.Cin; if (++t_kx == a.k) { t_kx = 0; ++t_ky; } }
+        while (t_ci >= a.Cin) { t_ci -= a.Cin; if (++t_kx == kw) { t_kx = 0; ++t_ky; } }
 #pragma unroll
         for (int i = 0; i < B_F4; ++i) {
             const int e = tid + 256 * i;
@@ -129,8 +132,8 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
         const int k = kt0 * BK + a_k4;
         const int tap = k / a.Cin;
         t_ci = k - tap * a.Cin;
-        t_ky = tap / a.k;
-        t_kx = tap - t_ky * a.k;
+        t_ky = tap / kw;
+        t_kx = tap - t_ky * kw;
     }
     load_tiles(kt0);
     store_tiles(0);
@@ -191,7 +194,9 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
                     while (pix >= howo) { pix -= howo; ++b; }
                     float v = act_apply(acc[i][j][r] + bias, act);
                     if (a.res) v = v + a.res[(long long)b * a.r_bs + (long long)pix * a.r_cs + a.r_co + n];
-                    a.y[(long long)b * a.y_bs + (long long)pix * a.y_cs + a.y_co + n] = v;
+                    long long yo = (long long)pix * a.y_cs;
+                    if (a.y_rp) { const int oy = pix / a.Wo; yo = (long long)oy * a.y_rp + (long long)(pix - oy * a.Wo) * a.y_cs; }
+                    a.y[(long long)b * a.y_bs + yo + a.y_co + n] = v;
                 }
             }
         }
@@ -212,7 +217,9 @@ __global__ void k_splitk_reduce(ConvArgs a)
         v = act_apply(v + (a.bias ? a.bias[n] : 0.0f), act);
         const int b = m / howo, pix = m - b * howo;
         if (a.res) v = v + a.res[(long long)b * a.r_bs + (long long)pix * a.r_cs + a.r_co + n];
-        a.y[(long long)b * a.y_bs + (long long)pix * a.y_cs + a.y_co + n] = v;
+        long long yo = (long long)pix * a.y_cs;
+        if (a.y_rp) { const int oy = pix / a.Wo; yo = (long long)oy * a.y_rp + (long long)(pix - oy * a.Wo) * a.y_cs; }
+        a.y[(long long)b * a.y_bs + yo + a.y_co + n] = v;
     }
 }
 

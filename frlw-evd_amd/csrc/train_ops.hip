@@ -37,7 +37,10 @@ namespace {
 // fwd[(ky*k + kx)*Cin + ci][co] = w[co][ci][ky][kx];  dgr[((k-1-ky)*k + (k-1-kx))*Cout + co][ci] = w[co][ci][ky][kx]
 // One thread per element of the padded forward operand (rows (ky, kx, ci), np_f columns) and of the padded
 // data-gradient operand: every element, padding included, is written, so no memset is needed.
-__global__ void k_weight_layouts(const float *w, int Cout, int Cin, int k, float *fwd, int np_f, float *dgr, int np_d)
+// `parity` != 0 (stride-2, k = 3): the data-gradient operand is grouped by output parity class (py, px) in the order
+// (0,0) (0,1) (1,0) (1,1) with 1, 2, 2, 4 taps -- row blocks starting at 0, 1, 3, 5 times Cout; inside a class the rows
+// are (t_ky, t_kx, co) where tap t reads dz[o' + t] and stands for kernel index 1 (parity 0) or 2, 0 (parity 1, t = 0, 1).
+__global__ void k_weight_layouts(const float *w, int Cout, int Cin, int k, float *fwd, int np_f, float *dgr, int np_d, int parity)
 {
     const int kk = k * k;
     const long long nf = fwd ? (long long)kk * Cin * np_f : 0, nd = dgr ? (long long)kk * Cout * np_d : 0;
@@ -52,7 +55,16 @@ __global__ void k_weight_layouts(const float *w, int Cout, int Cin, int k, float
             const int ci = (int)(e % np_d);
             const long long row = e / np_d;
             const int co = (int)(row % Cout), tapf = (int)(row / Cout); // tapf = flipped tap index
-            dgr[e] = ci < Cin ? w[((long long)co * Cin + ci) * kk + (kk - 1 - tapf)] : 0.0f;
+            int tap = kk - 1 - tapf;
+            if (parity) {
+                const int cls = tapf < 1 ? 0 : (tapf < 3 ? 1 : (tapf < 5 ? 2 : 3));
+                const int tl = tapf - (cls == 0 ? 0 : (cls == 1 ? 1 : (cls == 2 ? 3 : 5)));
+                const int py = cls >> 1, px = cls & 1, kwc = px ? 2 : 1;
+                const int t_ky = tl / kwc, t_kx = tl - t_ky * kwc;
+                const int ky = py ? (t_ky == 0 ? 2 : 0) : 1, kx = px ? (t_kx == 0 ? 2 : 0) : 1;
+                tap = ky * 3 + kx;
+            }
+            dgr[e] = ci < Cin ? w[((long long)co * Cin + ci) * kk + tap] : 0.0f;
         }
     }
 }
@@ -163,6 +175,24 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(WgradArgs a)
             const int rr = r0 + wr * 32 * TM + 32 * i + 4 * (lane >> 5) + (e & 3) + 8 * (e >> 2);
             if (rr < a.R && n < a.Cout) dst[(long long)rr * a.Cout + n] = acc[i][e];
         }
+}
+
+// Thin layers have few output tiles and therefore many pixel splits: first add groups of kWgradGroup partial tiles
+// in parallel (same layout), then the final pass below runs over the group sums.  Fixed order -> deterministic.
+constexpr int kWgradGroup = 16;
+__global__ void k_wgrad_group_sum(const float *partial, int splits, long long per, float *out)
+{
+    const int g = blockIdx.y;
+    const int z0 = g * kWgradGroup, z1 = z0 + kWgradGroup < splits ? z0 + kWgradGroup : splits;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < per; i += (long long)gridDim.x * blockDim.x) {
+        float t[kWgradGroup];
+#pragma unroll
+        for (int u = 0; u < kWgradGroup; ++u) t[u] = z0 + u < z1 ? partial[(long long)(z0 + u) * per + i] : 0.0f;
+        float v = 0.0f;
+#pragma unroll
+        for (int u = 0; u < kWgradGroup; ++u) v += t[u];
+        out[(long long)g * per + i] = v;
+    }
 }
 
 // dw[co][ci][ky][kx] = sum over splits of partial[z][(ky*k + kx)*Cin + ci][co].  32 x 32 tiles through LDS: the
@@ -395,14 +425,15 @@ inline int npad32(int n) { return (n + 31) / 32 * 32; }
 
 extern "C" {
 
-int frlw_conv_weight_layouts(const float *w, int Cout, int Cin, int k, float *w_fwd, float *w_dgrad, frlw_stream_t stream)
+int frlw_conv_weight_layouts(const float *w, int Cout, int Cin, int k, int stride, float *w_fwd, float *w_dgrad,
+                             frlw_stream_t stream)
 {
     (void)hipGetLastError(); // other libraries in the process (torch's BLAS look-ups) leave stale errors behind
     if (!w || Cout < 1 || Cin < 1 || k < 1 || (!w_fwd && !w_dgrad)) return FRLW_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     const long long total = (w_fwd ? (long long)k * k * Cin * npad32(Cout) : 0) + (w_dgrad ? (long long)k * k * Cout * npad32(Cin) : 0);
     hipLaunchKernelGGL(k_weight_layouts, dim3(conv_grid_1d(total)), dim3(256), 0, s, w, Cout, Cin, k, w_fwd, npad32(Cout),
-                       w_dgrad, npad32(Cin));
+                       w_dgrad, npad32(Cin), (stride == 2 && k == 3) ? 1 : 0);
     TRY_HIP(hipGetLastError());
     return FRLW_OK;
 }
@@ -440,6 +471,28 @@ int frlw_conv2d_dgrad(const float *dz, int B, int Ho, int Wo, int Cout, const fl
     // dz (transposed gather for s = 2) with the flipped operand and padding k - 1 - pad = pad (odd k)
     if (stride != 1 && stride != 2) return FRLW_ERR_UNSUPPORTED;
     if (!(k & 1)) return FRLW_ERR_UNSUPPORTED;
+    if (stride == 2 && k == 3) {
+        // four stride-1 convolutions of dz, one per output parity class, with 1 / 2 / 2 / 4 of the nine taps (no
+        // multiplications by the zeros of the up-sampled gradient); class (py, px) writes dx[2 o' + (py, px)]
+        if ((H & 1) || (W & 1) || Ho * 2 != H || Wo * 2 != W) return FRLW_ERR_UNSUPPORTED;
+        if (!dz || !w_dgrad || !dx || B < 1 || Cout < 4 || (Cout & 3) || Cin < 1) return FRLW_ERR_ARG;
+        (void)hipGetLastError();
+        static const int row0[4] = {0, 1, 3, 5};
+        for (int cls = 0; cls < 4; ++cls) {
+            const int py = cls >> 1, px = cls & 1, kh = py ? 2 : 1, kwc = px ? 2 : 1;
+            ConvArgs c = {};
+            c.x = dz; c.H = Ho; c.W = Wo; c.Cin = Cout; c.x_cs = Cout; c.x_co = 0; c.x_bs = (long long)Ho * Wo * Cout;
+            c.w = w_dgrad + (long long)row0[cls] * Cout * npad32(Cin); c.bias = nullptr;
+            c.Cout = Cin; c.Npad = npad32(Cin); c.k = kh; c.kw = kwc; c.stride = 1; c.pad = 0;
+            c.y = dx; c.Ho = Ho; c.Wo = Wo; c.y_cs = 2 * Cin; c.y_rp = 2 * W * Cin; c.y_co = (py * W + px) * Cin;
+            c.y_bs = (long long)H * W * Cin;
+            c.res = nullptr; c.act = ACT_NONE;
+            c.M = B * Ho * Wo; c.K = kh * kwc * Cout;
+            launch_conv(c, scratch, scratch ? scratch_floats : 0, (hipStream_t)stream);
+        }
+        if (hipGetLastError() != hipSuccess) return FRLW_ERR_HIP;
+        return FRLW_OK;
+    }
     return conv_common(dz, B, Ho, Wo, Cout, w_dgrad, Cin, k, 1, stride == 2 ? 2 : 0, H, W, dx, scratch, scratch_floats,
                        (hipStream_t)stream);
 }
@@ -448,11 +501,26 @@ int64_t frlw_conv2d_wgrad_scratch_floats(int B, int Ho, int Wo, int Cin, int Cou
 {
     const long long R = (long long)k * k * Cin, bm = R > 64 ? 128 : 64, tiles = ((R + bm - 1) / bm) * ((Cout + 63) / 64);
     const long long nk = ((long long)B * Ho * Wo + 15) / 16;
-    long long sp = (1024 + tiles - 1) / tiles; // ~1024 workgroups, at most 64 partial tiles per output tile
-    if (sp > 64) sp = 64;
+    long long sp = (1024 + tiles - 1) / tiles; // ~1024 workgroups
+    if (sp > 256) sp = 256;                    // (more than 64 partial tiles per output tile: two-stage reduction)
     if (sp > nk / 4) sp = nk / 4;
     if (sp < 1) sp = 1;
-    return sp * R * Cout;
+    const long long groups = sp > 64 ? (sp + kWgradGroup - 1) / kWgradGroup : 0;
+    return (sp + groups) * R * Cout;
+}
+
+static long long wgrad_splits_for(long long scratch_floats, long long per, long long want_total)
+{
+    // want_total = (sp + groups) * per from the query; recover the largest sp that fits the given scratch
+    long long sp = want_total / per;
+    if (sp > 64) { // undo the group allowance: sp + ceil(sp / 16) <= want_total / per
+        long long s = sp * kWgradGroup / (kWgradGroup + 1);
+        while (s + (s + kWgradGroup - 1) / kWgradGroup > sp) --s;
+        sp = s;
+    }
+    long long fit = scratch_floats / per;
+    if (fit > 64) { long long s = fit * kWgradGroup / (kWgradGroup + 1); while (s + (s + kWgradGroup - 1) / kWgradGroup > fit) --s; fit = s > 64 ? s : 64; }
+    return sp < fit ? sp : fit;
 }
 
 int frlw_conv2d_wgrad(const float *x, int B, int H, int W, int Cin, const float *dz, int Ho, int Wo, int Cout, int k,
@@ -466,9 +534,7 @@ int frlw_conv2d_wgrad(const float *x, int B, int H, int W, int Cin, const float 
     a.k = k; a.stride = stride; a.pad = (k - 1) / 2;
     a.R = k * k * Cin; a.M = B * Ho * Wo;
     const long long per = (long long)a.R * Cout;
-    const long long want = frlw_conv2d_wgrad_scratch_floats(B, Ho, Wo, Cin, Cout, k) / per;
-    long long sp = scratch_floats / per;
-    if (sp > want) sp = want;
+    const long long sp = wgrad_splits_for(scratch_floats, per, frlw_conv2d_wgrad_scratch_floats(B, Ho, Wo, Cin, Cout, k));
     if (sp < 1) return FRLW_ERR_WORKSPACE;
     a.splits = (int)sp;
     a.partial = scratch;
@@ -477,7 +543,16 @@ int frlw_conv2d_wgrad(const float *x, int B, int H, int W, int Cin, const float 
         hipLaunchKernelGGL(k_wgrad_mfma<128>, dim3((a.R + 127) / 128, (Cout + 63) / 64, a.splits), dim3(256), 0, s, a);
     else
         hipLaunchKernelGGL(k_wgrad_mfma<64>, dim3((a.R + 63) / 64, (Cout + 63) / 64, a.splits), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((a.R + 31) / 32, (Cout + 31) / 32), dim3(256), 0, s, scratch, a.splits, a.R, Cout, Cin, k, dw);
+    const float *final_src = scratch;
+    int final_n = a.splits;
+    if (a.splits > 64) { // group sums go behind the partial tiles (the scratch query reserves the room)
+        const int groups = (a.splits + kWgradGroup - 1) / kWgradGroup;
+        float *gs = scratch + (long long)a.splits * per;
+        hipLaunchKernelGGL(k_wgrad_group_sum, dim3(conv_grid_1d(per), groups), dim3(256), 0, s, scratch, a.splits, per, gs);
+        final_src = gs;
+        final_n = groups;
+    }
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((a.R + 31) / 32, (Cout + 31) / 32), dim3(256), 0, s, final_src, final_n, a.R, Cout, Cin, k, dw);
     TRY_HIP(hipGetLastError());
     return FRLW_OK;
 }
@@ -581,7 +656,7 @@ int frlw_baseconv_train_fwd(const float *x, const float *w, const float *gamma, 
     const int64_t M = (int64_t)B * Ho * Wo;
     TrainScratch t = carve(scratch, B, Ho, Wo, Cin, Cout, k);
     int rc;
-    if ((rc = frlw_conv_weight_layouts(w, Cout, Cin, k, t.w_fwd, nullptr, stream)) != FRLW_OK) return rc;
+    if ((rc = frlw_conv_weight_layouts(w, Cout, Cin, k, stride, t.w_fwd, nullptr, stream)) != FRLW_OK) return rc;
     if ((rc = frlw_conv2d_fwd(x, B, H, W, Cin, t.w_fwd, Cout, k, stride, z, t.splitk, t.splitk_floats, stream)) != FRLW_OK) return rc;
     if ((rc = frlw_bn_stats(z, M, Cout, eps, mean, var, invstd, t.red, stream)) != FRLW_OK) return rc;
     return frlw_bn_silu_fwd(z, M, Cout, gamma, beta, mean, invstd, y, stream);
@@ -603,7 +678,7 @@ int frlw_baseconv_train_bwd(const float *dy, const float *x, const float *z, con
     int rc;
     if ((rc = frlw_bn_silu_bwd(dy, z, M, Cout, gamma, beta, mean, invstd, dz, dgamma, dbeta, t.red, t.sums, stream)) != FRLW_OK) return rc;
     if (dx) {
-        if ((rc = frlw_conv_weight_layouts(w, Cout, Cin, k, nullptr, t.w_dg, stream)) != FRLW_OK) return rc;
+        if ((rc = frlw_conv_weight_layouts(w, Cout, Cin, k, stride, nullptr, t.w_dg, stream)) != FRLW_OK) return rc;
         if ((rc = frlw_conv2d_dgrad(dz, B, Ho, Wo, Cout, t.w_dg, Cin, k, stride, H, W, dx, t.splitk, t.splitk_floats, stream)) != FRLW_OK) return rc;
     }
     return frlw_conv2d_wgrad(x, B, H, W, Cin, dz, Ho, Wo, Cout, k, stride, dw, t.wgrad, t.wgrad_floats, stream);
