@@ -325,8 +325,10 @@ __device__ __forceinline__ void bn_sum_partials(const double *partial, int n_wg,
 }
 
 // mean, biased variance, invstd = 1 / sqrt(var + eps) in float32 (what BatchNorm2d normalises with)
+// (+ the running statistics of nn.BatchNorm2d when given: momentum update with the unbiased variance)
 __global__ __launch_bounds__(256) void k_bn_stats_final(const double *partial, int n_wg, int C, long long M, float eps,
-                                                        float *mean, float *var, float *invstd)
+                                                        float *mean, float *var, float *invstd, float *run_mean,
+                                                        float *run_var, float momentum)
 {
     double s, ss;
     int c;
@@ -338,6 +340,11 @@ __global__ __launch_bounds__(256) void k_bn_stats_final(const double *partial, i
     mean[c] = (float)mu;
     var[c] = (float)v;
     invstd[c] = (float)(1.0 / sqrt(v + (double)eps));
+    if (run_mean) {
+        const float unbiased = (float)v * ((float)M / (float)(M > 1 ? M - 1 : 1));
+        run_mean[c] = run_mean[c] * (1.0f - momentum) + momentum * (float)mu;
+        run_var[c] = run_var[c] * (1.0f - momentum) + momentum * unbiased;
+    }
 }
 
 __device__ __forceinline__ float silu_f(float u) { return u / (1.0f + expf(-u)); }
@@ -563,8 +570,17 @@ int64_t frlw_bn_scratch_doubles(int64_t M, int C)
     return ((M + rows - 1) / rows) * (int64_t)C * 2;
 }
 
+static int bn_stats_impl(const float *z, int64_t M, int C, float eps, float *mean, float *var, float *invstd,
+                         double *scratch, float *run_mean, float *run_var, float momentum, frlw_stream_t stream);
+
 int frlw_bn_stats(const float *z, int64_t M, int C, float eps, float *mean, float *var, float *invstd, double *scratch,
                   frlw_stream_t stream)
+{
+    return bn_stats_impl(z, M, C, eps, mean, var, invstd, scratch, nullptr, nullptr, 0.0f, stream);
+}
+
+static int bn_stats_impl(const float *z, int64_t M, int C, float eps, float *mean, float *var, float *invstd,
+                         double *scratch, float *run_mean, float *run_var, float momentum, frlw_stream_t stream)
 {
     (void)hipGetLastError(); // other libraries in the process (torch's BLAS look-ups) leave stale errors behind
     if (!z || !mean || !var || !invstd || !scratch || M < 1 || C < 4 || (C & 3)) return FRLW_ERR_ARG;
@@ -572,7 +588,7 @@ int frlw_bn_stats(const float *z, int64_t M, int C, float eps, float *mean, floa
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(k_bn_stats_partial, dim3(n_wg), dim3(256), 0, s, z, (long long)M, C, scratch);
     hipLaunchKernelGGL(k_bn_stats_final, dim3((C + 15) / 16), dim3(256), 0, s, scratch, n_wg, C, (long long)M, eps, mean,
-                       var, invstd);
+                       var, invstd, run_mean, run_var, momentum);
     TRY_HIP(hipGetLastError());
     return FRLW_OK;
 }
@@ -647,7 +663,8 @@ inline TrainScratch carve(void *scratch, int B, int Ho, int Wo, int Cin, int Cou
  * the backward needs.  scratch: frlw_baseconv_train_scratch_bytes bytes, contents not needed afterwards. */
 int frlw_baseconv_train_fwd(const float *x, const float *w, const float *gamma, const float *beta, float eps, int B, int H,
                             int W, int Cin, int Cout, int k, int stride, float *z, float *y, float *mean, float *var,
-                            float *invstd, void *scratch, int64_t scratch_bytes, frlw_stream_t stream)
+                            float *invstd, float *running_mean, float *running_var, float momentum, void *scratch,
+                            int64_t scratch_bytes, frlw_stream_t stream)
 {
     if (!x || !w || !gamma || !beta || !z || !y || !mean || !var || !invstd || !scratch) return FRLW_ERR_ARG;
     if (scratch_bytes < frlw_baseconv_train_scratch_bytes(B, H, W, Cin, Cout, k, stride)) return FRLW_ERR_WORKSPACE;
@@ -658,7 +675,8 @@ int frlw_baseconv_train_fwd(const float *x, const float *w, const float *gamma, 
     int rc;
     if ((rc = frlw_conv_weight_layouts(w, Cout, Cin, k, stride, t.w_fwd, nullptr, stream)) != FRLW_OK) return rc;
     if ((rc = frlw_conv2d_fwd(x, B, H, W, Cin, t.w_fwd, Cout, k, stride, z, t.splitk, t.splitk_floats, stream)) != FRLW_OK) return rc;
-    if ((rc = frlw_bn_stats(z, M, Cout, eps, mean, var, invstd, t.red, stream)) != FRLW_OK) return rc;
+    if ((rc = bn_stats_impl(z, M, Cout, eps, mean, var, invstd, t.red, running_mean, running_mean ? running_var : nullptr,
+                            momentum, stream)) != FRLW_OK) return rc;
     return frlw_bn_silu_fwd(z, M, Cout, gamma, beta, mean, invstd, y, stream);
 }
 

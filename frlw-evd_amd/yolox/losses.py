@@ -14,8 +14,8 @@ def bboxes_iou_cxcywh(a, b):
     """Pairwise IoU of (N, 4) and (M, 4) boxes in cxcywh (boxes.py:79-102 with xyxy=False)."""
     tl = torch.max(a[:, None, :2] - a[:, None, 2:] / 2, b[:, :2] - b[:, 2:] / 2)
     br = torch.min(a[:, None, :2] + a[:, None, 2:] / 2, b[:, :2] + b[:, 2:] / 2)
-    area_a = torch.prod(a[:, 2:], 1)
-    area_b = torch.prod(b[:, 2:], 1)
+    area_a = a[:, 2] * a[:, 3]  # == torch.prod(a[:, 2:], 1), without prod's cumulative-product backward
+    area_b = b[:, 2] * b[:, 3]
     en = (tl < br).type(tl.type()).prod(dim=2)
     area_i = torch.prod(br - tl, 2) * en
     return area_i / (area_a[:, None] + area_b - area_i)
@@ -27,10 +27,11 @@ def iou_loss(pred, target):
     target = target.view(-1, 4)
     tl = torch.max(pred[:, :2] - pred[:, 2:] / 2, target[:, :2] - target[:, 2:] / 2)
     br = torch.min(pred[:, :2] + pred[:, 2:] / 2, target[:, :2] + target[:, 2:] / 2)
-    area_p = torch.prod(pred[:, 2:], 1)
-    area_g = torch.prod(target[:, 2:], 1)
+    area_p = pred[:, 2] * pred[:, 3]  # == torch.prod(pred[:, 2:], 1) (boxes are (n, 4)); prod's backward scans
+    area_g = target[:, 2] * target[:, 3]
     en = (tl < br).type(tl.type()).prod(dim=1)
-    area_i = torch.prod(br - tl, 1) * en
+    d = br - tl
+    area_i = d[:, 0] * d[:, 1] * en
     iou = area_i / (area_p + area_g - area_i + 1e-16)
     return 1 - iou ** 2
 

@@ -47,7 +47,8 @@ def native_enabled():
 
 class _BaseConvTrain(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, stride, eps):
+    def forward(ctx, x, weight, gamma, beta, stride, eps, run_mean, run_var, momentum):
+        ctx.set_materialize_grads(False)
         lib = _lib.load()
         dev = x.device
         x = _nhwc(x.float())
@@ -64,16 +65,16 @@ class _BaseConvTrain(torch.autograd.Function):
         sc = _scratch(dev, "block", lib.frlw_baseconv_train_scratch_bytes(B, H, W, Cin, Cout, k, stride), torch.uint8)
         _lib.check(lib.frlw_baseconv_train_fwd(x.data_ptr(), w.data_ptr(), g.data_ptr(), b.data_ptr(), C.c_float(eps), B, H, W,
                                                Cin, Cout, k, stride, z.data_ptr(), y.data_ptr(), stats[0].data_ptr(),
-                                               stats[1].data_ptr(), stats[2].data_ptr(), sc.data_ptr(), sc.numel(),
-                                               _stream(dev)), "baseconv_train_fwd")
+                                               stats[1].data_ptr(), stats[2].data_ptr(),
+                                               run_mean.data_ptr() if run_mean is not None else None,
+                                               run_var.data_ptr() if run_var is not None else None, C.c_float(momentum),
+                                               sc.data_ptr(), sc.numel(), _stream(dev)), "baseconv_train_fwd")
         ctx.save_for_backward(x, z, w, g, b, stats)
         ctx.geom = (B, Cin, H, W, Cout, k, stride)
-        mean, var = stats[0], stats[1]
-        ctx.mark_non_differentiable(mean, var)
-        return y, mean, var
+        return y
 
     @staticmethod
-    def backward(ctx, dy, _dmean, _dvar):
+    def backward(ctx, dy):
         lib = _lib.load()
         x, z, w, g, b, stats = ctx.saved_tensors
         B, Cin, H, W, Cout, k, stride = ctx.geom
@@ -90,20 +91,19 @@ class _BaseConvTrain(torch.autograd.Function):
                                                stride, dz.data_ptr(), dx.data_ptr() if dx is not None else None,
                                                dw.data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(), sc.data_ptr(),
                                                sc.numel(), _stream(dev)), "baseconv_train_bwd")
-        return dx, dw, dgb[0], dgb[1], None, None
+        return dx, dw, dgb[0], dgb[1], None, None, None, None, None
 
 
 def base_conv_train(x, conv, bn):
-    """silu(bn(conv(x))) with batch statistics, running statistics updated like nn.BatchNorm2d.forward."""
-    y, mean, var = _BaseConvTrain.apply(x, conv.weight, bn.weight, bn.bias, conv.stride[0], bn.eps)
-    if bn.track_running_stats:
-        with torch.no_grad():
-            n = y.numel() // y.shape[1]
-            bn.num_batches_tracked += 1
-            m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
-            bn.running_mean.mul_(1 - m).add_(mean, alpha=m)
-            bn.running_var.mul_(1 - m).add_(var * (n / max(n - 1, 1)), alpha=m)
-    return y
+    """silu(bn(conv(x))) with batch statistics; the running statistics are updated in the same launch sequence like
+    nn.BatchNorm2d.forward does (momentum, unbiased variance, num_batches_tracked)."""
+    track = bn.track_running_stats and bn.running_mean is not None
+    momentum = 0.0
+    if track:
+        bn.num_batches_tracked += 1
+        momentum = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+    return _BaseConvTrain.apply(x, conv.weight, bn.weight, bn.bias, conv.stride[0], bn.eps,
+                                bn.running_mean if track else None, bn.running_var if track else None, float(momentum))
 
 
 def eligible(x, conv, bn, act):

@@ -306,11 +306,14 @@ int frlw_bn_silu_bwd(const float *dy, const float *z, int64_t M, int C, const fl
 /* The whole block in one call per direction (what frlw-evd_amd/yolox/train_ops.py uses): forward = weight layout +
  * convolution + batch statistics + BatchNorm/SiLU; backward = BatchNorm/SiLU backward + data gradient (dx may be NULL)
  * + weight gradient.  x (B, H, W, Cin), z / y / dy / dz (B, Ho, Wo, Cout) NHWC; w and dw in torch's (Cout, Cin, k, k).
- * mean / var (biased) / invstd: (Cout).  scratch: frlw_baseconv_train_scratch_bytes(...) bytes, reusable between calls. */
+ * mean / var (biased) / invstd: (Cout).  running_mean / running_var (may be NULL) are updated in place like
+ * nn.BatchNorm2d: r = (1 - momentum) r + momentum * {mean, unbiased variance}.
+ * scratch: frlw_baseconv_train_scratch_bytes(...) bytes, reusable between calls. */
 int64_t frlw_baseconv_train_scratch_bytes(int B, int H, int W, int Cin, int Cout, int k, int stride);
 int frlw_baseconv_train_fwd(const float *x, const float *w, const float *gamma, const float *beta, float eps, int B, int H,
                             int W, int Cin, int Cout, int k, int stride, float *z, float *y, float *mean, float *var,
-                            float *invstd, void *scratch, int64_t scratch_bytes, frlw_stream_t stream);
+                            float *invstd, float *running_mean, float *running_var, float momentum, void *scratch,
+                            int64_t scratch_bytes, frlw_stream_t stream);
 int frlw_baseconv_train_bwd(const float *dy, const float *x, const float *z, const float *w, const float *gamma,
                             const float *beta, const float *mean, const float *invstd, int B, int H, int W, int Cin,
                             int Cout, int k, int stride, float *dz, float *dx, float *dw, float *dgamma, float *dbeta,
