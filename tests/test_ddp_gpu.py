@@ -1,0 +1,80 @@
+"""Train step under DistributedDataParallel with the native BaseConv kernels: two ranks share the one GPU of the
+test box (gloo rendezvous on 127.0.0.1; the driver's multi-GPU runs use RCCL, same code path above the backend).
+Checks that the custom autograd Function fires DDP's gradient hooks: after one backward both ranks hold the same
+gradients = the mean of the per-rank gradients, and those equal a single-process run of the two half batches."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+import torch.multiprocessing as mp  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _inputs(rank, B=2):
+    rng = np.random.default_rng(500 + rank)
+    x = torch.from_numpy(rng.integers(0, 256, size=(B, 16, 128, 160, 1, 1)).astype(np.float32) / np.float32(255))
+    lab = torch.zeros(B, 80, 5, dtype=torch.float64)
+    lab[:, 0] = torch.tensor([0, 60.0 + 10 * rank, 50.0, 40.0, 30.0])
+    lab[:, 1] = torch.tensor([1, 100.0, 90.0 - 5 * rank, 30.0, 50.0])
+    return x, lab
+
+
+def _build():
+    from frlw_evd_amd.yolox import build_yolox
+    from frlw_evd_amd.yolox.model import recipe_state_dict
+    m = build_yolox(16, 2)
+    m.load_state_dict(recipe_state_dict(m, seed=77))
+    return m.cuda().train()
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), FRLW_DIST_BACKEND="gloo")
+    from frlw_evd_amd import dist as fd
+    from torch.nn.parallel import DistributedDataParallel
+    fd.init_from_env("gloo")
+    torch.cuda.set_device(0)
+    ddp = DistributedDataParallel(_build(), device_ids=[0], broadcast_buffers=False)  # core/exp.py:391
+    x, lab = _inputs(rank)
+    loss = ddp(x.cuda(), lab.cuda(), None, None)
+    loss.backward()
+    torch.cuda.synchronize()
+    g = torch.cat([p.grad.flatten().double().cpu() for p in ddp.module.parameters()])
+    np.save(os.path.join(out_dir, f"g{rank}.npy"), g.numpy())
+    np.save(os.path.join(out_dir, f"l{rank}.npy"), np.array(float(loss.detach())))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_ddp_ranks_native_train_ops(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    g0, g1 = (np.load(tmp_path / f"g{r}.npy") for r in range(world))
+    assert np.array_equal(g0, g1)  # the all-reduced (averaged) gradient is the same on both ranks
+    # single process: mean of the two per-rank gradients (each rank normalises its loss by its own foreground count)
+    m = _build()
+    want = None
+    for r in range(world):
+        m.zero_grad(set_to_none=True)
+        x, lab = _inputs(r)
+        loss = m(x.cuda(), lab.cuda(), None, None)
+        assert float(loss.detach()) == pytest.approx(float(np.load(tmp_path / f"l{r}.npy")), rel=1e-5)
+        loss.backward()
+        g = torch.cat([p.grad.flatten().double().cpu() for p in m.parameters()]).numpy()
+        want = g if want is None else want + g
+        m.load_state_dict(_build().state_dict())  # undo the running-statistics update of this pass
+    want = want / world
+    assert np.abs(g0 - want).max() <= 1e-3 * np.abs(want).max()
