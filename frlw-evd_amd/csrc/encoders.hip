@@ -423,7 +423,7 @@ __global__ __launch_bounds__(NT) void k_ev_tile(const uint2 *rec, const uint32_t
 
 // ---- TAF -------------------------------------------------------------------------------------
 struct TafParams {
-    int H, W, twl, tiles_x, K, n_windows, flip, dbg;
+    int H, W, twl, tiles_x, K, n_windows, flip;
     const WsHeader *hdr;
     const uint32_t *leaky_thr; // level thresholds of uint8(leaky_transform(.)), built by k_hist
     float *state;    // (H, W, 2, K)
@@ -486,7 +486,7 @@ __device__ __forceinline__ void taf_tile_body(const uint2 *rec, const uint32_t *
     // closes window w for the thread's cells: FIFO step (skipped when the window is empty in the whole
     // frame, generate_taf.py:40-41), accumulators back to zero
     auto close_window = [&](int w) {
-        const bool has = ((wmask >> w) & 1ull) && !(q.dbg & 2);
+        const bool has = (wmask >> w) & 1ull;
 #pragma unroll
         for (int j = 0; j < C; ++j) {
             if (has) taf_fifo(st[j], K, num[j], sum[j]);
@@ -509,9 +509,7 @@ __device__ __forceinline__ void taf_tile_body(const uint2 *rec, const uint32_t *
         for (; cur_w < wlo; ++cur_w) close_window(cur_w);
         uint32_t c[C], o[C], a[C];
         PROF_MARK(0);
-        if (q.dbg & 8) continue;
         slice_sort<NT, C>(rec, s0, span, sel, cnt, slot, red, c, o, cb);
-        if (q.dbg & 4) continue;
         PROF_RESET;
         segments_order<C>(c, o, slot, SLICE - 1);
         PROF_MARK(4);
@@ -658,7 +656,7 @@ int frlw_debug_prof(unsigned long long *out, int reset)
 }
 #endif
 
-const char *frlw_version(void) { return "frlw_evd 0.3.0 gfx950"; }
+const char *frlw_version(void) { return "frlw_evd 0.4.0 gfx950"; }
 
 size_t frlw_encoder_workspace_bytes(int64_t n_events, int H, int W)
 {
@@ -761,7 +759,6 @@ int frlw_taf_encode(const frlw_events_t *ev, int H, int W, int K, int64_t t_star
     q.n_windows = n_windows;
     q.flip = (flags & FRLW_TAF_U8_FLIP_K) ? 1 : 0;
     q.hdr = pt.hdr; q.state = state; q.view_f32 = view_f32; q.out_u8 = out_u8; q.leaky_thr = pt.leaky_thr;
-    q.dbg = frlw::env_int("FRLW_DBG", 0);
     LAUNCH_TILE_Q(k_taf_tile, pt.plan, s, pt.records, pt.base, q);
     HIP_TRY(hipGetLastError());
     return FRLW_OK;

@@ -60,7 +60,6 @@ struct Decode {
     int time_filter;    // DAT8 EV / SAE: drop t <= t0
     uint32_t win_magic; // floor(2^32 / win), TAF DAT8
     const float *tlut;  // TAF DAT8: tlut[r] = float(r / (win + 1e-8)) - 1 for r in [0, win], or NULL
-    int dbg;            // FRLW_DBG ablation switches (timing experiments only; results are wrong when set)
 };
 
 struct Pos {

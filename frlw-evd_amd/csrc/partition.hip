@@ -234,8 +234,7 @@ __global__ __launch_bounds__(kPartThreads, 8) void k_scatter(Decode P, int bpw, 
             const bool act = o.tile >= 0;
             cells[j >> 1] |= (o.cell & 0xffffu) << (16 * (j & 1));
             const uint64_t am = __ballot(act);
-            if (P.dbg & 512) { if (act) where[j] = (uint32_t)o.tile << 16; }
-            if (am != 0ull && !(P.dbg & 512)) {
+            if (am != 0ull) {
                 if (act) tag[o.tile] = (uint8_t)lane;
                 const int seen = act ? (int)tag[o.tile] : lane; // LDS ops of a wave execute in order
                 uint64_t cm = __ballot(act && seen != lane);
@@ -304,7 +303,7 @@ __global__ __launch_bounds__(kPartThreads, 8) void k_scatter(Decode P, int bpw, 
         if (j < bpw && where[j] != 0xffffffffu) {
             const uint32_t b = where[j] >> 16;
             const uint32_t pos = gs[b] + (uint32_t)woff[b] + (where[j] & 0xffffu);
-            if (!(P.dbg & 256)) records[pos] = make_uint2(meta[j], valb[j]);
+            records[pos] = make_uint2(meta[j], valb[j]);
         }
     }
     if (KIND == KIND_TAF) { // which windows hold events at all: decides "all(forward)", generate_taf.py:40
@@ -450,7 +449,6 @@ int partition_events(const frlw_events_t *ev, int H, int W, int kind, long long 
     if (kind == KIND_TAF && ev->layout == FRLW_LAYOUT_DAT8 && win <= kMaxTlut && !env_int("FRLW_NOLUT", 0)) tlut_w = (float *)(w8 + p.off_tlut);
     d.tlut = tlut_w;
     uint32_t *leaky_w = kind == KIND_TAF ? (uint32_t *)(w8 + p.off_leaky) : nullptr;
-    d.dbg = env_int("FRLW_DBG", 0);
 
     (void)hipGetLastError(); // stale errors of other libraries in the process
     HIP_TRY(hipMemsetAsync(hdr, 0, kHeaderBytes, s));
