@@ -298,6 +298,18 @@ class DetectorEngine:
         bufs, B = self._run(x, 0, self.n_forward_ops)
         return bufs[self.raw_buf].view(B, self.A, self.F)
 
+    def _nms_large(self, dec):
+        """yolo_head.py:276-301 for one image from its decoded (A, 5 + nc) rows."""
+        from .yolox.yolo_head import nms_reference
+        head = self.net.head
+        o = dec[dec[:, 4] > head.obj_threshold]
+        xyxy = torch.cat([o[:, 0:1] - o[:, 2:3] / 2, o[:, 1:2] - o[:, 3:4] / 2, o[:, 0:1] + o[:, 2:3] / 2,
+                          o[:, 1:2] + o[:, 3:4] / 2], dim=-1)
+        o = o[nms_reference(xyxy, o[:, 4], head.nms_threshold)]
+        nc = head.num_classes
+        return torch.cat([o[:, 0:4], torch.argmax(o[:, 5:5 + nc], 1)[:, None].to(o.dtype),
+                          (o[:, 4] * torch.max(o[:, 5:5 + nc], 1)[0])[:, None]], dim=1)
+
     def detect(self, x, return_decoded=False):
         """Full eval forward: list of (n_i, 6) [cx, cy, w, h, cls, obj * max cls] per image."""
         bufs, B = self._run(x, 0, -1)
@@ -306,7 +318,11 @@ class DetectorEngine:
         out = []
         for b, n in enumerate(counts):
             if n < 0:
-                raise RuntimeError("more than 2048 NMS candidates in one image: not handled on device yet")
+                # more than 2048 candidates (the LDS sort of k_decode_nms holds 2048): rare -- an untrained head --
+                # so this image takes the box-by-box procedure on the decoded rows the kernel left in HBM (ROCm
+                # tensors, torch ops; same arithmetic and visiting order as the kernel)
+                out.append(self._nms_large(bufs[self.dec_buf].view(B, self.A, self.F)[b]))
+                continue
             out.append(dets[b, :n].clone() if n > 0 else torch.zeros((1, 6), device=self.device))
         if return_decoded:
             return out, bufs[self.dec_buf].view(B, self.A, self.F)
