@@ -409,7 +409,10 @@ __global__ __launch_bounds__(NT) void k_ev_tile(const uint2 *rec, const uint32_t
     __shared__ uint32_t cnt[NT * CPT];
     __shared__ uint2 slot[TileLds<NT>::SLICE];
     __shared__ uint32_t red[32];
-    (void)n_tiles;
+    if (n_tiles < 0) { // small frame (-n_tiles tiles): every tile as four quarters, grid = 4 * tiles
+        ev_tile_body<NT, 1>(rec, base, q, (int)blockIdx.x >> 2, (int)blockIdx.x & 3, cnt, slot, red);
+        return;
+    }
     if ((int)blockIdx.x >= 4 * kMaxHot) {
         const int tile = (int)blockIdx.x - 4 * kMaxHot;
         if (tile_is_listed(q.hdr, base, tile)) return; // hot: left to its quarters
@@ -614,7 +617,10 @@ __global__ __launch_bounds__(NT) void k_taf_tile(const uint2 *rec, const uint32_
     __shared__ uint2 slot[TileLds<NT>::SLICE];
     __shared__ uint32_t red[48];
     __shared__ uint32_t thr[kLeakyLevels];
-    (void)n_tiles;
+    if (n_tiles < 0) { // small frame (-n_tiles tiles): every tile as four quarters, grid = 4 * tiles
+        taf_tile_body<NT, 1>(rec, base, q, (int)blockIdx.x >> 2, (int)blockIdx.x & 3, cnt, slot, red, thr);
+        return;
+    }
     if ((int)blockIdx.x >= 4 * kMaxHot) {
         const int tile = (int)blockIdx.x - 4 * kMaxHot;
         if (tile_is_listed(q.hdr, base, tile)) return; // hot: left to its quarters
@@ -636,9 +642,17 @@ __global__ __launch_bounds__(NT) void k_taf_tile(const uint2 *rec, const uint32_
             hipLaunchKernelGGL(KERNEL<256>, dim3(GRID), dim3(256), 0, STREAM, __VA_ARGS__);             \
     } while (0)
 #define LAUNCH_TILE(KERNEL, PLAN, STREAM, ...) LAUNCH_TILE_GRID(KERNEL, (PLAN).n_tiles, PLAN, STREAM, __VA_ARGS__)
-// with the four quarters of every listed hot tile in front of the per-tile workgroups (skew)
-#define LAUNCH_TILE_Q(KERNEL, PLAN, STREAM, ...) \
-    LAUNCH_TILE_GRID(KERNEL, (PLAN).n_tiles + kMaxHot * 4, PLAN, STREAM, __VA_ARGS__, (PLAN).n_tiles)
+// With the four quarters of every listed hot tile in front of the per-tile workgroups (skew).  A frame whose tiles
+// do not even give every SIMD of the chip one wavefront (GEN1: 150 tiles x 4 wavefronts on 1024 SIMDs) runs ALL its
+// tiles as quarters: four times the wavefronts, one cell per thread, each quarter streaming its tile's records.
+#define LAUNCH_TILE_Q(KERNEL, PLAN, STREAM, ...)                                                                   \
+    do {                                                                                                           \
+        static const int small_ = frlw::env_int("FRLW_QUARTER_BELOW", 1024);                                        \
+        if ((PLAN).n_tiles * ((4 << (PLAN).twl) / kWave) <= small_)                                                \
+            LAUNCH_TILE_GRID(KERNEL, (PLAN).n_tiles * 4, PLAN, STREAM, __VA_ARGS__, -(PLAN).n_tiles);              \
+        else                                                                                                       \
+            LAUNCH_TILE_GRID(KERNEL, (PLAN).n_tiles + kMaxHot * 4, PLAN, STREAM, __VA_ARGS__, (PLAN).n_tiles);     \
+    } while (0)
 
 } // namespace
 
