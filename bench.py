@@ -119,7 +119,8 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": f"{args.workload}: TAF K={K} encode + leaky transform + uint8, {n} events, {W}x{H}, "
+            "workload": f"{args.workload} (BASELINE.json configs[2]{' at the GEN1 shape' if args.workload == 'taf_gen1' else ''}): "
+                        f"TAF K={K} encode + leaky transform + uint8, {n} events, {W}x{H}, "
                         f"{n_win} windows x {win_us} us, raw 8-byte DAT records resident in HBM"
                         + (", hotspot" if args.hotspot else ""),
             "events_per_step_per_gpu": n,
@@ -157,7 +158,8 @@ def main():
             er.encode_taf_dat(dat2, (H2, W2), st2, 0, wu2, nw2, K2, check=False)
         sync_all()
         dt2, = fd.max_over_ranks([time.perf_counter() - t0])
-        result["also"] = [{"workload": "taf_gen1: TAF K=8 encode + leaky + uint8, 1000000 events, 304x240, 8 windows",
+        result["also"] = [{"workload": "taf_gen1 (the GEN1 304x240 shape BASELINE.json's metric names): TAF K=8 encode + leaky + "
+                                       "uint8, 1000000 events, 304x240, 8 windows",
                            "value": round(n_gpus * n2 / (dt2 / args.steps) / 1e6, 2), "unit": "Mevents/s",
                            "ms_per_step": round(dt2 / args.steps * 1e3, 4)}]
     if not args.no_detector:
@@ -263,7 +265,7 @@ def bench_detector(args, torch, dist, world, rank, sync_all):
     elapsed, dev_ms = fd.max_over_ranks([elapsed, dev_ms])
     tflops = eng.flops_per_image * B / (dev_ms * 1e-3) / 1e12
     out = {
-        "metric": "YOLOX-S (CSPDarknet + PAFPN + decoupled head) eval forward to the pre-NMS tensor",
+        "metric": "YOLOX-S (CSPDarknet + PAFPN + decoupled head) eval forward to the pre-NMS tensor (BASELINE.json configs[3])",
         "value": round(world * B / (elapsed / steps), 1), "unit": "frames/s", "batch_per_gpu": B,
         "input": "(B, 10, 256, 320) f32, recipe weights", "steps": steps, "ms_per_batch": round(elapsed / steps * 1e3, 3),
         "dtype": "f32", "fwd_plus_decode_nms_ms": round(full_ms, 3),
