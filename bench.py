@@ -207,6 +207,23 @@ def bench_train(args, torch, world, rank, local_rank, sync_all):
         return dt, loss
 
     dt, loss = timed()  # BaseConv forward / backward in the gfx950 kernels of csrc/train_ops.hip (the default)
+    # BASELINE.json configs[4]: the same step fed by the TAF encode of its batch (B GEN1-shaped streams of 8 x 125 000
+    # events -> TAF K=8 -> leaky -> uint8 -> nearest 256x320 -> /255), everything on this GPU
+    src = e2e.SyntheticTafSource(B, seed=1005 + 1000 * rank)
+    idx = list(range(B))
+    for i in range(2):
+        tr.train_step(src.encode_batch(idx), lab, i)
+    sync_all()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        tr.train_step(src.encode_batch(idx), lab, 2 + i)
+    sync_all()
+    dt_e2e, = fd.max_over_ranks([time.perf_counter() - t0])
+    t0 = time.perf_counter()
+    for i in range(steps):
+        src.encode_batch(idx)
+    sync_all()
+    dt_enc, = fd.max_over_ranks([time.perf_counter() - t0])
     prev = os.environ.get("FRLW_NATIVE_TRAIN")
     os.environ["FRLW_NATIVE_TRAIN"] = "0"  # the same step with torch autograd / MIOpen convolutions, for comparison
     try:
@@ -220,7 +237,11 @@ def bench_train(args, torch, world, rank, local_rank, sync_all):
             "ms_per_step": round(dt / steps * 1e3, 3), "per_gpu_batch": B, "steps": steps, "loss": round(loss, 4),
             "parallelism": f"ddp{world}" if world > 1 else "single", "scaling": "weak",
             "convolutions": "csrc/train_ops.hip (fp32 MFMA fwd / dgrad / wgrad, BatchNorm + SiLU fwd / bwd), SimOTA csrc/simota.hip",
-            "same_step_with_miopen_convs": {"value": round(world * B * steps / dt_t, 1), "ms_per_step": round(dt_t / steps * 1e3, 3)}}
+            "same_step_with_miopen_convs": {"value": round(world * B * steps / dt_t, 1), "ms_per_step": round(dt_t / steps * 1e3, 3)},
+            "encode_plus_train_step": {"workload": "BASELINE.json configs[4]: TAF encode of the batch (8 x 125 000 events per "
+                                                   "304x240 sample) + train step", "value": round(world * B * steps / dt_e2e, 1),
+                                       "unit": "frames/s", "ms_per_step": round(dt_e2e / steps * 1e3, 3),
+                                       "encode_ms_per_batch": round(dt_enc / steps * 1e3, 3)}}
 
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, f32 in / f32 accumulate

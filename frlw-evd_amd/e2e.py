@@ -27,18 +27,23 @@ class SyntheticTafSource:
         H, W = GEN1_SENSOR
         self.n_windows, self.K = n_windows, 8
         self.streams = []
-        stacked = []
         for i in range(n_samples):
             ev = synth.synth_events(seed + i, events_per_window * n_windows, W, H, 10_000 * n_windows)
             self.streams.append(torch.from_numpy(synth.to_dat8(ev).view(np.uint8).reshape(-1, 8)).to(device))
-            ev = dict(ev)
-            ev["y"] = ev["y"] + i * H  # sample i occupies rows [i*H, (i+1)*H) of one tall frame
-            stacked.append(synth.to_dat8(ev))
-        # One launch sequence for the whole batch: the samples are independent sequences, so their streams can
-        # be concatenated in any order once every sample has its own rows (DAT y field: 14 bits = 16383 rows).
-        self.batched = n_samples * H <= 16383
-        if self.batched:
-            self.stacked = torch.from_numpy(np.concatenate(stacked).view(np.uint8).reshape(-1, 8)).to(device)
+        # One launch sequence per group of up to 32 samples: the samples are independent sequences, so their streams
+        # can be concatenated in any order once every sample has its own rows of a tall frame (32 x 240 rows = 1920
+        # tiles, under the partition's 2048-tile limit; the DAT y field has 14 bits = 16383 rows).
+        self.group = 32
+        self.stacked = []
+        for g0 in range(0, n_samples, self.group):
+            part = []
+            for j, i in enumerate(range(g0, min(g0 + self.group, n_samples))):
+                ev = synth.synth_events(seed + i, events_per_window * n_windows, W, H, 10_000 * n_windows)
+                ev = dict(ev)
+                ev["y"] = ev["y"] + j * H
+                part.append(synth.to_dat8(ev))
+            self.stacked.append(torch.from_numpy(np.concatenate(part).view(np.uint8).reshape(-1, 8)).to(device))
+        self.batched = True
         self.device = device
 
     def labels(self, n):
@@ -55,11 +60,14 @@ class SyntheticTafSource:
         """-> (B, 16, 256, 320, 1, 1) f32 in [0, 1]: what propheseeTafDataset hands to the model."""
         H, W = GEN1_SENSOR
         if self.batched and list(idx) == list(range(len(self.streams))):
-            B = len(self.streams)
-            state = torch.full((B * H, W, 2, self.K), -6000.0, device=self.device)
-            u8, _ = er.encode_taf_dat(self.stacked, (B * H, W), state, 0, 10_000, self.n_windows, self.K, check=False)
-            u8 = u8.reshape(2 * self.K, B, H, W).permute(1, 0, 2, 3).reshape(B * 2 * self.K, H, W).contiguous()
-            u8 = er.resize_nearest(u8, GEN1_DETECTOR).reshape(B, 2 * self.K, *GEN1_DETECTOR)
+            parts = []
+            for gi, dat in enumerate(self.stacked):
+                B = min(self.group, len(self.streams) - gi * self.group)
+                state = torch.full((B * H, W, 2, self.K), -6000.0, device=self.device)
+                u8, _ = er.encode_taf_dat(dat, (B * H, W), state, 0, 10_000, self.n_windows, self.K, check=False)
+                u8 = u8.reshape(2 * self.K, B, H, W).permute(1, 0, 2, 3).reshape(B * 2 * self.K, H, W).contiguous()
+                parts.append(er.resize_nearest(u8, GEN1_DETECTOR).reshape(B, 2 * self.K, *GEN1_DETECTOR))
+            u8 = parts[0] if len(parts) == 1 else torch.cat(parts, 0)
             return (u8.float() / 255.0)[..., None, None]
         out = []
         for i in idx:
