@@ -98,13 +98,23 @@ class DetectorEngine:
         self._conv_raw(w, b, src, dst, bc.conv.kernel_size[0], bc.conv.stride[0], ACT_SILU, res)
 
     def _csp(self, csp, src, dst):
-        """CSPLayer (network_blocks.py:156-194): conv1 -> n bottlenecks || conv2, concat, conv3."""
+        """CSPLayer (network_blocks.py:156-194): conv1 -> n bottlenecks || conv2, concat, conv3.
+
+        conv1 and conv2 are both 1x1 on the same input: ONE convolution with the two weight sets stacked writes
+        [conv1(x) | conv2(x)] into the concat buffer (twice the N per launch for these small, launch-bound layers).
+        The bottleneck chain starts from the first half and its last convolution writes back over it (its input is
+        `mid`, the residual is read and written element by element at the same address), so the buffer ends up as
+        cat[m(conv1(x)), conv2(x)] without a copy."""
         hidden = csp.conv1.conv.out_channels
         cat = self._new_buf(src.h, src.w, 2 * hidden)
-        self._baseconv(csp.conv2, src, cat.slice(hidden, hidden))
+        w1, b1 = fold_bn(csp.conv1.conv, csp.conv1.bn)
+        w2, b2 = fold_bn(csp.conv2.conv, csp.conv2.bn)
+        for bc in (csp.conv1, csp.conv2):
+            if not isinstance(bc.act, torch.nn.SiLU):
+                raise NotImplementedError("only SiLU BaseConv is on the hot path")
+        self._conv_raw(torch.cat([w1, w2], 0), torch.cat([b1, b2], 0), src, cat, 1, 1, ACT_SILU)
         n = len(csp.m)
-        cur = cat.slice(0, hidden) if n == 0 else self._new_buf(src.h, src.w, hidden)
-        self._baseconv(csp.conv1, src, cur)
+        cur = cat.slice(0, hidden)
         for i, bott in enumerate(csp.m):
             mid = self._new_buf(src.h, src.w, bott.conv1.conv.out_channels)
             self._baseconv(bott.conv1, cur, mid)
@@ -226,21 +236,21 @@ class DetectorEngine:
             _lib.check(lib.frlw_det_set_lane(self.handle, k if (lanes and k <= 2) else 0), "lane")
             hs = self._new_buf(v.h, v.w, 256)
             self._baseconv(head.stems[k], v, hs)
-            feats = []
-            for tower in (head.cls_convs[k], head.reg_convs[k]):
+            # the two towers end in the halves of one 512-channel buffer [reg_feat | cls_feat], so the three biased 1x1
+            # prediction convolutions are ONE launch with a block weight matrix [[W_reg, 0], [W_obj, 0], [0, W_cls]]
+            both = self._new_buf(v.h, v.w, 512)
+            for tower, half in ((head.reg_convs[k], both.slice(0, 256)), (head.cls_convs[k], both.slice(256, 256))):
                 t1 = self._new_buf(v.h, v.w, 256)
                 self._baseconv(tower[0], hs, t1)
-                t2 = self._new_buf(v.h, v.w, 256)
-                self._baseconv(tower[1], t1, t2)
-                feats.append(t2)
-            cls_feat, reg_feat = feats
-            w_ro = torch.cat([head.reg_preds[k].weight.detach(), head.obj_preds[k].weight.detach()], 0).float()
-            b_ro = torch.cat([head.reg_preds[k].bias.detach(), head.obj_preds[k].bias.detach()], 0).float()
-            dst = View(raw.buf, F, off * F, 5, v.h, v.w)
-            self._conv_raw(w_ro, b_ro, reg_feat, dst, 1, 1, ACT_SIGMOID, dst_bs=A * F, sig_from=4)
-            dst = View(raw.buf, F, off * F + 5, nc, v.h, v.w)
-            self._conv_raw(head.cls_preds[k].weight.detach().float(), head.cls_preds[k].bias.detach().float(), cls_feat,
-                           dst, 1, 1, ACT_SIGMOID, dst_bs=A * F, sig_from=0)
+                self._baseconv(tower[1], t1, half)
+            w_p = torch.zeros((F, 512, 1, 1), dtype=torch.float32)
+            w_p[0:4, 0:256] = head.reg_preds[k].weight.detach().float().cpu()
+            w_p[4:5, 0:256] = head.obj_preds[k].weight.detach().float().cpu()
+            w_p[5:F, 256:512] = head.cls_preds[k].weight.detach().float().cpu()
+            b_p = torch.cat([head.reg_preds[k].bias.detach(), head.obj_preds[k].bias.detach(),
+                             head.cls_preds[k].bias.detach()], 0).float().cpu()
+            dst = View(raw.buf, F, off * F, F, v.h, v.w)
+            self._conv_raw(w_p, b_p, both, dst, 1, 1, ACT_SIGMOID, dst_bs=A * F, sig_from=4)
             off += v.h * v.w
         _lib.check(lib.frlw_det_set_lane(self.handle, 0), "lane")
         if lanes:
