@@ -234,10 +234,14 @@ inline void launch_conv(ConvArgs &c, float *scratch, long long scratch_floats, h
     static const long long split_below = [] { const char *e = getenv("FRLW_CONV_SPLIT_BELOW"); return e ? atoll(e) : 700ll; }();
     static const long long split_target = [] { const char *e = getenv("FRLW_CONV_SPLIT_TARGET"); return e ? atoll(e) : 1024ll; }();
     static const long long big_min = [] { const char *e = getenv("FRLW_CONV_BIG_MIN"); return e ? atoll(e) : 1000000ll; }();
+    static const long long wide_min = [] { const char *e = getenv("FRLW_CONV_WIDE_MIN"); return e ? atoll(e) : 1200ll; }();
     if (c.Npad <= 32) { // small N (prediction convs, the stem's data gradient)
         hipLaunchKernelGGL((k_conv_mfma<128, 32, 4, 1, 16>), dim3((c.M + 127) / 128, 1), dim3(256), 0, s, c);
     } else if (big >= big_min && c.Npad >= 128) {
         hipLaunchKernelGGL((k_conv_mfma<128, 128, 2, 2, CONV_BK_BIG>), dim3((c.M + 127) / 128, (c.Npad + 127) / 128), dim3(256), 0, s, c);
+    } else if (c.Npad >= 128 && (long long)((c.M + 63) / 64) * ((c.Npad + 127) / 128) >= wide_min) {
+        // 64 x 128: half the im2col gathers per output of the 64 x 64 tile, still > 4 workgroups per CU
+        hipLaunchKernelGGL((k_conv_mfma<64, 128, 2, 2, 16>), dim3((c.M + 63) / 64, (c.Npad + 127) / 128), dim3(256), 0, s, c);
     } else {
         const long long wgs = (long long)((c.M + 63) / 64) * ((c.Npad + 63) / 64);
         const int nk = (c.K + kSplitBK - 1) / kSplitBK;
