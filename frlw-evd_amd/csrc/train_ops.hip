@@ -83,11 +83,12 @@ struct WgradArgs {
     float *partial; // [splits][R][Cout]
 };
 
-// BM = 64 or 128 rows (r) x 64 columns (co) per workgroup; the 4 wavefronts are 2 x 2, each TM = BM / 64 MFMA tiles tall.
-template <int BM>
+// BM = 64 or 128 rows (r) x BN = 64 or 128 columns (co) per workgroup; the 4 wavefronts are 2 x 2, each
+// TM x TN = (BM / 64) x (BN / 64) MFMA tiles of 32 x 32.
+template <int BM, int BN>
 __global__ __launch_bounds__(256) void k_wgrad_mfma(WgradArgs a)
 {
-    constexpr int BN = 64, BK = 16, LDA = BM + 4, LDB = BN + 4, TM = BM / 64;
+    constexpr int BK = 16, LDA = BM + 4, LDB = BN + 4, TM = BM / 64, TN = BN / 64;
     __shared__ float As[2][BK][LDA]; // [pixel][r]
     __shared__ float Bs[2][BK][LDB]; // [pixel][co]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(WgradArgs a)
     const int r0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     // staging: thread -> pixel (tid / 16) of the k-tile, float4 #(tid % 16) of each 64-wide group of r / co columns
     const int pk = tid >> 4, q4 = (tid & 15) * 4;
-    bool r_ok[TM];
+    bool r_ok[TM], n_ok[TN];
     int ci[TM], ky[TM], kx[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) { // the (tap, ci) of this thread's float4 in r-group i (Cin % 4 == 0: one tap per float4)
@@ -106,7 +107,8 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(WgradArgs a)
         ky[i] = tap / a.k;
         kx[i] = tap - ky[i] * a.k;
     }
-    const bool n_ok = n0 + q4 < a.Cout;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) n_ok[j] = n0 + 64 * j + q4 < a.Cout;
     const int howo = a.Ho * a.Wo;
     const int nk_all = (a.M + BK - 1) / BK;
     const int kt0 = (int)((long long)nk_all * blockIdx.z / a.splits), kt1 = (int)((long long)nk_all * (blockIdx.z + 1) / a.splits);
@@ -119,11 +121,13 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(WgradArgs a)
         poy = pix / a.Wo;
         pox = pix - poy * a.Wo;
     }
-    float4 ra[TM], rb;
+    float4 ra[TM], rb[TN];
     auto load_tiles = [&]() {
-        rb = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int i = 0; i < TM; ++i) ra[i] = rb;
+        for (int i = 0; i < TM; ++i) ra[i] = zero;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) rb[j] = zero;
         if (pb * howo + poy * a.Wo + pox < a.M) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -131,7 +135,10 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(WgradArgs a)
                 if (r_ok[i] && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
                     ra[i] = *(const float4 *)(a.x + (long long)pb * a.x_bs + ((long long)iy * a.W + ix) * a.x_cs + ci[i]);
             }
-            if (n_ok) rb = *(const float4 *)(a.dz + (long long)pb * a.dz_bs + ((long long)poy * a.Wo + pox) * a.dz_cs + n0 + q4);
+            const float *dzp = a.dz + (long long)pb * a.dz_bs + ((long long)poy * a.Wo + pox) * a.dz_cs + n0 + q4;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                if (n_ok[j]) rb[j] = *(const float4 *)(dzp + 64 * j);
         }
         pox += BK;
         while (pox >= a.Wo) { pox -= a.Wo; if (++poy == a.Ho) { poy = 0; ++pb; } }
@@ -139,41 +146,53 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(WgradArgs a)
     auto store_tiles = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) *(float4 *)&As[buf][pk][64 * i + q4] = ra[i];
-        *(float4 *)&Bs[buf][pk][q4] = rb;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) *(float4 *)&Bs[buf][pk][64 * j + q4] = rb[j];
     };
-    f32x16 acc[TM];
+    f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][e] = 0.0f;
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
     const int nk = kt1 - kt0;
     if (nk > 0) {
         load_tiles();
         store_tiles(0);
     }
     __syncthreads();
-    const int fm = wr * 32 * TM + (lane & 31), fn = wc * 32 + (lane & 31), fk = lane >> 5;
+    const int fm = wr * 32 * TM + (lane & 31), fn = wc * 32 * TN + (lane & 31), fk = lane >> 5;
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) load_tiles();
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
-            const float fb = Bs[buf][kk + fk][fn];
+            float fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = As[buf][kk + fk][fm + 32 * i];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = Bs[buf][kk + fk][fn + 32 * j];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(As[buf][kk + fk][fm + 32 * i], fb, acc[i], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
         if (kt + 1 < nk) store_tiles(buf ^ 1);
         __syncthreads();
     }
     float *dst = a.partial + (long long)blockIdx.z * a.R * a.Cout;
-    const int n = n0 + wc * 32 + (lane & 31);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int rr = r0 + wr * 32 * TM + 32 * i + 4 * (lane >> 5) + (e & 3) + 8 * (e >> 2);
-            if (rr < a.R && n < a.Cout) dst[(long long)rr * a.Cout + n] = acc[i][e];
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wc * 32 * TN + 32 * j + (lane & 31);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int rr = r0 + wr * 32 * TM + 32 * i + 4 * (lane >> 5) + (e & 3) + 8 * (e >> 2);
+                if (rr < a.R && n < a.Cout) dst[(long long)rr * a.Cout + n] = acc[i][j][e];
+            }
         }
 }
 
@@ -504,9 +523,17 @@ int frlw_conv2d_dgrad(const float *dz, int B, int Ho, int Wo, int Cout, const fl
                        (hipStream_t)stream);
 }
 
+// 128 x 128 tiles (half the x gathers and half the dz reads per output) when that still leaves >= 32 output tiles
+static bool wgrad_wide(long long R, int Cout)
+{
+    static const long long min_tiles = [] { const char *e = getenv("FRLW_WGRAD_WIDE_TILES"); return e ? atoll(e) : 32ll; }();
+    return Cout >= 128 && R >= 128 && ((R + 127) / 128) * ((Cout + 127) / 128) >= min_tiles;
+}
+
 int64_t frlw_conv2d_wgrad_scratch_floats(int B, int Ho, int Wo, int Cin, int Cout, int k)
 {
-    const long long R = (long long)k * k * Cin, bm = R > 64 ? 128 : 64, tiles = ((R + bm - 1) / bm) * ((Cout + 63) / 64);
+    const long long R = (long long)k * k * Cin, bm = R > 64 ? 128 : 64, bn = wgrad_wide(R, Cout) ? 128 : 64;
+    const long long tiles = ((R + bm - 1) / bm) * ((Cout + bn - 1) / bn);
     const long long nk = ((long long)B * Ho * Wo + 15) / 16;
     long long sp = (1024 + tiles - 1) / tiles; // ~1024 workgroups
     if (sp > 256) sp = 256;                    // (more than 64 partial tiles per output tile: two-stage reduction)
@@ -546,10 +573,12 @@ int frlw_conv2d_wgrad(const float *x, int B, int H, int W, int Cin, const float 
     a.splits = (int)sp;
     a.partial = scratch;
     hipStream_t s = (hipStream_t)stream;
-    if (a.R > 64)
-        hipLaunchKernelGGL(k_wgrad_mfma<128>, dim3((a.R + 127) / 128, (Cout + 63) / 64, a.splits), dim3(256), 0, s, a);
+    if (wgrad_wide(a.R, Cout))
+        hipLaunchKernelGGL((k_wgrad_mfma<128, 128>), dim3((a.R + 127) / 128, (Cout + 127) / 128, a.splits), dim3(256), 0, s, a);
+    else if (a.R > 64)
+        hipLaunchKernelGGL((k_wgrad_mfma<128, 64>), dim3((a.R + 127) / 128, (Cout + 63) / 64, a.splits), dim3(256), 0, s, a);
     else
-        hipLaunchKernelGGL(k_wgrad_mfma<64>, dim3((a.R + 63) / 64, (Cout + 63) / 64, a.splits), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((k_wgrad_mfma<64, 64>), dim3((a.R + 63) / 64, (Cout + 63) / 64, a.splits), dim3(256), 0, s, a);
     const float *final_src = scratch;
     int final_n = a.splits;
     if (a.splits > 64) { // group sums go behind the partial tiles (the scratch query reserves the room)
