@@ -19,6 +19,9 @@
 //        position), and every owner thread adds its cells' segments sequentially -- no conflict
 //        handling, no float atomics.  TAF does this per 10 ms window with FIFO ageing in registers;
 //        leaky transform, uint8 truncation and the (2K, H, W) permute are fused into the write-out.
+//        The bodies are templated on the cells per thread: 4 for a whole tile; 1 for a "quarter" -- four
+//        workgroups per tile -- used for tiles the partition lists as hot (skew) and for every tile of a
+//        frame too small to give each SIMD a wavefront.
 //
 // Everything is exact-f32 arithmetic in the reference's operation order (-ffp-contract=off).
 
