@@ -267,7 +267,7 @@ struct Plan {
     long long chunk;  // events per partition workgroup = 1024 * bpw
     int units, slabs; // partition workgroups, slabs of 32
     unsigned hot_thr; // a tile with more records than this is shared by several workgroups (EV / TAF)
-    size_t off_counts, off_slabtot, off_base, off_tlut, off_leaky, off_records, bytes;
+    size_t off_counts, off_slabtot, off_base, off_errs, off_tlut, off_leaky, off_records, bytes;
 };
 
 struct Partitioned {

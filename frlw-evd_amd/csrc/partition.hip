@@ -39,13 +39,15 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 template <int LAYOUT, int KIND, bool HAS_MAP>
 __global__ __launch_bounds__(kPartThreads) void k_hist(Decode P, int bpw, uint32_t *counts,
-                                                        WsHeader *hdr, float *tlut_w, uint32_t *leaky_w)
+                                                        int32_t *errs, float *tlut_w, uint32_t *leaky_w)
 {
     extern __shared__ uint32_t lds[];
     uint32_t *hist = lds; // [n_tiles]
+    __shared__ int serr;
     const int tid = threadIdx.x;
     const long long wg = blockIdx.x;
     for (int b = tid; b < P.n_tiles; b += kPartThreads) hist[b] = 0;
+    if (tid == 0) serr = 0;
     __syncthreads();
     const long long begin = wg * (long long)kPartThreads * bpw;
     int err = 0;
@@ -90,10 +92,13 @@ __global__ __launch_bounds__(kPartThreads) void k_hist(Decode P, int bpw, uint32
             }
         }
     }
+    if (err) atomicOr(&serr, err);
     __syncthreads();
     uint32_t *row = counts + wg * (long long)P.n_tiles;
     for (int b = tid; b < P.n_tiles; b += kPartThreads) row[b] = hist[b];
-    if (err) atomicOr(&hdr->status, err);
+    // data-dependent errors of this chunk: a plain store per workgroup, OR-ed into the header by k_tilescan (which
+    // also resets the header -- no memset launch, no pre-zeroed workspace needed)
+    if (tid == 0) errs[wg] = serr;
 }
 
 // counts[u][b], u in one slab of 32 workgroups -> exclusive prefix over u (in place), slabtot[slab][b]
@@ -123,11 +128,18 @@ __global__ __launch_bounds__(kWave) void k_slabscan(uint32_t *counts, int units,
 
 // slabtot[s][b] -> exclusive prefix over s (in place); then exclusive scan over tiles -> base[0..n]
 __global__ __launch_bounds__(1024) void k_tilescan(uint32_t *slabtot, int slabs, int n, uint32_t *base,
-                                                   WsHeader *hdr, uint32_t hot_thr)
+                                                   WsHeader *hdr, uint32_t hot_thr, const int32_t *errs, int units)
 {
     __shared__ uint32_t tot[kMaxTiles];
     __shared__ uint32_t wsum[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) { hdr->status = 0; hdr->pad = 0; hdr->wmask = 0ull; hdr->n_hot = 0u; hdr->hot_thr = hot_thr; }
+    __syncthreads();
+    {
+        int e = 0;
+        for (int u = tid; u < units; u += 1024) e |= errs[u];
+        if (e) atomicOr(&hdr->status, e);
+    }
     for (int b = tid; b < n; b += 1024) {
         uint32_t run = 0;
         for (int s0 = 0; s0 < slabs; s0 += 8) { // 8 independent loads in flight, then the 8 prefix stores
@@ -146,7 +158,6 @@ __global__ __launch_bounds__(1024) void k_tilescan(uint32_t *slabtot, int slabs,
             if (slot < (uint32_t)kMaxHot) hdr->hot[slot] = (uint32_t)b;
         }
     }
-    if (tid == 0) hdr->hot_thr = hot_thr;
     __syncthreads();
     const int per = (n + 1023) / 1024;
     const int b0 = tid * per;
@@ -330,39 +341,39 @@ __global__ __launch_bounds__(kPartThreads, 8) void k_scatter(Decode P, int bpw, 
 
 template <int LAYOUT, int KIND, bool HAS_MAP>
 void launch_partition_m(const Decode &d, const Plan &p, uint32_t *counts, uint32_t *slabtot,
-                      uint32_t *base, uint2 *records, WsHeader *hdr, float *tlut_w, uint32_t *leaky_w, hipStream_t s)
+                      uint32_t *base, uint2 *records, WsHeader *hdr, int32_t *errs, float *tlut_w, uint32_t *leaky_w, hipStream_t s)
 {
     const size_t lds_hist = (size_t)p.n_tiles * 4;
     const int nt2 = (p.n_tiles + 1) & ~1;
     const size_t lds_sc = (size_t)p.n_tiles * 4 + (size_t)kPartWaves * nt2 * 2 +
                           (size_t)kPartWaves * p.n_tiles + 16;
-    hipLaunchKernelGGL((k_hist<LAYOUT, KIND, HAS_MAP>), dim3(p.units), dim3(kPartThreads), lds_hist, s, d, p.bpw, counts, hdr, tlut_w, leaky_w);
+    hipLaunchKernelGGL((k_hist<LAYOUT, KIND, HAS_MAP>), dim3(p.units), dim3(kPartThreads), lds_hist, s, d, p.bpw, counts, errs, tlut_w, leaky_w);
     hipLaunchKernelGGL(k_slabscan, dim3((p.n_tiles + kWave - 1) / kWave, p.slabs), dim3(kWave), 0, s, counts,
                        p.units, p.n_tiles, slabtot);
-    hipLaunchKernelGGL(k_tilescan, dim3(1), dim3(1024), 0, s, slabtot, p.slabs, p.n_tiles, base, hdr, p.hot_thr);
+    hipLaunchKernelGGL(k_tilescan, dim3(1), dim3(1024), 0, s, slabtot, p.slabs, p.n_tiles, base, hdr, p.hot_thr, errs, p.units);
     hipLaunchKernelGGL((k_scatter<LAYOUT, KIND, HAS_MAP>), dim3(p.units), dim3(kPartThreads), lds_sc, s, d, p.bpw, counts,
                        slabtot, base, records, hdr);
 }
 
 template <int LAYOUT, int KIND>
 void launch_partition(const Decode &d, const Plan &p, uint32_t *counts, uint32_t *slabtot, uint32_t *base,
-                      uint2 *records, WsHeader *hdr, float *tlut_w, uint32_t *leaky_w, hipStream_t s)
+                      uint2 *records, WsHeader *hdr, int32_t *errs, float *tlut_w, uint32_t *leaky_w, hipStream_t s)
 {
     if (LAYOUT == FRLW_LAYOUT_DAT8 && d.xmap)
-        launch_partition_m<LAYOUT, KIND, true>(d, p, counts, slabtot, base, records, hdr, tlut_w, leaky_w, s);
+        launch_partition_m<LAYOUT, KIND, true>(d, p, counts, slabtot, base, records, hdr, errs, tlut_w, leaky_w, s);
     else
-        launch_partition_m<LAYOUT, KIND, false>(d, p, counts, slabtot, base, records, hdr, tlut_w, leaky_w, s);
+        launch_partition_m<LAYOUT, KIND, false>(d, p, counts, slabtot, base, records, hdr, errs, tlut_w, leaky_w, s);
 }
 
 template <int LAYOUT>
 void launch_partition_kind(int kind, const Decode &d, const Plan &p, uint32_t *counts, uint32_t *slabtot,
-                           uint32_t *base, uint2 *records, WsHeader *hdr, float *tlut_w, uint32_t *leaky_w, hipStream_t s)
+                           uint32_t *base, uint2 *records, WsHeader *hdr, int32_t *errs, float *tlut_w, uint32_t *leaky_w, hipStream_t s)
 {
     switch (kind) {
-    case KIND_ECI: launch_partition<LAYOUT, KIND_ECI>(d, p, counts, slabtot, base, records, hdr, tlut_w, leaky_w, s); break;
-    case KIND_EV: launch_partition<LAYOUT, KIND_EV>(d, p, counts, slabtot, base, records, hdr, tlut_w, leaky_w, s); break;
-    case KIND_SAE: launch_partition<LAYOUT, KIND_SAE>(d, p, counts, slabtot, base, records, hdr, tlut_w, leaky_w, s); break;
-    default: launch_partition<LAYOUT, KIND_TAF>(d, p, counts, slabtot, base, records, hdr, tlut_w, leaky_w, s); break;
+    case KIND_ECI: launch_partition<LAYOUT, KIND_ECI>(d, p, counts, slabtot, base, records, hdr, errs, tlut_w, leaky_w, s); break;
+    case KIND_EV: launch_partition<LAYOUT, KIND_EV>(d, p, counts, slabtot, base, records, hdr, errs, tlut_w, leaky_w, s); break;
+    case KIND_SAE: launch_partition<LAYOUT, KIND_SAE>(d, p, counts, slabtot, base, records, hdr, errs, tlut_w, leaky_w, s); break;
+    default: launch_partition<LAYOUT, KIND_TAF>(d, p, counts, slabtot, base, records, hdr, errs, tlut_w, leaky_w, s); break;
     }
 }
 
@@ -402,6 +413,7 @@ bool make_plan(long long n, int H, int W, Plan &p)
     p.off_counts = off;  off = align_up(off + (size_t)p.units * p.n_tiles * 4, 256);
     p.off_slabtot = off; off = align_up(off + (size_t)p.slabs * p.n_tiles * 4, 256);
     p.off_base = off;    off = align_up(off + (size_t)(p.n_tiles + 1) * 4, 256);
+    p.off_errs = off;    off = align_up(off + (size_t)p.units * 4, 256);
     p.off_tlut = off;    off = align_up(off + (size_t)(kMaxTlut + 1) * 4, 256);
     p.off_leaky = off;   off = align_up(off + (size_t)kLeakyLevels * 4, 256);
     p.off_records = off; off = align_up(off + (size_t)(n > 0 ? n : 1) * 8, 256);
@@ -434,6 +446,7 @@ int partition_events(const frlw_events_t *ev, int H, int W, int kind, long long 
     uint32_t *counts = (uint32_t *)(w8 + p.off_counts);
     uint32_t *slabtot = (uint32_t *)(w8 + p.off_slabtot);
     uint32_t *base = (uint32_t *)(w8 + p.off_base);
+    int32_t *errs = (int32_t *)(w8 + p.off_errs);
     uint2 *records = (uint2 *)(w8 + p.off_records);
 
     Decode d;
@@ -451,11 +464,10 @@ int partition_events(const frlw_events_t *ev, int H, int W, int kind, long long 
     uint32_t *leaky_w = kind == KIND_TAF ? (uint32_t *)(w8 + p.off_leaky) : nullptr;
 
     (void)hipGetLastError(); // stale errors of other libraries in the process
-    HIP_TRY(hipMemsetAsync(hdr, 0, kHeaderBytes, s));
     if (ev->layout == FRLW_LAYOUT_DAT8)
-        launch_partition_kind<FRLW_LAYOUT_DAT8>(kind, d, p, counts, slabtot, base, records, hdr, tlut_w, leaky_w, s);
+        launch_partition_kind<FRLW_LAYOUT_DAT8>(kind, d, p, counts, slabtot, base, records, hdr, errs, tlut_w, leaky_w, s);
     else
-        launch_partition_kind<FRLW_LAYOUT_XYTP_F64>(kind, d, p, counts, slabtot, base, records, hdr, tlut_w, leaky_w, s);
+        launch_partition_kind<FRLW_LAYOUT_XYTP_F64>(kind, d, p, counts, slabtot, base, records, hdr, errs, tlut_w, leaky_w, s);
     HIP_TRY(hipGetLastError());
     out.records = records; out.base = base; out.hdr = hdr; out.plan = p; out.leaky_thr = leaky_w;
     return FRLW_OK;
