@@ -72,6 +72,7 @@ SYMBOLS = {
     "frlw_sample_transform_u8": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
     "frlw_eval_transform_dt": (_I, [_P, _P, _P, _I64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                    _P, _P, _P]),
+    "frlw_conv2d_dgrad_parity": (_I, [_I, _I, _I, _I]),
     "frlw_conv_weight_layouts": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
     "frlw_conv2d_fwd": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _P, _P, _I64, _P]),
     "frlw_conv2d_dgrad": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _P, _P, _I64, _P]),

@@ -451,7 +451,12 @@ inline int npad32(int n) { return (n + 31) / 32 * 32; }
 
 extern "C" {
 
-int frlw_conv_weight_layouts(const float *w, int Cout, int Cin, int k, int stride, float *w_fwd, float *w_dgrad,
+int frlw_conv2d_dgrad_parity(int k, int stride, int H, int W)
+{
+    return (stride == 2 && k == 3 && !(H & 1) && !(W & 1)) ? 1 : 0;
+}
+
+int frlw_conv_weight_layouts(const float *w, int Cout, int Cin, int k, int dgrad_parity, float *w_fwd, float *w_dgrad,
                              frlw_stream_t stream)
 {
     (void)hipGetLastError(); // other libraries in the process (torch's BLAS look-ups) leave stale errors behind
@@ -459,7 +464,7 @@ int frlw_conv_weight_layouts(const float *w, int Cout, int Cin, int k, int strid
     hipStream_t s = (hipStream_t)stream;
     const long long total = (w_fwd ? (long long)k * k * Cin * npad32(Cout) : 0) + (w_dgrad ? (long long)k * k * Cout * npad32(Cin) : 0);
     hipLaunchKernelGGL(k_weight_layouts, dim3(conv_grid_1d(total)), dim3(256), 0, s, w, Cout, Cin, k, w_fwd, npad32(Cout),
-                       w_dgrad, npad32(Cin), (stride == 2 && k == 3) ? 1 : 0);
+                       w_dgrad, npad32(Cin), (dgrad_parity && k == 3) ? 1 : 0);
     TRY_HIP(hipGetLastError());
     return FRLW_OK;
 }
@@ -497,10 +502,10 @@ int frlw_conv2d_dgrad(const float *dz, int B, int Ho, int Wo, int Cout, const fl
     // dz (transposed gather for s = 2) with the flipped operand and padding k - 1 - pad = pad (odd k)
     if (stride != 1 && stride != 2) return FRLW_ERR_UNSUPPORTED;
     if (!(k & 1)) return FRLW_ERR_UNSUPPORTED;
-    if (stride == 2 && k == 3) {
+    if (frlw_conv2d_dgrad_parity(k, stride, H, W)) {
         // four stride-1 convolutions of dz, one per output parity class, with 1 / 2 / 2 / 4 of the nine taps (no
         // multiplications by the zeros of the up-sampled gradient); class (py, px) writes dx[2 o' + (py, px)]
-        if ((H & 1) || (W & 1) || Ho * 2 != H || Wo * 2 != W) return FRLW_ERR_UNSUPPORTED;
+        if (Ho * 2 != H || Wo * 2 != W) return FRLW_ERR_ARG;
         if (!dz || !w_dgrad || !dx || B < 1 || Cout < 4 || (Cout & 3) || Cin < 1) return FRLW_ERR_ARG;
         (void)hipGetLastError();
         static const int row0[4] = {0, 1, 3, 5};
@@ -702,7 +707,7 @@ int frlw_baseconv_train_fwd(const float *x, const float *w, const float *gamma, 
     const int64_t M = (int64_t)B * Ho * Wo;
     TrainScratch t = carve(scratch, B, Ho, Wo, Cin, Cout, k);
     int rc;
-    if ((rc = frlw_conv_weight_layouts(w, Cout, Cin, k, stride, t.w_fwd, nullptr, stream)) != FRLW_OK) return rc;
+    if ((rc = frlw_conv_weight_layouts(w, Cout, Cin, k, 0, t.w_fwd, nullptr, stream)) != FRLW_OK) return rc;
     if ((rc = frlw_conv2d_fwd(x, B, H, W, Cin, t.w_fwd, Cout, k, stride, z, t.splitk, t.splitk_floats, stream)) != FRLW_OK) return rc;
     if ((rc = bn_stats_impl(z, M, Cout, eps, mean, var, invstd, t.red, running_mean, running_mean ? running_var : nullptr,
                             momentum, stream)) != FRLW_OK) return rc;
@@ -725,7 +730,7 @@ int frlw_baseconv_train_bwd(const float *dy, const float *x, const float *z, con
     int rc;
     if ((rc = frlw_bn_silu_bwd(dy, z, M, Cout, gamma, beta, mean, invstd, dz, dgamma, dbeta, t.red, t.sums, stream)) != FRLW_OK) return rc;
     if (dx) {
-        if ((rc = frlw_conv_weight_layouts(w, Cout, Cin, k, stride, nullptr, t.w_dg, stream)) != FRLW_OK) return rc;
+        if ((rc = frlw_conv_weight_layouts(w, Cout, Cin, k, frlw_conv2d_dgrad_parity(k, stride, H, W), nullptr, t.w_dg, stream)) != FRLW_OK) return rc;
         if ((rc = frlw_conv2d_dgrad(dz, B, Ho, Wo, Cout, t.w_dg, Cin, k, stride, H, W, dx, t.splitk, t.splitk_floats, stream)) != FRLW_OK) return rc;
     }
     return frlw_conv2d_wgrad(x, B, H, W, Cin, dz, Ho, Wo, Cout, k, stride, dw, t.wgrad, t.wgrad_floats, stream);

@@ -273,16 +273,19 @@ int frlw_eval_transform_dt(const float *dets, const int32_t *img_of_row, const i
  * dense (pixel stride = channels).  Cin % 4 == 0 and Cout % 4 == 0.  `scratch` buffers are caller-owned.
  * ------------------------------------------------------------------------------------------- */
 /* torch weight (Cout, Cin, k, k) -> forward operand (k*k*Cin, pad32(Cout)) and / or data-gradient operand
- * (k*k*Cout, pad32(Cin)) with flipped taps (stride 2, k = 3: rows grouped by output parity class, see
- * frlw_conv2d_dgrad); pad32(n) = n rounded up to 32.  Either output may be NULL.  `stride` = the convolution's. */
-int frlw_conv_weight_layouts(const float *w, int Cout, int Cin, int k, int stride, float *w_fwd, float *w_dgrad,
+ * (k*k*Cout, pad32(Cin)) with flipped taps; with dgrad_parity = frlw_conv2d_dgrad_parity(k, stride, H, W) != 0 the
+ * rows of the latter are grouped by output parity class (see frlw_conv2d_dgrad).  pad32(n) = n rounded up to 32.
+ * Either output may be NULL. */
+int frlw_conv2d_dgrad_parity(int k, int stride, int H, int W);
+int frlw_conv_weight_layouts(const float *w, int Cout, int Cin, int k, int dgrad_parity, float *w_fwd, float *w_dgrad,
                              frlw_stream_t stream);
 /* z (B, Ho, Wo, Cout) = conv2d(x (B, H, W, Cin), w), padding (k - 1) / 2, stride 1 or 2.  scratch: optional split-K
  * partial sums (scratch_floats floats; NULL = never split). */
 int frlw_conv2d_fwd(const float *x, int B, int H, int W, int Cin, const float *w_fwd, int Cout, int k, int stride, float *z,
                     float *scratch, int64_t scratch_floats, frlw_stream_t stream);
 /* dx (B, H, W, Cin) = gradient of the convolution above with respect to x, from dz (B, Ho, Wo, Cout).  Stride 2 with
- * k = 3 and even H, W runs as four stride-1 convolutions, one per output parity class (1 / 2 / 2 / 4 taps). */
+ * k = 3 and even H, W (frlw_conv2d_dgrad_parity) runs as four stride-1 convolutions, one per output parity class
+ * (1 / 2 / 2 / 4 taps) and needs the parity-grouped operand; other stride-2 shapes use a transposed gather. */
 int frlw_conv2d_dgrad(const float *dz, int B, int Ho, int Wo, int Cout, const float *w_dgrad, int Cin, int k, int stride,
                       int H, int W, float *dx, float *scratch, int64_t scratch_floats, frlw_stream_t stream);
 /* dw in torch's (Cout, Cin, k, k) layout = gradient with respect to the weight; scratch is REQUIRED
