@@ -184,7 +184,14 @@ __global__ __launch_bounds__(1024) void k_tilescan(uint32_t *slabtot, int slabs,
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int LAYOUT, int KIND, bool HAS_MAP>
+constexpr int kStageCap = 4096; // records staged in LDS per write-out window of the staged scatter
+// byte offset (16-aligned) of the staging area behind gs | wcnt | tag in the scatter workgroup's LDS
+__host__ __device__ inline size_t stage_off(int n_tiles)
+{
+    const size_t nt2 = (size_t)((n_tiles + 1) & ~1);
+    return ((size_t)n_tiles * 4 + (size_t)kPartWaves * nt2 * 2 + (size_t)kPartWaves * n_tiles + 15) & ~(size_t)15;
+}
+template <int LAYOUT, int KIND, bool HAS_MAP, bool STAGED>
 __global__ __launch_bounds__(kPartThreads, 8) void k_scatter(Decode P, int bpw, const uint32_t *counts,
                                                            const uint32_t *slabtot,
                                                            const uint32_t *base, uint2 *records,
@@ -282,6 +289,7 @@ __global__ __launch_bounds__(kPartThreads, 8) void k_scatter(Decode P, int bpw, 
                 run += v;
             }
             gs[b] = b == tid ? gs_pre : base[b] + srow[b] + row[b];
+            if (STAGED) ((uint32_t *)((uint8_t *)lds + stage_off(P.n_tiles)))[b] = run; // loff[b] <- tile total
         }
     }
     __syncthreads();
@@ -309,12 +317,60 @@ __global__ __launch_bounds__(kPartThreads, 8) void k_scatter(Decode P, int bpw, 
             if (KIND == KIND_TAF) wseen |= 1ull << window;
         }
     }
+    if (STAGED) {
+        // Large streams: records go through LDS in workgroup-sorted order (tile-major) and leave in windows of
+        // kStageCap consecutive slots: consecutive threads write consecutive records of a tile's run, so the stores
+        // of a wave cover whole lines instead of 64 separate 8-byte pieces (HBM write traffic of the scatter: 2.6x
+        // its payload with direct stores).  Small streams keep the direct stores: fewer barriers.
+        uint32_t *loff = (uint32_t *)((uint8_t *)lds + stage_off(P.n_tiles)); // [n_tiles + 2]
+        uint2 *stage = (uint2 *)(loff + ((P.n_tiles + 2 + 1) & ~1));
+        uint16_t *stile = (uint16_t *)(stage + kStageCap);
+        __shared__ uint32_t wtot[kPartWaves];
+        // per-tile totals of this workgroup = prefix end of the last wave + its count: recompute from the wave
+        // prefixes (woff of wave 15 + that wave's count is not kept) -> phase B left the totals in loff[]
+        __syncthreads();
+        uint32_t a0 = 0, a1 = 0;
+        if (2 * tid < P.n_tiles) a0 = loff[2 * tid];
+        if (2 * tid + 1 < P.n_tiles) a1 = loff[2 * tid + 1];
+        uint32_t inc = a0 + a1;
 #pragma unroll
-    for (int j = 0; j < kMaxBpw; ++j) {
-        if (j < bpw && where[j] != 0xffffffffu) {
-            const uint32_t b = where[j] >> 16;
-            const uint32_t pos = gs[b] + (uint32_t)woff[b] + (where[j] & 0xffffu);
-            records[pos] = make_uint2(meta[j], valb[j]);
+        for (int off = 1; off < kWave; off <<= 1) {
+            const uint32_t v = __shfl_up(inc, off);
+            if (lane >= off) inc += v;
+        }
+        if (lane == kWave - 1) wtot[wv] = inc;
+        __syncthreads();
+        uint32_t pre = 0, total = 0;
+        for (int k = 0; k < kPartWaves; ++k) { if (k < wv) pre += wtot[k]; total += wtot[k]; }
+        const uint32_t excl = pre + inc - (a0 + a1);
+        if (2 * tid < P.n_tiles) loff[2 * tid] = excl;
+        if (2 * tid + 1 < P.n_tiles) loff[2 * tid + 1] = excl + a0;
+        __syncthreads();
+        for (uint32_t w0 = 0; w0 < total; w0 += kStageCap) {
+#pragma unroll
+            for (int j = 0; j < kMaxBpw; ++j) {
+                if (j < bpw && where[j] != 0xffffffffu) {
+                    const uint32_t b = where[j] >> 16;
+                    const uint32_t slot = loff[b] + (uint32_t)woff[b] + (where[j] & 0xffffu) - w0;
+                    if (slot < (uint32_t)kStageCap) { stage[slot] = make_uint2(meta[j], valb[j]); stile[slot] = (uint16_t)b; }
+                }
+            }
+            __syncthreads();
+            const uint32_t nwin = total - w0 < (uint32_t)kStageCap ? total - w0 : (uint32_t)kStageCap;
+            for (uint32_t qi = tid; qi < nwin; qi += kPartThreads) {
+                const uint32_t b = stile[qi];
+                records[gs[b] + (w0 + qi - loff[b])] = stage[qi];
+            }
+            __syncthreads();
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < kMaxBpw; ++j) {
+            if (j < bpw && where[j] != 0xffffffffu) {
+                const uint32_t b = where[j] >> 16;
+                const uint32_t pos = gs[b] + (uint32_t)woff[b] + (where[j] & 0xffffu);
+                records[pos] = make_uint2(meta[j], valb[j]);
+            }
         }
     }
     if (KIND == KIND_TAF) { // which windows hold events at all: decides "all(forward)", generate_taf.py:40
@@ -345,14 +401,28 @@ void launch_partition_m(const Decode &d, const Plan &p, uint32_t *counts, uint32
 {
     const size_t lds_hist = (size_t)p.n_tiles * 4;
     const int nt2 = (p.n_tiles + 1) & ~1;
-    const size_t lds_sc = (size_t)p.n_tiles * 4 + (size_t)kPartWaves * nt2 * 2 +
-                          (size_t)kPartWaves * p.n_tiles + 16;
+    const size_t lds_sc = (size_t)p.n_tiles * 4 + (size_t)kPartWaves * nt2 * 2 + (size_t)kPartWaves * p.n_tiles + 16;
+    const size_t lds_staged = stage_off(p.n_tiles) + (size_t)((p.n_tiles + 2 + 1) & ~1) * 4 + (size_t)kStageCap * 8 +
+                              (size_t)kStageCap * 2 + 16;
+    // staged write-out pays off for long streams with long chunks (10 M events: -11 us); on short ones the extra
+    // barriers cost more than the write traffic saves (GEN1-shaped 1 M events: 66 -> 74 us).
+    // FRLW_SCATTER_STAGED=0/1 forces it.
+    static const int force = env_int("FRLW_SCATTER_STAGED", -1);
+    const bool staged = (force >= 0 ? force != 0 : (p.bpw >= 4 && d.n >= 3000000)) && lds_staged <= 150 * 1024;
     hipLaunchKernelGGL((k_hist<LAYOUT, KIND, HAS_MAP>), dim3(p.units), dim3(kPartThreads), lds_hist, s, d, p.bpw, counts, errs, tlut_w, leaky_w);
     hipLaunchKernelGGL(k_slabscan, dim3((p.n_tiles + kWave - 1) / kWave, p.slabs), dim3(kWave), 0, s, counts,
                        p.units, p.n_tiles, slabtot);
     hipLaunchKernelGGL(k_tilescan, dim3(1), dim3(1024), 0, s, slabtot, p.slabs, p.n_tiles, base, hdr, p.hot_thr, errs, p.units);
-    hipLaunchKernelGGL((k_scatter<LAYOUT, KIND, HAS_MAP>), dim3(p.units), dim3(kPartThreads), lds_sc, s, d, p.bpw, counts,
-                       slabtot, base, records, hdr);
+    if (staged) {
+        if (lds_staged > 64 * 1024)
+            (void)hipFuncSetAttribute((const void *)k_scatter<LAYOUT, KIND, HAS_MAP, true>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_staged);
+        hipLaunchKernelGGL((k_scatter<LAYOUT, KIND, HAS_MAP, true>), dim3(p.units), dim3(kPartThreads), lds_staged, s, d, p.bpw,
+                           counts, slabtot, base, records, hdr);
+    } else {
+        hipLaunchKernelGGL((k_scatter<LAYOUT, KIND, HAS_MAP, false>), dim3(p.units), dim3(kPartThreads), lds_sc, s, d, p.bpw,
+                           counts, slabtot, base, records, hdr);
+    }
 }
 
 template <int LAYOUT, int KIND>
