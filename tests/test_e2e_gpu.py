@@ -28,3 +28,15 @@ def test_encode_then_train_and_eval_step():
     with torch.no_grad():
         dets = net(x)
     assert len(dets) == 2 and dets[0].shape[1] == 6
+
+
+def test_batched_encode_layout_equals_per_sample():
+    """11 samples = one big frame 8 samples wide, 2 high (last row partial): same bytes as 11 separate encodes."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from frlw_evd_amd import e2e
+    src = e2e.SyntheticTafSource(11, seed=321, events_per_window=6_000)
+    x = src.encode_batch(list(range(11)))
+    one = torch.cat([src.encode_batch([i]) for i in range(11)])
+    assert x.shape == (11, 16, 256, 320, 1, 1)
+    assert torch.equal(x, one)
