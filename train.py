@@ -59,7 +59,7 @@ def main():
     if rank == 0:
         print(json.dumps({"metric": "E2E TAF encode + YOLOX train step", "value": round(world * B * args.steps / dt, 1),
                           "unit": "frames/s", "n_gpus": world, "global_batch": B * world, "loss": loss, "lr": lr,
-                          "backward": "torch autograd (HIP backward kernels not built yet)"}))
+                          "backward": "csrc/train_ops.hip (fp32 MFMA dgrad / wgrad, BatchNorm + SiLU backward), SimOTA csrc/simota.hip"}))
     if world > 1:
         torch.distributed.destroy_process_group()
 
