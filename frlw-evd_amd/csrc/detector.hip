@@ -34,19 +34,25 @@ namespace {
 #include "conv_mfma.h"
 
 // ---- glue kernels ------------------------------------------------------------------------------
-// Focus: (B, C, H, W) NCHW -> (B, H/2, W/2, 4C) NHWC, channel blocks TL, BL, TR, BR (network_blocks.py:205-217)
-__global__ void k_focus(const float *x, int B, int C, int H, int W, float *y)
+// Focus: (B, C, H, W) NCHW -> (B, H/2, W/2, 4C) NHWC, channel blocks TL, BL, TR, BR (network_blocks.py:205-217).
+// One workgroup per output row (b, oy): the 2C input rows are read along x (coalesced), transposed through LDS and
+// the output row (Wo x 4C floats, contiguous) is written along its memory order.
+__global__ __launch_bounds__(256) void k_focus(const float *x, int B, int C, int H, int W, float *y)
 {
-    const int Ho = H / 2, Wo = W / 2, C4 = 4 * C;
-    const long long total = (long long)B * Ho * Wo * C4;
-    for (long long o = blockIdx.x * (long long)blockDim.x + threadIdx.x; o < total; o += (long long)gridDim.x * blockDim.x) {
-        const int c4 = (int)(o % C4);
-        const long long p = o / C4;
-        const int ox = (int)(p % Wo), oy = (int)((p / Wo) % Ho), b = (int)(p / ((long long)Wo * Ho));
-        const int q = c4 / C, c = c4 - q * C;
-        const int iy = 2 * oy + (q & 1), ix = 2 * ox + (q >> 1); // q: 0 TL, 1 BL, 2 TR, 3 BR
-        y[o] = x[(((long long)b * C + c) * H + iy) * W + ix];
+    extern __shared__ float frow[]; // [Wo][4C + 1]
+    const int Ho = H / 2, Wo = W / 2, C4 = 4 * C, LD = C4 + 1;
+    const int b = blockIdx.x / Ho, oy = blockIdx.x - b * Ho;
+    // source rows: (c, q & 1) -> x[b][c][2 oy + (q & 1)][:], column parity q >> 1
+    for (int i = threadIdx.x; i < 2 * C * W; i += 256) {
+        const int ix = i % W, r = i / W;      // r = c * 2 + row parity
+        const int c = r >> 1, py = r & 1;
+        const float v = x[(((long long)b * C + c) * H + 2 * oy + py) * W + ix];
+        const int q = py + 2 * (ix & 1);      // 0 TL, 1 BL, 2 TR, 3 BR
+        frow[(ix >> 1) * LD + q * C + c] = v;
     }
+    __syncthreads();
+    float *dst = y + ((long long)b * Ho + oy) * Wo * C4;
+    for (int i = threadIdx.x; i < Wo * C4; i += 256) dst[i] = frow[(i / C4) * LD + (i % C4)];
 }
 
 // BFM stem, per-pixel part (core/Others/Temporal_Active_Focus.py:62-127, Temporal_Active_Focus_connect.forward
@@ -543,8 +549,9 @@ int frlw_det_run(const frlw_detector_t *d, int B, void *const *bufs, int n_bufs,
         auto buf = [&](int i) -> float * { return (i >= 0 && i < n_bufs) ? (float *)bufs[i] : nullptr; };
         switch (op.type) {
         case OP_FOCUS: {
-            const long long total = (long long)B * (op.H / 2) * (op.W / 2) * 4 * op.C;
-            hipLaunchKernelGGL(k_focus, dim3(grid_1d(total)), dim3(256), 0, s, buf(op.src), B, op.C, op.H, op.W, buf(op.dst));
+            const size_t lds = (size_t)(op.W / 2) * (4 * op.C + 1) * sizeof(float);
+            if (lds > 150 * 1024) return FRLW_ERR_UNSUPPORTED;
+            hipLaunchKernelGGL(k_focus, dim3(B * (op.H / 2)), dim3(256), lds, s, buf(op.src), B, op.C, op.H, op.W, buf(op.dst));
             break;
         }
         case OP_BFM: {
