@@ -36,6 +36,20 @@ int hip_fail(hipError_t e, const char *what, int line)
 
 namespace {
 
+// Workgroups are handed to the 8 XCDs round-robin (block b runs on XCD b % 8) and every XCD has its own L2.  Chunk
+// c of the stream is therefore given to block (c - start_k) * 8 + k with k the XCD that owns the contiguous chunk range
+// [start_k, start_{k+1}): consecutive chunks -- whose runs are neighbours in every tile's record list -- are written
+// through the SAME L2, which merges the lines they share before they reach the HBM.
+__device__ __forceinline__ long long chunk_of_block(unsigned block, unsigned n_blocks)
+{
+#ifdef FRLW_NO_XCD_REMAP
+    return block;
+#else
+    const unsigned k = block & 7u, idx = block >> 3, q = n_blocks >> 3, r = n_blocks & 7u;
+    return (long long)k * q + (k < r ? k : r) + idx;
+#endif
+}
+
 // ---------------------------------------------------------------------------------------------
 template <int LAYOUT, int KIND, bool HAS_MAP>
 __global__ __launch_bounds__(kPartThreads) void k_hist(Decode P, int bpw, uint32_t *counts,
@@ -45,7 +59,7 @@ __global__ __launch_bounds__(kPartThreads) void k_hist(Decode P, int bpw, uint32
     uint32_t *hist = lds; // [n_tiles]
     __shared__ int serr;
     const int tid = threadIdx.x;
-    const long long wg = blockIdx.x;
+    const long long wg = chunk_of_block(blockIdx.x, gridDim.x);
     for (int b = tid; b < P.n_tiles; b += kPartThreads) hist[b] = 0;
     if (tid == 0) serr = 0;
     __syncthreads();
@@ -204,7 +218,7 @@ __global__ __launch_bounds__(kPartThreads, 8) void k_scatter(Decode P, int bpw, 
     const int nt2 = (P.n_tiles + 1) & ~1;
     uint8_t *tag_all = (uint8_t *)(wcnt_all + (size_t)kPartWaves * nt2);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const long long wg = blockIdx.x;
+    const long long wg = chunk_of_block(blockIdx.x, gridDim.x);
     // volatile: the tag write-then-read-back must reach LDS (another lane may have overwritten it)
     volatile uint16_t *wcnt = wcnt_all + (size_t)wv * nt2;
     volatile uint8_t *tag = tag_all + (size_t)wv * P.n_tiles;
