@@ -162,6 +162,20 @@ def main():
                                        "uint8, 1000000 events, 304x240, 8 windows",
                            "value": round(n_gpus * n2 / (dt2 / args.steps) / 1e6, 2), "unit": "Mevents/s",
                            "ms_per_step": round(dt2 / args.steps * 1e3, 4)}]
+        # BASELINE.json configs[1]: Event Volume, 1 M events, 304x240, 5 bins (bit-exactness is the tests' job; this is its rate)
+        ev4 = synth.synth_events(1002 + 7919 * rank, 1_000_000, W2, H2, 250_000)
+        dat4 = torch.from_numpy(synth.to_dat8(ev4).view(np.uint8).reshape(-1, 8)).cuda()
+        for _ in range(3):
+            er.encode_ev_dat(dat4, (H2, W2), 250_000, 250_000, volume_bins=5, check=False)
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            er.encode_ev_dat(dat4, (H2, W2), 250_000, 250_000, volume_bins=5, check=False)
+        sync_all()
+        dt4, = fd.max_over_ranks([time.perf_counter() - t0])
+        result["also"].append({"workload": "ev_gen1 (BASELINE.json configs[1]): Event Volume 5 bins, 1000000 events, 304x240",
+                               "value": round(n_gpus * 1_000_000 / (dt4 / args.steps) / 1e6, 2), "unit": "Mevents/s",
+                               "ms_per_step": round(dt4 / args.steps * 1e3, 4)})
         if not args.hotspot:
             # SURVEY.md section 8d "report both": the contention variant of the headline workload (25 % of the events in
             # a sigma = 8 px blob -> a few tiles hold most of them; hot tiles are split over workgroups)
