@@ -460,6 +460,7 @@ __device__ __forceinline__ void taf_tile_body(const uint2 *rec, const uint32_t *
     const int t = threadIdx.x;
     const int K = q.K;
     for (int i = t; i < kLeakyLevels; i += NT) thr[i] = q.leaky_thr[i];
+    __syncthreads(); // a tile without records reaches the write-out (which reads thr[]) without any other barrier
     const int cb = q.twl + 4; // cell bits
     const TileGeom g = tile_geom(tile, q.tiles_x, q.twl, q.H, q.W);
     const Owner<C> ow = make_owner<NT, C>(g, q.W, j0);

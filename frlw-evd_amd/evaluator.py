@@ -67,21 +67,32 @@ class evaluator:
             self.represent_time += represent_time
             self.infer_count += 1
 
+    def _scale(self):
+        return np.array([self.rw, self.rh, self.rw, self.rh])
+
     def transform_gt(self, bounding_box):
         """(80, 8) [cx, cy, w, h, class, t, confidence, track] -> rows [t, x, y, w, h, class, confidence, track]
         in sensor pixels; padding rows (confidence 0) dropped (evaluator.py:43-54)."""
-        g = bounding_box.cpu().numpy()
-        g = g[(g[:, 6] > 0)]
-        return np.array([g[:, 5], (g[:, 0] - g[:, 2] / 2) * self.rw, (g[:, 1] - g[:, 3] / 2) * self.rh, g[:, 2] * self.rw,
-                         g[:, 3] * self.rh, g[:, 4], g[:, 6], g[:, 7]]).T
+        return self.transform_gt_batch(bounding_box[None])[0]
+
+    def transform_gt_batch(self, bounding_boxes):
+        """Whole batch (B, 80, 8) in one device->host copy -> list of B arrays (n_i, 8), float64 like the labels."""
+        g = (bounding_boxes.cpu().numpy() if torch.is_tensor(bounding_boxes) else np.asarray(bounding_boxes))
+        corner = np.concatenate([g[..., 0:2] - g[..., 2:4] / 2, g[..., 2:4]], axis=-1) * self._scale()
+        rows = np.concatenate([g[..., 5:6], corner, g[..., 4:5], g[..., 6:8]], axis=-1)
+        return [r[c > 0] for r, c in zip(rows, g[..., 6])]
 
     def transform_dt(self, detected_bbox, bins_time_stamp):
-        """(n, 6) [cx, cy, w, h, class, score] -> (n, 8) [t, x, y, w, h, class, score, 0] (evaluator.py:56-63)."""
-        d = torch.cat([(detected_bbox[..., 0:1] - detected_bbox[..., 2:3] / 2) * self.rw,
-                       (detected_bbox[..., 1:2] - detected_bbox[..., 3:4] / 2) * self.rh,
-                       detected_bbox[..., 2:3] * self.rw, detected_bbox[..., 3:4] * self.rh,
-                       detected_bbox[..., 4:]], dim=-1).cpu().numpy()
-        return np.concatenate([np.zeros_like(d[:, :1]) + int(bins_time_stamp), d, np.zeros_like(d[:, :1])], axis=1)
+        """(n, 6) [cx, cy, w, h, class, score] -> (n, 8) [t, x, y, w, h, class, score, 0] (evaluator.py:56-63);
+        host-side twin of ``frlw_eval_transform_dt`` for detections that are not on the GPU, same float32 arithmetic."""
+        d = detected_bbox.reshape(-1, 6)
+        sc = torch.tensor([self.rw, self.rh, self.rw, self.rh])
+        corner = torch.cat([d[:, 0:2] - d[:, 2:4] / 2, d[:, 2:4]], dim=1) * sc.to(d.device)
+        out = np.zeros((d.shape[0], 8), dtype=corner.cpu().numpy().dtype)
+        out[:, 0] = int(bins_time_stamp)
+        out[:, 1:5] = corner.cpu().numpy()
+        out[:, 5:7] = d[:, 4:6].cpu().numpy()
+        return out
 
     def transform_dt_batch(self, outputs, bins_time_stamps):
         """All images of a batch at once on the GPU -> list of (n_i, 8) float32 arrays (one device->host copy)."""
@@ -110,8 +121,9 @@ class evaluator:
         self.cal_time(infer_time, represent_time)
         on_gpu = len(outputs) > 0 and all(torch.is_tensor(o) and o.is_cuda for o in outputs)
         dts = self.transform_dt_batch(outputs, bins_time_stamps)[0] if on_gpu else None
+        gts = self.transform_gt_batch(torch.stack(list(bounding_box)) if not torch.is_tensor(bounding_box) else bounding_box)
         for i in range(len(outputs)):
-            gt_trans = self.transform_gt(bounding_box[i])
+            gt_trans = gts[i]
             if len(gt_trans) == 0:
                 continue
             self.gt_to_eval.append(gt_trans)
@@ -133,18 +145,19 @@ class evaluator:
                 dts.append(np.array([[g[0, 0], 0, 0, 0, 0, 0, 0, 0]]) if len(d) == 0 else d)
         return gts, dts
 
-    def evaluate(self):
+    def evaluate(self, metric_fn=None):
+        """``metric_fn``: the COCO scorer to hand the paired lists to -- the reference calls
+        ``evaluate_detection(gt_boxes_list, dt_boxes_list, time_tol=, classes=, height=, width=)``
+        (evaluate/src/metrics/coco_eval.py, pycocotools).  It is third-party and never imported from here: without a
+        callable the keyword arguments of that call are returned."""
         gts, dts = self.filtered_lists()
         if self.recorder is not None:
             self.recorder.save()
-        try:
-            from evaluate.src.metrics.coco_eval import evaluate_detection  # third-party path of the reference tree
-        except Exception:
-            return {"gt_boxes_list": gts, "dt_boxes_list": dts, "time_tol": self.tol, "classes": self.classes,
-                    "height": self.ori_height, "width": self.ori_width,
-                    "avg_infer_ms": 1000 * self.infer_time / max(self.infer_count, 1)}
-        return evaluate_detection(gts, dts, time_tol=self.tol, classes=self.classes, height=self.ori_height,
-                                  width=self.ori_width)
+        kw = {"time_tol": self.tol, "classes": self.classes, "height": self.ori_height, "width": self.ori_width}
+        if metric_fn is not None:
+            return metric_fn(gts, dts, **kw)
+        return dict(kw, gt_boxes_list=gts, dt_boxes_list=dts,
+                    avg_infer_ms=1000 * self.infer_time / max(self.infer_count, 1))
 
 
 class recorder:

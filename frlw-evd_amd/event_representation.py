@@ -68,8 +68,12 @@ def _events_dat(dat, xmap=None, ymap=None):
     if nbytes % 8:
         raise ValueError("DAT records are 8 bytes each")
     mw = mh = 0
+    if (xmap is None) != (ymap is None):
+        raise ValueError("xmap and ymap come together")
     if xmap is not None:
-        assert ymap is not None and xmap.dtype == torch.int16 or xmap.dtype == torch.uint16
+        for m in (xmap, ymap):  # the kernels read both tables as uint16_t
+            if m.dtype not in (torch.int16, torch.uint16) or not m.is_cuda or not m.is_contiguous() or m.dim() != 1:
+                raise ValueError("coordinate maps must be contiguous 1-D int16 / uint16 CUDA tensors")
         mw, mh = xmap.numel(), ymap.numel()
     return d, _lib.FrlwEvents(d.data_ptr(), nbytes // 8, _lib.LAYOUT_DAT8, 0, _ptr(xmap), _ptr(ymap), mw, mh)
 

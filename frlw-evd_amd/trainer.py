@@ -8,8 +8,10 @@ Quirks kept on purpose, because they change the optimisation trajectory (SURVEY.
   * per-GPU batch = batch_size / nodes, lr = 0.0133333 / 64 * per_gpu_batch * nodes (settings.py:41,87);
   * DistributedDataParallel(broadcast_buffers=False): BatchNorm statistics stay per rank (core/exp.py:391).
 
-The forward/backward of the network run through torch autograd on ROCm; the gradient all-reduce is DDP's
-bucketed RCCL all-reduce.  HIP backward kernels for the convolutions are not built yet.
+Every training-mode ``BaseConv`` on a ROCm tensor runs forward and backward in the gfx950 kernels of
+csrc/train_ops.hip (``yolox/train_ops.py``: fp32 MFMA convolution, data and weight gradient, BatchNorm + SiLU), SimOTA
+in csrc/simota.hip; torch autograd only strings the blocks together.  The gradient all-reduce is DDP's bucketed RCCL
+all-reduce, or the direct reduce-scatter + all-gather hook of ``dist.py``.
 """
 from __future__ import annotations
 

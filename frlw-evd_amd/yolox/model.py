@@ -26,6 +26,7 @@ class model(nn.Module):
         self.memory = memory
         self.head = head
         self._engine = None
+        self._engine_sig = None
 
     def reference_outputs(self, x):
         """Plain-PyTorch eval forward up to the pre-NMS tensor (B, A, 5 + nc); x: (B, C, H, W, 1)."""
@@ -33,11 +34,36 @@ class model(nn.Module):
         self.head.hw = [o.shape[-2:] for o in outs]
         return torch.cat([o.flatten(start_dim=2) for o in outs], dim=2).permute(0, 2, 1)
 
+    def _weights_signature(self):
+        """Identity + in-place version of every parameter and buffer: changes on optimizer steps, load_state_dict(),
+        BatchNorm running-statistics updates and .to() / .cuda()."""
+        return tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
+
     def engine(self):
-        if self._engine is None:
+        """The gfx950 engine for the CURRENT weights.  The engine folds BatchNorm into the convolutions and keeps its
+        own device copies, so it is rebuilt whenever a parameter or buffer has changed since it was built (the
+        reference alternates train and validation epochs on one model, core/exp.py:237-258)."""
+        sig = self._weights_signature()
+        if self._engine is None or self._engine_sig != sig:
             from ..detector import DetectorEngine
             self._engine = DetectorEngine(self)
+            self._engine_sig = sig
         return self._engine
+
+    def drop_engine(self):
+        self._engine = None
+        self._engine_sig = None
+
+    def train(self, mode=True):
+        if mode:
+            self.drop_engine()
+        return super().train(mode)
+
+    def __getstate__(self):  # the engine holds a ctypes handle: never pickled / deep-copied
+        d = self.__dict__.copy()
+        d["_engine"] = None
+        d["_engine_sig"] = None
+        return d
 
     def detect(self, x):
         """Eval forward of one time step: list of (n_i, 6) detections per image."""
