@@ -17,6 +17,8 @@ FRLW_ERR_WORKSPACE = -3
 FRLW_ERR_HIP = -4
 FRLW_ERR_POLARITY = -5
 FRLW_ERR_UNSUPPORTED = -6
+FRLW_ERR_SPAN = -7
+MAX_SEQUENCES = 64
 
 LAYOUT_XYTP_F64 = 0
 LAYOUT_DAT8 = 1
@@ -29,6 +31,7 @@ _ERR_TEXT = {
     FRLW_ERR_HIP: "HIP runtime error",
     FRLW_ERR_POLARITY: "polarity outside {0, 1}",
     FRLW_ERR_UNSUPPORTED: "unsupported size",
+    FRLW_ERR_SPAN: "event outside the encode span",
 }
 
 
@@ -49,6 +52,10 @@ SYMBOLS = {
     "frlw_ev_encode": (_I, [_EV, _I, _I, _I, _I64, _I64, _P, _P, _P, _SZ, _P]),
     "frlw_sae_encode": (_I, [_EV, _I, _I, C.POINTER(C.c_double), _I, _P, _P, _I64, _I64, _P, _P, _P, _SZ, _P]),
     "frlw_taf_encode": (_I, [_EV, _I, _I, _I, _I64, _I64, _I, _P, _P, _P, _I, _P, _SZ, _P]),
+    "frlw_selftest_lds_atomic_order": (_I, [_I, _I, _P, _P]),
+    "frlw_taf_batch_workspace_bytes": (_SZ, [_I64, _I, _I, _I, _I64]),
+    "frlw_taf_encode_batch": (_I, [_EV, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _I, _I, _I, _I, _I64, _I, _P, _P, _P, _I,
+                                  _P, _SZ, _P]),
     "frlw_leaky_transform": (_I, [_P, _I64, _P, _P, _P]),
     "frlw_resize_nearest_f32": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     "frlw_resize_nearest_u8": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
@@ -127,6 +134,6 @@ def check(rc: int, what: str = "frlw"):
     msg = f"{what}: {_ERR_TEXT.get(rc, 'error')} ({rc})"
     if rc == FRLW_ERR_INDEX:
         raise IndexError(msg)
-    if rc in (FRLW_ERR_ARG, FRLW_ERR_POLARITY, FRLW_ERR_UNSUPPORTED):
+    if rc in (FRLW_ERR_ARG, FRLW_ERR_POLARITY, FRLW_ERR_UNSUPPORTED, FRLW_ERR_SPAN):
         raise ValueError(msg)
     raise RuntimeError(msg)

@@ -690,7 +690,7 @@ int frlw_encoder_status(const void *workspace, frlw_stream_t stream, int *status
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(hipMemcpyAsync(&st, workspace, sizeof(st), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    *status_out = (st & ST_INDEX) ? FRLW_ERR_INDEX : (st & ST_POLARITY) ? FRLW_ERR_POLARITY : FRLW_OK;
+    *status_out = (st & ST_INDEX) ? FRLW_ERR_INDEX : (st & ST_POLARITY) ? FRLW_ERR_POLARITY : (st & ST_SPAN) ? FRLW_ERR_SPAN : FRLW_OK;
     return FRLW_OK;
 }
 

@@ -27,7 +27,7 @@ constexpr int kMaxBpw = 8;        // batches of 64 events per wavefront per work
 constexpr int kSlabUnits = 32;    // workgroups per slab of the two-level column scan
 
 enum Kind : int { KIND_ECI = 0, KIND_EV = 1, KIND_SAE = 2, KIND_TAF = 3 };
-enum : int { ST_INDEX = 1, ST_POLARITY = 2 };
+enum : int { ST_INDEX = 1, ST_POLARITY = 2, ST_SPAN = 4 };
 
 // First kHeaderBytes of the workspace.
 constexpr int kMaxHot = 32;     // tiles per encode whose cells are split over several workgroups (skew)
@@ -163,6 +163,20 @@ __device__ __forceinline__ float f64_value(double t)
     return (float)t;
 }
 
+// Workgroups are handed to the 8 XCDs round-robin (block b runs on XCD b % 8) and every XCD has its own L2.  Chunk
+// c of the stream is therefore given to block (c - start_k) * 8 + k with k the XCD that owns the contiguous chunk range
+// [start_k, start_{k+1}): consecutive chunks -- whose runs are neighbours in every tile's record list -- are written
+// through the SAME L2, which merges the lines they share before they reach the HBM.
+__device__ __forceinline__ long long chunk_of_block(unsigned block, unsigned n_blocks)
+{
+#ifdef FRLW_NO_XCD_REMAP
+    return block;
+#else
+    const unsigned k = block & 7u, idx = block >> 3, q = n_blocks >> 3, r = n_blocks & 7u;
+    return (long long)k * q + (k < r ? k : r) + idx;
+#endif
+}
+
 __device__ __forceinline__ uint64_t lanemask_lt()
 {
     return (1ull << (threadIdx.x & 63)) - 1ull;
@@ -246,7 +260,8 @@ __device__ __forceinline__ void leaky_u8_lookup_n(const float (&v)[N], const uin
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         const float x = fabsf(v[i]);
-        const float g = 255.0f * (1.0f - (__log2f(1.0f + x) * 0.69314718f) / 8.7f);
+        // first guess only (the table pair below decides): multiply instead of the exact routine's divide
+        const float g = 255.0f - (__log2f(1.0f + x) * (255.0f * 0.69314718f / 8.7f));
         k[i] = g > 0.0f ? (g > 254.0f ? 254 : (int)g) : 0; // k + 1 stays inside the table
     }
 #pragma unroll

@@ -36,20 +36,6 @@ int hip_fail(hipError_t e, const char *what, int line)
 
 namespace {
 
-// Workgroups are handed to the 8 XCDs round-robin (block b runs on XCD b % 8) and every XCD has its own L2.  Chunk
-// c of the stream is therefore given to block (c - start_k) * 8 + k with k the XCD that owns the contiguous chunk range
-// [start_k, start_{k+1}): consecutive chunks -- whose runs are neighbours in every tile's record list -- are written
-// through the SAME L2, which merges the lines they share before they reach the HBM.
-__device__ __forceinline__ long long chunk_of_block(unsigned block, unsigned n_blocks)
-{
-#ifdef FRLW_NO_XCD_REMAP
-    return block;
-#else
-    const unsigned k = block & 7u, idx = block >> 3, q = n_blocks >> 3, r = n_blocks & 7u;
-    return (long long)k * q + (k < r ? k : r) + idx;
-#endif
-}
-
 // ---------------------------------------------------------------------------------------------
 template <int LAYOUT, int KIND, bool HAS_MAP>
 __global__ __launch_bounds__(kPartThreads) void k_hist(Decode P, int bpw, uint32_t *counts,

@@ -1,0 +1,1009 @@
+// taf_fast.hip -- the fast Temporal Active Focus path: a batch of independent, in-span DAT streams.
+//
+// Replaces, for B sequences at once, the harness loop generate_taf.py:193-235 around taf_cuda (:19-58): window
+// selection, f64 time normalisation, per-window count / mean-time accumulation, K-deep FIFO ageing, leaky transform,
+// uint8 truncation.  Same contract as the general path (encoders.hip): f32 sums in STREAM ORDER, bit for bit.
+//
+// What makes it fast (measured reasons in DESIGN.md section 3):
+//   * 4-byte records {r | window | cell}: r = t - window start (the f32 value is tlut[r], one table of win + 1
+//     floats), 12-bit cell inside a 4096-cell tile.  Half the record traffic of the general path.
+//   * the stable partition ranks a batch of 64 consecutive events with ONE returning LDS atomic per event: gfx950
+//     serves the lanes of a wave-instruction that hit one LDS address in ascending lane order (tools/lds_order_test.hip,
+//     tests/test_taf_fast_gpu.py::test_lds_atomic_lane_order), so the returned value IS the stream rank.
+//   * the tile kernel never sorts.  A chunk of the tile's records is split (stably, the same atomic) over the 16
+//     wavefronts of the workgroup by sub-tile: wavefront v owns cells [256 v, 256 v + 256) and their FIFO state in
+//     registers.  It then walks ITS records 64 at a time, wave-synchronously: count by returning LDS atomic, and the
+//     f32 sums of the lanes that share a cell are applied in rank order (one round per multiplicity) -- the reference's
+//     sequential index_add_.  Windows are closed per wavefront (FIFO step in registers), no workgroup barrier inside.
+//   * sequences of a batch are independent problems in one launch sequence: own tiles, own window mask
+//     (generate_taf.py:40-41 is a per-sequence rule), own t_start.
+//
+// Requirements, checked on device (violations -> status, NOTHING is written, the caller falls back to frlw_taf_encode):
+// every event inside [t_start, t_start + n_windows * window_us] of its sequence and inside the frame.
+
+#include "frlw_common.h"
+
+using namespace frlw;
+
+namespace {
+
+constexpr int kFT = 1024;                 // threads of every workgroup here
+constexpr int kFW = kFT / kWave;          // 16 wavefronts
+constexpr int kCellBits = 12;
+constexpr int kCells = 1 << kCellBits;    // cells (pixel x polarity) per tile
+constexpr int kSubCells = kCells / kFW;   // 256 cells owned by one wavefront of the tile kernel
+constexpr int kPixLog = 11;               // log2 pixels per tile
+constexpr int kMaxSeq = FRLW_MAX_SEQUENCES;
+constexpr int kMaxFastTiles = 1024;       // tiles per sequence (LDS of the scatter workgroup: 72 B per tile)
+constexpr int kMaxPairs = 8192;           // (sequence, tile) pairs per call (LDS of the tile scan)
+constexpr int kFastSlab = 32;             // chunks per slab of the two-level column scan
+constexpr int ST_MULBAD = 8;              // per-chunk flag next to the ST_* error bits (not an error)
+
+struct SeqTab { // kernel argument, built on the host
+    int n_seq;
+    int chunk0[kMaxSeq + 1];    // first chunk of sequence s; [n_seq] = total
+    int slab0[kMaxSeq + 1];     // first slab
+    long long ev0[kMaxSeq + 1]; // first event
+    long long t0[kMaxSeq];      // t_start
+};
+
+struct FastGeom {
+    const uint2 *data;
+    const uint16_t *xmap, *ymap;
+    int map_w, map_h;
+    int H, W, twl, thl, tiles_x, T;
+    int bpw; // batches of 64 events per wavefront of a partition workgroup
+    int n_windows, wb;
+    uint32_t win, win_magic;
+};
+
+struct FastHeader {
+    int32_t status; // ST_* flags; same offset as WsHeader::status (frlw_encoder_status reads it)
+    uint32_t filtered_tiles; // diagnostic: sub-tiles whose records were not window-sorted (unsorted stream)
+    unsigned long long wmask[kMaxSeq]; // bit w set <=> window w of the sequence holds at least one event
+    uint32_t mul_bad; // != 0: float(r * (1 / den)) differs from float(r / den) for some r in [0, win]: use the table
+};
+static_assert(sizeof(FastHeader) <= kHeaderBytes, "header");
+
+struct FastPlan {
+    int twl, thl, tiles_x, tiles_y, T;
+    int bpw, chunk;
+    int chunks, slabs, pairs;
+    size_t off_counts, off_slabtot, off_base, off_sub, off_errs, off_tlut, off_leaky, off_records, off_records2, bytes;
+};
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Tile shape: 2^twl x 2^(11 - twl) pixels, the one that covers the frame with the fewest tiles (ties: the widest,
+// longest contiguous rows).
+bool fast_plan(long long n, int n_seq, int H, int W, FastPlan &p)
+{
+    if (H <= 0 || W <= 0 || n < 0 || n_seq < 1 || n_seq > kMaxSeq || n >= (1ll << 31)) return false;
+    long long best = -1;
+    for (int twl = 5; twl <= 8; ++twl) {
+        const int tw = 1 << twl, th = 1 << (kPixLog - twl);
+        const long long t = (long long)((W + tw - 1) / tw) * ((H + th - 1) / th);
+        if (best < 0 || t <= best) { best = t; p.twl = twl; }
+    }
+    p.thl = kPixLog - p.twl;
+    p.tiles_x = (W + (1 << p.twl) - 1) >> p.twl;
+    p.tiles_y = (H + (1 << p.thl) - 1) >> p.thl;
+    p.T = p.tiles_x * p.tiles_y;
+    if (p.T > kMaxFastTiles || (long long)p.T * n_seq > kMaxPairs) return false;
+    p.pairs = p.T * n_seq;
+    long long bpw = (n + 512ll * kFT - 1) / (512ll * kFT); // >= 2 workgroups per CU before the chunks grow
+    p.bpw = (int)(bpw < 1 ? 1 : (bpw > kMaxBpw ? kMaxBpw : bpw));
+    p.chunk = kFT * p.bpw;
+    return true;
+}
+
+// per-sequence chunk / slab tables + workspace layout
+bool fast_layout(const int64_t *seq_offsets, const int64_t *t_start, int n_seq, FastPlan &p, SeqTab &S, uint32_t win)
+{
+    S.n_seq = n_seq;
+    int c = 0, sl = 0;
+    for (int s = 0; s < n_seq; ++s) {
+        const long long n_s = seq_offsets[s + 1] - seq_offsets[s];
+        if (n_s < 0) return false;
+        S.chunk0[s] = c;
+        S.slab0[s] = sl;
+        S.ev0[s] = seq_offsets[s];
+        S.t0[s] = t_start[s];
+        int cs = (int)((n_s + p.chunk - 1) / p.chunk);
+        if (cs < 1) cs = 1; // an empty sequence keeps one (empty) chunk: no special cases downstream
+        c += cs;
+        sl += (cs + kFastSlab - 1) / kFastSlab;
+    }
+    S.chunk0[n_seq] = c;
+    S.slab0[n_seq] = sl;
+    S.ev0[n_seq] = seq_offsets[n_seq];
+    p.chunks = c;
+    p.slabs = sl;
+    const long long n = seq_offsets[n_seq] - seq_offsets[0];
+    size_t off = kHeaderBytes;
+    p.off_counts = off;  off = align_up(off + (size_t)(c > 0 ? c : 1) * p.T * 4, 256);
+    p.off_slabtot = off; off = align_up(off + (size_t)(sl > 0 ? sl : 1) * p.T * 4, 256);
+    p.off_base = off;    off = align_up(off + (size_t)(p.pairs + 1) * 4, 256);
+    p.off_sub = off;     off = align_up(off + ((size_t)p.pairs * kFW + 1) * 4, 256);
+    p.off_errs = off;    off = align_up(off + (size_t)(c > 0 ? c : 1) * 4, 256);
+    p.off_tlut = off;    off = align_up(off + (size_t)(win + 1) * 4, 256);
+    p.off_leaky = off;   off = align_up(off + (size_t)kLeakyLevels * 4, 256);
+    p.off_records = off; off = align_up(off + (size_t)(n > 0 ? n : 1) * 4, 256);
+    p.off_records2 = off; off = align_up(off + (size_t)(n > 0 ? n : 1) * 4, 256);
+    p.bytes = off;
+    return true;
+}
+
+// ---- decode ----------------------------------------------------------------------------------------
+struct FastEv {
+    int tile;      // < 0: not encoded (err says why)
+    uint32_t word; // r << (12 + wb) | window << 12 | cell
+    uint32_t window;
+    int err;
+};
+
+// src/io/dat_events_tools.py:96-98 (bit fields), generate_taf.py:197-203 (window), :215-219 (coordinate scaling via the
+// maps); the flat index x + W * y of generate_taf.py:23 aliases x >= W into the next row like the general path.
+template <bool HAS_MAP>
+__device__ __forceinline__ FastEv fast_decode(const FastGeom &G, uint2 r, long long t0)
+{
+    FastEv o;
+    o.tile = -1; o.word = 0; o.window = 0; o.err = 0;
+    int x = (int)(r.y & 16383u), y = (int)((r.y >> 14) & 16383u);
+    const uint32_t p = (r.y >> 28) & 1u;
+    if (HAS_MAP) {
+        if (x >= G.map_w || y >= G.map_h) { o.err = ST_INDEX; return o; }
+        x = G.xmap[x];
+        y = G.ymap[y];
+    }
+    if (x >= G.W || y >= G.H) {
+        const long long flat = (long long)x + (long long)G.W * y;
+        if (flat >= (long long)G.H * G.W) { o.err = ST_INDEX; return o; }
+        y = (int)(flat / G.W);
+        x = (int)(flat - (long long)y * G.W);
+    }
+    const long long rel = (long long)r.x - t0;
+    if (rel < 0 || rel > (long long)G.n_windows * G.win) { o.err = ST_SPAN; return o; }
+    const uint32_t relu = (uint32_t)rel;
+    uint32_t z = __umulhi(relu, G.win_magic); // floor(rel / win) - {0, 1, 2}
+    uint32_t rem = relu - z * G.win;
+    if (rem >= G.win) { ++z; rem -= G.win; }
+    if (rem >= G.win) { ++z; rem -= G.win; }
+    if (z >= (uint32_t)G.n_windows) { z = (uint32_t)G.n_windows - 1u; rem = G.win; } // t == end of the last window
+    const int tw1 = (1 << G.twl) - 1, th1 = (1 << G.thl) - 1;
+    o.tile = (y >> G.thl) * G.tiles_x + (x >> G.twl);
+    const uint32_t cell = (uint32_t)((((y & th1) << G.twl) | (x & tw1)) << 1) | p;
+    o.window = z;
+    o.word = (rem << (kCellBits + G.wb)) | (z << kCellBits) | cell;
+    return o;
+}
+
+__device__ __forceinline__ int seq_of_chunk(const SeqTab &S, int chunk)
+{
+    int s = 0;
+    while (s + 1 < S.n_seq && chunk >= S.chunk0[s + 1]) ++s;
+    return s;
+}
+
+// ---- 1. histogram ------------------------------------------------------------------------------------
+template <bool HAS_MAP>
+__global__ __launch_bounds__(kFT) void kf_hist(FastGeom G, SeqTab S, uint32_t *counts, int32_t *errs, float *tlut_w,
+                                               uint32_t *leaky_w)
+{
+    extern __shared__ uint32_t lds[];
+    uint32_t *hist = lds; // [T]
+    __shared__ int serr;
+    const int tid = threadIdx.x;
+    const int chunk = (int)chunk_of_block(blockIdx.x, gridDim.x);
+    const int s = seq_of_chunk(S, chunk);
+    for (int b = tid; b < G.T; b += kFT) hist[b] = 0;
+    if (tid == 0) serr = 0;
+    __syncthreads();
+    int mul_err = 0;
+    if (chunk == (int)gridDim.x - 1 && tid < kLeakyLevels) // generate_taf.py:69-76 as a 256-level threshold table
+        leaky_w[tid] = tid == 0 ? 0x7f800000u : leaky_threshold_bits(tid);
+    {
+        // tlut[r] = float(r / (win + 1e-8)) - 1 (generate_taf.py:215, :26): one correctly rounded f64 division per
+        // distinct in-window time instead of one per event
+        // The walk kernel would rather multiply by 1 / den than gather from the table: allowed only if that gives the
+        // same float for EVERY r of the domain, which is checked right here, exhaustively, per call.
+        const double den = (double)G.win + 1e-8, rcp = 1.0 / den;
+        for (long long r = (long long)chunk * kFT + tid; r <= (long long)G.win; r += (long long)gridDim.x * kFT) {
+            const float exact = (float)((double)r / den);
+            if ((float)((double)r * rcp) != exact) mul_err = ST_MULBAD;
+            tlut_w[r] = exact - 1.0f;
+        }
+    }
+    const int chunk_ev = kFT * G.bpw;
+    const long long begin = S.ev0[s] + (long long)(chunk - S.chunk0[s]) * chunk_ev;
+    const long long left = S.ev0[s + 1] - begin;
+    const uint32_t nloc = left < chunk_ev ? (uint32_t)(left < 0 ? 0 : left) : (uint32_t)chunk_ev;
+    const uint2 *src = G.data + begin;
+    const long long t0 = S.t0[s];
+    uint2 q[kMaxBpw];
+#pragma unroll
+    for (int j = 0; j < kMaxBpw; ++j) {
+        const uint32_t i = (uint32_t)(j * kFT + tid);
+        q[j] = i < nloc ? src[i] : make_uint2(0u, 0u);
+    }
+    int err = mul_err;
+#pragma unroll
+    for (int j = 0; j < kMaxBpw; ++j) {
+        const uint32_t i = (uint32_t)(j * kFT + tid);
+        if (i < nloc) {
+            const FastEv o = fast_decode<HAS_MAP>(G, q[j], t0);
+            err |= o.err;
+            if (o.tile >= 0) atomicAdd(&hist[o.tile], 1u);
+        }
+    }
+    if (err) atomicOr(&serr, err);
+    __syncthreads();
+    uint32_t *row = counts + (long long)chunk * G.T;
+    for (int b = tid; b < G.T; b += kFT) row[b] = hist[b];
+    if (tid == 0) errs[chunk] = serr;
+}
+
+// ---- 2. scans ----------------------------------------------------------------------------------------
+// counts[c][b], c in one slab of 32 chunks of ONE sequence -> exclusive prefix over c (in place), slabtot[slab][b]
+__global__ __launch_bounds__(kWave) void kf_slabscan(SeqTab S, uint32_t *counts, int T, uint32_t *slabtot)
+{
+    const int b = blockIdx.x * kWave + threadIdx.x;
+    const int slab = blockIdx.y;
+    if (b >= T) return;
+    int s = 0;
+    while (s + 1 < S.n_seq && slab >= S.slab0[s + 1]) ++s;
+    const int c0 = S.chunk0[s] + (slab - S.slab0[s]) * kFastSlab, cend = S.chunk0[s + 1];
+    uint32_t v[kFastSlab];
+#pragma unroll
+    for (int k = 0; k < kFastSlab; ++k) v[k] = (c0 + k < cend) ? counts[(long long)(c0 + k) * T + b] : 0u;
+    uint32_t run = 0;
+#pragma unroll
+    for (int k = 0; k < kFastSlab; ++k) {
+        const uint32_t t = v[k];
+        v[k] = run;
+        run += t;
+    }
+#pragma unroll
+    for (int k = 0; k < kFastSlab; ++k)
+        if (c0 + k < cend) counts[(long long)(c0 + k) * T + b] = v[k];
+    slabtot[(long long)slab * T + b] = run;
+}
+
+// slabtot[slab][b] -> exclusive prefix over the slabs of each sequence (in place); exclusive scan over the
+// (sequence, tile) pairs -> base[0..pairs]; resets the header and folds the per-chunk error flags into it.
+__global__ __launch_bounds__(kFT) void kf_tilescan(SeqTab S, uint32_t *slabtot, int T, uint32_t *base, FastHeader *hdr,
+                                                   const int32_t *errs, int chunks)
+{
+    __shared__ uint32_t tot[kMaxPairs];
+    __shared__ uint32_t wsum[kFW];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int pairs = S.n_seq * T;
+    if (tid == 0) { hdr->status = 0; hdr->filtered_tiles = 0u; hdr->mul_bad = 0u; }
+    if (tid < kMaxSeq) hdr->wmask[tid] = 0ull;
+    __syncthreads();
+    {
+        int e = 0;
+        for (int c = tid; c < chunks; c += kFT) e |= errs[c];
+        if (e & ~ST_MULBAD) atomicOr(&hdr->status, e & ~ST_MULBAD);
+        if (e & ST_MULBAD) hdr->mul_bad = 1u;
+    }
+    for (int idx = tid; idx < pairs; idx += kFT) {
+        const int s = idx / T, b = idx - s * T;
+        uint32_t run = 0;
+        const int sl1 = S.slab0[s + 1];
+        for (int sl = S.slab0[s]; sl < sl1; sl += 8) { // 8 independent loads in flight, then the 8 prefix stores
+            uint32_t v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = sl + k < sl1 ? slabtot[(long long)(sl + k) * T + b] : 0u;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (sl + k < sl1) slabtot[(long long)(sl + k) * T + b] = run;
+                run += v[k];
+            }
+        }
+        tot[idx] = run;
+    }
+    __syncthreads();
+    const int per = (pairs + kFT - 1) / kFT;
+    const int b0 = tid * per;
+    int b1 = b0 + per;
+    if (b1 > pairs) b1 = pairs;
+    uint32_t sum = 0;
+    for (int b = b0; b < b1; ++b) sum += tot[b];
+    uint32_t inc = sum;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        const uint32_t v = __shfl_up(inc, off);
+        if (lane >= off) inc += v;
+    }
+    if (lane == kWave - 1) wsum[wv] = inc;
+    __syncthreads();
+    uint32_t pre = 0;
+    for (int k = 0; k < wv; ++k) pre += wsum[k];
+    uint32_t run = pre + inc - sum;
+    for (int b = b0; b < b1; ++b) {
+        base[b] = run;
+        run += tot[b];
+    }
+    if (tid == kFT - 1) base[pairs] = pre + inc;
+}
+
+// ---- 3. stable scatter ---------------------------------------------------------------------------------
+// LDS (dynamic): wcnt[16][T] u32 | loff[T + 1] u32 | stage[chunk] u32 | stile[chunk] u16  (78.6 KB at T = 450 with
+// 8192-event chunks: two workgroups per CU)
+__host__ __device__ inline size_t scatter_lds_bytes(int T, int chunk)
+{
+    return (size_t)kFW * T * 4 + (size_t)(T + 2) * 4 + (size_t)chunk * 4 + (size_t)chunk * 2 + 16;
+}
+
+template <bool HAS_MAP>
+__global__ __launch_bounds__(kFT) void kf_scatter(FastGeom G, SeqTab S, const uint32_t *counts, const uint32_t *slabtot,
+                                                  const uint32_t *base, uint32_t *records, FastHeader *hdr)
+{
+    extern __shared__ uint32_t lds[];
+    const int T = G.T;
+    uint32_t *wcnt_all = lds;                  // [16][T]: per-wavefront running counts, then prefixes
+    uint32_t *loff = wcnt_all + (size_t)kFW * T; // [T + 1] slot of tile b's first record in the staged chunk; after
+                                                 // the staging: global slot of that record MINUS its staged slot
+    uint32_t *stage = loff + ((T + 2) & ~1);
+    uint16_t *stile = (uint16_t *)(stage + kFT * G.bpw);
+    __shared__ uint32_t wtot[kFW];
+    __shared__ unsigned long long wg_seen;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int chunk = (int)chunk_of_block(blockIdx.x, gridDim.x);
+    const int s = seq_of_chunk(S, chunk);
+    uint32_t *wcnt = wcnt_all + (size_t)wv * T;
+    for (int b = tid; b < kFW * T; b += kFT) wcnt_all[b] = 0;
+    if (tid == 0) wg_seen = 0ull;
+    __syncthreads();
+
+    const int chunk_ev = kFT * G.bpw;
+    const long long chunk_begin = S.ev0[s] + (long long)(chunk - S.chunk0[s]) * chunk_ev;
+    const long long wave_begin = chunk_begin + (long long)wv * kWave * G.bpw; // wavefront w owns the w-th run of the chunk
+    const long long left = S.ev0[s + 1] - wave_begin;
+    const uint32_t nloc = left < (long long)kWave * G.bpw ? (uint32_t)(left < 0 ? 0 : left) : (uint32_t)(kWave * G.bpw);
+    const long long t0 = S.t0[s];
+    const uint2 *src = G.data + wave_begin;
+    uint2 q[kMaxBpw];
+#pragma unroll
+    for (int j = 0; j < kMaxBpw; ++j) {
+        const uint32_t i = (uint32_t)(j * kWave + lane);
+        q[j] = i < nloc ? src[i] : make_uint2(0u, 0u);
+    }
+    // global slot of this chunk's run in every tile (needed after the ranks: issue the loads now)
+    const int slab = S.slab0[s] + (chunk - S.chunk0[s]) / kFastSlab;
+    uint32_t gs_pre = 0;
+    if (tid < T) gs_pre = base[s * T + tid] + slabtot[(long long)slab * T + tid] + counts[(long long)chunk * T + tid];
+    // ---- phase A: stream rank of every event inside (wavefront, tile): batches of 64 consecutive events, one
+    // returning LDS atomic each -- same-address lanes are served in lane order, and a wavefront's LDS instructions in
+    // program order, so the returned count is the number of earlier events of the wavefront's run in the same tile.
+    uint32_t where[kMaxBpw], word[kMaxBpw];
+    unsigned long long wseen = 0ull;
+#pragma unroll
+    for (int j = 0; j < kMaxBpw; ++j) {
+        where[j] = 0xffffffffu;
+        word[j] = 0u;
+        if (j < G.bpw) {
+            const uint32_t i = (uint32_t)(j * kWave + lane);
+            if (i < nloc) {
+                const FastEv o = fast_decode<HAS_MAP>(G, q[j], t0);
+                if (o.tile >= 0) {
+                    const uint32_t r = atomicAdd(&wcnt[o.tile], 1u);
+                    where[j] = ((uint32_t)o.tile << 16) | r;
+                    word[j] = o.word;
+                    wseen |= 1ull << o.window;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase B: per tile, exclusive prefix of the 16 wavefront counts; chunk-local offsets of the tiles
+    uint32_t mine = 0; // records of tile `tid` in this chunk
+    for (int b = tid; b < T; b += kFT) {
+        uint32_t run = 0;
+#pragma unroll
+        for (int w = 0; w < kFW; ++w) {
+            const uint32_t v = wcnt_all[(size_t)w * T + b];
+            wcnt_all[(size_t)w * T + b] = run;
+            run += v;
+        }
+        mine = run;
+    }
+    uint32_t inc = mine;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        const uint32_t v = __shfl_up(inc, off);
+        if (lane >= off) inc += v;
+    }
+    if (lane == kWave - 1) wtot[wv] = inc;
+    __syncthreads();
+    uint32_t pre = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < kFW; ++k) { if (k < wv) pre += wtot[k]; total += wtot[k]; }
+    if (tid < T) loff[tid] = pre + inc - mine;
+    __syncthreads();
+    // ---- phase C: stage the chunk tile-major in LDS, then leave in one linear sweep: consecutive threads write
+    // consecutive records of a tile's run (whole lines instead of 64 scattered 4-byte stores)
+#pragma unroll
+    for (int j = 0; j < kMaxBpw; ++j) {
+        if (j < G.bpw && where[j] != 0xffffffffu) {
+            const uint32_t b = where[j] >> 16;
+            const uint32_t slot = loff[b] + wcnt[b] + (where[j] & 0xffffu);
+            stage[slot] = word[j];
+            stile[slot] = (uint16_t)b;
+        }
+    }
+    // which windows of the sequence hold events at all ("all(forward)", generate_taf.py:40): OR inside the wavefront,
+    // inside the workgroup, and touch the global word only for bits it does not show yet
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const unsigned lo = __shfl_xor((unsigned)wseen, off), hi = __shfl_xor((unsigned)(wseen >> 32), off);
+        wseen |= ((unsigned long long)hi << 32) | lo;
+    }
+    if (lane == 0 && wseen) atomicOr(&wg_seen, wseen);
+    __syncthreads();
+    if (tid < T) loff[tid] = gs_pre - loff[tid]; // wraps around harmlessly (mod 2^32)
+    __syncthreads();
+    for (uint32_t qi = tid; qi < total; qi += kFT) records[loff[stile[qi]] + qi] = stage[qi];
+    if (tid == 0) {
+        const unsigned long long m = wg_seen;
+        const unsigned long long have = __hip_atomic_load(&hdr->wmask[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (m & ~have) atomicOr(&hdr->wmask[s], m);
+    }
+}
+
+// ---- 4. per-tile split by sub-tile, 5. one wavefront per sub-tile -----------------------------------------
+struct TileP {
+    int H, W, twl, thl, tiles_x, T, K, n_windows, wb, flip;
+    uint32_t win;
+    const uint32_t *rec;   // tile-major records (scatter output)
+    uint32_t *rec2;        // the same records, inside every tile sub-tile-major (split output)
+    const uint32_t *base;  // [pairs + 1]
+    uint32_t *sub;         // [pairs * 16 + 1] first record of every sub-tile in rec2
+    const float *tlut;
+    const uint32_t *leaky_thr;
+    FastHeader *hdr;
+    float *state;    // (B, H, W, 2, K)
+    float *view_f32; // (B, 2K, H, W) or NULL
+    uint8_t *out_u8; // (B, K, 2, H, W) or NULL
+};
+
+constexpr int kMaxK = 8;
+
+// One FIFO step of one cell, generate_taf.py:27,35-49.  Cell without events: every slot - 1; otherwise shift down
+// (slot k + 1, - 1) and the mean enters at K - 1.  `has` false (window empty in the whole sequence, :40-41): unchanged.
+__device__ __forceinline__ void fifo_step(float (&st)[kMaxK], int K, bool has, uint32_t n, float sum)
+{
+    const bool hit = n != 0u;
+    const float mean = sum / ((float)n + 1e-8f);
+#pragma unroll
+    for (int k = 0; k < kMaxK; ++k) {
+        const float nxt = k + 1 < kMaxK ? st[k + 1] : 0.0f;
+        const float v = (hit ? nxt : st[k]) - 1.0f;
+        const float nv = (hit && k == K - 1) ? mean : v;
+        st[k] = has ? nv : st[k];
+    }
+}
+
+#define LDS_FENCE() asm volatile("" ::: "memory")
+
+// 4. One workgroup per (sequence, tile): reorders the tile's records sub-tile-major (sub-tile = the 256 cells
+// [256 v, 256 v + 256) one wavefront of kf_taf_walk owns), STABLY, so that every sub-tile's list is still in stream
+// order.  Pass 1 counts the 16 sub-tiles; pass 2 ranks chunk by chunk with one returning LDS atomic per record on
+// (round, wavefront, sub-tile) counters: lanes of one instruction are served in lane order, (round, wavefront) is the
+// stream order of the 64-record batches.
+constexpr int kSplitRpt = 8;
+__global__ __launch_bounds__(kFT) void kf_split(TileP q)
+{
+    constexpr int RPT = kSplitRpt, CH = RPT * kFT, NE = RPT * kFW;
+    __shared__ uint32_t scnt[RPT][kFW][kFW]; // [round][wavefront][sub-tile]
+    __shared__ uint32_t wtot[kFW][kFW];      // pass 1: [wavefront][sub-tile]
+    __shared__ uint32_t run[kFW];            // next free slot of every sub-tile's list
+    __shared__ uint32_t btot[kFW];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int g = blockIdx.x;
+    if (q.hdr->status != 0) return;
+    const uint32_t beg = q.base[g], end = q.base[g + 1];
+    if (tid < kFW * kFW) (&wtot[0][0])[tid] = 0u;
+    __syncthreads();
+    for (uint32_t i = beg + tid; i < end; i += kFT) atomicAdd(&wtot[wv][(q.rec[i] & (kCells - 1)) >> 8], 1u);
+    __syncthreads();
+    if (tid < kFW) {
+        uint32_t t = 0;
+#pragma unroll
+        for (int w = 0; w < kFW; ++w) t += wtot[w][tid];
+        uint32_t inc = t;
+#pragma unroll
+        for (int o2 = 1; o2 < kFW; o2 <<= 1) {
+            const uint32_t u = __shfl_up(inc, o2);
+            if (lane >= o2) inc += u;
+        }
+        run[tid] = beg + inc - t;
+        q.sub[(long long)g * kFW + tid] = beg + inc - t;
+        if (g == (int)gridDim.x - 1 && tid == kFW - 1) q.sub[(long long)gridDim.x * kFW] = end;
+    }
+    for (uint32_t c0 = beg; c0 < end; c0 += CH) {
+        const uint32_t nrec = end - c0 < (uint32_t)CH ? end - c0 : (uint32_t)CH;
+        for (int i = tid; i < RPT * kFW * kFW; i += kFT) (&scnt[0][0][0])[i] = 0u;
+        __syncthreads();
+        uint32_t m[RPT], rk[RPT];
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) {
+            const uint32_t i = (uint32_t)(u * kFT + tid);
+            m[u] = i < nrec ? q.rec[c0 + i] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) {
+            const uint32_t i = (uint32_t)(u * kFT + tid);
+            rk[u] = 0u;
+            if (i < nrec) rk[u] = atomicAdd(&scnt[u][wv][(m[u] & (kCells - 1)) >> 8], 1u);
+        }
+        __syncthreads();
+        {
+            // wavefront b: exclusive prefix of sub-tile b's counts over (round, wavefront) = stream order
+            uint32_t v0 = 0, v1 = 0;
+            const int e0 = 2 * lane, e1 = 2 * lane + 1;
+            if (e0 < NE) v0 = scnt[e0 / kFW][e0 % kFW][wv];
+            if (e1 < NE) v1 = scnt[e1 / kFW][e1 % kFW][wv];
+            uint32_t inc = v0 + v1;
+#pragma unroll
+            for (int o2 = 1; o2 < kWave; o2 <<= 1) {
+                const uint32_t t = __shfl_up(inc, o2);
+                if (lane >= o2) inc += t;
+            }
+            const uint32_t ex = inc - (v0 + v1);
+            if (e0 < NE) scnt[e0 / kFW][e0 % kFW][wv] = ex;
+            if (e1 < NE) scnt[e1 / kFW][e1 % kFW][wv] = ex + v0;
+            if (lane == kWave - 1) btot[wv] = inc;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) {
+            const uint32_t i = (uint32_t)(u * kFT + tid);
+            if (i < nrec) {
+                const uint32_t b = (m[u] & (kCells - 1)) >> 8;
+                q.rec2[run[b] + scnt[u][wv][b] + rk[u]] = m[u];
+            }
+        }
+        __syncthreads();
+        if (tid < kFW) run[tid] += btot[tid];
+    }
+}
+
+// 5. One wavefront per (sequence, tile, sub-tile): no workgroup, no barrier.  The wavefront owns the 256 cells
+// [256 v, 256 v + 256) of the tile; lane l owns cells l, l + 64, l + 128, l + 192 of them (cell = pixel * 2 + polarity,
+// so polarity = l & 1 and the lane's pixels are 32 apart) with their K-deep FIFO, their running f32 sum and count of the
+// open window in REGISTERS -- consecutive lanes hold consecutive 32-byte FIFO rows of the (H, W, 2, K) state, so state
+// loads and stores sweep whole lines.  The list is consumed in passes of up to 256 records of the open window:
+//   1. every record takes a ticket from its cell's LDS counter with one returning atomic: lanes of one instruction are
+//      served in lane order and the four instructions of a pass are in stream order, so the ticket is the record's
+//      stream rank inside its cell -- a STABLE counting sort without any ordering pass;
+//   2. the owners read their cells' counts, a wavefront scan turns them into segment offsets;
+//   3. every record's f32 value goes to sorted[offset of its cell + ticket];
+//   4. every owner adds its cells' segments front to back into its registers: the reference's sequential
+//      `sum += t - 1` (generate_taf.py:25-26).
+// A record of a later window ends the pass; the open window is then closed (FIFO step in registers, :27-49).
+// (ds_add_f32 would do the ordered sum in one instruction -- it applies same-address lanes in lane order with v_add_f32
+// rounding, checked by the self-test below -- but runs at 192 cycles per wave-instruction per CU: measured, not used.)
+constexpr int kWalkRpt = 4;                 // records per lane and pass
+constexpr int kWalkChunk = kWalkRpt * kWave;
+
+template <bool K8>
+__global__ __launch_bounds__(kWave) void kf_taf_walk(TileP q)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t lds_buf[2 * kSubCells]; // cnt | off; the uint8 staging at the end
+    __shared__ float sorted[kWalkChunk];
+    __shared__ uint32_t thr[kLeakyLevels];
+    uint32_t *cnt = lds_buf, *off = lds_buf + kSubCells;
+    const int lane = threadIdx.x;
+    const int sg = blockIdx.x, g = sg / kFW, wv = sg - g * kFW;
+    const int s = g / q.T, tile = g - s * q.T;
+    if (q.hdr->status != 0) return; // data-dependent error: nothing is written (the caller re-runs the general path)
+    const int K = K8 ? 8 : q.K;
+    for (int i = lane; i < kLeakyLevels; i += kWave) thr[i] = q.leaky_thr[i];
+    for (int i = lane; i < kSubCells; i += kWave) cnt[i] = 0u;
+    const unsigned long long wmask = q.hdr->wmask[s];
+    const bool use_mul = q.hdr->mul_bad == 0u; // checked for every r of the domain by kf_hist
+    const double rcp = 1.0 / ((double)q.win + 1e-8);
+    const uint32_t beg = q.sub[sg], end = q.sub[sg + 1];
+    const int ty = tile / q.tiles_x, tx = tile - ty * q.tiles_x;
+    const int x0 = tx << q.twl, y0 = ty << q.thl, tw1 = (1 << q.twl) - 1;
+    const int pol = lane & 1;
+    const long long plane = (long long)q.H * q.W;
+    // cell j of this lane: pixel wv * 128 + 32 j + lane / 2 of the tile
+    bool ok[4];
+    uint32_t pixoff[4]; // y * W + x inside the sequence's frame
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int pt = wv * (kSubCells / 2) + 32 * j + (lane >> 1);
+        const int y = y0 + (pt >> q.twl), x = x0 + (pt & tw1);
+        ok[j] = y < q.H && x < q.W;
+        pixoff[j] = (uint32_t)(y * q.W + x);
+    }
+    float st[4][kMaxK], sum[4];
+    uint32_t num[4];
+
+    auto load_state = [&]() {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float *src = q.state + (((long long)s * plane + pixoff[j]) * 2 + pol) * K;
+#pragma unroll
+            for (int k = 0; k < kMaxK; ++k) st[j][k] = 0.0f;
+            sum[j] = 0.0f;
+            num[j] = 0u;
+            if (ok[j]) {
+                if (K8) {
+                    const float4 a = ((const float4 *)src)[0], b = ((const float4 *)src)[1];
+                    st[j][0] = a.x; st[j][1] = a.y; st[j][2] = a.z; st[j][3] = a.w;
+                    st[j][4] = b.x; st[j][5] = b.y; st[j][6] = b.z; st[j][7] = b.w;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < kMaxK; ++k)
+                        if (k < K) st[j][k] = src[k];
+                }
+            }
+        }
+    };
+    // closes window w: FIFO step of the four cells (skipped when the window is empty in the whole sequence,
+    // generate_taf.py:40-41), accumulators back to zero
+    auto close_window = [&](int w) {
+        if ((wmask >> w) & 1ull) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                fifo_step(st[j], K, true, num[j], sum[j]);
+                __builtin_amdgcn_sched_barrier(0); // one cell at a time: the four divisions side by side cost registers
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { sum[j] = 0.0f; num[j] = 0u; }
+    };
+    const uint32_t wfield = (1u << q.wb) - 1u;
+    const int rshift = kCellBits + q.wb;
+
+    // The list is walked window by window.  Sorted mode (a time-sorted stream gives a window-sorted list: the partition
+    // and the split are stable): a pass takes the records of the open window at the front of the next 256; the first
+    // record of a later window ends it.  A record whose window runs backwards switches to the general mode (nothing has
+    // been written yet): one sweep over the whole list per window, taking that window's records wherever they are.
+    int cur_w = 0;
+    uint32_t ptr = beg;
+    bool general = false, need_state = true, have_next = false;
+    uint32_t m_next[kWalkRpt];
+#pragma unroll
+    for (int u = 0; u < kWalkRpt; ++u) m_next[u] = 0xffffffffu;
+#pragma nounroll
+    for (;;) {
+        if (need_state) { load_state(); need_state = false; } // ONE copy of the loads
+        if (ptr >= end) { // end of the list: close what is open
+            if (!general) {
+                for (; cur_w < q.n_windows; ++cur_w) close_window(cur_w);
+                break;
+            }
+            close_window(cur_w);
+            if (++cur_w == q.n_windows) break;
+            ptr = beg;
+            have_next = false;
+            continue;
+        }
+        // ---- one pass: the records [ptr, ptr + 256) of window cur_w -> sums / counts in their owners' registers
+        uint32_t m[kWalkRpt], rk[kWalkRpt];
+        if (have_next) {
+#pragma unroll
+            for (int u = 0; u < kWalkRpt; ++u) m[u] = m_next[u];
+        } else {
+#pragma unroll
+            for (int u = 0; u < kWalkRpt; ++u) {
+                const uint32_t i = ptr + (uint32_t)(u * kWave + lane);
+                m[u] = i < end ? q.rec2[i] : 0xffffffffu;
+            }
+        }
+        uint32_t taken = 0;
+        bool order_ok = true, more = false;
+#pragma unroll
+        for (int u = 0; u < kWalkRpt; ++u) {
+            const bool valid = ptr + (uint32_t)(u * kWave + lane) < end;
+            const int w = (int)((m[u] >> kCellBits) & wfield);
+            const bool take = valid && w == cur_w;
+            const unsigned long long tm = __ballot(take), om = __ballot(valid && w != cur_w);
+            // sorted mode: the taken records must be a prefix of the chunk and nothing may be of an earlier window
+            if (__ballot(valid && w < cur_w)) order_ok = false;
+            if (tm && more) order_ok = false;
+            if (tm && om && (63 - __builtin_clzll(tm)) > __builtin_ctzll(om)) order_ok = false;
+            if (om) more = true;
+            taken += (uint32_t)__popcll(tm);
+            rk[u] = 0xffffffffu; // not taken
+            if (take) rk[u] = atomicAdd(&cnt[m[u] & 255u], 1u); // 1. the ticket = stream rank inside the cell
+        }
+        // the next pass starts right behind the taken records (sorted mode) / the chunk (general mode): its loads are
+        // issued now and land while this pass sorts and adds
+        {
+            const uint32_t nptr = general ? ptr + (uint32_t)kWalkChunk : ptr + taken;
+            have_next = nptr < end && (general || order_ok);
+            if (have_next) {
+#pragma unroll
+                for (int u = 0; u < kWalkRpt; ++u) {
+                    const uint32_t i = nptr + (uint32_t)(u * kWave + lane);
+                    m_next[u] = i < end ? q.rec2[i] : 0xffffffffu;
+                }
+            }
+        }
+        if (!general && !order_ok) {
+            if (lane == 0) atomicAdd(&q.hdr->filtered_tiles, 1u);
+            LDS_FENCE();
+            for (int i = lane; i < kSubCells; i += kWave) cnt[i] = 0u;
+            LDS_FENCE();
+            need_state = true;
+            general = true;
+            cur_w = 0;
+            ptr = beg;
+            continue;
+        }
+        LDS_FENCE();
+        // 2. counts of my four cells -> segment offsets (cells in the order lane-major, then j)
+        uint32_t n[4], o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) n[j] = cnt[64 * j + lane];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cnt[64 * j + lane] = 0u;
+        {
+            const uint32_t tl = n[0] + n[1] + n[2] + n[3];
+            uint32_t inc = tl;
+#pragma unroll
+            for (int o2 = 1; o2 < kWave; o2 <<= 1) {
+                const uint32_t t = __shfl_up(inc, o2);
+                if (lane >= o2) inc += t;
+            }
+            o[0] = inc - tl; o[1] = o[0] + n[0]; o[2] = o[1] + n[1]; o[3] = o[2] + n[2];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) off[64 * j + lane] = o[j];
+        LDS_FENCE();
+        // 3. values to their slots: t - 1 with t = (t - t_min) / (w + 1e-8) in f64 (generate_taf.py:215, :26)
+#pragma unroll
+        for (int u = 0; u < kWalkRpt; ++u) {
+            if (rk[u] != 0xffffffffu) {
+                const uint32_t r = m[u] >> rshift;
+                const float v = use_mul ? (float)((double)r * rcp) - 1.0f : q.tlut[r];
+                sorted[off[m[u] & 255u] + rk[u]] = v;
+            }
+        }
+        LDS_FENCE();
+        // 4. every owner adds its segments front to back
+        uint32_t nmax = n[0] > n[1] ? n[0] : n[1];
+        nmax = n[2] > nmax ? n[2] : nmax;
+        nmax = n[3] > nmax ? n[3] : nmax;
+#pragma nounroll
+        for (uint32_t a = 0; __ballot(a < nmax); ++a) {
+            float e[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t at = o[j] + a;
+                e[j] = sorted[at < (uint32_t)kWalkChunk ? at : (uint32_t)kWalkChunk - 1u];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float ns = sum[j] + e[j]; // sum += t - 1 in stream order, generate_taf.py:26
+                sum[j] = a < n[j] ? ns : sum[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) num[j] += n[j];
+        LDS_FENCE();
+        if (general) {
+            ptr += kWalkChunk;
+        } else {
+            ptr += taken;
+            if (more) { close_window(cur_w); ++cur_w; } // the rest of the chunk belongs to later windows
+        }
+    }
+
+    // ---- write-out: state, optional f32 view (2K, H, W), optional uint8 leaky transform (K, 2, H, W)
+    uint8_t *ob = (uint8_t *)lds_buf; // [2K planes][128 pixels of the sub-tile]
+    LDS_FENCE();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (ok[j]) {
+            float *dst = q.state + (((long long)s * plane + pixoff[j]) * 2 + pol) * K;
+            if (K8) {
+                ((float4 *)dst)[0] = make_float4(st[j][0], st[j][1], st[j][2], st[j][3]);
+                ((float4 *)dst)[1] = make_float4(st[j][4], st[j][5], st[j][6], st[j][7]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < kMaxK; ++k)
+                    if (k < K) dst[k] = st[j][k];
+            }
+            if (q.view_f32) {
+                float *vw = q.view_f32 + (long long)s * 2 * K * plane + pixoff[j];
+#pragma unroll
+                for (int k = 0; k < kMaxK; ++k)
+                    if (k < K) vw[(long long)(2 * k + pol) * plane] = st[j][k]; // generate_taf.py:55
+            }
+        }
+        if (q.out_u8) {
+            uint8_t lv[kMaxK];
+            leaky_u8_lookup_n<kMaxK>(st[j], thr, lv); // the eight table look-ups in flight together
+#pragma unroll
+            for (int k = 0; k < kMaxK; ++k) {
+                if (k < K) {
+                    const int ko = q.flip ? (K - 1 - k) : k;
+                    ob[(2 * ko + pol) * (kSubCells / 2) + 32 * j + (lane >> 1)] = lv[k];
+                }
+            }
+        }
+    }
+    if (q.out_u8) {
+        // the (K, 2, H, W) volume leaves plane by plane in 16-pixel pieces: one 16-byte store where the row allows
+        LDS_FENCE();
+        for (int c = lane; c < 2 * K * 8; c += kWave) {
+            const int pl = c >> 3, part = c & 7;
+            const int pt = wv * (kSubCells / 2) + 16 * part;
+            const int y = y0 + (pt >> q.twl), x = x0 + (pt & tw1);
+            if (y >= q.H || x >= q.W) continue;
+            const uint8_t *src = ob + pl * (kSubCells / 2) + 16 * part;
+            uint8_t *dst = q.out_u8 + ((long long)s * 2 * K + pl) * plane + (long long)y * q.W + x;
+            if (x + 16 <= q.W && (((uintptr_t)dst) & 15u) == 0) {
+                *(uint4 *)dst = *(const uint4 *)src;
+            } else {
+                const int nv = q.W - x < 16 ? q.W - x : 16;
+                for (int e = 0; e < nv; ++e) dst[e] = src[e];
+            }
+        }
+    }
+}
+
+// Self-test of the two hardware properties this file rests on, for lanes of ONE wave-instruction that hit the same LDS
+// address: (1) a returning integer atomic serves them in ascending lane order (the returned count is the stream rank);
+// (2) ds_add_f32 applies them in ascending lane order with the rounding of v_add_f32, i.e. it IS the sequential
+// `sum = sum + v` of the lanes.  Random addresses and values in (-1, 0]; reference by counting / adding over lower lanes.
+__global__ __launch_bounds__(kFT) void kf_selftest_lane_order(int n_addr, int iters, unsigned long long *out)
+{
+    extern __shared__ uint32_t lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    uint32_t *mine = lds + (size_t)wv * 3 * n_addr;
+    float *facc = (float *)(mine + n_addr);  // accumulated by the atomic
+    float *fref = facc + n_addr;             // accumulated sequentially, lane by lane
+    unsigned long long bad = 0, conf = 0, fbad = 0;
+    for (int a = lane; a < n_addr; a += kWave) { facc[a] = 0.0f; fref[a] = 0.0f; }
+    for (int it = 0; it < iters; ++it) {
+        for (int a = lane; a < n_addr; a += kWave) mine[a] = 0;
+        LDS_FENCE();
+        uint32_t h = (blockIdx.x * (uint32_t)kFT + tid) * 2654435761u + it * 40503u;
+        h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+        const uint32_t addr = h % (uint32_t)n_addr;
+        const float v = (float)((double)(h >> 8 & 16383u) / 10000.00000001) - 1.0f; // the shape of the TAF values
+        const uint32_t got = atomicAdd(&mine[addr], 1u);
+        atomicAdd(&facc[addr], v);
+        uint32_t want = 0;
+        for (int l = 0; l < kWave; ++l) {
+            const uint32_t other = __shfl(addr, l);
+            const float ov = __shfl(v, l);
+            if (l < lane && other == addr) ++want;
+            LDS_FENCE();
+            if (l == lane) ((volatile float *)fref)[addr] = ((volatile float *)fref)[addr] + ov;
+            LDS_FENCE();
+        }
+        if (got != want) ++bad;
+        if (want) ++conf;
+        LDS_FENCE();
+        if (__float_as_uint(((volatile float *)facc)[addr]) != __float_as_uint(((volatile float *)fref)[addr])) ++fbad;
+        LDS_FENCE();
+        if ((it & 7) == 7) // let the sums grow over 8 batches, then start again
+            for (int a = lane; a < n_addr; a += kWave) { facc[a] = 0.0f; fref[a] = 0.0f; }
+    }
+    if (bad) atomicAdd(&out[0], bad);
+    if (conf) atomicAdd(&out[1], conf);
+    if (fbad) atomicAdd(&out[2], fbad);
+}
+
+template <bool HAS_MAP>
+void launch_fast(const FastGeom &G, const SeqTab &S, const FastPlan &p, char *w8, hipStream_t st)
+{
+    FastHeader *hdr = (FastHeader *)w8;
+    uint32_t *counts = (uint32_t *)(w8 + p.off_counts);
+    uint32_t *slabtot = (uint32_t *)(w8 + p.off_slabtot);
+    uint32_t *base = (uint32_t *)(w8 + p.off_base);
+    int32_t *errs = (int32_t *)(w8 + p.off_errs);
+    float *tlut = (float *)(w8 + p.off_tlut);
+    uint32_t *leaky = (uint32_t *)(w8 + p.off_leaky);
+    uint32_t *records = (uint32_t *)(w8 + p.off_records);
+    const size_t lds_sc = scatter_lds_bytes(p.T, p.chunk);
+    if (lds_sc > 64 * 1024)
+        (void)hipFuncSetAttribute((const void *)kf_scatter<HAS_MAP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc);
+    hipLaunchKernelGGL((kf_hist<HAS_MAP>), dim3(p.chunks), dim3(kFT), (size_t)p.T * 4, st, G, S, counts, errs, tlut, leaky);
+    hipLaunchKernelGGL(kf_slabscan, dim3((p.T + kWave - 1) / kWave, p.slabs), dim3(kWave), 0, st, S, counts, p.T, slabtot);
+    hipLaunchKernelGGL(kf_tilescan, dim3(1), dim3(kFT), 0, st, S, slabtot, p.T, base, hdr, errs, p.chunks);
+    hipLaunchKernelGGL((kf_scatter<HAS_MAP>), dim3(p.chunks), dim3(kFT), lds_sc, st, G, S, counts, slabtot, base, records, hdr);
+}
+
+} // namespace
+
+extern "C" {
+
+int frlw_selftest_lds_atomic_order(int n_addr, int iters, unsigned long long *out_dev, frlw_stream_t stream)
+{
+    if (!out_dev || n_addr < 1 || n_addr > 512 || iters < 1) return FRLW_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    (void)hipFuncSetAttribute((const void *)kf_selftest_lane_order, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              kFW * 512 * 12);
+    HIP_TRY(hipMemsetAsync(out_dev, 0, 24, st));
+    hipLaunchKernelGGL(kf_selftest_lane_order, dim3(256), dim3(kFT), (size_t)kFW * n_addr * 12, st, n_addr, iters, out_dev);
+    HIP_TRY(hipGetLastError());
+    return FRLW_OK;
+}
+
+size_t frlw_taf_batch_workspace_bytes(int64_t n_events, int n_seq, int H, int W, int64_t window_us)
+{
+    FastPlan p;
+    if (window_us < 1 || window_us >= (1ll << 20) || !fast_plan(n_events, n_seq, H, W, p)) return 0;
+    // the layout depends on how the events are spread over the sequences only through the chunk count: every sequence
+    // can add one partly filled chunk and one partly filled slab
+    const size_t chunks = (size_t)(n_events + p.chunk - 1) / p.chunk + n_seq;
+    const size_t slabs = chunks / kFastSlab + n_seq + 1;
+    size_t off = kHeaderBytes;
+    off = align_up(off + chunks * p.T * 4, 256);
+    off = align_up(off + slabs * p.T * 4, 256);
+    off = align_up(off + (size_t)(p.pairs + 1) * 4, 256);
+    off = align_up(off + ((size_t)p.pairs * kFW + 1) * 4, 256);
+    off = align_up(off + chunks * 4, 256);
+    off = align_up(off + (size_t)(window_us + 1) * 4, 256);
+    off = align_up(off + (size_t)kLeakyLevels * 4, 256);
+    off = align_up(off + (size_t)(n_events > 0 ? n_events : 1) * 4, 256);
+    off = align_up(off + (size_t)(n_events > 0 ? n_events : 1) * 4, 256);
+    return off;
+}
+
+int frlw_taf_encode_batch(const frlw_events_t *ev, const int64_t *seq_offsets, const int64_t *t_start, int n_seq, int H,
+                          int W, int K, int64_t window_us, int n_windows, float *state, float *view_f32, uint8_t *out_u8,
+                          int flags, void *workspace, size_t workspace_bytes, frlw_stream_t stream)
+{
+    if (!ev || !seq_offsets || !t_start || !state || !workspace) return FRLW_ERR_ARG;
+    if (K < 1 || K > FRLW_MAX_BINS || n_windows < 1 || n_windows > FRLW_MAX_WINDOWS || window_us < 1) return FRLW_ERR_ARG;
+    if (n_seq < 1 || n_seq > kMaxSeq) return FRLW_ERR_ARG;
+    if (ev->layout != FRLW_LAYOUT_DAT8) return FRLW_ERR_UNSUPPORTED;
+    if ((ev->xmap == nullptr) != (ev->ymap == nullptr)) return FRLW_ERR_ARG;
+    if (seq_offsets[0] < 0 || seq_offsets[n_seq] > ev->n) return FRLW_ERR_ARG;
+    if (seq_offsets[n_seq] > seq_offsets[0] && !ev->data) return FRLW_ERR_ARG;
+    // record = r | window | cell in 32 bits
+    int wb = 0, rb = 0;
+    while ((1 << wb) < n_windows) ++wb;
+    while ((1ll << rb) <= window_us) ++rb;
+    if (kCellBits + wb + rb > 32 || (long long)n_windows * window_us >= (1ll << 32)) return FRLW_ERR_UNSUPPORTED;
+    const long long n = seq_offsets[n_seq] - seq_offsets[0];
+    FastPlan p;
+    if (!fast_plan(n, n_seq, H, W, p)) return FRLW_ERR_UNSUPPORTED;
+    SeqTab S;
+    if (!fast_layout(seq_offsets, t_start, n_seq, p, S, (uint32_t)window_us)) return FRLW_ERR_ARG;
+    if (workspace_bytes < p.bytes) return FRLW_ERR_WORKSPACE;
+    if (scatter_lds_bytes(p.T, p.chunk) > 160 * 1024) return FRLW_ERR_UNSUPPORTED;
+
+    FastGeom G;
+    G.data = (const uint2 *)ev->data;
+    G.xmap = ev->xmap; G.ymap = ev->ymap; G.map_w = ev->map_w; G.map_h = ev->map_h;
+    G.H = H; G.W = W; G.twl = p.twl; G.thl = p.thl; G.tiles_x = p.tiles_x; G.T = p.T; G.bpw = p.bpw;
+    G.n_windows = n_windows; G.wb = wb; G.win = (uint32_t)window_us;
+    const unsigned long long magic = (1ull << 32) / (unsigned long long)window_us;
+    G.win_magic = magic > 0xffffffffull ? 0xffffffffu : (uint32_t)magic;
+
+    hipStream_t st = (hipStream_t)stream;
+    char *w8 = (char *)workspace;
+    (void)hipGetLastError();
+    if (ev->xmap) launch_fast<true>(G, S, p, w8, st);
+    else launch_fast<false>(G, S, p, w8, st);
+    TileP q;
+    q.H = H; q.W = W; q.twl = p.twl; q.thl = p.thl; q.tiles_x = p.tiles_x; q.T = p.T; q.K = K; q.n_windows = n_windows;
+    q.wb = wb; q.flip = (flags & FRLW_TAF_U8_FLIP_K) ? 1 : 0; q.win = (uint32_t)window_us;
+    q.rec = (const uint32_t *)(w8 + p.off_records);
+    q.rec2 = (uint32_t *)(w8 + p.off_records2);
+    q.base = (const uint32_t *)(w8 + p.off_base);
+    q.sub = (uint32_t *)(w8 + p.off_sub);
+    q.tlut = (const float *)(w8 + p.off_tlut);
+    q.leaky_thr = (const uint32_t *)(w8 + p.off_leaky);
+    q.hdr = (FastHeader *)w8;
+    q.state = state; q.view_f32 = view_f32; q.out_u8 = out_u8;
+    hipLaunchKernelGGL(kf_split, dim3(p.pairs), dim3(kFT), 0, st, q);
+    if (K == 8) hipLaunchKernelGGL(kf_taf_walk<true>, dim3(p.pairs * kFW), dim3(kWave), 0, st, q);
+    else hipLaunchKernelGGL(kf_taf_walk<false>, dim3(p.pairs * kFW), dim3(kWave), 0, st, q);
+    HIP_TRY(hipGetLastError());
+    return FRLW_OK;
+}
+
+} // extern "C"

@@ -40,7 +40,8 @@ enum {
     FRLW_ERR_WORKSPACE = -3, /* workspace too small */
     FRLW_ERR_HIP = -4,       /* a HIP runtime call failed */
     FRLW_ERR_POLARITY = -5,  /* polarity outside {0, 1} */
-    FRLW_ERR_UNSUPPORTED = -6
+    FRLW_ERR_UNSUPPORTED = -6,
+    FRLW_ERR_SPAN = -7       /* frlw_taf_encode_batch: an event outside [t_start, t_start + n_windows * window_us] */
 };
 
 /* Event array layouts. */
@@ -81,7 +82,7 @@ typedef struct frlw_events {
 size_t frlw_encoder_workspace_bytes(int64_t n_events, int H, int W);
 
 /* Synchronise `stream` and fetch the data-dependent status of the last encoder call that used
- * `workspace`: FRLW_OK, FRLW_ERR_INDEX or FRLW_ERR_POLARITY. */
+ * `workspace`: FRLW_OK, FRLW_ERR_INDEX, FRLW_ERR_POLARITY or FRLW_ERR_SPAN. */
 int frlw_encoder_status(const void *workspace, frlw_stream_t stream, int *status_out);
 
 /*
@@ -137,6 +138,35 @@ int frlw_taf_encode(const frlw_events_t *ev, int H, int W, int K, int64_t t_star
                     int64_t window_us, int n_windows, float *state, float *view_f32,
                     uint8_t *out_u8, int flags, void *workspace, size_t workspace_bytes,
                     frlw_stream_t stream);
+
+/*
+ * Temporal Active Focus, fast path for a BATCH of independent sequences (csrc/taf_fast.hip) -- the same harness loop
+ * (generate_taf.py:193-235) for n_seq <= FRLW_MAX_SEQUENCES streams in one launch sequence.  Sequence s owns the DAT8
+ * records [seq_offsets[s], seq_offsets[s + 1]) of ev->data (HOST array of n_seq + 1 event indices), starts at
+ * t_start[s] (HOST array) and has its own FIFO state, its own outputs and its own "window without any event leaves the
+ * state untouched" rule (:40-41 is evaluated per file, :143-160):
+ *   state (n_seq, H, W, 2, K) in place; view_f32 (n_seq, 2K, H, W) or NULL; out_u8 (n_seq, K, 2, H, W) or NULL.
+ * Bit-identical to n_seq calls of frlw_taf_encode.  Differences in contract:
+ *   - DAT8 only; 12 + ceil(log2 n_windows) + bits(window_us) <= 32 (else FRLW_ERR_UNSUPPORTED at launch);
+ *   - every event must lie inside [t_start[s], t_start[s] + n_windows * window_us] (the harness cuts the stream with
+ *     seek_time, :162-193).  Checked on device: frlw_encoder_status() then reports FRLW_ERR_SPAN (or FRLW_ERR_INDEX)
+ *     and NOTHING has been written -- state and outputs are untouched, so the caller can fall back to
+ *     frlw_taf_encode, which places such events like the reference does.
+ * The stream may be in any order (sums follow stream order); a time-sorted stream is the fast case.
+ * Workspace: frlw_taf_batch_workspace_bytes(total events, n_seq, H, W, window_us); 0 = unsupported shape.
+ */
+#define FRLW_MAX_SEQUENCES 64
+size_t frlw_taf_batch_workspace_bytes(int64_t n_events, int n_seq, int H, int W, int64_t window_us);
+int frlw_taf_encode_batch(const frlw_events_t *ev, const int64_t *seq_offsets, const int64_t *t_start, int n_seq, int H,
+                          int W, int K, int64_t window_us, int n_windows, float *state, float *view_f32,
+                          uint8_t *out_u8, int flags, void *workspace, size_t workspace_bytes, frlw_stream_t stream);
+
+/* Self-test of the gfx950 properties frlw_taf_encode_batch relies on, for the lanes of one LDS atomic instruction that
+ * hit the same address: a returning integer add serves them in ascending lane order, and ds_add_f32 applies them in that
+ * order with v_add_f32 rounding (= the reference's sequential f32 sum).  256 workgroups x `iters` batches of random
+ * addresses in [0, n_addr <= 512); out_dev (device, 3 x uint64): [0] = rank mismatches (must be 0), [1] = lanes that
+ * shared their address with a lower lane (the sample size), [2] = f32 sums that differ from the sequential sum (must be 0). */
+int frlw_selftest_lds_atomic_order(int n_addr, int iters, unsigned long long *out_dev, frlw_stream_t stream);
 
 /* leaky_transform(ecd), generate_taf.py:69-76, on n floats; either output may be NULL. */
 int frlw_leaky_transform(const float *in, int64_t n, float *out_f32, uint8_t *out_u8,

@@ -1,0 +1,199 @@
+"""The fast / batched TAF path (csrc/taf_fast.hip, ``frlw_taf_encode_batch``) against the CPU oracle (itself pinned to
+the reference's goldens, tests/test_oracle_golden.py) and against the general path, bit for bit.
+
+Covers what the reference's per-file harness loop implies (generate_taf.py:143-235): independent sequences with their
+own "window without events leaves the state untouched" rule (:40-41), own start time, state carried from call to call.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from frlw_evd_amd import synth  # noqa: E402
+from golden_util import assert_bitexact, assert_u8_budget  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def er():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from frlw_evd_amd import event_representation
+    return event_representation
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+    return oracle
+
+
+def to_dev(rec):
+    return torch.from_numpy(np.ascontiguousarray(rec).view(np.uint8).reshape(-1, 8).copy()).cuda()
+
+
+def host(t):
+    return t.cpu().numpy()
+
+
+def oracle_taf(orc, rec, shape, K, t_start, win, n_win, state0, flip=True):
+    H, W = shape
+    view, st = orc.taf_stream_dat8(rec, shape, shape, K, t_start, win, n_win, state0)
+    u8 = orc.quantize_u8(orc.leaky_transform(view.reshape(K, 2, H, W)))
+    return view, st, (np.ascontiguousarray(u8[::-1]) if flip else u8)
+
+
+def test_lds_atomic_lane_order():
+    """The hardware property the stable ranks rest on (see csrc/taf_fast.hip): zero mismatches over many conflicts."""
+    from frlw_evd_amd import _lib
+    lib = _lib.load()
+    out = torch.zeros(3, dtype=torch.int64, device="cuda")
+    for n_addr in (1, 3, 16, 40, 450, 512):
+        _lib.check(lib.frlw_selftest_lds_atomic_order(n_addr, 50, C.c_void_p(out.data_ptr()),
+                                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        bad, conflicts, fbad = (int(v) for v in out.cpu())
+        assert conflicts > 10_000, (n_addr, conflicts)
+        assert bad == 0, f"{bad} rank mismatches with {n_addr} addresses"
+        assert fbad == 0, f"{fbad} ds_add_f32 sums differ from the sequential f32 sum with {n_addr} addresses"
+
+
+@pytest.mark.parametrize("hotspot", [False, True])
+def test_gen1_vs_oracle(er, orc, hotspot):
+    H, W, K = 240, 304, 8
+    ev = synth.synth_events(5150, 1_000_000, W, H, 80_000, hotspot=hotspot)
+    rec = synth.to_dat8(ev)
+    st = torch.full((H, W, 2, K), -6000.0, device="cuda")
+    u8, view = er.encode_taf_dat(to_dev(rec), (H, W), st, 0, 10_000, 8, K, want_view=True, fast=True)
+    oview, ost, ou8 = oracle_taf(orc, rec, (H, W), K, 0, 10_000, 8, np.full((H, W, 2, K), -6000, np.float32))
+    assert_bitexact(host(st), ost, "state")
+    assert_bitexact(host(view), oview, "view")
+    assert_u8_budget(host(u8), ou8, 1e-5, "uint8")
+
+
+CASES = [
+    # H, W, n, K, n_windows, window_us, hotspot
+    (17, 33, 5_000, 8, 8, 10_000, False),
+    (17, 33, 60_000, 4, 3, 977, True),
+    (64, 64, 200_000, 5, 16, 5_000, False),
+    (240, 304, 300_000, 8, 1, 10_000, False),
+    (100, 1000, 400_000, 8, 8, 10_000, True),
+    (720, 1280, 2_000_000, 8, 8, 10_000, False),
+    (720, 1280, 1_500_000, 8, 8, 10_000, True),
+    (31, 2047, 100_000, 2, 64, 250, False),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[f"{c[0]}x{c[1]}-n{c[2]}-K{c[3]}-w{c[4]}" for c in CASES])
+def test_fast_equals_general(er, case):
+    H, W, n, K, n_win, win, hotspot = case
+    ev = synth.synth_events(H * 7 + n_win, n, W, H, n_win * win, hotspot=hotspot, t_offset=123_456)
+    ev["t"][-3:] = 123_456 + n_win * win  # exactly the end of the last window (generate_taf.py:197-203)
+    dat = to_dev(synth.to_dat8(ev))
+    init = torch.from_numpy(np.random.default_rng(3).uniform(-50, 0, (H, W, 2, K)).astype(np.float32)).cuda()
+    sa, sb = init.clone(), init.clone()
+    ua, va = er.encode_taf_dat(dat, (H, W), sa, 123_456, win, n_win, K, want_view=True, fast=True)
+    ub, vb = er.encode_taf_dat(dat, (H, W), sb, 123_456, win, n_win, K, want_view=True, fast=False)
+    assert not torch.equal(sa, init)
+    assert torch.equal(sa, sb), "state"
+    assert torch.equal(va, vb), "view"
+    assert torch.equal(ua, ub), "uint8"
+
+
+def test_batch_sparse_samples_vs_oracle(er, orc):
+    """Sample 1 has no event in window 3, sample 2 is entirely empty, sample 3 starts late (windows 0-1 empty): each
+    follows its OWN all(forward) rule (generate_taf.py:40-41), exactly like four separate files."""
+    H, W, K, win, n_win = 240, 304, 8, 10_000, 8
+    recs, starts = [], [0, 1_000_000, 5_000, 70_000]
+    for j, t0 in enumerate(starts):
+        ev = synth.synth_events(900 + j, 150_000, W, H, n_win * win, t_offset=t0)
+        keep = np.ones(len(ev["t"]), bool)
+        if j == 1:
+            keep = (ev["t"] - t0) // win != 3
+        if j == 2:
+            keep[:] = False
+        if j == 3:
+            keep = (ev["t"] - t0) >= 2 * win + 17
+        recs.append(synth.to_dat8({k: v[keep] for k, v in ev.items()}))
+    offs = np.concatenate([[0], np.cumsum([len(r) for r in recs])])
+    dat = to_dev(np.concatenate(recs))
+    state0 = np.random.default_rng(5).uniform(-30, 0, (4, H, W, 2, K)).astype(np.float32)
+    st = torch.from_numpy(state0).cuda()
+    u8, view = er.encode_taf_batch(dat, offs, (H, W), st, starts, win, n_win, K, want_view=True)
+    for j in range(4):
+        oview, ost, ou8 = oracle_taf(orc, recs[j], (H, W), K, starts[j], win, n_win, state0[j])
+        assert_bitexact(host(st[j]), ost, f"state of sample {j}")
+        assert_bitexact(host(view[j]), oview, f"view of sample {j}")
+        assert_u8_budget(host(u8[j]), ou8, 1e-4, f"uint8 of sample {j}")
+        # and the per-sample general path agrees bit for bit
+        sj = torch.from_numpy(state0[j]).cuda()
+        uj, _ = er.encode_taf_dat(to_dev(recs[j]) if len(recs[j]) else torch.empty((0, 8), dtype=torch.uint8, device="cuda"),
+                                  (H, W), sj, starts[j], win, n_win, K, fast=False)
+        assert torch.equal(sj, st[j]) and torch.equal(uj, u8[j]), f"general path, sample {j}"
+    assert_bitexact(host(st[2]), state0[2], "an empty sequence leaves its state untouched")
+
+
+def test_unsorted_stream(er, orc):
+    H, W, K, win, n_win = 64, 96, 8, 10_000, 8
+    ev = synth.synth_events(77, 120_000, W, H, n_win * win, hotspot=True)
+    perm = np.random.default_rng(1).permutation(len(ev["t"]))
+    ev = {k: v[perm] for k, v in ev.items()}
+    rec = synth.to_dat8(ev)
+    st = torch.full((1, H, W, 2, K), -6000.0, device="cuda")
+    u8, view = er.encode_taf_batch(to_dev(rec), [0, len(rec)], (H, W), st, 0, win, n_win, K, want_view=True)
+    oview, ost, ou8 = oracle_taf(orc, rec, (H, W), K, 0, win, n_win, np.full((H, W, 2, K), -6000, np.float32))
+    assert_bitexact(host(st[0]), ost, "state")
+    assert_bitexact(host(view[0]), oview, "view")
+
+
+def test_span_violation_writes_nothing_and_falls_back(er):
+    H, W, K, win, n_win = 48, 80, 8, 10_000, 4
+    ev = synth.synth_events(31, 50_000, W, H, n_win * win, t_offset=100_000)
+    ev["t"][10] = 99_000       # before t_start
+    ev["t"][-1] = 100_000 + n_win * win + 5  # after the last window
+    dat = to_dev(synth.to_dat8(ev))
+    init = torch.full((H, W, 2, K), -7.0, device="cuda")
+    st = init.clone()
+    with pytest.raises(ValueError):
+        er.encode_taf_batch(dat, [0, len(ev["t"])], (H, W), st.view(1, H, W, 2, K), 100_000, win, n_win, K)
+    assert torch.equal(st, init), "nothing may be written after a span violation"
+    sa, sb = init.clone(), init.clone()
+    ua, _ = er.encode_taf_dat(dat, (H, W), sa, 100_000, win, n_win, K, fast=True)   # falls back by itself
+    ub, _ = er.encode_taf_dat(dat, (H, W), sb, 100_000, win, n_win, K, fast=False)
+    assert torch.equal(sa, sb) and torch.equal(ua, ub) and not torch.equal(sa, init)
+    with pytest.raises(IndexError):  # out of frame: the general path reports it like torch's index_add_
+        oob = dict(ev)
+        oob["y"] = ev["y"].copy()
+        oob["y"][0] = H + 3
+        oob["t"] = np.clip(ev["t"], 100_000, 100_000 + n_win * win)
+        er.encode_taf_dat(to_dev(synth.to_dat8(oob)), (H, W), init.clone(), 100_000, win, n_win, K, fast=True)
+
+
+def test_state_carry_and_downscale_maps(er, orc):
+    """Two consecutive labels of one sequence (state carried, generate_taf.py:175-186) on the down-scaled 1 Mpx geometry
+    (coordinate maps = x * rw, y * rh + truncation, :216-219)."""
+    Hs, Ws, H, W, K, win, n_win = 720, 1280, 512, 640, 8, 10_000, 4
+    xmap, ymap = er.coordinate_maps((Hs, Ws), (H, W), "cuda")
+    st = torch.full((1, H, W, 2, K), -6000.0, device="cuda")
+    ost = np.full((H, W, 2, K), -6000, np.float32)
+    for part in range(2):
+        ev = synth.synth_events(400 + part, 600_000, Ws, Hs, n_win * win, t_offset=part * n_win * win)
+        rec = synth.to_dat8(ev)
+        er.encode_taf_batch(to_dev(rec), [0, len(rec)], (H, W), st, part * n_win * win, win, n_win, K, xmap=xmap, ymap=ymap)
+        _, ost = orc.taf_stream_dat8(rec, (Hs, Ws), (H, W), K, part * n_win * win, win, n_win, ost)
+        assert_bitexact(host(st[0]), ost, f"state after part {part}")
+
+
+def test_gen1_batch64_equals_per_sample(er):
+    """BASELINE.json configs[4] encode shape: 64 GEN1 streams of 8 x 125 000 events in one call == 64 single calls."""
+    H, W, K, win, n_win, B = 240, 304, 8, 10_000, 8, 64
+    recs = [synth.to_dat8(synth.synth_events(2000 + j, 1_000_000 if j < 2 else 60_000, W, H, n_win * win)) for j in range(B)]
+    offs = np.concatenate([[0], np.cumsum([len(r) for r in recs])])
+    st = torch.full((B, H, W, 2, K), -6000.0, device="cuda")
+    u8, _ = er.encode_taf_batch(to_dev(np.concatenate(recs)), offs, (H, W), st, 0, win, n_win, K)
+    for j in (0, 1, 2, 31, 63):
+        sj = torch.full((H, W, 2, K), -6000.0, device="cuda")
+        uj, _ = er.encode_taf_dat(to_dev(recs[j]), (H, W), sj, 0, win, n_win, K, fast=False)
+        assert torch.equal(sj, st[j]) and torch.equal(uj, u8[j]), f"sample {j}"
