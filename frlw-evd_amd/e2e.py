@@ -26,28 +26,17 @@ class SyntheticTafSource:
     def __init__(self, n_samples, seed=1005, events_per_window=125_000, n_windows=8, device="cuda"):
         H, W = GEN1_SENSOR
         self.n_windows, self.K = n_windows, 8
-        self.streams = []
-        for i in range(n_samples):
-            ev = synth.synth_events(seed + i, events_per_window * n_windows, W, H, 10_000 * n_windows)
-            self.streams.append(torch.from_numpy(synth.to_dat8(ev).view(np.uint8).reshape(-1, 8)).to(device))
-        # One launch sequence per group of up to 32 samples: the samples are independent sequences, so their streams
-        # can be concatenated in any order once every sample has its own rectangle of one big frame (the DAT x / y
-        # fields have 14 bits).  Measured for 32 x 1 M events: samples stacked along y only (304 x 7680) 1.27 ms,
-        # 2 / 4 / 8 samples per row 1.42 / 1.50 / 1.64 ms -- the tall frame wins although its second 256-px tile column
-        # is 81 % empty: a partition chunk then touches the tiles of one sample only.
-        self.group, self.cols = 32, 1
-        self.stacked = []
-        for g0 in range(0, n_samples, self.group):
-            part = []
-            for j, i in enumerate(range(g0, min(g0 + self.group, n_samples))):
-                ev = synth.synth_events(seed + i, events_per_window * n_windows, W, H, 10_000 * n_windows)
-                ev = dict(ev)
-                ev["x"] = ev["x"] + (j % self.cols) * W
-                ev["y"] = ev["y"] + (j // self.cols) * H
-                part.append(synth.to_dat8(ev))
-            self.stacked.append(torch.from_numpy(np.concatenate(part).view(np.uint8).reshape(-1, 8)).to(device))
-        self.batched = True
+        recs = [synth.to_dat8(synth.synth_events(seed + i, events_per_window * n_windows, W, H, 10_000 * n_windows))
+                for i in range(n_samples)]
+        self.offsets = np.concatenate([[0], np.cumsum([len(r) for r in recs])]).astype(np.int64)
+        # all sequences back to back: sample i owns records [offsets[i], offsets[i + 1]) -- what frlw_taf_encode_batch
+        # takes.  Every sequence keeps its own FIFO state and its own "window without events" rule
+        # (generate_taf.py:40-41 is evaluated per file), unlike a frame of stacked samples.
+        self.dat = torch.from_numpy(np.concatenate(recs).view(np.uint8).reshape(-1, 8)).to(device)
         self.device = device
+
+    def __len__(self):
+        return len(self.offsets) - 1
 
     def labels(self, n):
         """(n, 80, 5) float64 [cls, cx, cy, w, h] with 2 boxes per sample, zero-padded (data/dataset.py:211-217)."""
@@ -59,32 +48,41 @@ class SyntheticTafSource:
                                           rng.uniform(20, 80), rng.uniform(20, 80)])
         return lab.to(self.device)
 
-    def encode_batch(self, idx):
-        """-> (B, 16, 256, 320, 1, 1) f32 in [0, 1]: what propheseeTafDataset hands to the model."""
+    def encode_u8(self, idx, batched=True):
+        """-> (B, 16, 240, 304) uint8, the files the reference would write (generate_taf.py:228-235), newest slot first.
+        ``batched``: runs of consecutive samples go through ONE ``frlw_taf_encode_batch`` call (up to 64 sequences);
+        otherwise one general-path encode per sample -- the two agree bit for bit (tests/test_e2e_gpu.py)."""
         H, W = GEN1_SENSOR
-        if self.batched and list(idx) == list(range(len(self.streams))):
-            parts = []
-            for gi, dat in enumerate(self.stacked):
-                B = min(self.group, len(self.streams) - gi * self.group)
-                cols = min(self.cols, B)
-                rows = (B + cols - 1) // cols
-                Hb, Wb = rows * H, cols * W
-                state = torch.full((Hb, Wb, 2, self.K), -6000.0, device=self.device)
-                u8, _ = er.encode_taf_dat(dat, (Hb, Wb), state, 0, 10_000, self.n_windows, self.K, check=False)
-                # (K, 2, rows*H, cols*W) -> (rows*cols, 2K, H, W), sample j at (j // cols, j % cols)
-                u8 = u8.reshape(2 * self.K, rows, H, cols, W).permute(1, 3, 0, 2, 4).reshape(rows * cols, 2 * self.K, H, W)[:B]
-                u8 = u8.reshape(B * 2 * self.K, H, W).contiguous()
-                parts.append(er.resize_nearest(u8, GEN1_DETECTOR).reshape(B, 2 * self.K, *GEN1_DETECTOR))
-            u8 = parts[0] if len(parts) == 1 else torch.cat(parts, 0)
-            return (u8.float() / 255.0)[..., None, None]
-        out = []
-        for i in idx:
-            state = torch.full((H, W, 2, self.K), -6000.0, device=self.device)
-            u8, _ = er.encode_taf_dat(self.streams[i], (H, W), state, 0, 10_000, self.n_windows, self.K, check=False)
-            u8 = er.resize_nearest(u8.reshape(2 * self.K, H, W), GEN1_DETECTOR)
-            out.append(u8)
-        x = torch.stack(out).float() / 255.0
-        return x[..., None, None]
+        idx = list(idx)
+        out = torch.empty((len(idx), 2 * self.K, H, W), dtype=torch.uint8, device=self.device)
+        pos = 0
+        while pos < len(idx):
+            run = 1
+            if batched:
+                while pos + run < len(idx) and run < 64 and idx[pos + run] == idx[pos + run - 1] + 1:
+                    run += 1
+            i0 = idx[pos]
+            lo, hi = int(self.offsets[i0]), int(self.offsets[i0 + run])
+            if batched:
+                state = torch.full((run, H, W, 2, self.K), -6000.0, device=self.device)
+                u8, _ = er.encode_taf_batch(self.dat[lo:hi], self.offsets[i0:i0 + run + 1] - lo, (H, W), state, 0, 10_000,
+                                            self.n_windows, self.K, check=False)
+                out[pos:pos + run] = u8.reshape(run, 2 * self.K, H, W)
+            else:
+                state = torch.full((H, W, 2, self.K), -6000.0, device=self.device)
+                u8, _ = er.encode_taf_dat(self.dat[lo:hi], (H, W), state, 0, 10_000, self.n_windows, self.K, check=False,
+                                          fast=False)
+                out[pos] = u8.reshape(2 * self.K, H, W)
+            pos += run
+        return out
+
+    def encode_batch(self, idx, batched=True):
+        """-> (B, 16, 256, 320, 1, 1) f32 in [0, 1]: what propheseeTafDataset hands to the model (uint8 file / 255,
+        data/dataset.py:294-308, after the nearest resize to the detector shape, generate_taf.py:221-222)."""
+        u8 = self.encode_u8(idx, batched)
+        B = u8.shape[0]
+        u8 = er.resize_nearest(u8.reshape(B * 2 * self.K, *GEN1_SENSOR), GEN1_DETECTOR).reshape(B, 2 * self.K, *GEN1_DETECTOR)
+        return (u8.float() / 255.0)[..., None, None]
 
 
 def build_model(in_channels=16, num_classes=2, device="cuda", seed=1004):

@@ -13,8 +13,7 @@ def test_encode_then_train_and_eval_step():
     from frlw_evd_amd.trainer import Trainer
     src = e2e.SyntheticTafSource(2, events_per_window=20_000)
     x = src.encode_batch([0, 1])
-    assert src.batched
-    one = torch.cat([src.encode_batch([0]), src.encode_batch([1])])  # per-sample launches: same bytes
+    one = src.encode_batch([0, 1], batched=False)  # per-sample launches of the general path: same bytes
     assert torch.equal(x, one)
     assert x.shape == (2, 16, 256, 320, 1, 1) and float(x.min()) >= 0.0 and float(x.max()) <= 1.0
     q = (x * 255).round()
@@ -30,13 +29,44 @@ def test_encode_then_train_and_eval_step():
     assert len(dets) == 2 and dets[0].shape[1] == 6
 
 
-def test_batched_encode_layout_equals_per_sample():
-    """11 samples = one big frame 8 samples wide, 2 high (last row partial): same bytes as 11 separate encodes."""
+def test_batched_encode_equals_per_sample():
+    """11 sequences through one frlw_taf_encode_batch call (sample 3 starts two windows late, sample 7 has no events in
+    its last windows): same bytes as 11 separate general-path encodes -- every sequence follows its own
+    window-without-events rule (generate_taf.py:40-41)."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from frlw_evd_amd import e2e
     src = e2e.SyntheticTafSource(11, seed=321, events_per_window=6_000)
+    # thin two samples out on the device copy: record = (t: u32, word: u32)
+    rec = src.dat.view(torch.int32).reshape(-1, 2)
+    t = rec[:, 0]
+    lo3, hi3, lo7, hi7 = (int(src.offsets[i]) for i in (3, 4, 7, 8))
+    keep = torch.ones(len(t), dtype=torch.bool, device=t.device)
+    keep[lo3:hi3] = t[lo3:hi3] >= 20_000
+    keep[lo7:hi7] = t[lo7:hi7] < 50_000
+    counts = [int(keep[int(src.offsets[i]):int(src.offsets[i + 1])].sum()) for i in range(11)]
+    src.dat = src.dat[keep].contiguous()
+    src.offsets = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
     x = src.encode_batch(list(range(11)))
-    one = torch.cat([src.encode_batch([i]) for i in range(11)])
+    one = src.encode_batch(list(range(11)), batched=False)
     assert x.shape == (11, 16, 256, 320, 1, 1)
     assert torch.equal(x, one)
+    assert not torch.equal(x[3], x[4])
+
+
+def test_train_batch64_is_finite_and_deterministic():
+    """BASELINE.json configs[4] at its stated per-GPU size on one GPU: 64 GEN1 streams -> TAF -> one train step, twice
+    from the same initial weights: finite, and the same loss to the last bit (the whole step is deterministic)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from frlw_evd_amd import e2e
+    from frlw_evd_amd.trainer import Trainer
+    src = e2e.SyntheticTafSource(64, seed=77, events_per_window=30_000)
+    x = src.encode_batch(list(range(64)))
+    assert torch.equal(x[:4], src.encode_batch([0, 1, 2, 3], batched=False))
+    losses = []
+    for _ in range(2):
+        torch.manual_seed(0)
+        tr = Trainer(e2e.build_model(16, 2), global_batch=64, nodes=1, iters_per_epoch=10)
+        losses.append(tr.train_step(x, src.labels(64), 0)[0])
+    assert np.isfinite(losses[0]) and losses[0] == losses[1]
