@@ -286,6 +286,45 @@ def encode_taf_dat(dat, shape, state, t_start, window_us=10000, n_windows=8, vol
     return u8, view
 
 
+def encode_taf_label(dat, shape, state, start_time, window_us, bins, volume_bins=8, flip_k=True, xmap=None, ymap=None,
+                     check=True, fast="auto"):
+    """One annotation timestamp of the TAF harness (generate_taf.py:197-235): the time-sorted records ``dat`` of
+    ``[start_time, start_time + bins * window_us]`` (``dat_io.taf_label_slices`` says which) through ``bins`` windows;
+    ``state`` is updated in place, the newest-first uint8 volume (K, 2, H, W) is returned.
+
+    ``bins`` is unbounded in the reference (the first label of a file spans everything before it); one launch takes at
+    most 64 windows, so longer labels run in groups of 64 with the FIFO state carried -- an event on a group boundary
+    belongs to the later window, as in the reference's ``z`` column (:197-203).  ``bins == 0`` (a label that rounds onto
+    the previous one, :181) encodes nothing and returns the transform of the state as it stands.
+    """
+    H, W = int(shape[0]), int(shape[1])
+    K = int(volume_bins)
+    lib = _lib.load()
+    max_w = 64
+    n = dat.numel() * dat.element_size() // 8
+    if bins <= 0:
+        vol = leaky_transform(state.permute(3, 2, 0, 1).contiguous())  # (K, 2, H, W), :226-227
+        u8 = quantize_u8(vol)
+        return torch.flip(u8, dims=[0]).contiguous() if flip_k else u8
+    cuts = [0]
+    if bins > max_w and n:
+        t = dat.contiguous().view(torch.int32).reshape(-1, 2)[:, 0].to(torch.int64) & 0xFFFFFFFF
+        bounds = torch.tensor([start_time + g * max_w * window_us for g in range(1, (bins + max_w - 1) // max_w)],
+                              dtype=torch.int64, device=t.device)
+        cuts += [int(c) for c in torch.searchsorted(t, bounds, right=False).tolist()]
+    elif bins > max_w:
+        cuts += [0] * ((bins + max_w - 1) // max_w - 1)
+    cuts.append(n)
+    rows = dat.contiguous().view(torch.uint8).reshape(-1, 8)
+    u8 = None
+    for g in range(len(cuts) - 1):
+        nw = min(max_w, bins - g * max_w)
+        last = g == len(cuts) - 2
+        u8, _ = encode_taf_dat(rows[cuts[g]:cuts[g + 1]], (H, W), state, start_time + g * max_w * window_us, window_us, nw, K,
+                               want_view=False, want_u8=last, flip_k=flip_k, xmap=xmap, ymap=ymap, check=check, fast=fast)
+    return u8
+
+
 def encode_ev_dat(dat, shape, t_end, window_us, volume_bins=5, want_f32=True, want_u8=False, xmap=None, ymap=None,
                   check=True):
     """generate_eventvolume.py:139-157 on device -> (f32 (2*bins, H, W) or None, u8 or None)."""
