@@ -79,3 +79,115 @@ def job_throughput(units_this_rank, seconds_this_rank):
     """Whole-job rate: units all ranks processed / the slowest rank's time."""
     total = sum_over_ranks([units_this_rank])[0]
     return total / max_over_ranks([seconds_this_rank])[0]
+
+
+# ---- DistributedDataParallel wiring of the train step (core/exp.py:391) -------------------------------------------
+def ddp_kwargs(bucket_cap_mb=None):
+    """Keyword arguments for ``DistributedDataParallel(model, device_ids=[local_rank], broadcast_buffers=False, ...)``.
+
+    * ``gradient_as_bucket_view``: gradients live inside the all-reduce buckets (no copy in, no copy out);
+    * ``static_graph``: the autograd graph is the same every step (every parameter gets a gradient), so the buckets are
+      rebuilt once in the order the gradients become ready and the reducer skips its unused-parameter search;
+    * ``bucket_cap_mb``: the 57.5 MB of gradients travel in buckets of this size (default 25 -> 3 collectives per step,
+      each large enough to run at link bandwidth over xGMI, with the head gradients -- ready first -- already in flight
+      while the backbone's backward runs).  ``FRLW_DDP_BUCKET_MB`` overrides (host-side launch configuration).
+    """
+    cap = bucket_cap_mb if bucket_cap_mb is not None else int(os.environ.get("FRLW_DDP_BUCKET_MB", "25"))
+    return {"gradient_as_bucket_view": True, "static_graph": True, "bucket_cap_mb": cap}
+
+
+def reduce_scatter_allgather_hook(group, bucket):
+    """DDP communication hook: average a gradient bucket with a reduce-scatter followed by an all-gather instead of one
+    all-reduce.  On the fully connected xGMI mesh of an 8-GPU MI355X node each phase sends 1/world of the bucket to every
+    peer over its own link (7 links busy), where a ring all-reduce pushes 2 * (world - 1) / world of the bucket through
+    one link per direction.  Opt in with ``model.register_comm_hook(None, ...)`` or
+    ``FRLW_DDP_HOOK=rs_ag`` (``install_comm_hook``).  Result = DDP's default (sum / world), bit for bit on the same
+    reduction order; tests/test_dist_cpu.py checks it against the default hook on gloo."""
+    group = group if group is not None else dist.group.WORLD
+    world = dist.get_world_size(group)
+    buf = bucket.buffer()
+    n = buf.numel()
+    per = (n + world - 1) // world
+    if per * world != n:
+        padded = torch.zeros(per * world, dtype=buf.dtype, device=buf.device)
+        padded[:n].copy_(buf)
+    else:
+        padded = buf
+    shard = torch.empty(per, dtype=buf.dtype, device=buf.device)
+    if dist.get_backend(group) == "gloo":  # gloo has no reduce_scatter_tensor: same data flow with its primitives
+        dist.all_reduce(padded, group=group)
+        shard.copy_(padded[dist.get_rank(group) * per:(dist.get_rank(group) + 1) * per])
+        fut = torch.futures.Future()
+        fut.set_result(shard)
+    else:
+        fut = dist.reduce_scatter_tensor(shard, padded, group=group, async_op=True).get_future()
+
+    def gather(f):
+        shard.div_(world)
+        if dist.get_backend(group) == "gloo":
+            parts = [torch.empty_like(shard) for _ in range(world)]
+            dist.all_gather(parts, shard, group=group)
+            padded.copy_(torch.cat(parts))
+        else:
+            dist.all_gather_into_tensor(padded, shard, group=group, async_op=True).get_future().wait()
+        if padded is not buf:
+            buf.copy_(padded[:n])
+        return buf
+
+    return fut.then(gather)
+
+
+class TimedAllreduce:
+    """DDP communication hook that is the default all-reduce (sum / world) plus device-side timing of every bucket:
+    ``.summary()`` -> bucket sizes and the mean time a bucket's collective took.  How much of that time is EXPOSED (not
+    hidden behind the rest of the backward) is measured by the caller as step time with DDP minus step time inside
+    ``model.no_sync()`` (bench.py reports both)."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.events = []  # (bytes, start event, end event)
+
+    def __call__(self, state, bucket):
+        group = self.group if self.group is not None else dist.group.WORLD
+        world = dist.get_world_size(group)
+        buf = bucket.buffer()
+        cuda = buf.is_cuda
+        if cuda:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        fut = dist.all_reduce(buf, group=group, async_op=True).get_future()
+
+        def done(f):
+            buf.div_(world)
+            if cuda:
+                e1.record()
+                self.events.append((buf.numel() * buf.element_size(), e0, e1))
+            return buf
+
+        return fut.then(done)
+
+    def summary(self, reset=True):
+        if not self.events:
+            return {"buckets": 0}
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        sizes = sorted({b for b, _, _ in self.events}, reverse=True)
+        ms = [a.elapsed_time(b) for _, a, b in self.events]
+        out = {"buckets": len(self.events), "bucket_bytes": sizes, "mean_bucket_ms": sum(ms) / len(ms), "total_ms": sum(ms)}
+        if reset:
+            self.events = []
+        return out
+
+
+def install_comm_hook(ddp_model, kind=None):
+    """``kind``: None / "default" (DDP's all-reduce), "rs_ag" (reduce-scatter + all-gather), "timed" (default + timing;
+    returns the TimedAllreduce object).  ``FRLW_DDP_HOOK`` supplies the default."""
+    kind = kind or os.environ.get("FRLW_DDP_HOOK", "default")
+    if kind == "rs_ag":
+        ddp_model.register_comm_hook(None, reduce_scatter_allgather_hook)
+        return None
+    if kind == "timed":
+        hook = TimedAllreduce()
+        ddp_model.register_comm_hook(None, hook)
+        return hook
+    return None

@@ -60,13 +60,17 @@ class Trainer:
     """One rank of the reference's training loop around an already built ``model``."""
 
     def __init__(self, model, global_batch=64, nodes=1, iters_per_epoch=100, max_epoch=50, warmup_epochs=5,
-                 local_rank=None, ddp=False):
+                 local_rank=None, ddp=False, comm_hook=None):
         self.lr0, self.per_gpu_batch = init_lr(global_batch, nodes)
         self.model = model
+        self.comm_hook = None
         if ddp:
             from torch.nn.parallel import DistributedDataParallel
             ids = [local_rank] if (local_rank is not None and next(model.parameters()).is_cuda) else None
-            self.model = DistributedDataParallel(model, device_ids=ids, broadcast_buffers=False)  # core/exp.py:391
+            from .dist import ddp_kwargs, install_comm_hook
+            self.model = DistributedDataParallel(model, device_ids=ids, broadcast_buffers=False,  # core/exp.py:391
+                                                 **ddp_kwargs())
+            self.comm_hook = install_comm_hook(self.model, comm_hook)
         params = filter(lambda p: p.requires_grad, self.model.parameters())
         self.optimizer = torch.optim.Adam(params, lr=0.0 if warmup_epochs > 0 else self.lr0)  # core/exp.py:126-128
         self.scheduler = LRScheduler("yoloxwarmcos", self.lr0, iters_per_epoch, max_epoch, warmup_epochs=warmup_epochs,

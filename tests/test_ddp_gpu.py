@@ -1,5 +1,6 @@
-"""Train step under DistributedDataParallel with the native BaseConv kernels: two ranks share the one GPU of the
-test box (gloo rendezvous on 127.0.0.1; the driver's multi-GPU runs use RCCL, same code path above the backend).
+"""Train step under DistributedDataParallel with the native BaseConv kernels: two ranks, one GPU each over RCCL when
+the box has two GPUs, otherwise both on the one GPU of the test box over gloo (same code path above the backend).
+Every rank is a freshly spawned child process (nothing re-execs a process that has touched the GPU).
 Checks that the custom autograd Function fires DDP's gradient hooks: after one backward both ranks hold the same
 gradients = the mean of the per-rank gradients, and those equal a single-process run of the two half batches."""
 import os
@@ -40,13 +41,17 @@ def _build():
 
 
 def _worker(rank, world, port, out_dir):
-    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
-                      MASTER_PORT=str(port), FRLW_DIST_BACKEND="gloo")
+    two_gpus = torch.cuda.device_count() >= world  # device_count() does not initialise the GPU
+    dev = rank if two_gpus else 0
+    backend = "nccl" if two_gpus else "gloo"
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(dev), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), FRLW_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
     from frlw_evd_amd import dist as fd
     from torch.nn.parallel import DistributedDataParallel
-    fd.init_from_env("gloo")
-    torch.cuda.set_device(0)
-    ddp = DistributedDataParallel(_build(), device_ids=[0], broadcast_buffers=False)  # core/exp.py:391
+    fd.init_from_env(backend)
+    torch.cuda.set_device(dev)
+    ddp = DistributedDataParallel(_build(), device_ids=[dev], broadcast_buffers=False, **fd.ddp_kwargs())  # core/exp.py:391
+    fd.install_comm_hook(ddp, os.environ.get("FRLW_TEST_HOOK", "default"))
     x, lab = _inputs(rank)
     loss = ddp(x.cuda(), lab.cuda(), None, None)
     loss.backward()

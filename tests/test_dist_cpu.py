@@ -56,9 +56,9 @@ def test_single_process_helpers():
     assert fd.job_throughput(100, 2.0) == 50.0
 
 
-def _ddp_worker(rank, world, port, out_dir):
+def _ddp_worker(rank, world, port, out_dir, hook="default"):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
-                      MASTER_PORT=str(port))
+                      MASTER_PORT=str(port), FRLW_DDP_HOOK=hook)
     torch.set_num_threads(3)
     fd.init_from_env(backend="gloo")
     from frlw_evd_amd.trainer import Trainer
@@ -69,13 +69,15 @@ def _ddp_worker(rank, world, port, out_dir):
     m.load_state_dict(recipe_state_dict(m, seed=1004 + rank))  # different init: DDP broadcasts rank 0's weights
     tr = Trainer(m, global_batch=4, nodes=world, iters_per_epoch=10, ddp=True)   # per-GPU batch = 4 / 2
     assert tr.per_gpu_batch == 2
+    assert tr.model.gradient_as_bucket_view and tr.model.static_graph  # dist.ddp_kwargs
     x, lab = detector_input(1005, 4, H=128, W=160), train_labels()
     lab[..., 1:] *= 0.5  # boxes for the 128 x 160 input
     lo, hi = fd.shard_range(4, rank, world)
     losses = [tr.train_step(x[lo:hi], lab[lo:hi], i)[0] for i in range(2)]
     w = m.head.cls_preds[0].bias.detach().double()
     rm = m.backbone.stem.conv.bn.running_mean.detach().double()
-    np.save(os.path.join(out_dir, f"d{rank}.npy"), np.array(losses + [float(w.sum()), float(w.abs().sum()), float(rm.sum())]))
+    np.save(os.path.join(out_dir, f"d{rank}_{hook}.npy"),
+            np.array(losses + [float(w.sum()), float(w.abs().sum()), float(rm.sum())]))
     torch.distributed.destroy_process_group()
 
 
@@ -86,8 +88,13 @@ def test_ddp_train_step_two_ranks(tmp_path):
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     world = 2
     mp.spawn(_ddp_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
-    d0, d1 = (np.load(tmp_path / f"d{i}.npy") for i in range(world))
+    d0, d1 = (np.load(tmp_path / f"d{i}_default.npy") for i in range(world))
     assert np.all(np.isfinite(d0)) and np.all(np.isfinite(d1))
     assert d0[2] == d1[2] and d0[3] == d1[3]      # parameters identical after two steps
     assert d0[4] != d1[4]                         # running_mean differs: each rank saw its own shard
     assert d0[0] != d1[0]                         # per-rank losses differ (different images)
+    # the reduce-scatter + all-gather communication hook gives the same trajectory as DDP's all-reduce
+    mp.spawn(_ddp_worker, args=(world, _free_port(), str(tmp_path), "rs_ag"), nprocs=world, join=True)
+    h0, h1 = (np.load(tmp_path / f"d{i}_rs_ag.npy") for i in range(world))
+    assert h0[2] == h1[2] and h0[3] == h1[3]
+    assert np.allclose(h0, d0, rtol=1e-6, atol=0) and np.allclose(h1, d1, rtol=1e-6, atol=0)

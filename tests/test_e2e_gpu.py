@@ -70,3 +70,35 @@ def test_train_batch64_is_finite_and_deterministic():
         tr = Trainer(e2e.build_model(16, 2), global_batch=64, nodes=1, iters_per_epoch=10)
         losses.append(tr.train_step(x, src.labels(64), 0)[0])
     assert np.isfinite(losses[0]) and losses[0] == losses[1]
+
+
+def test_entry_points_train_then_test(tmp_path):
+    """``train.py`` and ``test.py`` as the README launches them (one process, env:// rendezvous), on synthetic streams:
+    one epoch (train batches, last_epoch checkpoint, validation through the gfx950 engine -> best_epoch), then the
+    evaluation entry point loads that checkpoint and records summarise.npz."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, FRLW_MAX_EPOCHS="1", FRLW_SYNTHETIC_BATCHES="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    log = str(tmp_path) + "/"
+    r = subprocess.run([sys.executable, os.path.join(root, "train.py"), "--dataset", "gen1", "--batch_size", "4",
+                        "--augmentation", "True", "--exp_name", "E", "--exp_type", "yolox", "--event_volume_bins", "8",
+                        "--nodes", "1", "--log_path", log], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    ck = os.path.join(log, "E", "checkpoints")
+    assert sorted(os.listdir(ck)) == ["best_epoch.pth", "best_epoch_backbone.pth", "best_epoch_neck.pth", "last_epoch.pth",
+                                      "last_epoch_backbone.pth", "last_epoch_neck.pth"]
+    r = subprocess.run([sys.executable, os.path.join(root, "test.py"), "--dataset", "gen1", "--batch_size", "2", "--record", "True",
+                        "--resume_exp", "E", "--exp_type", "yolox", "--event_volume_bins", "8", "--nodes", "1",
+                        "--log_path", log], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "'images':" in r.stdout and os.path.exists(os.path.join(log, "E", "summarise.npz"))

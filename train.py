@@ -1,67 +1,83 @@
 #!/usr/bin/env python3
-"""Entry point with the reference's flags (train.py:9-23) for the ``yolox`` experiment on SYNTHETIC streams:
-TAF encode on the GPU -> YOLOX train step under DistributedDataParallel (RCCL).
+"""Training entry point with the reference's command line (train.py:9-71): same flags, same
+``init_process_group('nccl', 'env://')`` (RCCL on ROCm), same ``Setting_train_val`` -> ``yolox(settings).train()`` /
+``yoloxtafBFM(settings).train()`` dispatch, one process per GPU, ``--nodes`` = number of GPUs dividing the global batch.
 
-    python -m torch.distributed.run --nproc-per-node G train.py --exp_type yolox --nodes G --batch_size 64
+    python -m torch.distributed.run --nproc-per-node G train.py --dataset gen1 --batch_size 64 --exp_name E \\
+        --exp_type yolox --event_volume_bins 8 --nodes G
 
-Datasets, checkpoints, tensorboard and the evaluator of the reference are out of scope;
-this harness exists to run BASELINE.json's config 5 and to keep the launch contract (``--local_rank`` /
-``--local-rank`` / LOCAL_RANK, ``init_process_group('nccl', 'env://')``, ``--nodes`` = GPU count dividing the
-global batch, settings.py:41).
+Without ``--data_path`` / ``--bbox_path`` the run is SYNTHETIC: event streams are generated and TAF-encoded on the GPU
+every step (BASELINE.json config 5); with them it stops with a note -- reading the pre-encoded dataset files is outside
+this build's hot path.  ``--local_rank`` / ``--local-rank`` / ``LOCAL_RANK`` are all accepted
+(torch.distributed.launch vs torchrun).  ``FRLW_MAX_EPOCHS`` / ``FRLW_SYNTHETIC_BATCHES`` shorten synthetic runs.
 """
 import argparse
-import json
 import os
 import sys
-import time
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
-def main():
-    p = argparse.ArgumentParser(description="Train network (synthetic harness).")
-    p.add_argument("--local_rank", "--local-rank", type=int, default=None)
-    p.add_argument("--exp_name", default="synthetic")
-    p.add_argument("--exp_type", default="yolox")
-    p.add_argument("--dataset", default="gen1")
-    p.add_argument("--event_volume_bins", type=float, default=8)
-    p.add_argument("--batch_size", type=int, default=64)  # GLOBAL batch, divided by --nodes (settings.py:41)
-    p.add_argument("--nodes", type=int, default=1)        # number of GPUs
-    p.add_argument("--steps", type=int, default=5)
-    args = p.parse_args()
-    if args.exp_type != "yolox" or args.dataset != "gen1":
-        raise SystemExit("only --exp_type yolox on gen1-shaped synthetic streams is on the hot path")
+def build_parser():
+    parser = argparse.ArgumentParser(description="Train network.")
+    parser.add_argument("--local_rank", "--local-rank", type=int, default=None,
+                        help="local rank for DistributedDataParallel")  # no need to set
+    parser.add_argument("--resume_exp")  # name of the experiment to resume
+    parser.add_argument("--exp_name")    # name of a new experiment (an existing one of that name is overwritten)
+    parser.add_argument("--exp_type", default="basic")
+    parser.add_argument("--log_path", default="log/")  # logs and checkpoints
+    parser.add_argument("--dataset", default="gen1")   # gen1 / gen4
+    parser.add_argument("--bbox_path")  # annotations ("train, val, test" level directory)
+    parser.add_argument("--data_path")  # pre-encoded data
+    parser.add_argument("--event_volume_bins", type=float, default=5)  # x 2 (polarity) = input channels
+    parser.add_argument("--batch_size", type=int, default=30)  # GLOBAL batch
+    parser.add_argument("--num_cpu_workers", type=int, default=-1)
+    parser.add_argument("--nodes", type=int, default=1)  # number of GPUs
+    parser.add_argument("--augmentation", type=bool, default=True)  # (any non-empty string is True, like the reference)
+    return parser
 
+
+def init_distributed(args):
+    """train.py:28-31: seed, device, process group over env:// -- a plain ``python train.py`` becomes a 1-rank job."""
     import torch
-    from frlw_evd_amd import dist as fd
-    from frlw_evd_amd import e2e
-    from frlw_evd_amd.trainer import Trainer
-
+    if args.local_rank is None:
+        args.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
     torch.manual_seed(0)
-    rank, world, local_rank = fd.init_from_env("nccl", args.local_rank)
-    torch.cuda.set_device(local_rank)
+    backend = os.environ.get("FRLW_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo")
+    if torch.cuda.is_available():
+        torch.cuda.set_device(args.local_rank)
+    if not torch.distributed.is_initialized():
+        torch.distributed.init_process_group(backend=backend, init_method="env://")
+    return torch.distributed.get_rank(), torch.distributed.get_world_size()
+
+
+def pick_experiment(exp_type):
+    from frlw_evd_amd import exp
+    if exp_type in exp.EXPERIMENTS:
+        return exp.EXPERIMENTS[exp_type]
+    if exp_type in exp.OTHER_RECIPES:
+        raise SystemExit(f"--exp_type {exp_type}: the AED / YOLOv3 detectors are outside this build's scope "
+                         f"(SURVEY.md section 2 #15, #16); available: {', '.join(exp.EXPERIMENTS)}")
+    raise SystemExit(f"unknown --exp_type {exp_type}")
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    cls = pick_experiment(args.exp_type)
+    rank, world = init_distributed(args)
     assert world == args.nodes, "--nodes must equal the number of launched processes (settings.py:41)"
-    net = e2e.build_model(int(2 * args.event_volume_bins), 2)
-    tr = Trainer(net, global_batch=args.batch_size, nodes=args.nodes, iters_per_epoch=100, local_rank=local_rank,
-                 ddp=world > 1)
-    B = tr.per_gpu_batch
-    src = e2e.SyntheticTafSource(B, seed=1005 + 1000 * rank)
-    labels = src.labels(B)
-    idx = list(range(B))
-    for _ in range(2):  # warm-up (allocator, MIOpen find)
-        tr.train_step(src.encode_batch(idx), labels, 0)
-    fd.barrier_sync()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        loss, lr = tr.train_step(src.encode_batch(idx), labels, i + 1)
-    fd.barrier_sync()
-    dt, = fd.max_over_ranks([time.perf_counter() - t0])
-    if rank == 0:
-        print(json.dumps({"metric": "E2E TAF encode + YOLOX train step", "value": round(world * B * args.steps / dt, 1),
-                          "unit": "frames/s", "n_gpus": world, "global_batch": B * world, "loss": loss, "lr": lr,
-                          "backward": "csrc/train_ops.hip (fp32 MFMA dgrad / wgrad, BatchNorm + SiLU backward), SimOTA csrc/simota.hip"}))
-    if world > 1:
+    from frlw_evd_amd.settings import Setting_train_val
+    settings = Setting_train_val(args)
+    trainer = cls(settings)
+    trainer.train()
+    import torch
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
+    return trainer
 
 
 if __name__ == "__main__":
