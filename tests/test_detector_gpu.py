@@ -269,3 +269,35 @@ def test_more_than_2048_candidates_per_image(gpu):
         want = m.head.decode_outputs(raw)
     assert len(got) == 1 and got[0].shape == want[0].shape and got[0].shape[0] > 0
     assert torch.allclose(got[0], want[0], rtol=1e-5, atol=1e-4)
+
+
+def test_engine_follows_the_weights(gpu):
+    """The reference alternates train and validation epochs on ONE model (core/exp.py:237-258): the engine folds
+    BatchNorm and copies weights at build time, so it has to be rebuilt after an optimizer step, a load_state_dict and a
+    BatchNorm statistics update -- eval, one train step, eval again must track the plain-PyTorch forward each time."""
+    import copy
+    from frlw_evd_amd.trainer import Trainer
+    m = build_yolox(16, 2)
+    m.load_state_dict(recipe_state_dict(m, seed=1004))
+    m.to(gpu).eval()
+    x = detector_input(7, 2, 16).to(gpu)
+    with torch.no_grad():
+        e0 = m.engine()
+        raw0 = e0.raw_outputs(x[..., 0, 0]).clone()
+        assert m.engine() is e0  # nothing changed: same engine
+        assert rel_err(raw0, m.reference_outputs(x[..., 0])) <= TOL
+    lab = torch.zeros(2, 80, 5, dtype=torch.float64, device=gpu)
+    lab[:, 0] = torch.tensor([1, 100.0, 120.0, 40.0, 60.0])
+    Trainer(m, global_batch=2, nodes=1, iters_per_epoch=10, warmup_epochs=0).train_step(x, lab, 0)
+    m.eval()
+    with torch.no_grad():
+        e1 = m.engine()
+        assert e1 is not e0
+        raw1 = e1.raw_outputs(x[..., 0, 0]).clone()
+        ref1 = m.reference_outputs(x[..., 0])
+    assert rel_err(raw1, ref1) <= TOL
+    assert rel_err(raw1, raw0) > 10 * TOL, "the train step must have moved the outputs"
+    m.load_state_dict(recipe_state_dict(m, seed=1004))  # back to the first weights
+    with torch.no_grad():
+        assert rel_err(m.engine().raw_outputs(x[..., 0, 0]), raw0) <= 1e-6
+    copy.deepcopy(m)  # the engine's ctypes handle must not break copying / pickling
