@@ -35,10 +35,21 @@ _ERR_TEXT = {
 }
 
 
+class FrlwTuning(C.Structure):
+    """frlw_tuning_t: per-call overrides of the launch heuristics, every field < 0 = the library's choice."""
+    _fields_ = [("tile_width_log2", C.c_int32), ("batches_per_wave", C.c_int32), ("hot_tile_records", C.c_int32),
+                ("staged_scatter", C.c_int32), ("quarter_below", C.c_int32), ("no_value_table", C.c_int32)]
+
+    def __init__(self, **kw):
+        super().__init__(*[int(kw.pop(name, -1)) for name, _ in self._fields_])
+        if kw:
+            raise TypeError(f"unknown tuning fields {sorted(kw)}")
+
+
 class FrlwEvents(C.Structure):
     _fields_ = [("data", C.c_void_p), ("n", C.c_int64), ("layout", C.c_int32),
                 ("row_stride", C.c_int32), ("xmap", C.c_void_p), ("ymap", C.c_void_p),
-                ("map_w", C.c_int32), ("map_h", C.c_int32)]
+                ("map_w", C.c_int32), ("map_h", C.c_int32), ("tuning", C.POINTER(FrlwTuning))]
 
 
 # every symbol include/frlw_evd.h declares: name -> (restype, argtypes)

@@ -8,6 +8,16 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Launch heuristics are compile-time constants in the product library: it reads no environment and prints nothing.  A
+// developer build (-DFRLW_DEV_BUILD) lets the environment override them for A/B runs and logs HIP errors.
+#ifdef FRLW_DEV_BUILD
+inline long long dev_knob(const char *name, long long dflt) { const char *e = getenv(name); return e ? atoll(e) : dflt; }
+#define FRLW_DEV_LOG(...) fprintf(stderr, __VA_ARGS__)
+#else
+constexpr long long dev_knob(const char *, long long dflt) { return dflt; }
+#define FRLW_DEV_LOG(...) do { } while (0)
+#endif
+
 enum : int { ACT_NONE = 0, ACT_SILU = 1, ACT_SIGMOID = 2 };
 
 struct ConvArgs {
@@ -231,10 +241,10 @@ inline void launch_conv(ConvArgs &c, float *scratch, long long scratch_floats, h
     c.splits = 1;
     c.partial = nullptr;
     const long long big = (long long)((c.M + 127) / 128) * ((c.Npad + 127) / 128);
-    static const long long split_below = [] { const char *e = getenv("FRLW_CONV_SPLIT_BELOW"); return e ? atoll(e) : 700ll; }();
-    static const long long split_target = [] { const char *e = getenv("FRLW_CONV_SPLIT_TARGET"); return e ? atoll(e) : 1024ll; }();
-    static const long long big_min = [] { const char *e = getenv("FRLW_CONV_BIG_MIN"); return e ? atoll(e) : 1000000ll; }();
-    static const long long wide_min = [] { const char *e = getenv("FRLW_CONV_WIDE_MIN"); return e ? atoll(e) : 1200ll; }();
+    static const long long split_below = dev_knob("FRLW_CONV_SPLIT_BELOW", 700ll);
+    static const long long split_target = dev_knob("FRLW_CONV_SPLIT_TARGET", 1024ll);
+    static const long long big_min = dev_knob("FRLW_CONV_BIG_MIN", 1000000ll);
+    static const long long wide_min = dev_knob("FRLW_CONV_WIDE_MIN", 1200ll);
     if (c.Npad <= 32) { // small N (prediction convs, the stem's data gradient)
         hipLaunchKernelGGL((k_conv_mfma<128, 32, 4, 1, 16>), dim3((c.M + 127) / 128, 1), dim3(256), 0, s, c);
     } else if (big >= big_min && c.Npad >= 128) {

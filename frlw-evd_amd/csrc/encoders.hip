@@ -430,7 +430,7 @@ __global__ __launch_bounds__(NT) void k_ev_tile(const uint2 *rec, const uint32_t
 // ---- TAF -------------------------------------------------------------------------------------
 struct TafParams {
     int H, W, twl, tiles_x, K, n_windows, flip;
-    const WsHeader *hdr;
+    WsHeader *hdr;
     const uint32_t *leaky_thr; // level thresholds of uint8(leaky_transform(.)), built by k_hist
     float *state;    // (H, W, 2, K)
     float *view_f32; // (2K, H, W) or NULL
@@ -560,7 +560,7 @@ __device__ __forceinline__ void taf_tile_body(const uint2 *rec, const uint32_t *
         // ---- general path (stream not time-sorted): nothing has been written yet.  One pass per window
         // over the whole list, slices in list order, records selected by window.
         __syncthreads();
-        if (t == 0) atomicAdd(const_cast<uint32_t *>(&q.hdr->pad), 1u); // diagnostic: tiles on the general path
+        if (t == 0) atomicAdd(&q.hdr->pad, 1u); // diagnostic: tiles on the general path
         load_state();
         for (int w = 0; w < q.n_windows; ++w) {
             for (uint32_t s0 = beg; s0 < end; s0 += SLICE) {
@@ -651,8 +651,7 @@ __global__ __launch_bounds__(NT) void k_taf_tile(const uint2 *rec, const uint32_
 // tiles as quarters: four times the wavefronts, one cell per thread, each quarter streaming its tile's records.
 #define LAUNCH_TILE_Q(KERNEL, PLAN, STREAM, ...)                                                                   \
     do {                                                                                                           \
-        static const int small_ = frlw::env_int("FRLW_QUARTER_BELOW", 1024);                                        \
-        if ((PLAN).n_tiles * ((4 << (PLAN).twl) / kWave) <= small_)                                                \
+        if ((PLAN).n_tiles * ((4 << (PLAN).twl) / kWave) <= (PLAN).quarter_below)                                   \
             LAUNCH_TILE_GRID(KERNEL, (PLAN).n_tiles * 4, PLAN, STREAM, __VA_ARGS__, -(PLAN).n_tiles);              \
         else                                                                                                       \
             LAUNCH_TILE_GRID(KERNEL, (PLAN).n_tiles + kMaxHot * 4, PLAN, STREAM, __VA_ARGS__, (PLAN).n_tiles);     \
@@ -679,7 +678,7 @@ const char *frlw_version(void) { return "frlw_evd 0.4.0 gfx950"; }
 size_t frlw_encoder_workspace_bytes(int64_t n_events, int H, int W)
 {
     Plan p;
-    if (!make_plan(n_events, H, W, p)) return 0;
+    if (!make_plan(n_events, H, W, nullptr, p)) return 0;
     return p.bytes;
 }
 

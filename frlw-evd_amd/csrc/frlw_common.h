@@ -12,7 +12,7 @@ namespace frlw {
 
 constexpr int kWave = 64;
 // A tile is (1 << twl) pixels wide and 8 rows high; twl = 8 for frames wider than 512 px, else 6
-// (measured best on MI355X; FRLW_TWL overrides for experiments).
+// (measured best on MI355X; frlw_tuning_t::tile_width_log2 overrides for experiments).
 // One tile = one workgroup of the tile kernels = NT = 4 << twl threads owning 4 cells each
 // (cell = (pixel, polarity)).  A tile row is a whole number of wavefronts of consecutive cells,
 // so the (H, W, 2, K) state and the (C, H, W) outputs are read / written in full lines.
@@ -282,6 +282,9 @@ struct Plan {
     long long chunk;  // events per partition workgroup = 1024 * bpw
     int units, slabs; // partition workgroups, slabs of 32
     unsigned hot_thr; // a tile with more records than this is shared by several workgroups (EV / TAF)
+    int staged;       // < 0: by size
+    int quarter_below;
+    int no_lut;
     size_t off_counts, off_slabtot, off_base, off_errs, off_tlut, off_leaky, off_records, bytes;
 };
 
@@ -293,8 +296,7 @@ struct Partitioned {
     Plan plan;
 };
 
-bool make_plan(long long n, int H, int W, Plan &p);
-int env_int(const char *name, int dflt);
+bool make_plan(long long n, int H, int W, const frlw_tuning_t *tuning, Plan &p);
 int hip_fail(hipError_t e, const char *what, int line);
 
 // hist -> scans -> stable scatter: tile-major 8-byte records {window << (twl + 4) | cell, f32 bits}.

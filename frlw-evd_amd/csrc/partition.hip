@@ -21,16 +21,13 @@
 
 namespace frlw {
 
-int env_int(const char *name, int dflt)
-{
-    const char *s = getenv(name);
-    return s && *s ? atoi(s) : dflt;
-}
-
 int hip_fail(hipError_t e, const char *what, int line)
 {
-    if (env_int("FRLW_DEBUG", 0))
-        fprintf(stderr, "frlw_evd: %s failed at line %d: %s\n", what, line, hipGetErrorString(e));
+#ifdef FRLW_DEV_BUILD // developer build only: the product library prints nothing and reads no environment
+    fprintf(stderr, "frlw_evd: %s failed at line %d: %s\n", what, line, hipGetErrorString(e));
+#else
+    (void)e; (void)what; (void)line;
+#endif
     return FRLW_ERR_HIP;
 }
 
@@ -406,9 +403,8 @@ void launch_partition_m(const Decode &d, const Plan &p, uint32_t *counts, uint32
                               (size_t)kStageCap * 2 + 16;
     // staged write-out pays off for long streams with long chunks (10 M events: -11 us); on short ones the extra
     // barriers cost more than the write traffic saves (GEN1-shaped 1 M events: 66 -> 74 us).
-    // FRLW_SCATTER_STAGED=0/1 forces it.
-    static const int force = env_int("FRLW_SCATTER_STAGED", -1);
-    const bool staged = (force >= 0 ? force != 0 : (p.bpw >= 4 && d.n >= 3000000)) && lds_staged <= 150 * 1024;
+    // frlw_tuning_t::staged_scatter forces it.
+    const bool staged = (p.staged >= 0 ? p.staged != 0 : (p.bpw >= 4 && d.n >= 3000000)) && lds_staged <= 150 * 1024;
     hipLaunchKernelGGL((k_hist<LAYOUT, KIND, HAS_MAP>), dim3(p.units), dim3(kPartThreads), lds_hist, s, d, p.bpw, counts, errs, tlut_w, leaky_w);
     hipLaunchKernelGGL(k_slabscan, dim3((p.n_tiles + kWave - 1) / kWave, p.slabs), dim3(kWave), 0, s, counts,
                        p.units, p.n_tiles, slabtot);
@@ -451,10 +447,11 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 } // namespace
 
-bool make_plan(long long n, int H, int W, Plan &p)
+bool make_plan(long long n, int H, int W, const frlw_tuning_t *tuning, Plan &p)
 {
     if (H <= 0 || W <= 0 || n < 0) return false;
-    p.twl = env_int("FRLW_TWL", W > 512 ? 8 : 6);
+    const auto knob = [&](int32_t frlw_tuning_t::*f, int dflt) { return tuning && tuning->*f >= 0 ? (int)(tuning->*f) : dflt; };
+    p.twl = knob(&frlw_tuning_t::tile_width_log2, W > 512 ? 8 : 6);
     if (p.twl < 6 || p.twl > 8) return false;
     for (;; ++p.twl) { // tall frames (a batch of sequences stacked along y): widen the tiles to stay under kMaxTiles
         const int tw = 1 << p.twl;
@@ -473,7 +470,7 @@ bool make_plan(long long n, int H, int W, Plan &p)
         const long long want = (n + slots * rounds * kPartThreads - 1) / (slots * rounds * kPartThreads);
         if (want <= kMaxBpw) { bpw = (int)(want < 1 ? 1 : want); break; }
     }
-    p.bpw = env_int("FRLW_BPW", bpw);
+    p.bpw = knob(&frlw_tuning_t::batches_per_wave, bpw);
     if (p.bpw < 1 || p.bpw > kMaxBpw) return false;
     p.chunk = (long long)kPartThreads * p.bpw;
     p.units = (int)((n + p.chunk - 1) / p.chunk);
@@ -488,10 +485,13 @@ bool make_plan(long long n, int H, int W, Plan &p)
     p.off_leaky = off;   off = align_up(off + (size_t)kLeakyLevels * 4, 256);
     p.off_records = off; off = align_up(off + (size_t)(n > 0 ? n : 1) * 8, 256);
     p.bytes = off;
-    // more than two slices and more than 4x the mean: worth sharing (FRLW_HOT_THR: tests force the shared path)
+    // more than two slices and more than 4x the mean: worth sharing (frlw_tuning_t::hot_tile_records: tests force it)
     const long long slice2 = 2ll * kSliceMult * (4 << p.twl), mean4 = 4 * (n / p.n_tiles);
     const long long thr = slice2 > mean4 ? slice2 : mean4;
-    p.hot_thr = (unsigned)env_int("FRLW_HOT_THR", thr > 0x7fffffffll ? 0x7fffffff : (int)thr);
+    p.hot_thr = (unsigned)knob(&frlw_tuning_t::hot_tile_records, thr > 0x7fffffffll ? 0x7fffffff : (int)thr);
+    p.staged = knob(&frlw_tuning_t::staged_scatter, -1);
+    p.quarter_below = knob(&frlw_tuning_t::quarter_below, 1024);
+    p.no_lut = knob(&frlw_tuning_t::no_value_table, 0);
     return true;
 }
 
@@ -509,7 +509,7 @@ int partition_events(const frlw_events_t *ev, int H, int W, int kind, long long 
         ((long long)n_windows * win >= (1ll << 32) || win >= (1ll << 31)))
         return FRLW_ERR_UNSUPPORTED;
     Plan p;
-    if (!make_plan(ev->n, H, W, p)) return FRLW_ERR_UNSUPPORTED;
+    if (!make_plan(ev->n, H, W, ev->tuning, p)) return FRLW_ERR_UNSUPPORTED;
     if (ws_bytes < p.bytes) return FRLW_ERR_WORKSPACE;
     char *w8 = (char *)ws;
     WsHeader *hdr = (WsHeader *)w8;
@@ -529,7 +529,7 @@ int partition_events(const frlw_events_t *ev, int H, int W, int kind, long long 
     const unsigned long long magic = (1ull << 32) / (unsigned long long)win;
     d.win_magic = magic > 0xffffffffull ? 0xffffffffu : (uint32_t)magic;
     float *tlut_w = nullptr;
-    if (kind == KIND_TAF && ev->layout == FRLW_LAYOUT_DAT8 && win <= kMaxTlut && !env_int("FRLW_NOLUT", 0)) tlut_w = (float *)(w8 + p.off_tlut);
+    if (kind == KIND_TAF && ev->layout == FRLW_LAYOUT_DAT8 && win <= kMaxTlut && !p.no_lut) tlut_w = (float *)(w8 + p.off_tlut);
     d.tlut = tlut_w;
     uint32_t *leaky_w = kind == KIND_TAF ? (uint32_t *)(w8 + p.off_leaky) : nullptr;
 

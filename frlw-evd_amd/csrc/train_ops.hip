@@ -30,7 +30,7 @@ namespace {
 #include "conv_mfma.h"
 
 #define TRY_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
-        if (getenv("FRLW_DEBUG")) fprintf(stderr, "frlw_evd train_ops: %s -> %s\n", #expr, hipGetErrorString(e_)); \
+        FRLW_DEV_LOG("frlw_evd train_ops: %s -> %s\n", #expr, hipGetErrorString(e_)); \
         return FRLW_ERR_HIP; } } while (0)
 
 // ---- weight layouts -----------------------------------------------------------------------------
@@ -531,7 +531,7 @@ int frlw_conv2d_dgrad(const float *dz, int B, int Ho, int Wo, int Cout, const fl
 // 128 x 128 tiles (half the x gathers and half the dz reads per output) when that still leaves >= 32 output tiles
 static bool wgrad_wide(long long R, int Cout)
 {
-    static const long long min_tiles = [] { const char *e = getenv("FRLW_WGRAD_WIDE_TILES"); return e ? atoll(e) : 32ll; }();
+    static const long long min_tiles = dev_knob("FRLW_WGRAD_WIDE_TILES", 32ll);
     return Cout >= 128 && R >= 128 && ((R + 127) / 128) * ((Cout + 127) / 128) >= min_tiles;
 }
 

@@ -27,6 +27,8 @@ import torch
 from . import _lib
 
 _WORKSPACES = {}
+TUNING = None  # a _lib.FrlwTuning to attach to every encoder call (experiments / tests forcing a path); None = defaults
+TUNING = None  # a _lib.FrlwTuning to attach to every encoder call (experiments / tests forcing a path); None = defaults
 FAST_MIN_EVENTS = 3_000_000  # single streams shorter than this take the general TAF path (encode_taf_dat, fast="auto")
 
 
@@ -57,7 +59,8 @@ def _events_f64(events):
     if events.dtype != torch.float64 or events.dim() != 2 or events.shape[1] < 4:
         raise ValueError("events must be (N, >=4) float64 [x, y, t, p]")
     ev = events.contiguous()
-    return ev, _lib.FrlwEvents(ev.data_ptr(), ev.shape[0], _lib.LAYOUT_XYTP_F64, ev.shape[1], None, None, 0, 0)
+    return ev, _lib.FrlwEvents(ev.data_ptr(), ev.shape[0], _lib.LAYOUT_XYTP_F64, ev.shape[1], None, None, 0, 0,
+                               C.pointer(TUNING) if TUNING is not None else None)
 
 
 def _events_dat(dat, xmap=None, ymap=None):
@@ -76,7 +79,8 @@ def _events_dat(dat, xmap=None, ymap=None):
             if m.dtype not in (torch.int16, torch.uint16) or not m.is_cuda or not m.is_contiguous() or m.dim() != 1:
                 raise ValueError("coordinate maps must be contiguous 1-D int16 / uint16 CUDA tensors")
         mw, mh = xmap.numel(), ymap.numel()
-    return d, _lib.FrlwEvents(d.data_ptr(), nbytes // 8, _lib.LAYOUT_DAT8, 0, _ptr(xmap), _ptr(ymap), mw, mh)
+    return d, _lib.FrlwEvents(d.data_ptr(), nbytes // 8, _lib.LAYOUT_DAT8, 0, _ptr(xmap), _ptr(ymap), mw, mh,
+                              C.pointer(TUNING) if TUNING is not None else None)
 
 
 def _finish(ws, what):

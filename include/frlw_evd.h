@@ -57,6 +57,17 @@ enum {
     FRLW_LAYOUT_DAT8 = 1
 };
 
+/* Optional per-call overrides of the launch heuristics (experiments, and tests that force a rarely taken path).
+ * Every field: < 0 = the library's choice.  There is no process-wide state: the knobs travel with the call. */
+typedef struct frlw_tuning {
+    int32_t tile_width_log2; /* 6..8 */
+    int32_t batches_per_wave; /* 1..8: 64-event batches per wavefront of a partition workgroup */
+    int32_t hot_tile_records; /* a tile with more records than this is shared by several workgroups (EV / TAF) */
+    int32_t staged_scatter;   /* 0 / 1: records leave the partition through an LDS staging area */
+    int32_t quarter_below;    /* frames with at most this many wavefronts run every tile as four quarter workgroups */
+    int32_t no_value_table;   /* 1: TAF DAT8 computes the f64 division per event instead of the per-call table */
+} frlw_tuning_t;
+
 typedef struct frlw_events {
     const void *data;  /* device pointer to the event array */
     int64_t n;         /* number of events */
@@ -69,6 +80,7 @@ typedef struct frlw_events {
     const uint16_t *ymap;
     int32_t map_w;
     int32_t map_h;
+    const frlw_tuning_t *tuning; /* HOST pointer or NULL */
 } frlw_events_t;
 
 #define FRLW_MAX_WINDOWS 64

@@ -181,10 +181,11 @@ def test_taf_unsorted_stream(er, orc):
 
 @pytest.mark.parametrize("thr", [0, 300, 3000])
 def test_hot_tile_sharing_forced(er, orc, monkeypatch, thr):
-    """Skew path: with FRLW_HOT_THR forced low, (up to 32) tiles are shared by several workgroups, each summing
-    only its own 128 cells; more than 32 hot tiles -> the rest stay whole.  Same bits either way, EV and TAF,
-    sorted and shuffled streams."""
-    monkeypatch.setenv("FRLW_HOT_THR", str(thr))
+    """Skew path: with frlw_tuning_t::hot_tile_records forced low, (up to 32) tiles are shared by several workgroups,
+    each summing only its own 128 cells; more than 32 hot tiles -> the rest stay whole.  Same bits either way, EV and
+    TAF (general path), sorted and shuffled streams."""
+    from frlw_evd_amd import _lib
+    monkeypatch.setattr(er, "TUNING", _lib.FrlwTuning(hot_tile_records=thr))
     H, W, K = 100, 300, 8
     ev = synth.synth_events(31 + thr, 300_000, W, H, 80_000, hotspot=True)
     dat = synth.to_dat8(ev)

@@ -7,7 +7,7 @@ depths, sorted and shuffled streams, events outside the window span, forced hot-
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from frlw_evd_amd import synth, event_representation as er
+from frlw_evd_amd import _lib, synth, event_representation as er
 from oracle import oracle as orc
 
 def dev(a): return torch.from_numpy(np.ascontiguousarray(a)).cuda()
@@ -43,8 +43,7 @@ def main():
         span = nw * wus + (wus // 2 if rng.random() < 0.3 else 0)
         t_off = int(rng.integers(0, 3)) * 5000
         desc = f"case {case}: {W}x{H} n={n} K={K} nw={nw} w={wus} {mode} shuffle={shuffle} thr={thr} toff={t_off}"
-        if thr is None: os.environ.pop("FRLW_HOT_THR", None)
-        else: os.environ["FRLW_HOT_THR"] = str(int(thr))
+        er.TUNING = None if thr is None else _lib.FrlwTuning(hot_tile_records=int(thr))
         ev = make_events(rng, n, W, H, max(span, 1), mode)
         ev["t"] = ev["t"] + t_off
         if shuffle and n:
@@ -83,7 +82,7 @@ def main():
         if not ok:
             bad += 1
             print("MISMATCH", desc)
-    os.environ.pop("FRLW_HOT_THR", None)
+    er.TUNING = None
     print(f"{n_cases} cases, {bad} mismatches")
     sys.exit(1 if bad else 0)
 
