@@ -44,8 +44,10 @@ constexpr int kSplitBK = 16; // granularity the split-K heuristics count k-tiles
 
 __device__ __forceinline__ float act_apply(float v, int act)
 {
-    if (act == ACT_SILU) return v / (1.0f + expf(-v));      // x * sigmoid(x)
-    if (act == ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
+    // hardware exponential and reciprocal (~2 ulp): the epilogue runs with no MFMA left to hide it, and the detector's
+    // tolerance is 1e-3 (the exact expf + IEEE division cost 25 instructions per output, this costs 6)
+    if (act == ACT_SILU) return v * __frcp_rn(1.0f + __expf(-v));      // x * sigmoid(x)
+    if (act == ACT_SIGMOID) return __frcp_rn(1.0f + __expf(-v));
     return v;
 }
 
@@ -59,8 +61,12 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
     constexpr int LDA = BM + 4, LDB = BN + 4; // +4 floats: k rows land on different banks for the staging writes
     constexpr int A_F4 = BM * BK / 4 / 256;   // float4 loads per thread for the A tile
     constexpr int B_F4 = (BN * BK / 4 + 255) / 256;
-    __shared__ float As[2][BK][LDA];
-    __shared__ float Bs[2][BK][LDB];
+    constexpr int EPLD = 36;                          // row pitch of the epilogue staging (16-byte aligned rows)
+    constexpr int kTileFloats = 2 * BK * (LDA + LDB);
+    constexpr int kEpiFloats = 4 * 32 * EPLD;         // one 32 x 32 MFMA tile per wavefront
+    __shared__ __attribute__((aligned(16))) float smem[kTileFloats > kEpiFloats ? kTileFloats : kEpiFloats];
+    float (*As)[BK][LDA] = (float (*)[BK][LDA])smem;
+    float (*Bs)[BK][LDB] = (float (*)[BK][LDB])(smem + 2 * BK * LDA);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wr = wv / WCOLS, wc = wv % WCOLS;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
@@ -151,24 +157,56 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
     const int fm = wr * TM * 32 + (lane & 31), fn = wc * TN * 32 + (lane & 31), fk = lane >> 5;
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
+#if !defined(CONV_EXP) || CONV_EXP < 1
         if (kt + 1 < nk) load_tiles(kt0 + kt + 1);
+#endif
+        // all operand fragments of the k-tile are requested up front, into their own registers: the LDS answers in
+        // order, so the first MFMAs start as soon as their fragments are there while the rest is still in flight
+        // (fragment reads issued one k-step at a time leave every wavefront waiting a full LDS round trip per step:
+        // measured 117 -> see DESIGN.md section 4)
+        float fa[BK / 2][TM], fb[BK / 2][TN];
+#if defined(CONV_EXP) && CONV_EXP == 4
+        if (kt == 0)
+#endif
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
-            float fa[TM], fb[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = As[buf][kk + fk][fm + 32 * i];
+            for (int i = 0; i < TM; ++i) fa[kk / 2][i] = As[buf][kk + fk][fm + 32 * i];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = Bs[buf][kk + fk][fn + 32 * j];
+            for (int j = 0; j < TN; ++j) fb[kk / 2][j] = Bs[buf][kk + fk][fn + 32 * j];
+        }
+#if defined(CONV_EXP) && CONV_EXP >= 5
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk / 2][i], fb[kk / 2][j], acc[i][j], 0, 0, 0);
         }
+#if !defined(CONV_EXP) || CONV_EXP < 2
         if (kt + 1 < nk) store_tiles(buf ^ 1);
+#endif
+#if !defined(CONV_EXP) || CONV_EXP < 3
         __syncthreads();
+#endif
     }
 
+#if defined(CONV_EXP) && CONV_EXP == 6
+    {   // experiment: no epilogue at all (a never-taken store keeps the accumulators alive)
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+        if (t == 123.456f) a.y[0] = t;
+        return;
+    }
+#endif
     // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     if (a.splits > 1) { // raw partial sums; k_splitk_reduce applies bias / activation / residual
         float *dst = a.partial + (long long)blockIdx.z * a.M * a.Npad;
@@ -186,6 +224,54 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
         return;
     }
     const int howo = a.Ho * a.Wo;
+    if (((a.Cout | a.y_cs | a.y_co | a.r_cs | a.r_co) & 3) == 0 && (a.y_bs & 3) == 0 && (a.r_bs & 3) == 0 && a.y_rp == 0) {
+        // Vector epilogue: every 32 x 32 accumulator tile goes through a wavefront-private LDS staging area and leaves
+        // as 16-byte rows (4 consecutive channels per lane): 4 stores per lane and tile instead of 16.  The epilogue
+        // runs with no MFMA left to overlap (all workgroups of a layer finish together): it is store-ISSUE bound.
+        float *epw = smem + wv * 32 * EPLD; // the last k-tile's barrier has freed the operand tiles
+        const int er = lane >> 3, ec = (lane & 7) * 4; // this lane's rows er, er + 8, er + 16, er + 24; columns ec..ec+3
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int tm0 = m0 + wr * TM * 32 + 32 * i;
+            const int mfirst = tm0 + er;
+            const int b0 = mfirst / howo, pix0 = mfirst - b0 * howo; // one division per tile row group
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int tn0 = n0 + wc * TN * 32 + 32 * j;
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    epw[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EPLD + (lane & 31)] = acc[i][j][r];
+                asm volatile("" ::: "memory");
+                const int n = tn0 + ec;
+                if (n < a.Cout) {
+                    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (a.bias) bias = *(const float4 *)(a.bias + n);
+                    int b = b0, pix = pix0;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const float4 v4 = *(const float4 *)&epw[(er + 8 * t) * EPLD + ec];
+                        if (mfirst + 8 * t < a.M) {
+                            float o[4] = {v4.x + bias.x, v4.y + bias.y, v4.z + bias.z, v4.w + bias.w};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int act = (a.act == ACT_SIGMOID && n + e < a.sig_from) ? ACT_NONE : a.act;
+                                o[e] = act_apply(o[e], act);
+                            }
+                            if (a.res) {
+                                const float4 rr = *(const float4 *)(a.res + (long long)b * a.r_bs + (long long)pix * a.r_cs + a.r_co + n);
+                                o[0] += rr.x; o[1] += rr.y; o[2] += rr.z; o[3] += rr.w;
+                            }
+                            *(float4 *)(a.y + (long long)b * a.y_bs + (long long)pix * a.y_cs + a.y_co + n) = make_float4(o[0], o[1], o[2], o[3]);
+                        }
+                        pix += 8;
+                        while (pix >= howo) { pix -= howo; ++b; }
+                    }
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int mrow0 = m0 + wr * TM * 32 + 32 * i + 4 * (lane >> 5); // first row of this lane in the tile

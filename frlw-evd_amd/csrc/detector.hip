@@ -374,7 +374,57 @@ struct frlw_detector {
     hipEvent_t ev_fork = nullptr, ev_join[kSideLanes] = {};
 };
 
+// Bare fp32 MFMA loop: every wavefront of every CU issues v_mfma_f32_32x32x2_f32 back to back on four accumulators,
+// operands in registers (random, so that the chip sees the switching activity of real data).  What this sustains is the
+// rate the convolutions can at best approach on this chip under load: the 157.3 TFLOP/s of the data sheet assume 2.4 GHz.
+template <int NACC>
+__global__ __launch_bounds__(256) void k_mfma_f32_rate(int iters, const float *seed, float *sink)
+{
+    const int lane = threadIdx.x & 63;
+    float a0 = seed[lane], a1 = seed[64 + lane], b0 = seed[128 + lane], b1 = seed[192 + lane];
+    f32x16 c00, c01, c10, c11;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { c00[r] = 0.f; c01[r] = 0.f; c10[r] = 0.f; c11[r] = 0.f; }
+#pragma nounroll
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, c00, 0, 0, 0);
+            c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, c01, 0, 0, 0);
+            if (NACC == 4) {
+                c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, c10, 0, 0, 0);
+                c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, c11, 0, 0, 0);
+            } else if (NACC == 2) {
+                c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, c00, 0, 0, 0);
+                c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, c01, 0, 0, 0);
+            } else {
+                c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, c00, 0, 0, 0);
+                c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, c00, 0, 0, 0);
+            }
+        }
+        a0 = -a0; b1 = -b1; // keep the sums bounded
+    }
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += c00[r] + c01[r] + c10[r] + c11[r];
+    if (t == 123.456f) sink[0] = t; // never true: keeps the loop alive
+}
+
 extern "C" {
+
+// iters x 32 MFMAs per wavefront on `blocks` workgroups of 4 wavefronts; `seed`: 256 random floats (device).
+int frlw_selftest_mfma_f32_rate(int blocks, int iters, const float *seed, float *sink, frlw_stream_t stream)
+{
+    int blocks_sel = 4;
+    if (blocks < 0) { blocks_sel = (-blocks) % 10; blocks = (-blocks) / 10; } // developer experiments: -(blocks * 10 + nacc)
+    if (blocks < 1 || iters < 1 || !seed || !sink) return FRLW_ERR_ARG;
+    const int nacc = iters < 0 ? 0 : 4; // (developer experiments: negative blocks select fewer accumulators)
+    (void)nacc;
+    if (blocks_sel == 2) hipLaunchKernelGGL(k_mfma_f32_rate<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, iters, seed, sink);
+    else if (blocks_sel == 1) hipLaunchKernelGGL(k_mfma_f32_rate<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, iters, seed, sink);
+    else hipLaunchKernelGGL(k_mfma_f32_rate<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, iters, seed, sink);
+    return hipGetLastError() == hipSuccess ? FRLW_OK : FRLW_ERR_HIP;
+}
 
 frlw_detector_t *frlw_det_create(void) { return new frlw_detector(); }
 void frlw_det_destroy(frlw_detector_t *d)

@@ -364,6 +364,12 @@ int frlw_baseconv_train_bwd(const float *dy, const float *x, const float *z, con
                             int Cout, int k, int stride, float *dz, float *dx, float *dw, float *dgamma, float *dbeta,
                             void *scratch, int64_t scratch_bytes, frlw_stream_t stream);
 
+/* Measurement aid: a bare loop of v_mfma_f32_32x32x2_f32 (the instruction of every convolution here) on `blocks`
+ * workgroups of four wavefronts, iters x 32 MFMAs (= iters x 131072 FLOP) per wavefront, operands = the 256 floats of
+ * `seed` (device).  Timed by the caller (bench.py): the fp32 matrix rate the chip SUSTAINS on non-trivial data, which is
+ * what the convolutions can approach -- the data-sheet peak assumes the maximum clock. */
+int frlw_selftest_mfma_f32_rate(int blocks, int iters, const float *seed, float *sink, frlw_stream_t stream);
+
 /* Library identification: "frlw_evd <version> gfx950". */
 const char *frlw_version(void);
 
