@@ -184,37 +184,48 @@ struct DecodeArgs {
     int *counts;      // (B): detections per image (0 = the reference's single all-zero row)
 };
 
-constexpr int NMS_MAX = 2048;
+constexpr int NMS_MAX = 8192; // candidates per image the device NMS holds (1 Mpx detector shape: 6720 anchors)
+// LDS (dynamic, one workgroup per image): phase 1 = the sort keys, skey[n] f32 | sidx[n] i32; phase 2 = the sorted
+// boxes, x1 | y1 | x2 | y2 [n] f32 + suppressed flags [n] u8.  n = candidates rounded up to a power of two.
+__host__ __device__ inline size_t nms_lds_bytes(int cap) { return (size_t)cap * 17 + 64; }
 
-__global__ __launch_bounds__(1024) void k_decode_nms(DecodeArgs a)
+__global__ __launch_bounds__(1024) void k_decode_nms(DecodeArgs a, int cap)
 {
-    __shared__ float sx1[NMS_MAX], sy1[NMS_MAX], sx2[NMS_MAX], sy2[NMS_MAX], sarea[NMS_MAX];
-    __shared__ float skey[NMS_MAX];
-    __shared__ int sidx[NMS_MAX];
-    __shared__ unsigned char ssup[NMS_MAX];
+    extern __shared__ __attribute__((aligned(16))) unsigned char nms_lds[];
+    float *skey = (float *)nms_lds;        // phase 1
+    int *sidx = (int *)(skey + cap);
+    float *sx1 = (float *)nms_lds, *sy1 = sx1 + cap, *sx2 = sy1 + cap, *sy2 = sx2 + cap; // phase 2
+    unsigned char *ssup = (unsigned char *)(sy2 + cap);
     __shared__ int scount;
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const int F = 5 + a.nc;
+    int *count_out = a.counts + (long long)b * (1 + a.A);
+    int *order = count_out + 1; // scratch: anchor index of every candidate in score order
     if (tid == 0) scount = 0;
     __syncthreads();
+    auto anchor_box = [&](int i, float &cx, float &cy, float &w, float &h) {
+        int lvl = 0, off = i;
+        while (lvl + 1 < a.n_levels && off >= a.lvl_h[lvl] * a.lvl_w[lvl]) { off -= a.lvl_h[lvl] * a.lvl_w[lvl]; ++lvl; }
+        const float gx = (float)(off % a.lvl_w[lvl]), gy = (float)(off / a.lvl_w[lvl]), s = (float)a.lvl_stride[lvl];
+        const float *r = a.raw + ((long long)b * a.A + i) * F;
+        cx = (r[0] + gx) * s;      // (xy + grid) * stride, yolo_head.py:271
+        cy = (r[1] + gy) * s;
+        w = (r[2] * r[2]) * s;     // square(wh) * stride, :272
+        h = (r[3] * r[3]) * s;
+    };
     // ---- decode; candidates = obj > threshold, compacted in anchor order by a block-wide stable scan
     // (sort stability must not depend on thread timing): do it in chunks of nt anchors
     for (int base = 0; base < a.A; base += nt) {
         const int i = base + tid;
         bool cand = false;
-        float cx = 0, cy = 0, w = 0, h = 0, obj = 0;
+        float obj = 0;
         if (i < a.A) {
-            int lvl = 0, off = i;
-            while (lvl + 1 < a.n_levels && off >= a.lvl_h[lvl] * a.lvl_w[lvl]) { off -= a.lvl_h[lvl] * a.lvl_w[lvl]; ++lvl; }
-            const float gx = (float)(off % a.lvl_w[lvl]), gy = (float)(off / a.lvl_w[lvl]), s = (float)a.lvl_stride[lvl];
             const float *r = a.raw + ((long long)b * a.A + i) * F;
-            cx = (r[0] + gx) * s;      // (xy + grid) * stride, yolo_head.py:271
-            cy = (r[1] + gy) * s;
-            w = (r[2] * r[2]) * s;     // square(wh) * stride, :272
-            h = (r[3] * r[3]) * s;
             obj = r[4];
             cand = obj > a.obj_thr;    // :276
             if (a.decoded) {
+                float cx, cy, w, h;
+                anchor_box(i, cx, cy, w, h);
                 float *d = a.decoded + ((long long)b * a.A + i) * F;
                 d[0] = cx; d[1] = cy; d[2] = w; d[3] = h;
                 for (int c = 4; c < F; ++c) d[c] = r[c];
@@ -229,18 +240,14 @@ __global__ __launch_bounds__(1024) void k_decode_nms(DecodeArgs a)
         int pre = scount;
         for (int k = 0; k < wv; ++k) pre += wcount[k];
         const int slot = pre + __popcll(bal & ((1ull << lane) - 1ull));
-        if (cand && slot < NMS_MAX) {
-            sx1[slot] = cx - w / 2; sy1[slot] = cy - h / 2; sx2[slot] = cx + w / 2; sy2[slot] = cy + h / 2; // :280
-            skey[slot] = obj;
-            sidx[slot] = i;
-        }
+        if (cand && slot < cap) { skey[slot] = obj; sidx[slot] = i; }
         __syncthreads();
         if (tid == 0) { int t = scount; for (int k = 0; k < (nt + 63) / 64; ++k) t += wcount[k]; scount = t; }
         __syncthreads();
     }
-    if (scount > NMS_MAX) { if (tid == 0) a.counts[b] = -1; return; } // more candidates than the LDS sort holds
+    if (scount > cap) { if (tid == 0) *count_out = -1; return; } // more candidates than the LDS holds (A > 8192 only)
     const int n = scount;
-    if (n == 0) { if (tid == 0) a.counts[b] = 0; return; }
+    if (n == 0) { if (tid == 0) *count_out = 0; return; }
     // ---- sort candidates by score descending, ties by anchor index ascending (= a stable sort):
     // bitonic network over the next power of two, keys (score, -index)
     int np2 = 1;
@@ -256,20 +263,24 @@ __global__ __launch_bounds__(1024) void k_decode_nms(DecodeArgs a)
                     const float ki = skey[i], kj = skey[j];
                     const int ii = sidx[i], ij = sidx[j];
                     const bool i_first = ki > kj || (ki == kj && ii < ij); // i should precede j in the final order
-                    if (up ? !i_first : i_first) {
-                        skey[i] = kj; skey[j] = ki; sidx[i] = ij; sidx[j] = ii;
-                        float t;
-                        t = sx1[i]; sx1[i] = sx1[j]; sx1[j] = t;
-                        t = sy1[i]; sy1[i] = sy1[j]; sy1[j] = t;
-                        t = sx2[i]; sx2[i] = sx2[j]; sx2[j] = t;
-                        t = sy2[i]; sy2[i] = sy2[j]; sy2[j] = t;
-                    }
+                    if (up ? !i_first : i_first) { skey[i] = kj; skey[j] = ki; sidx[i] = ij; sidx[j] = ii; }
                 }
             }
             __syncthreads();
         }
     }
-    for (int i = tid; i < n; i += nt) { sarea[i] = (sx2[i] - sx1[i]) * (sy2[i] - sy1[i]); ssup[i] = 0; }
+    // ---- the order leaves the LDS (global scratch), the sorted boxes take its place
+    for (int i = tid; i < n; i += nt) order[i] = sidx[i];
+    __syncthreads();
+    for (int i = tid; i < n; i += nt) {
+        float cx, cy, w, h;
+        anchor_box(order[i], cx, cy, w, h);
+        const float x1 = cx - w / 2, y1 = cy - h / 2, x2 = cx + w / 2, y2 = cy + h / 2; // :280
+        // (order[i] was written by this very thread; the barrier above ended every read of the sort keys, whose LDS
+        // words change meaning here)
+        sx1[i] = x1; sy1[i] = y1; sx2[i] = x2; sy2[i] = y2;
+        ssup[i] = 0;
+    }
     __syncthreads();
     // ---- greedy suppression in score order, IoU = inter / (area_i + area_j - inter) > thr, resolved 64
     // boxes at a time: (a) the chunk's 64 x 64 "i suppresses j" bit matrix in parallel, (b) one thread walks
@@ -282,7 +293,8 @@ __global__ __launch_bounds__(1024) void k_decode_nms(DecodeArgs a)
         const float xx2 = fminf(sx2[i], sx2[j]), yy2 = fminf(sy2[i], sy2[j]);
         const float iw = fmaxf(xx2 - xx1, 0.0f), ih = fmaxf(yy2 - yy1, 0.0f);
         const float inter = iw * ih;
-        return inter / (sarea[i] + sarea[j] - inter) > a.iou_thr;
+        const float ai = (sx2[i] - sx1[i]) * (sy2[i] - sy1[i]), aj = (sx2[j] - sx1[j]) * (sy2[j] - sy1[j]);
+        return inter / (ai + aj - inter) > a.iou_thr;
     };
     for (int c0 = 0; c0 < n; c0 += 64) {
         const int nb = n - c0 < 64 ? n - c0 : 64;
@@ -328,22 +340,20 @@ __global__ __launch_bounds__(1024) void k_decode_nms(DecodeArgs a)
         for (int k = 0; k < wv; ++k) pre += wtot[k];
         const int row = pre + __popcll(bal & ((1ull << lane) - 1ull));
         if (keep) {
-            const float *r = a.raw + ((long long)b * a.A + sidx[i]) * F;
-            int lvl = 0, off = sidx[i];
-            while (lvl + 1 < a.n_levels && off >= a.lvl_h[lvl] * a.lvl_w[lvl]) { off -= a.lvl_h[lvl] * a.lvl_w[lvl]; ++lvl; }
-            const float gx = (float)(off % a.lvl_w[lvl]), gy = (float)(off / a.lvl_w[lvl]), s = (float)a.lvl_stride[lvl];
+            const int anchor = order[i];
+            const float *r = a.raw + ((long long)b * a.A + anchor) * F;
             int best = 0;
             float bv = r[5];
             for (int c = 1; c < a.nc; ++c) if (r[5 + c] > bv) { bv = r[5 + c]; best = c; } // first max, like argmax
             float *d = a.dets + ((long long)b * a.A + row) * 6;
-            d[0] = (r[0] + gx) * s; d[1] = (r[1] + gy) * s; d[2] = (r[2] * r[2]) * s; d[3] = (r[3] * r[3]) * s;
+            anchor_box(anchor, d[0], d[1], d[2], d[3]);
             d[4] = (float)best;
             d[5] = r[4] * bv; // obj * max cls, yolo_head.py:301
         }
         for (int k = 0; k < (nt + 63) / 64; ++k) run += wtot[k];
         __syncthreads();
     }
-    if (tid == 0) a.counts[b] = run;
+    if (tid == 0) *count_out = run;
 }
 
 // ---- plan ------------------------------------------------------------------------------------------
@@ -636,7 +646,12 @@ int frlw_det_run(const frlw_detector_t *d, int B, void *const *bufs, int n_bufs,
             a.raw = buf(op.src); a.decoded = buf(op.decoded_buf); a.dets = buf(op.dets_buf);
             a.counts = (int *)buf(op.counts_buf);
             if (!a.raw || !a.dets || !a.counts) return FRLW_ERR_ARG;
-            hipLaunchKernelGGL(k_decode_nms, dim3(B), dim3(1024), 0, s, a);
+            int cap = 1024; // LDS sized for the anchors of this network, up to NMS_MAX candidates
+            while (cap < a.A && cap < NMS_MAX) cap <<= 1;
+            const size_t lds = nms_lds_bytes(cap);
+            if (lds > 64 * 1024)
+                (void)hipFuncSetAttribute((const void *)k_decode_nms, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(k_decode_nms, dim3(B), dim3(1024), lds, s, a, cap);
             break;
         }
         default: return FRLW_ERR_ARG;

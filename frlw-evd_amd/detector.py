@@ -259,7 +259,7 @@ class DetectorEngine:
         # ---- decode + NMS (yolo_head.py:258-303)
         self.dec_buf = self._new_buf(1, A, F).buf
         self.dets_buf = self._new_buf(1, A, 6).buf
-        self.counts_buf = self._new_buf(1, 1, 1).buf
+        self.counts_buf = self._new_buf(1, 1, 1 + A).buf  # per image: [count, scratch of A ints]
         n = len(levels)
         arr = C.c_int * n
         _lib.check(lib.frlw_det_add_decode_nms(self.handle, raw.buf, A, nc, n, arr(*[v.h for v in levels]),
@@ -279,7 +279,7 @@ class DetectorEngine:
         bufs = self._bufs.get(B)
         if bufs is None:
             bufs = [None] + [torch.empty(B * n, dtype=torch.float32, device=self.device) for n in self._shapes[1:]]
-            bufs[self.counts_buf] = torch.zeros(B, dtype=torch.int32, device=self.device)
+            bufs[self.counts_buf] = torch.zeros(B * (1 + self.A), dtype=torch.int32, device=self.device)
             bufs[self.scratch_buf] = torch.empty(3 * self.scratch_floats, dtype=torch.float32, device=self.device)
             self._bufs[B] = bufs
         return bufs
@@ -323,14 +323,14 @@ class DetectorEngine:
     def detect(self, x, return_decoded=False):
         """Full eval forward: list of (n_i, 6) [cx, cy, w, h, cls, obj * max cls] per image."""
         bufs, B = self._run(x, 0, -1)
-        counts = bufs[self.counts_buf].cpu().tolist()  # the reference loops over images on the host too
+        counts = bufs[self.counts_buf].view(B, 1 + self.A)[:, 0].cpu().tolist()  # the reference loops on the host too
         dets = bufs[self.dets_buf].view(B, self.A, 6)
         out = []
         for b, n in enumerate(counts):
             if n < 0:
-                # more than 2048 candidates (the LDS sort of k_decode_nms holds 2048): rare -- an untrained head --
-                # so this image takes the box-by-box procedure on the decoded rows the kernel left in HBM (ROCm
-                # tensors, torch ops; same arithmetic and visiting order as the kernel)
+                # more than 8192 candidates (what k_decode_nms holds in LDS): only possible for inputs beyond the
+                # 1 Mpx detector shape (6720 anchors).  Such an image takes the box-by-box procedure on the decoded
+                # rows the kernel left in HBM (ROCm tensors, torch ops; same arithmetic and visiting order)
                 out.append(self._nms_large(bufs[self.dec_buf].view(B, self.A, self.F)[b]))
                 continue
             out.append(dets[b, :n].clone() if n > 0 else torch.zeros((1, 6), device=self.device))

@@ -263,8 +263,9 @@ int frlw_det_add_conv(frlw_detector_t *d, int src_buf, int src_cs, int src_co, i
  * obj > obj_thr, class-agnostic NMS at iou_thr (the documented torchvision.ops.nms semantics: descending
  * score, suppress IoU > thr), emit [cx, cy, w, h, argmax cls, obj * max cls] in descending-score order.
  *   raw_buf    : (B, A, 5 + nc) f32     decoded_buf: optional (B, A, 5 + nc), < 0 for none
- *   dets_buf   : (B, A, 6) f32          counts_buf : (B) int32; 0 = nothing passed (the reference then
- *                returns one all-zero row), -1 = more than 2048 candidates (not handled on device)
+ *   dets_buf   : (B, A, 6) f32          counts_buf : (B, 1 + A) int32; [b][0] = detections of image b: 0 = nothing
+ *                passed (the reference then returns one all-zero row), -1 = more than 8192 candidates (only reachable
+ *                with A > 8192; not handled on device); [b][1..] = scratch (the candidates' anchors in score order)
  */
 int frlw_det_add_decode_nms(frlw_detector_t *d, int raw_buf, int A, int nc, int n_levels, const int *lvl_h,
                             const int *lvl_w, const int *lvl_stride, float obj_thr, float iou_thr,
