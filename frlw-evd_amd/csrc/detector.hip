@@ -146,30 +146,45 @@ __global__ void k_upsample2x(const float *x, int B, int H, int W, int C, int x_c
 }
 
 // SPP: channels [0, C) of an NHWC buffer -> max-pools 5 / 9 / 13 (stride 1, -inf padding) into [C, 4C)
-__global__ void k_spp_pool(float *buf, int B, int H, int W, int C, int cs)
+// (network_blocks.py:139-151).  max-pool 9 = 5 o 5 and 13 = 5 o 5 o 5 for stride-1 pools with -inf padding, and each
+// 5 x 5 pool is a row pass followed by a column pass: 30 reads per output instead of 169.  One workgroup per
+// (image, group of 32 channels) keeps the H x W x 32 tile in LDS through the six passes.
+constexpr int kSppCh = 32;
+constexpr int kSppMaxPix = 512; // 16 x 20 maps and smaller (the SPP sits on the stride-32 map): 2 x 66 KB of LDS at most
+__global__ __launch_bounds__(256) void k_spp_pool(float *buf, int H, int W, int C, int cs)
 {
-    const long long total = (long long)B * H * W * C;
-    for (long long o = blockIdx.x * (long long)blockDim.x + threadIdx.x; o < total; o += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(o % C);
-        const long long p = o / C;
-        const int x = (int)(p % W), y = (int)((p / W) % H), b = (int)(p / ((long long)W * H));
-        float m5 = -INFINITY, m9 = -INFINITY, m13 = -INFINITY;
-        for (int dy = -6; dy <= 6; ++dy) {
-            const int yy = y + dy;
-            if (yy < 0 || yy >= H) continue;
-            for (int dx = -6; dx <= 6; ++dx) {
-                const int xx = x + dx;
-                if (xx < 0 || xx >= W) continue;
-                const float v = buf[(((long long)b * H + yy) * W + xx) * cs + c];
-                m13 = fmaxf(m13, v);
-                if (dy >= -4 && dy <= 4 && dx >= -4 && dx <= 4) m9 = fmaxf(m9, v);
-                if (dy >= -2 && dy <= 2 && dx >= -2 && dx <= 2) m5 = fmaxf(m5, v);
+    extern __shared__ float spp_lds[];
+    const int b = blockIdx.y, c0 = blockIdx.x * kSppCh, tid = threadIdx.x, n = H * W;
+    float (*ta)[kSppCh + 1] = (float (*)[kSppCh + 1])spp_lds;
+    float (*tb)[kSppCh + 1] = (float (*)[kSppCh + 1])(spp_lds + (size_t)n * (kSppCh + 1));
+    float *base = buf + (long long)b * n * cs;
+    for (int e = tid; e < n * kSppCh; e += blockDim.x) {
+        const int p = e / kSppCh, c = e - p * kSppCh;
+        ta[p][c] = c0 + c < C ? base[(long long)p * cs + c0 + c] : -INFINITY;
+    }
+    __syncthreads();
+    for (int round = 1; round <= 3; ++round) {
+        for (int e = tid; e < n * kSppCh; e += blockDim.x) { // along x
+            const int p = e / kSppCh, c = e - p * kSppCh, y = p / W, x = p - y * W;
+            float m = ta[p][c];
+            for (int d = 1; d <= 2; ++d) {
+                if (x - d >= 0) m = fmaxf(m, ta[p - d][c]);
+                if (x + d < W) m = fmaxf(m, ta[p + d][c]);
             }
+            tb[p][c] = m;
         }
-        float *dst = buf + (((long long)b * H + y) * W + x) * cs + c;
-        dst[C] = m5;
-        dst[2 * C] = m9;
-        dst[3 * C] = m13;
+        __syncthreads();
+        for (int e = tid; e < n * kSppCh; e += blockDim.x) { // along y, and out: round r = pool 4 r + 1
+            const int p = e / kSppCh, c = e - p * kSppCh, y = p / W;
+            float m = tb[p][c];
+            for (int d = 1; d <= 2; ++d) {
+                if (y - d >= 0) m = fmaxf(m, tb[p - d * W][c]);
+                if (y + d < H) m = fmaxf(m, tb[p + d * W][c]);
+            }
+            ta[p][c] = m;
+            if (c0 + c < C) base[(long long)p * cs + round * C + c0 + c] = m;
+        }
+        __syncthreads();
     }
 }
 
@@ -529,6 +544,7 @@ int frlw_det_add_upsample(frlw_detector_t *d, int src_buf, int cs_src, int co_sr
 int frlw_det_add_spp_pool(frlw_detector_t *d, int buf, int cs, int C, int H, int W)
 {
     if (!d || cs < 4 * C) return FRLW_ERR_ARG;
+    if (H * W > kSppMaxPix) return FRLW_ERR_UNSUPPORTED;
     Op op = {};
     op.type = OP_SPP; op.src = buf; op.dst = buf; op.C = C; op.H = H; op.W = W; op.cs_src = cs;
     op.lane = d->cur_lane;
@@ -628,8 +644,10 @@ int frlw_det_run(const frlw_detector_t *d, int B, void *const *bufs, int n_bufs,
             break;
         }
         case OP_SPP: {
-            const long long total = (long long)B * op.H * op.W * op.C;
-            hipLaunchKernelGGL(k_spp_pool, dim3(grid_1d(total)), dim3(256), 0, s, buf(op.src), B, op.H, op.W, op.C, op.cs_src);
+            const size_t lds = (size_t)2 * op.H * op.W * (kSppCh + 1) * sizeof(float);
+            if (lds > 64 * 1024)
+                (void)hipFuncSetAttribute((const void *)k_spp_pool, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(k_spp_pool, dim3((op.C + kSppCh - 1) / kSppCh, B), dim3(256), lds, s, buf(op.src), op.H, op.W, op.C, op.cs_src);
             break;
         }
         case OP_CONV: {
