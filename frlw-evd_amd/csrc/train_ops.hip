@@ -326,21 +326,37 @@ __global__ __launch_bounds__(256) void k_bn_stats_partial(const float *z, long l
     });
 }
 
-// adds the partials of 16 channels per workgroup, 16 lanes per channel -> tot[c] = {sum a, sum b}
+// adds the partials of kFinCh channels per workgroup, 256 / kFinCh lanes per channel, in a fixed order
+// -> tot[c] = {sum a, sum b}.  (16 channels x 16 lanes left 16 workgroups on the chip for a 256-channel layer and took
+// 14 us, twice the pass that produced the partials; 4 x 64: C / 4 workgroups, a quarter of the rows per lane.)
+constexpr int kFinCh = 4;
 __device__ __forceinline__ void bn_sum_partials(const double *partial, int n_wg, int C, double &s0, double &s1, int &c_out)
 {
+    constexpr int L = 256 / kFinCh;
     __shared__ double red2[256][2];
-    const int tid = threadIdx.x, cl = tid & 15, lane = tid >> 4;
-    const int c = blockIdx.x * 16 + cl;
+    const int tid = threadIdx.x, cl = tid % kFinCh, lane = tid / kFinCh;
+    const int c = blockIdx.x * kFinCh + cl;
     double a = 0.0, b = 0.0;
-    if (c < C)
-        for (int w = lane; w < n_wg; w += 16) { a += partial[((long long)w * C + c) * 2]; b += partial[((long long)w * C + c) * 2 + 1]; }
+    if (c < C) {
+        int w = lane;
+        for (; w + 3 * L < n_wg; w += 4 * L) { // four independent rows in flight
+            const double2 p0 = *(const double2 *)(partial + ((long long)w * C + c) * 2);
+            const double2 p1 = *(const double2 *)(partial + ((long long)(w + L) * C + c) * 2);
+            const double2 p2 = *(const double2 *)(partial + ((long long)(w + 2 * L) * C + c) * 2);
+            const double2 p3 = *(const double2 *)(partial + ((long long)(w + 3 * L) * C + c) * 2);
+            a += (p0.x + p1.x) + (p2.x + p3.x);
+            b += (p0.y + p1.y) + (p2.y + p3.y);
+        }
+        for (; w < n_wg; w += L) { a += partial[((long long)w * C + c) * 2]; b += partial[((long long)w * C + c) * 2 + 1]; }
+    }
     red2[tid][0] = a;
     red2[tid][1] = b;
     __syncthreads();
-    if (lane == 0)
-        for (int l = 1; l < 16; ++l) { a += red2[cl + 16 * l][0]; b += red2[cl + 16 * l][1]; }
-    s0 = a; s1 = b; c_out = (lane == 0 && c < C) ? c : -1;
+    for (int half = L / 2; half >= 1; half >>= 1) { // fixed tree over the lanes of a channel
+        if (lane < half) { red2[tid][0] += red2[tid + half * kFinCh][0]; red2[tid][1] += red2[tid + half * kFinCh][1]; }
+        __syncthreads();
+    }
+    s0 = red2[cl][0]; s1 = red2[cl][1]; c_out = (lane == 0 && c < C) ? c : -1;
 }
 
 // mean, biased variance, invstd = 1 / sqrt(var + eps) in float32 (what BatchNorm2d normalises with)
@@ -621,7 +637,7 @@ static int bn_stats_impl(const float *z, int64_t M, int C, float eps, float *mea
     const int n_wg = (int)((M + bn_rows_per_wg(M) - 1) / bn_rows_per_wg(M));
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(k_bn_stats_partial, dim3(n_wg), dim3(256), 0, s, z, (long long)M, C, scratch);
-    hipLaunchKernelGGL(k_bn_stats_final, dim3((C + 15) / 16), dim3(256), 0, s, scratch, n_wg, C, (long long)M, eps, mean,
+    hipLaunchKernelGGL(k_bn_stats_final, dim3((C + kFinCh - 1) / kFinCh), dim3(256), 0, s, scratch, n_wg, C, (long long)M, eps, mean,
                        var, invstd, run_mean, run_var, momentum);
     TRY_HIP(hipGetLastError());
     return FRLW_OK;
@@ -649,7 +665,7 @@ int frlw_bn_silu_bwd(const float *dy, const float *z, int64_t M, int C, const fl
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(k_bn_silu_bwd_partial, dim3(n_wg), dim3(256), 0, s, dy, z, (long long)M, C, gamma, beta, mean, invstd,
                        scratch);
-    hipLaunchKernelGGL(k_bn_silu_bwd_final, dim3((C + 15) / 16), dim3(256), 0, s, scratch, n_wg, C, (long long)M, dgamma,
+    hipLaunchKernelGGL(k_bn_silu_bwd_final, dim3((C + kFinCh - 1) / kFinCh), dim3(256), 0, s, scratch, n_wg, C, (long long)M, dgamma,
                        dbeta, sums);
     const long long n4 = (long long)M * C / 4;
     hipLaunchKernelGGL(k_bn_silu_bwd_apply, dim3(conv_grid_1d(n4)), dim3(256), 0, s, dy, z, n4, C, gamma, beta, mean, invstd,
@@ -659,6 +675,11 @@ int frlw_bn_silu_bwd(const float *dy, const float *z, int64_t M, int C, const fl
 }
 
 /* ---- one call per BaseConv and direction (the per-operator entry points above stay for tests / other callers) ---- */
+int64_t frlw_baseconv_weight_cache_floats(int Cin, int Cout, int k)
+{
+    return (int64_t)k * k * Cin * npad32(Cout) + (int64_t)k * k * Cout * npad32(Cin);
+}
+
 int64_t frlw_baseconv_train_scratch_bytes(int B, int H, int W, int Cin, int Cout, int k, int stride)
 {
     const int pad = (k - 1) / 2;
@@ -697,8 +718,8 @@ inline TrainScratch carve(void *scratch, int B, int Ho, int Wo, int Cin, int Cou
  * the backward needs.  scratch: frlw_baseconv_train_scratch_bytes bytes, contents not needed afterwards. */
 int frlw_baseconv_train_fwd(const float *x, const float *w, const float *gamma, const float *beta, float eps, int B, int H,
                             int W, int Cin, int Cout, int k, int stride, float *z, float *y, float *mean, float *var,
-                            float *invstd, float *running_mean, float *running_var, float momentum, void *scratch,
-                            int64_t scratch_bytes, frlw_stream_t stream)
+                            float *invstd, float *running_mean, float *running_var, float momentum, float *w_cache,
+                            void *scratch, int64_t scratch_bytes, frlw_stream_t stream)
 {
     if (!x || !w || !gamma || !beta || !z || !y || !mean || !var || !invstd || !scratch) return FRLW_ERR_ARG;
     if (scratch_bytes < frlw_baseconv_train_scratch_bytes(B, H, W, Cin, Cout, k, stride)) return FRLW_ERR_WORKSPACE;
@@ -707,8 +728,13 @@ int frlw_baseconv_train_fwd(const float *x, const float *w, const float *gamma, 
     const int64_t M = (int64_t)B * Ho * Wo;
     TrainScratch t = carve(scratch, B, Ho, Wo, Cin, Cout, k);
     int rc;
-    if ((rc = frlw_conv_weight_layouts(w, Cout, Cin, k, 0, t.w_fwd, nullptr, stream)) != FRLW_OK) return rc;
-    if ((rc = frlw_conv2d_fwd(x, B, H, W, Cin, t.w_fwd, Cout, k, stride, z, t.splitk, t.splitk_floats, stream)) != FRLW_OK) return rc;
+    const float *w_fwd = t.w_fwd;
+    if (w_cache) { // both operands in ONE launch, kept by the caller: the backward of this step finds its operand ready
+        float *w_dg = w_cache + (int64_t)k * k * Cin * npad32(Cout);
+        if ((rc = frlw_conv_weight_layouts(w, Cout, Cin, k, frlw_conv2d_dgrad_parity(k, stride, H, W), w_cache, w_dg, stream)) != FRLW_OK) return rc;
+        w_fwd = w_cache;
+    } else if ((rc = frlw_conv_weight_layouts(w, Cout, Cin, k, 0, t.w_fwd, nullptr, stream)) != FRLW_OK) return rc;
+    if ((rc = frlw_conv2d_fwd(x, B, H, W, Cin, w_fwd, Cout, k, stride, z, t.splitk, t.splitk_floats, stream)) != FRLW_OK) return rc;
     if ((rc = bn_stats_impl(z, M, Cout, eps, mean, var, invstd, t.red, running_mean, running_mean ? running_var : nullptr,
                             momentum, stream)) != FRLW_OK) return rc;
     return frlw_bn_silu_fwd(z, M, Cout, gamma, beta, mean, invstd, y, stream);
@@ -718,7 +744,7 @@ int frlw_baseconv_train_fwd(const float *x, const float *w, const float *gamma, 
 int frlw_baseconv_train_bwd(const float *dy, const float *x, const float *z, const float *w, const float *gamma,
                             const float *beta, const float *mean, const float *invstd, int B, int H, int W, int Cin,
                             int Cout, int k, int stride, float *dz, float *dx, float *dw, float *dgamma, float *dbeta,
-                            void *scratch, int64_t scratch_bytes, frlw_stream_t stream)
+                            const float *w_cache, void *scratch, int64_t scratch_bytes, frlw_stream_t stream)
 {
     if (!dy || !x || !z || !w || !gamma || !beta || !mean || !invstd || !dz || !dw || !dgamma || !dbeta || !scratch)
         return FRLW_ERR_ARG;
@@ -730,8 +756,10 @@ int frlw_baseconv_train_bwd(const float *dy, const float *x, const float *z, con
     int rc;
     if ((rc = frlw_bn_silu_bwd(dy, z, M, Cout, gamma, beta, mean, invstd, dz, dgamma, dbeta, t.red, t.sums, stream)) != FRLW_OK) return rc;
     if (dx) {
-        if ((rc = frlw_conv_weight_layouts(w, Cout, Cin, k, frlw_conv2d_dgrad_parity(k, stride, H, W), nullptr, t.w_dg, stream)) != FRLW_OK) return rc;
-        if ((rc = frlw_conv2d_dgrad(dz, B, Ho, Wo, Cout, t.w_dg, Cin, k, stride, H, W, dx, t.splitk, t.splitk_floats, stream)) != FRLW_OK) return rc;
+        const float *w_dg = t.w_dg;
+        if (w_cache) w_dg = w_cache + (int64_t)k * k * Cin * npad32(Cout); // laid out by the forward of this step
+        else if ((rc = frlw_conv_weight_layouts(w, Cout, Cin, k, frlw_conv2d_dgrad_parity(k, stride, H, W), nullptr, t.w_dg, stream)) != FRLW_OK) return rc;
+        if ((rc = frlw_conv2d_dgrad(dz, B, Ho, Wo, Cout, w_dg, Cin, k, stride, H, W, dx, t.splitk, t.splitk_floats, stream)) != FRLW_OK) return rc;
     }
     return frlw_conv2d_wgrad(x, B, H, W, Cin, dz, Ho, Wo, Cout, k, stride, dw, t.wgrad, t.wgrad_floats, stream);
 }

@@ -17,6 +17,19 @@ import torch
 from .. import _lib
 
 _SCRATCH = {}
+_WCACHE = {}  # id(weight parameter) -> (weakref, operand cache): forward + data-gradient layouts, rebuilt every forward
+
+
+def _weight_cache(lib, weight, Cin, Cout, k):
+    import weakref
+    key = id(weight)
+    hit = _WCACHE.get(key)
+    n = lib.frlw_baseconv_weight_cache_floats(Cin, Cout, k)
+    if hit is None or hit[0]() is not weight or hit[1].numel() < n or hit[1].device != weight.device:
+        buf = torch.empty(int(n), dtype=torch.float32, device=weight.device)
+        _WCACHE[key] = (weakref.ref(weight, lambda _r, key=key: _WCACHE.pop(key, None)), buf)
+        return buf
+    return hit[1]
 
 
 def _scratch(dev, key, numel, dtype):
@@ -63,12 +76,16 @@ class _BaseConvTrain(torch.autograd.Function):
         y = torch.empty_like(z)
         stats = torch.empty((3, Cout), dtype=torch.float32, device=dev)  # mean, biased variance, invstd
         sc = _scratch(dev, "block", lib.frlw_baseconv_train_scratch_bytes(B, H, W, Cin, Cout, k, stride), torch.uint8)
+        wc = _weight_cache(lib, weight, Cin, Cout, k)  # both GEMM operands of this weight, laid out once per step
         _lib.check(lib.frlw_baseconv_train_fwd(x.data_ptr(), w.data_ptr(), g.data_ptr(), b.data_ptr(), C.c_float(eps), B, H, W,
                                                Cin, Cout, k, stride, z.data_ptr(), y.data_ptr(), stats[0].data_ptr(),
                                                stats[1].data_ptr(), stats[2].data_ptr(),
                                                run_mean.data_ptr() if run_mean is not None else None,
                                                run_var.data_ptr() if run_var is not None else None, C.c_float(momentum),
-                                               sc.data_ptr(), sc.numel(), _stream(dev)), "baseconv_train_fwd")
+                                               wc.data_ptr(), sc.data_ptr(), sc.numel(), _stream(dev)), "baseconv_train_fwd")
+        ctx.wcache = wc
+        ctx.wversion = weight._version
+        ctx.weight_ref = weight
         ctx.save_for_backward(x, z, w, g, b, stats)
         ctx.geom = (B, Cin, H, W, Cout, k, stride)
         return y
@@ -86,10 +103,15 @@ class _BaseConvTrain(torch.autograd.Function):
         dw = torch.empty((Cout, Cin, k, k), dtype=torch.float32, device=dev)
         dgb = torch.empty((2, Cout), dtype=torch.float32, device=dev)
         sc = _scratch(dev, "block", lib.frlw_baseconv_train_scratch_bytes(B, H, W, Cin, Cout, k, stride), torch.uint8)
+        # the operand cache belongs to the forward of THIS graph only while the weight (and the cache) are untouched
+        # since: a second forward of the same layer before this backward would have overwritten it with the same
+        # weights' layout (fine), an in-place weight update in between would not (then lay out again)
+        fresh = ctx.weight_ref._version == ctx.wversion and _WCACHE.get(id(ctx.weight_ref), (None, None))[1] is ctx.wcache
         _lib.check(lib.frlw_baseconv_train_bwd(dy.data_ptr(), x.data_ptr(), z.data_ptr(), w.data_ptr(), g.data_ptr(),
                                                b.data_ptr(), stats[0].data_ptr(), stats[2].data_ptr(), B, H, W, Cin, Cout, k,
                                                stride, dz.data_ptr(), dx.data_ptr() if dx is not None else None,
-                                               dw.data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(), sc.data_ptr(),
+                                               dw.data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(),
+                                               ctx.wcache.data_ptr() if fresh else None, sc.data_ptr(),
                                                sc.numel(), _stream(dev)), "baseconv_train_bwd")
         return dx, dw, dgb[0], dgb[1], None, None, None, None, None
 

@@ -354,16 +354,20 @@ int frlw_bn_silu_bwd(const float *dy, const float *z, int64_t M, int C, const fl
  * + weight gradient.  x (B, H, W, Cin), z / y / dy / dz (B, Ho, Wo, Cout) NHWC; w and dw in torch's (Cout, Cin, k, k).
  * mean / var (biased) / invstd: (Cout).  running_mean / running_var (may be NULL) are updated in place like
  * nn.BatchNorm2d: r = (1 - momentum) r + momentum * {mean, unbiased variance}.
- * scratch: frlw_baseconv_train_scratch_bytes(...) bytes, reusable between calls. */
+ * scratch: frlw_baseconv_train_scratch_bytes(...) bytes, reusable between calls.
+ * w_cache (may be NULL): frlw_baseconv_weight_cache_floats(Cin, Cout, k) floats owned by the caller, one per layer: the
+ * forward then lays the weight out for itself AND for the data gradient in one launch, and the backward of the same
+ * step (weights unchanged in between) reuses it instead of laying the weight out again. */
+int64_t frlw_baseconv_weight_cache_floats(int Cin, int Cout, int k);
 int64_t frlw_baseconv_train_scratch_bytes(int B, int H, int W, int Cin, int Cout, int k, int stride);
 int frlw_baseconv_train_fwd(const float *x, const float *w, const float *gamma, const float *beta, float eps, int B, int H,
                             int W, int Cin, int Cout, int k, int stride, float *z, float *y, float *mean, float *var,
-                            float *invstd, float *running_mean, float *running_var, float momentum, void *scratch,
-                            int64_t scratch_bytes, frlw_stream_t stream);
+                            float *invstd, float *running_mean, float *running_var, float momentum, float *w_cache,
+                            void *scratch, int64_t scratch_bytes, frlw_stream_t stream);
 int frlw_baseconv_train_bwd(const float *dy, const float *x, const float *z, const float *w, const float *gamma,
                             const float *beta, const float *mean, const float *invstd, int B, int H, int W, int Cin,
                             int Cout, int k, int stride, float *dz, float *dx, float *dw, float *dgamma, float *dbeta,
-                            void *scratch, int64_t scratch_bytes, frlw_stream_t stream);
+                            const float *w_cache, void *scratch, int64_t scratch_bytes, frlw_stream_t stream);
 
 /* Measurement aid: a bare loop of v_mfma_f32_32x32x2_f32 (the instruction of every convolution here) on `blocks`
  * workgroups of four wavefronts, iters x 32 MFMAs (= iters x 131072 FLOP) per wavefront, operands = the 256 floats of
