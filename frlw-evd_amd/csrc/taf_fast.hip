@@ -570,273 +570,234 @@ __global__ __launch_bounds__(kFT) void kf_split(TileP q)
     }
 }
 
-// 5. One wavefront per (sequence, tile, sub-tile): no workgroup, no barrier.  The wavefront owns the 256 cells
-// [256 v, 256 v + 256) of the tile; lane l owns cells l, l + 64, l + 128, l + 192 of them (cell = pixel * 2 + polarity,
-// so polarity = l & 1 and the lane's pixels are 32 apart) with their K-deep FIFO, their running f32 sum and count of the
-// open window in REGISTERS -- consecutive lanes hold consecutive 32-byte FIFO rows of the (H, W, 2, K) state, so state
-// loads and stores sweep whole lines.  The list is consumed in passes of up to 256 records of the open window:
-//   1. every record takes a ticket from its cell's LDS counter with one returning atomic: lanes of one instruction are
-//      served in lane order and the four instructions of a pass are in stream order, so the ticket is the record's
-//      stream rank inside its cell -- a STABLE counting sort without any ordering pass;
-//   2. the owners read their cells' counts, a wavefront scan turns them into segment offsets;
-//   3. every record's f32 value goes to sorted[offset of its cell + ticket];
-//   4. every owner adds its cells' segments front to back into its registers: the reference's sequential
-//      `sum += t - 1` (generate_taf.py:25-26).
-// A record of a later window ends the pass; the open window is then closed (FIFO step in registers, :27-49).
+// 5. One workgroup of eight wavefronts per (sequence, tile, sub-tile of 256 cells).  The per-window sums of a cell do
+// not depend on each other -- only the FIFO steps that consume them are sequential -- so the eight wavefronts take ONE
+// WINDOW EACH (rounds of eight windows) and the FIFO steps follow with one cell per lane:
+//   phase 0  the list is scanned once for the first record of every window (the split is stable: a time-sorted stream
+//            gives a window-sorted list; a window that runs backwards switches the whole sub-tile to the general mode,
+//            where every wavefront sweeps the whole list for its window's records);
+//   phase 1  wavefront w, passes of up to 256 records of its window:
+//              1. every record takes a ticket from its cell's LDS counter with one returning atomic (two 16-bit
+//                 counters per word): lanes of one instruction are served in lane order and the four instructions of a
+//                 pass are in stream order, so the ticket is the record's stream rank inside its cell -- a STABLE
+//                 counting sort without any ordering pass;
+//              2. the lanes read the counts of their four cells, a wavefront scan turns them into segment offsets;
+//              3. every record's f32 value goes to sorted[offset of its cell + ticket];
+//              4. every lane adds its cells' segments front to back into registers: the reference's sequential
+//                 `sum += t - 1` (generate_taf.py:25-26);
+//            then (sum, count) of the 256 cells go to LDS;
+//   phase 2  lane c of the first four wavefronts owns cell c: K-deep FIFO row in registers (consecutive lanes hold
+//            consecutive 32-byte rows of the (H, W, 2, K) state: whole lines), one FIFO step per window in order
+//            (generate_taf.py:27-49), skipped for windows that are empty in the whole sequence (:40-41).
 // (ds_add_f32 would do the ordered sum in one instruction -- it applies same-address lanes in lane order with v_add_f32
 // rounding, checked by the self-test below -- but runs at 192 cycles per wave-instruction per CU: measured, not used.)
+constexpr int kWalkWaves = 8;
+constexpr int kWalkThreads = kWalkWaves * kWave;
 constexpr int kWalkRpt = 4;                 // records per lane and pass
 constexpr int kWalkChunk = kWalkRpt * kWave;
 
 template <bool K8>
-__global__ __launch_bounds__(kWave) void kf_taf_walk(TileP q)
+__global__ __launch_bounds__(kWalkThreads) void kf_taf_walk(TileP q)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t lds_buf[2 * kSubCells]; // cnt | off; the uint8 staging at the end
-    __shared__ float sorted[kWalkChunk];
+    __shared__ uint32_t s_cnt[kWalkWaves][kSubCells / 2];   // two 16-bit ticket counters per word
+    __shared__ uint16_t s_off[kWalkWaves][kSubCells];
+    __shared__ float s_sorted[kWalkWaves][kWalkChunk];
+    __shared__ __attribute__((aligned(16))) float res_sum[kWalkWaves][kSubCells]; // the uint8 staging at the end
+    __shared__ uint32_t res_cnt[kWalkWaves][kSubCells];
+    __shared__ uint32_t wstart[FRLW_MAX_WINDOWS + 1];
     __shared__ uint32_t thr[kLeakyLevels];
-    uint32_t *cnt = lds_buf, *off = lds_buf + kSubCells;
-    const int lane = threadIdx.x;
-    const int sg = blockIdx.x, g = sg / kFW, wv = sg - g * kFW;
+    __shared__ int s_unsorted;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int sg = blockIdx.x, g = sg / kFW, sub = sg - g * kFW;
     const int s = g / q.T, tile = g - s * q.T;
     if (q.hdr->status != 0) return; // data-dependent error: nothing is written (the caller re-runs the general path)
     const int K = K8 ? 8 : q.K;
-    for (int i = lane; i < kLeakyLevels; i += kWave) thr[i] = q.leaky_thr[i];
-    for (int i = lane; i < kSubCells; i += kWave) cnt[i] = 0u;
+    const int NW = q.n_windows;
+    for (int i = tid; i < kLeakyLevels; i += kWalkThreads) thr[i] = q.leaky_thr[i];
+    for (int i = lane; i < kSubCells / 2; i += kWave) s_cnt[wv][i] = 0u;
+    const uint32_t beg = q.sub[sg], end = q.sub[sg + 1];
+    for (int i = tid; i <= NW; i += kWalkThreads) wstart[i] = end;
+    if (tid == 0) s_unsorted = 0;
     const unsigned long long wmask = q.hdr->wmask[s];
     const bool use_mul = q.hdr->mul_bad == 0u; // checked for every r of the domain by kf_hist
     const double rcp = 1.0 / ((double)q.win + 1e-8);
-    const uint32_t beg = q.sub[sg], end = q.sub[sg + 1];
-    const int ty = tile / q.tiles_x, tx = tile - ty * q.tiles_x;
-    const int x0 = tx << q.twl, y0 = ty << q.thl, tw1 = (1 << q.twl) - 1;
-    const int pol = lane & 1;
-    const long long plane = (long long)q.H * q.W;
-    // cell j of this lane: pixel wv * 128 + 32 j + lane / 2 of the tile
-    bool ok[4];
-    uint32_t pixoff[4]; // y * W + x inside the sequence's frame
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int pt = wv * (kSubCells / 2) + 32 * j + (lane >> 1);
-        const int y = y0 + (pt >> q.twl), x = x0 + (pt & tw1);
-        ok[j] = y < q.H && x < q.W;
-        pixoff[j] = (uint32_t)(y * q.W + x);
-    }
-    float st[4][kMaxK], sum[4];
-    uint32_t num[4];
-
-    auto load_state = [&]() {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float *src = q.state + (((long long)s * plane + pixoff[j]) * 2 + pol) * K;
-#pragma unroll
-            for (int k = 0; k < kMaxK; ++k) st[j][k] = 0.0f;
-            sum[j] = 0.0f;
-            num[j] = 0u;
-            if (ok[j]) {
-                if (K8) {
-                    const float4 a = ((const float4 *)src)[0], b = ((const float4 *)src)[1];
-                    st[j][0] = a.x; st[j][1] = a.y; st[j][2] = a.z; st[j][3] = a.w;
-                    st[j][4] = b.x; st[j][5] = b.y; st[j][6] = b.z; st[j][7] = b.w;
-                } else {
-#pragma unroll
-                    for (int k = 0; k < kMaxK; ++k)
-                        if (k < K) st[j][k] = src[k];
-                }
-            }
-        }
-    };
-    // closes window w: FIFO step of the four cells (skipped when the window is empty in the whole sequence,
-    // generate_taf.py:40-41), accumulators back to zero
-    auto close_window = [&](int w) {
-        if ((wmask >> w) & 1ull) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                fifo_step(st[j], K, true, num[j], sum[j]);
-                __builtin_amdgcn_sched_barrier(0); // one cell at a time: the four divisions side by side cost registers
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { sum[j] = 0.0f; num[j] = 0u; }
-    };
     const uint32_t wfield = (1u << q.wb) - 1u;
     const int rshift = kCellBits + q.wb;
-
-    // The list is walked window by window.  Sorted mode (a time-sorted stream gives a window-sorted list: the partition
-    // and the split are stable): a pass takes the records of the open window at the front of the next 256; the first
-    // record of a later window ends it.  A record whose window runs backwards switches to the general mode (nothing has
-    // been written yet): one sweep over the whole list per window, taking that window's records wherever they are.
-    int cur_w = 0;
-    uint32_t ptr = beg;
-    bool general = false, need_state = true, have_next = false;
-    uint32_t m_next[kWalkRpt];
-#pragma unroll
-    for (int u = 0; u < kWalkRpt; ++u) m_next[u] = 0xffffffffu;
-#pragma nounroll
-    for (;;) {
-        if (need_state) { load_state(); need_state = false; } // ONE copy of the loads
-        if (ptr >= end) { // end of the list: close what is open
-            if (!general) {
-                for (; cur_w < q.n_windows; ++cur_w) close_window(cur_w);
-                break;
-            }
-            close_window(cur_w);
-            if (++cur_w == q.n_windows) break;
-            ptr = beg;
-            have_next = false;
-            continue;
+    __syncthreads();
+    // ---- phase 0: first record of every window; a window index that decreases = not window-sorted
+    for (uint32_t i = beg + tid; i < end; i += kWalkThreads) {
+        const uint32_t w = (q.rec2[i] >> kCellBits) & wfield;
+        const uint32_t wp = i > beg ? (q.rec2[i - 1] >> kCellBits) & wfield : 0xffffffffu;
+        if (wp == 0xffffffffu || w != wp) {
+            if (wp != 0xffffffffu && w < wp) s_unsorted = 1;
+            atomicMin(&wstart[w], i);
         }
-        // ---- one pass: the records [ptr, ptr + 256) of window cur_w -> sums / counts in their owners' registers
-        uint32_t m[kWalkRpt], rk[kWalkRpt];
-        if (have_next) {
+    }
+    __syncthreads();
+    const bool general = s_unsorted != 0;
+    if (tid == 0) { // a window without records starts where the next one does
+        if (general) atomicAdd(&q.hdr->filtered_tiles, 1u);
+        for (int w = NW - 1; w >= 0; --w) if (wstart[w] > wstart[w + 1]) wstart[w] = wstart[w + 1];
+    }
+    __syncthreads();
+
+    // phase-2 ownership: cell = tid (< 256): pixel 128 sub + tid / 2 of the tile, polarity tid & 1
+    const int ty = tile / q.tiles_x, tx = tile - ty * q.tiles_x;
+    const int x0 = tx << q.twl, y0 = ty << q.thl, tw1 = (1 << q.twl) - 1;
+    const long long plane = (long long)q.H * q.W;
+    const int pol = tid & 1;
+    const int pt = sub * (kSubCells / 2) + ((tid & (kSubCells - 1)) >> 1);
+    const int py = y0 + (pt >> q.twl), px = x0 + (pt & tw1);
+    const bool owner = tid < kSubCells, ok = owner && py < q.H && px < q.W;
+    float *srow = q.state + (((long long)s * plane + (long long)py * q.W + px) * 2 + pol) * K;
+    float st[kMaxK];
 #pragma unroll
-            for (int u = 0; u < kWalkRpt; ++u) m[u] = m_next[u];
+    for (int k = 0; k < kMaxK; ++k) st[k] = 0.0f;
+    if (ok) {
+        if (K8) {
+            const float4 a = ((const float4 *)srow)[0], b = ((const float4 *)srow)[1];
+            st[0] = a.x; st[1] = a.y; st[2] = a.z; st[3] = a.w; st[4] = b.x; st[5] = b.y; st[6] = b.z; st[7] = b.w;
         } else {
 #pragma unroll
-            for (int u = 0; u < kWalkRpt; ++u) {
-                const uint32_t i = ptr + (uint32_t)(u * kWave + lane);
-                m[u] = i < end ? q.rec2[i] : 0xffffffffu;
-            }
+            for (int k = 0; k < kMaxK; ++k)
+                if (k < K) st[k] = srow[k];
         }
-        uint32_t taken = 0;
-        bool order_ok = true, more = false;
-#pragma unroll
-        for (int u = 0; u < kWalkRpt; ++u) {
-            const bool valid = ptr + (uint32_t)(u * kWave + lane) < end;
-            const int w = (int)((m[u] >> kCellBits) & wfield);
-            const bool take = valid && w == cur_w;
-            const unsigned long long tm = __ballot(take), om = __ballot(valid && w != cur_w);
-            // sorted mode: the taken records must be a prefix of the chunk and nothing may be of an earlier window
-            if (__ballot(valid && w < cur_w)) order_ok = false;
-            if (tm && more) order_ok = false;
-            if (tm && om && (63 - __builtin_clzll(tm)) > __builtin_ctzll(om)) order_ok = false;
-            if (om) more = true;
-            taken += (uint32_t)__popcll(tm);
-            rk[u] = 0xffffffffu; // not taken
-            if (take) rk[u] = atomicAdd(&cnt[m[u] & 255u], 1u); // 1. the ticket = stream rank inside the cell
-        }
-        // the next pass starts right behind the taken records (sorted mode) / the chunk (general mode): its loads are
-        // issued now and land while this pass sorts and adds
-        {
-            const uint32_t nptr = general ? ptr + (uint32_t)kWalkChunk : ptr + taken;
-            have_next = nptr < end && (general || order_ok);
-            if (have_next) {
+    }
+
+    uint32_t *cnt = s_cnt[wv];
+    uint16_t *off = s_off[wv];
+    float *sorted = s_sorted[wv];
+#pragma nounroll
+    for (int g0 = 0; g0 < NW; g0 += kWalkWaves) {
+        // ---- phase 1: wavefront wv sums window g0 + wv
+        const int w = g0 + wv;
+        float sum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        uint32_t num[4] = {0u, 0u, 0u, 0u};
+        if (w < NW) {
+            const uint32_t lo = general ? beg : wstart[w], hi = general ? end : wstart[w + 1];
+#pragma nounroll
+            for (uint32_t ptr = lo; ptr < hi; ptr += kWalkChunk) {
+                uint32_t m[kWalkRpt], rk[kWalkRpt];
 #pragma unroll
                 for (int u = 0; u < kWalkRpt; ++u) {
-                    const uint32_t i = nptr + (uint32_t)(u * kWave + lane);
-                    m_next[u] = i < end ? q.rec2[i] : 0xffffffffu;
+                    const uint32_t i = ptr + (uint32_t)(u * kWave + lane);
+                    m[u] = i < hi ? q.rec2[i] : 0xffffffffu;
                 }
-            }
-        }
-        if (!general && !order_ok) {
-            if (lane == 0) atomicAdd(&q.hdr->filtered_tiles, 1u);
-            LDS_FENCE();
-            for (int i = lane; i < kSubCells; i += kWave) cnt[i] = 0u;
-            LDS_FENCE();
-            need_state = true;
-            general = true;
-            cur_w = 0;
-            ptr = beg;
-            continue;
-        }
-        LDS_FENCE();
-        // 2. counts of my four cells -> segment offsets (cells in the order lane-major, then j)
-        uint32_t n[4], o[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) n[j] = cnt[64 * j + lane];
+                for (int u = 0; u < kWalkRpt; ++u) {
+                    const bool take = ptr + (uint32_t)(u * kWave + lane) < hi && (int)((m[u] >> kCellBits) & wfield) == w;
+                    rk[u] = 0xffffffffu; // not taken
+                    if (take) { // 1. the ticket = stream rank inside the cell
+                        const uint32_t lc = m[u] & 255u, sh = 16u * (lc & 1u);
+                        rk[u] = (atomicAdd(&cnt[lc >> 1], 1u << sh) >> sh) & 0xffffu;
+                    }
+                }
+                LDS_FENCE();
+                // 2. counts of my four cells (64 j + lane) -> segment offsets (cells in the order lane-major, then j)
+                uint32_t n[4], o[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) cnt[64 * j + lane] = 0u;
-        {
-            const uint32_t tl = n[0] + n[1] + n[2] + n[3];
-            uint32_t inc = tl;
+                for (int j = 0; j < 4; ++j) n[j] = (cnt[32 * j + (lane >> 1)] >> (16 * (lane & 1))) & 0xffffu;
+                LDS_FENCE();
 #pragma unroll
-            for (int o2 = 1; o2 < kWave; o2 <<= 1) {
-                const uint32_t t = __shfl_up(inc, o2);
-                if (lane >= o2) inc += t;
-            }
-            o[0] = inc - tl; o[1] = o[0] + n[0]; o[2] = o[1] + n[1]; o[3] = o[2] + n[2];
-        }
+                for (int j = 0; j < 4; ++j)
+                    if (!(lane & 1)) cnt[32 * j + (lane >> 1)] = 0u; // after both lanes of the word have read it
+                {
+                    const uint32_t tl = n[0] + n[1] + n[2] + n[3];
+                    uint32_t inc = tl;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) off[64 * j + lane] = o[j];
-        LDS_FENCE();
-        // 3. values to their slots: t - 1 with t = (t - t_min) / (w + 1e-8) in f64 (generate_taf.py:215, :26)
+                    for (int o2 = 1; o2 < kWave; o2 <<= 1) {
+                        const uint32_t t = __shfl_up(inc, o2);
+                        if (lane >= o2) inc += t;
+                    }
+                    o[0] = inc - tl; o[1] = o[0] + n[0]; o[2] = o[1] + n[1]; o[3] = o[2] + n[2];
+                }
 #pragma unroll
-        for (int u = 0; u < kWalkRpt; ++u) {
-            if (rk[u] != 0xffffffffu) {
-                const uint32_t r = m[u] >> rshift;
-                const float v = use_mul ? (float)((double)r * rcp) - 1.0f : q.tlut[r];
-                sorted[off[m[u] & 255u] + rk[u]] = v;
-            }
-        }
-        LDS_FENCE();
-        // 4. every owner adds its segments front to back
-        uint32_t nmax = n[0] > n[1] ? n[0] : n[1];
-        nmax = n[2] > nmax ? n[2] : nmax;
-        nmax = n[3] > nmax ? n[3] : nmax;
+                for (int j = 0; j < 4; ++j) off[64 * j + lane] = (uint16_t)o[j];
+                LDS_FENCE();
+                // 3. values to their slots: t - 1 with t = (t - t_min) / (w + 1e-8) in f64 (generate_taf.py:215, :26)
+#pragma unroll
+                for (int u = 0; u < kWalkRpt; ++u) {
+                    if (rk[u] != 0xffffffffu) {
+                        const uint32_t r = m[u] >> rshift;
+                        const float v = use_mul ? (float)((double)r * rcp) - 1.0f : q.tlut[r];
+                        sorted[(uint32_t)off[m[u] & 255u] + rk[u]] = v;
+                    }
+                }
+                LDS_FENCE();
+                // 4. every lane adds its segments front to back, two slots per cell in flight
+                uint32_t nmax = n[0] > n[1] ? n[0] : n[1];
+                nmax = n[2] > nmax ? n[2] : nmax;
+                nmax = n[3] > nmax ? n[3] : nmax;
 #pragma nounroll
-        for (uint32_t a = 0; __ballot(a < nmax); ++a) {
-            float e[4];
+                for (uint32_t a = 0; __ballot(a < nmax); a += 2) {
+                    float e0[4], e1[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t at = o[j] + a;
-                e[j] = sorted[at < (uint32_t)kWalkChunk ? at : (uint32_t)kWalkChunk - 1u];
-            }
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t at = o[j] + a;
+                        e0[j] = sorted[at < (uint32_t)kWalkChunk ? at : (uint32_t)kWalkChunk - 1u];
+                        e1[j] = sorted[at + 1 < (uint32_t)kWalkChunk ? at + 1 : (uint32_t)kWalkChunk - 1u];
+                    }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float ns = sum[j] + e[j]; // sum += t - 1 in stream order, generate_taf.py:26
-                sum[j] = a < n[j] ? ns : sum[j];
+                    for (int j = 0; j < 4; ++j) {
+                        const float s0 = sum[j] + e0[j]; // sum += t - 1 in stream order, generate_taf.py:26
+                        sum[j] = a < n[j] ? s0 : sum[j];
+                        const float s1 = sum[j] + e1[j];
+                        sum[j] = a + 1 < n[j] ? s1 : sum[j];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) num[j] += n[j];
+                LDS_FENCE();
             }
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) num[j] += n[j];
-        LDS_FENCE();
-        if (general) {
-            ptr += kWalkChunk;
-        } else {
-            ptr += taken;
-            if (more) { close_window(cur_w); ++cur_w; } // the rest of the chunk belongs to later windows
+        for (int j = 0; j < 4; ++j) { res_sum[wv][64 * j + lane] = sum[j]; res_cnt[wv][64 * j + lane] = num[j]; }
+        __syncthreads();
+        // ---- phase 2: one cell per lane, the FIFO steps of this round's windows in order
+        if (owner) {
+#pragma nounroll
+            for (int ws = 0; ws < kWalkWaves && g0 + ws < NW; ++ws)
+                if ((wmask >> (g0 + ws)) & 1ull) fifo_step(st, K, true, res_cnt[ws][tid], res_sum[ws][tid]);
         }
+        __syncthreads();
     }
 
     // ---- write-out: state, optional f32 view (2K, H, W), optional uint8 leaky transform (K, 2, H, W)
-    uint8_t *ob = (uint8_t *)lds_buf; // [2K planes][128 pixels of the sub-tile]
-    LDS_FENCE();
+    uint8_t *ob = (uint8_t *)&res_sum[0][0]; // [2K planes][128 pixels of the sub-tile]
+    if (ok) {
+        if (K8) {
+            ((float4 *)srow)[0] = make_float4(st[0], st[1], st[2], st[3]);
+            ((float4 *)srow)[1] = make_float4(st[4], st[5], st[6], st[7]);
+        } else {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        if (ok[j]) {
-            float *dst = q.state + (((long long)s * plane + pixoff[j]) * 2 + pol) * K;
-            if (K8) {
-                ((float4 *)dst)[0] = make_float4(st[j][0], st[j][1], st[j][2], st[j][3]);
-                ((float4 *)dst)[1] = make_float4(st[j][4], st[j][5], st[j][6], st[j][7]);
-            } else {
-#pragma unroll
-                for (int k = 0; k < kMaxK; ++k)
-                    if (k < K) dst[k] = st[j][k];
-            }
-            if (q.view_f32) {
-                float *vw = q.view_f32 + (long long)s * 2 * K * plane + pixoff[j];
-#pragma unroll
-                for (int k = 0; k < kMaxK; ++k)
-                    if (k < K) vw[(long long)(2 * k + pol) * plane] = st[j][k]; // generate_taf.py:55
-            }
+            for (int k = 0; k < kMaxK; ++k)
+                if (k < K) srow[k] = st[k];
         }
-        if (q.out_u8) {
+        if (q.view_f32) {
+            float *vw = q.view_f32 + (long long)s * 2 * K * plane + (long long)py * q.W + px;
+#pragma unroll
+            for (int k = 0; k < kMaxK; ++k)
+                if (k < K) vw[(long long)(2 * k + pol) * plane] = st[k]; // generate_taf.py:55
+        }
+    }
+    if (q.out_u8) {
+        if (owner) {
             uint8_t lv[kMaxK];
-            leaky_u8_lookup_n<kMaxK>(st[j], thr, lv); // the eight table look-ups in flight together
+            leaky_u8_lookup_n<kMaxK>(st, thr, lv); // the eight table look-ups in flight together
 #pragma unroll
             for (int k = 0; k < kMaxK; ++k) {
                 if (k < K) {
                     const int ko = q.flip ? (K - 1 - k) : k;
-                    ob[(2 * ko + pol) * (kSubCells / 2) + 32 * j + (lane >> 1)] = lv[k];
+                    ob[(2 * ko + pol) * (kSubCells / 2) + (tid >> 1)] = lv[k];
                 }
             }
         }
-    }
-    if (q.out_u8) {
+        __syncthreads();
         // the (K, 2, H, W) volume leaves plane by plane in 16-pixel pieces: one 16-byte store where the row allows
-        LDS_FENCE();
-        for (int c = lane; c < 2 * K * 8; c += kWave) {
+        for (int c = tid; c < 2 * K * 8; c += kWalkThreads) {
             const int pl = c >> 3, part = c & 7;
-            const int pt = wv * (kSubCells / 2) + 16 * part;
-            const int y = y0 + (pt >> q.twl), x = x0 + (pt & tw1);
+            const int p16 = sub * (kSubCells / 2) + 16 * part;
+            const int y = y0 + (p16 >> q.twl), x = x0 + (p16 & tw1);
             if (y >= q.H || x >= q.W) continue;
             const uint8_t *src = ob + pl * (kSubCells / 2) + 16 * part;
             uint8_t *dst = q.out_u8 + ((long long)s * 2 * K + pl) * plane + (long long)y * q.W + x;
@@ -1000,8 +961,8 @@ int frlw_taf_encode_batch(const frlw_events_t *ev, const int64_t *seq_offsets, c
     q.hdr = (FastHeader *)w8;
     q.state = state; q.view_f32 = view_f32; q.out_u8 = out_u8;
     hipLaunchKernelGGL(kf_split, dim3(p.pairs), dim3(kFT), 0, st, q);
-    if (K == 8) hipLaunchKernelGGL(kf_taf_walk<true>, dim3(p.pairs * kFW), dim3(kWave), 0, st, q);
-    else hipLaunchKernelGGL(kf_taf_walk<false>, dim3(p.pairs * kFW), dim3(kWave), 0, st, q);
+    if (K == 8) hipLaunchKernelGGL(kf_taf_walk<true>, dim3(p.pairs * kFW), dim3(kWalkThreads), 0, st, q);
+    else hipLaunchKernelGGL(kf_taf_walk<false>, dim3(p.pairs * kFW), dim3(kWalkThreads), 0, st, q);
     HIP_TRY(hipGetLastError());
     return FRLW_OK;
 }
