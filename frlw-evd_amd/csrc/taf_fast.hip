@@ -38,6 +38,9 @@ constexpr int kMaxFastTiles = 1024;       // tiles per sequence (LDS of the scat
 constexpr int kMaxPairs = 8192;           // (sequence, tile) pairs per call (LDS of the tile scan)
 constexpr int kFastSlab = 32;             // chunks per slab of the two-level column scan
 constexpr int ST_MULBAD = 8;              // per-chunk flag next to the ST_* error bits (not an error)
+constexpr int kSplitSeg = 8192;           // records one workgroup of the sub-tile split handles
+constexpr int kSplitWhole = 8 * kSplitSeg; // tiles up to this many records are split by ONE workgroup (kf_split_whole)
+__host__ __device__ inline uint32_t split_segments(uint32_t n) { return n > (uint32_t)kSplitWhole ? (n + kSplitSeg - 1) / kSplitSeg : 0u; }
 
 struct SeqTab { // kernel argument, built on the host
     int n_seq;
@@ -69,7 +72,8 @@ struct FastPlan {
     int twl, thl, tiles_x, tiles_y, T;
     int bpw, chunk;
     int chunks, slabs, pairs;
-    size_t off_counts, off_slabtot, off_base, off_sub, off_errs, off_tlut, off_leaky, off_records, off_records2, bytes;
+    size_t off_counts, off_slabtot, off_base, off_sub, off_seg0, off_segcnt, off_errs, off_tlut, off_leaky, off_records, off_records2, bytes;
+    int max_segs;
 };
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -125,6 +129,9 @@ bool fast_layout(const int64_t *seq_offsets, const int64_t *t_start, int n_seq, 
     p.off_slabtot = off; off = align_up(off + (size_t)(sl > 0 ? sl : 1) * p.T * 4, 256);
     p.off_base = off;    off = align_up(off + (size_t)(p.pairs + 1) * 4, 256);
     p.off_sub = off;     off = align_up(off + ((size_t)p.pairs * kFW + 1) * 4, 256);
+    p.max_segs = (int)(n / kSplitSeg) + (int)(n / kSplitWhole) + 1; // only tiles above kSplitWhole: full + one partial each
+    p.off_seg0 = off;    off = align_up(off + (size_t)(p.pairs + 1) * 4, 256);
+    p.off_segcnt = off;  off = align_up(off + (size_t)p.max_segs * kFW * 4, 256);
     p.off_errs = off;    off = align_up(off + (size_t)(c > 0 ? c : 1) * 4, 256);
     p.off_tlut = off;    off = align_up(off + (size_t)(win + 1) * 4, 256);
     p.off_leaky = off;   off = align_up(off + (size_t)kLeakyLevels * 4, 256);
@@ -271,11 +278,11 @@ __global__ __launch_bounds__(kWave) void kf_slabscan(SeqTab S, uint32_t *counts,
 
 // slabtot[slab][b] -> exclusive prefix over the slabs of each sequence (in place); exclusive scan over the
 // (sequence, tile) pairs -> base[0..pairs]; resets the header and folds the per-chunk error flags into it.
-__global__ __launch_bounds__(kFT) void kf_tilescan(SeqTab S, uint32_t *slabtot, int T, uint32_t *base, FastHeader *hdr,
-                                                   const int32_t *errs, int chunks)
+__global__ __launch_bounds__(kFT) void kf_tilescan(SeqTab S, uint32_t *slabtot, int T, uint32_t *base, uint32_t *seg0,
+                                                   FastHeader *hdr, const int32_t *errs, int chunks)
 {
     __shared__ uint32_t tot[kMaxPairs];
-    __shared__ uint32_t wsum[kFW];
+    __shared__ uint32_t wsum[kFW], wsum2[kFW];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int pairs = S.n_seq * T;
     if (tid == 0) { hdr->status = 0; hdr->filtered_tiles = 0u; hdr->mul_bad = 0u; }
@@ -308,24 +315,28 @@ __global__ __launch_bounds__(kFT) void kf_tilescan(SeqTab S, uint32_t *slabtot, 
     const int b0 = tid * per;
     int b1 = b0 + per;
     if (b1 > pairs) b1 = pairs;
-    uint32_t sum = 0;
-    for (int b = b0; b < b1; ++b) sum += tot[b];
-    uint32_t inc = sum;
+    // two exclusive scans over the (sequence, tile) pairs: records -> base[], split segments (kSplitSeg records each,
+    // at least one per pair) -> seg0[]
+    uint32_t sum = 0, ssum = 0;
+    for (int b = b0; b < b1; ++b) { sum += tot[b]; ssum += split_segments(tot[b]); }
+    uint32_t inc = sum, sinc = ssum;
 #pragma unroll
     for (int off = 1; off < kWave; off <<= 1) {
-        const uint32_t v = __shfl_up(inc, off);
-        if (lane >= off) inc += v;
+        const uint32_t v = __shfl_up(inc, off), v2 = __shfl_up(sinc, off);
+        if (lane >= off) { inc += v; sinc += v2; }
     }
-    if (lane == kWave - 1) wsum[wv] = inc;
+    if (lane == kWave - 1) { wsum[wv] = inc; wsum2[wv] = sinc; }
     __syncthreads();
-    uint32_t pre = 0;
-    for (int k = 0; k < wv; ++k) pre += wsum[k];
-    uint32_t run = pre + inc - sum;
+    uint32_t pre = 0, spre = 0;
+    for (int k = 0; k < wv; ++k) { pre += wsum[k]; spre += wsum2[k]; }
+    uint32_t run = pre + inc - sum, srun = spre + sinc - ssum;
     for (int b = b0; b < b1; ++b) {
         base[b] = run;
+        seg0[b] = srun;
         run += tot[b];
+        srun += split_segments(tot[b]);
     }
-    if (tid == kFT - 1) base[pairs] = pre + inc;
+    if (tid == kFT - 1) { base[pairs] = pre + inc; seg0[pairs] = spre + sinc; }
 }
 
 // ---- 3. stable scatter ---------------------------------------------------------------------------------
@@ -460,6 +471,9 @@ struct TileP {
     uint32_t *rec2;        // the same records, inside every tile sub-tile-major (split output)
     const uint32_t *base;  // [pairs + 1]
     uint32_t *sub;         // [pairs * 16 + 1] first record of every sub-tile in rec2
+    const uint32_t *seg0;  // [pairs + 1] first split segment of every (sequence, tile) pair
+    uint32_t *segcnt;      // [segments][16] records of every sub-tile in a segment, then their offsets inside the sub-tile
+    int pairs;
     const float *tlut;
     const uint32_t *leaky_thr;
     FastHeader *hdr;
@@ -487,23 +501,56 @@ __device__ __forceinline__ void fifo_step(float (&st)[kMaxK], int K, bool has, u
 
 #define LDS_FENCE() asm volatile("" ::: "memory")
 
-// 4. One workgroup per (sequence, tile): reorders the tile's records sub-tile-major (sub-tile = the 256 cells
-// [256 v, 256 v + 256) one wavefront of kf_taf_walk owns), STABLY, so that every sub-tile's list is still in stream
-// order.  Pass 1 counts the 16 sub-tiles; pass 2 ranks chunk by chunk with one returning LDS atomic per record on
+__device__ __forceinline__ int pair_of_segment(const uint32_t *seg0, int pairs, uint32_t seg)
+{
+    int lo = 0, hi = pairs; // largest g with seg0[g] <= seg
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (seg0[mid] <= seg) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ void split_count_segment(const TileP &q, uint32_t seg, uint32_t (*wtot)[kFW])
+{
+    const int tid = threadIdx.x, wv = tid >> 6;
+    if (seg >= q.seg0[q.pairs]) return;
+    const int g = pair_of_segment(q.seg0, q.pairs, seg);
+    const uint32_t beg = q.base[g] + (seg - q.seg0[g]) * (uint32_t)kSplitSeg;
+    const uint32_t end = q.base[g + 1] - beg < (uint32_t)kSplitSeg ? q.base[g + 1] : beg + kSplitSeg;
+    if (tid < kFW * kFW) (&wtot[0][0])[tid] = 0u;
+    __syncthreads();
+    for (uint32_t i = beg + tid; i < end; i += kFT) atomicAdd(&wtot[wv][(q.rec[i] & (kCells - 1)) >> 8], 1u);
+    __syncthreads();
+    if (tid < kFW) {
+        uint32_t t = 0;
+#pragma unroll
+        for (int w = 0; w < kFW; ++w) t += wtot[w][tid];
+        q.segcnt[(long long)seg * kFW + tid] = t;
+    }
+}
+
+// 4a. Tiles of ordinary size (at most kSplitWhole records): ONE workgroup per (sequence, tile) reorders the tile's
+// records sub-tile-major, STABLY.  Pass 1 counts the 16 sub-tiles; pass 2 ranks chunk by chunk with one returning LDS atomic per record on
 // (round, wavefront, sub-tile) counters: lanes of one instruction are served in lane order, (round, wavefront) is the
 // stream order of the 64-record batches.
-constexpr int kSplitRpt = 8;
-__global__ __launch_bounds__(kFT) void kf_split(TileP q)
+__global__ __launch_bounds__(kFT) void kf_split_whole(TileP q)
 {
-    constexpr int RPT = kSplitRpt, CH = RPT * kFT, NE = RPT * kFW;
+    constexpr int RPT = kSplitSeg / kFT, CH = RPT * kFT, NE = RPT * kFW;
     __shared__ uint32_t scnt[RPT][kFW][kFW]; // [round][wavefront][sub-tile]
     __shared__ uint32_t wtot[kFW][kFW];      // pass 1: [wavefront][sub-tile]
     __shared__ uint32_t run[kFW];            // next free slot of every sub-tile's list
     __shared__ uint32_t btot[kFW];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int g = blockIdx.x;
     if (q.hdr->status != 0) return;
+    if ((int)blockIdx.x >= q.pairs) { // the blocks behind the tiles: one segment of a skewed tile each (4b, counting)
+        split_count_segment(q, blockIdx.x - (uint32_t)q.pairs, wtot);
+        return;
+    }
+    const int g = blockIdx.x;
     const uint32_t beg = q.base[g], end = q.base[g + 1];
+    if (g == q.pairs - 1 && tid == 0) q.sub[(long long)q.pairs * kFW] = end; // end of the last sub-tile's list
+    if (end - beg > (uint32_t)kSplitWhole) return; // a skewed tile: left to the segment kernels below
     if (tid < kFW * kFW) (&wtot[0][0])[tid] = 0u;
     __syncthreads();
     for (uint32_t i = beg + tid; i < end; i += kFT) atomicAdd(&wtot[wv][(q.rec[i] & (kCells - 1)) >> 8], 1u);
@@ -520,7 +567,6 @@ __global__ __launch_bounds__(kFT) void kf_split(TileP q)
         }
         run[tid] = beg + inc - t;
         q.sub[(long long)g * kFW + tid] = beg + inc - t;
-        if (g == (int)gridDim.x - 1 && tid == kFW - 1) q.sub[(long long)gridDim.x * kFW] = end;
     }
     for (uint32_t c0 = beg; c0 < end; c0 += CH) {
         const uint32_t nrec = end - c0 < (uint32_t)CH ? end - c0 : (uint32_t)CH;
@@ -567,6 +613,84 @@ __global__ __launch_bounds__(kFT) void kf_split(TileP q)
         }
         __syncthreads();
         if (tid < kFW) run[tid] += btot[tid];
+    }
+}
+
+// 4b. Skewed tiles (more than kSplitWhole records).  Reorders every tile's records sub-tile-major (sub-tile = the 256 cells [256 v, 256 v + 256) one workgroup of
+// kf_taf_walk owns), STABLY, so that every sub-tile's list is still in stream order.  A tile's list is cut into segments
+// of 8192 records, one workgroup each -- a tile that holds a large share of the stream (skew) is split by hundreds of
+// workgroups instead of one:
+//   kf_split_count    records of every sub-tile in the segment
+//   kf_split_offsets  one 16-lane group per tile: running sums over its segments -> where each segment's records of
+//                     sub-tile v go inside v's list, and where v's list starts (sub[])
+//   kf_split_place    ranks inside the segment with one returning LDS atomic per record on (round, wavefront, sub-tile)
+//                     counters: lanes of one instruction are served in lane order, (round, wavefront) is the stream
+//                     order of the 64-record batches.
+constexpr int kSplitRpt = kSplitSeg / kFT;
+__global__ __launch_bounds__(kFT) void kf_split_place(TileP q)
+{
+    constexpr int RPT = kSplitRpt, NE = RPT * kFW;
+    __shared__ uint32_t scnt[RPT][kFW][kFW]; // [round][wavefront][sub-tile]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t seg = blockIdx.x;
+    if (q.hdr->status != 0 || seg >= q.seg0[q.pairs]) return;
+    const int g = pair_of_segment(q.seg0, q.pairs, seg);
+    const uint32_t beg = q.base[g] + (seg - q.seg0[g]) * (uint32_t)kSplitSeg;
+    const uint32_t end = q.base[g + 1] - beg < (uint32_t)kSplitSeg ? q.base[g + 1] : beg + kSplitSeg;
+    const uint32_t nrec = end - beg;
+    for (int i = tid; i < RPT * kFW * kFW; i += kFT) (&scnt[0][0][0])[i] = 0u;
+    // where this segment's records of sub-tile v (= this wavefront) go: v's list starts behind the lists of the
+    // sub-tiles before it, and the earlier segments of the tile come first inside it.  Every workgroup adds up the
+    // tile's segment counts for itself (<= a few hundred segments x 16 values, L2-resident).
+    __shared__ uint32_t vtot[kFW];
+    uint32_t before = 0, total = 0;
+    for (uint32_t sg = q.seg0[g] + lane; sg < q.seg0[g + 1]; sg += kWave) {
+        const uint32_t c = q.segcnt[(long long)sg * kFW + wv];
+        total += c;
+        if (sg < seg) before += c;
+    }
+#pragma unroll
+    for (int o2 = 32; o2 >= 1; o2 >>= 1) { before += __shfl_xor(before, o2); total += __shfl_xor(total, o2); }
+    if (lane == 0) vtot[wv] = total;
+    __syncthreads();
+    uint32_t vstart = q.base[g];
+    for (int k = 0; k < wv; ++k) vstart += vtot[k];
+    if (seg == q.seg0[g] && lane == 0) q.sub[(long long)g * kFW + wv] = vstart; // the tile's first segment publishes sub[]
+    uint32_t m[RPT], rk[RPT];
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) {
+        const uint32_t i = (uint32_t)(u * kFT + tid);
+        m[u] = i < nrec ? q.rec[beg + i] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) {
+        const uint32_t i = (uint32_t)(u * kFT + tid);
+        rk[u] = 0u;
+        if (i < nrec) rk[u] = atomicAdd(&scnt[u][wv][(m[u] & (kCells - 1)) >> 8], 1u);
+    }
+    __syncthreads();
+    {
+        // wavefront b: exclusive prefix of sub-tile b's counts over (round, wavefront) = stream order, on top of where
+        // this segment's records of b go in b's list
+        uint32_t v0 = 0, v1 = 0;
+        const int e0 = 2 * lane, e1 = 2 * lane + 1;
+        if (e0 < NE) v0 = scnt[e0 / kFW][e0 % kFW][wv];
+        if (e1 < NE) v1 = scnt[e1 / kFW][e1 % kFW][wv];
+        uint32_t inc = v0 + v1;
+#pragma unroll
+        for (int o2 = 1; o2 < kWave; o2 <<= 1) {
+            const uint32_t t = __shfl_up(inc, o2);
+            if (lane >= o2) inc += t;
+        }
+        const uint32_t ex = inc - (v0 + v1) + vstart + before;
+        if (e0 < NE) scnt[e0 / kFW][e0 % kFW][wv] = ex;
+        if (e1 < NE) scnt[e1 / kFW][e1 % kFW][wv] = ex + v0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) {
+        const uint32_t i = (uint32_t)(u * kFT + tid);
+        if (i < nrec) q.rec2[scnt[u][wv][(m[u] & (kCells - 1)) >> 8] + rk[u]] = m[u];
     }
 }
 
@@ -871,7 +995,8 @@ void launch_fast(const FastGeom &G, const SeqTab &S, const FastPlan &p, char *w8
         (void)hipFuncSetAttribute((const void *)kf_scatter<HAS_MAP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc);
     hipLaunchKernelGGL((kf_hist<HAS_MAP>), dim3(p.chunks), dim3(kFT), (size_t)p.T * 4, st, G, S, counts, errs, tlut, leaky);
     hipLaunchKernelGGL(kf_slabscan, dim3((p.T + kWave - 1) / kWave, p.slabs), dim3(kWave), 0, st, S, counts, p.T, slabtot);
-    hipLaunchKernelGGL(kf_tilescan, dim3(1), dim3(kFT), 0, st, S, slabtot, p.T, base, hdr, errs, p.chunks);
+    hipLaunchKernelGGL(kf_tilescan, dim3(1), dim3(kFT), 0, st, S, slabtot, p.T, base, (uint32_t *)(w8 + p.off_seg0), hdr, errs,
+                       p.chunks);
     hipLaunchKernelGGL((kf_scatter<HAS_MAP>), dim3(p.chunks), dim3(kFT), lds_sc, st, G, S, counts, slabtot, base, records, hdr);
 }
 
@@ -904,6 +1029,8 @@ size_t frlw_taf_batch_workspace_bytes(int64_t n_events, int n_seq, int H, int W,
     off = align_up(off + slabs * p.T * 4, 256);
     off = align_up(off + (size_t)(p.pairs + 1) * 4, 256);
     off = align_up(off + ((size_t)p.pairs * kFW + 1) * 4, 256);
+    off = align_up(off + (size_t)(p.pairs + 1) * 4, 256);
+    off = align_up(off + ((size_t)(n_events / kSplitSeg) + (size_t)(n_events / kSplitWhole) + 1) * kFW * 4, 256);
     off = align_up(off + chunks * 4, 256);
     off = align_up(off + (size_t)(window_us + 1) * 4, 256);
     off = align_up(off + (size_t)kLeakyLevels * 4, 256);
@@ -956,11 +1083,15 @@ int frlw_taf_encode_batch(const frlw_events_t *ev, const int64_t *seq_offsets, c
     q.rec2 = (uint32_t *)(w8 + p.off_records2);
     q.base = (const uint32_t *)(w8 + p.off_base);
     q.sub = (uint32_t *)(w8 + p.off_sub);
+    q.seg0 = (const uint32_t *)(w8 + p.off_seg0);
+    q.segcnt = (uint32_t *)(w8 + p.off_segcnt);
+    q.pairs = p.pairs;
     q.tlut = (const float *)(w8 + p.off_tlut);
     q.leaky_thr = (const uint32_t *)(w8 + p.off_leaky);
     q.hdr = (FastHeader *)w8;
     q.state = state; q.view_f32 = view_f32; q.out_u8 = out_u8;
-    hipLaunchKernelGGL(kf_split, dim3(p.pairs), dim3(kFT), 0, st, q);
+    hipLaunchKernelGGL(kf_split_whole, dim3(p.pairs + p.max_segs), dim3(kFT), 0, st, q); // tiles, then segment counts
+    hipLaunchKernelGGL(kf_split_place, dim3(p.max_segs), dim3(kFT), 0, st, q);
     if (K == 8) hipLaunchKernelGGL(kf_taf_walk<true>, dim3(p.pairs * kFW), dim3(kWalkThreads), 0, st, q);
     else hipLaunchKernelGGL(kf_taf_walk<false>, dim3(p.pairs * kFW), dim3(kWalkThreads), 0, st, q);
     HIP_TRY(hipGetLastError());
