@@ -1,28 +1,35 @@
 #!/usr/bin/env python3
-"""bench.py -- the hot path of BASELINE.json on MI355X: TAF encode (Mevents/s) + roofline + CPU baseline.
+"""bench.py -- the hot path of BASELINE.json on MI355X: TAF encode (Mevents/s) + roofline + CPU baseline, then the other
+rows of SURVEY.md section 8(d): GEN1-shaped and batched encodes, Event Volume, detector forward, train step.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload taf_mpx|taf_gen1|ev_gen1]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload taf_mpx|taf_gen1] [--hotspot]
 
-A step = one pass of the fused TAF encoder (libfrlw_evd.so, `frlw_taf_encode`) over one batch of
-synthetic DAT records already resident in HBM: SURVEY.md section 8d cfg 3 -- seed 1003, 10 M events,
-1280x720 native, 8 windows x 10 ms, K = 8, leaky transform + uint8 output, FIFO state carried from
-step to step like consecutive labels of one sequence (generate_taf.py:175-186).
+A step = one pass of the TAF encoder over one batch of synthetic DAT records already resident in HBM: SURVEY.md 8(d)
+cfg 3 -- seed 1003, 10 M events, 1280x720 native, 8 windows x 10 ms, K = 8, leaky transform + uint8 output, FIFO state
+carried from step to step like consecutive labels of one sequence (generate_taf.py:175-186) -- through
+``frlw_taf_encode_batch`` (csrc/taf_fast.hip; the general path ``frlw_taf_encode`` is timed beside it).
 
-N > 1: one process per GPU (torch.distributed.run), every rank encodes its own independent stream
-(the path shards by sequence, no data-path collective) -> weak scaling; the timed region is
-bracketed by barrier + synchronize and the MAX over ranks is reported.
+N > 1: one process per GPU (torch.distributed.run), every rank encodes its own independent stream (the path shards by
+sequence, no data-path collective) -> weak scaling; the timed region is bracketed by barrier + synchronize and the MAX
+over ranks is reported.  The train leg runs under DistributedDataParallel (RCCL) and reports how much of the gradient
+all-reduce is exposed.
 
-The JSON line also carries
-  roofline     algorithmic bytes of the encode (8 B/event + FIFO state read + write + uint8 out) over
-               the device time of one encode measured with HIP events on the launch stream;
-  cpu_baseline the CPU oracle (oracle/frlw_oracle.c, a port of the reference's algorithm, 1 thread)
-               timed on this host on the same workload (rank 0, N = 1 only).
+The JSON line carries
+  roofline     algorithmic bytes of the encode (8 B/event + FIFO state read + write + uint8 out) over the device time
+               of one encode measured with HIP events on the launch stream; ``frac`` against the 8 TB/s of the data
+               sheet, ``frac_of_copy`` against the float4 copy rate measured in this run; ``traffic`` = HBM bytes per
+               encode from a separate rocprofv3 --pmc pass (profiles/traffic_<workload>.json), only while the kernel
+               sources are the ones that pass measured;
+  cpu_baseline the CPU oracle (oracle/frlw_oracle.c, a port of the reference's algorithm) timed on this host on the same
+               workload with 1 thread and with all cores (one independent stream per thread), rank 0 at N = 1 only.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
 import time
+from concurrent.futures import ThreadPoolExecutor
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -34,12 +41,89 @@ WORKLOADS = {
     "taf_mpx": (1003, 10_000_000, 720, 1280, 80_000, 8, 10_000, 8),
     "taf_gen1": (1005, 1_000_000, 240, 304, 80_000, 8, 10_000, 8),
 }
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, f32 in / f32 accumulate
 
 
 def taf_algorithmic_bytes(n, H, W, K):
-    """SURVEY.md section 8d: events once (8 B DAT record), FIFO state read once + written once, uint8 out once."""
+    """SURVEY.md 8(d): events once (8 B DAT record), FIFO state read once + written once, uint8 out once."""
     return 8 * n + 2 * (4 * 2 * K * H * W) + 2 * K * H * W
+
+
+def ev_algorithmic_bytes(n, H, W, bins):
+    """SURVEY.md 8(d) cfg 2: 8 B per event + the f32 (2 * bins, H, W) output."""
+    return 8 * n + 4 * 2 * bins * H * W
+
+
+def kernel_source_sha():
+    """Identity of the encoder kernels a PMC traffic figure belongs to."""
+    h = hashlib.sha256()
+    for name in ("taf_fast.hip", "partition.hip", "encoders.hip", "frlw_common.h"):
+        with open(os.path.join(ROOT, "frlw-evd_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+class Timer:
+    """K timed steps between barrier + synchronize on both sides; device time by HIP events on the launch stream."""
+
+    def __init__(self, torch, fd):
+        self.torch, self.fd = torch, fd
+
+    def run(self, fn, steps, warmup):
+        torch = self.torch
+        for _ in range(warmup):
+            fn()
+        self.fd.barrier_sync()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(steps):
+            fn()
+        e1.record()
+        self.fd.barrier_sync()
+        wall = time.perf_counter() - t0
+        wall, dev_ms = self.fd.max_over_ranks([wall, e0.elapsed_time(e1) / steps])
+        return wall / steps, dev_ms
+
+
+def roofline(alg_bytes, dev_ms, kernel, copy_gbs, units):
+    achieved = alg_bytes / (dev_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_of_copy": round(achieved / copy_gbs, 4) if copy_gbs else None,
+            "copy_GBs_measured": round(copy_gbs, 1) if copy_gbs else None, "algorithmic_bytes": alg_bytes,
+            "units_per_launch": units, "device_ms": round(dev_ms, 4), "traffic": None}
+
+
+def copy_bandwidth(torch):
+    """float32 copy of 1 GiB (read + write = 2 GiB of traffic) with torch's vectorised copy kernel."""
+    a = torch.empty(256 << 20, dtype=torch.float32, device="cuda")
+    b = torch.empty_like(a)
+    for _ in range(2):
+        b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2 * a.numel() * 4 / (e0.elapsed_time(e1) / 5 * 1e-3) / 1e9
+
+
+def dev_records(torch, synth, ev):
+    return torch.from_numpy(synth.to_dat8(ev).view(np.uint8).reshape(-1, 8)).cuda()
 
 
 def main():
@@ -53,7 +137,7 @@ def main():
     ap.add_argument("--no-detector", action="store_true", help="skip the detector forward leg")
     ap.add_argument("--det-batch", type=int, default=32)
     ap.add_argument("--no-train", action="store_true", help="skip the train-step leg")
-    ap.add_argument("--no-also", action="store_true", help="skip the GEN1-shaped TAF leg (clean per-kernel profiles)")
+    ap.add_argument("--no-also", action="store_true", help="skip the other encoder workloads (clean per-kernel profiles)")
     ap.add_argument("--train-batch", type=int, default=64, help="per-GPU batch of the train-step leg")
     ap.add_argument("--local_rank", "--local-rank", type=int, default=None)
     args = ap.parse_args()
@@ -70,49 +154,38 @@ def main():
     torch.cuda.set_device(local_rank)
     n_gpus = world
     _lib.load()
+    timer = Timer(torch, fd)
+    copy_gbs = copy_bandwidth(torch)
 
     seed, n, H, W, t_span, n_win, win_us, K = WORKLOADS[args.workload]
     ev = synth.synth_events(seed + 7919 * rank, n, W, H, t_span, hotspot=args.hotspot)
     dat_h = synth.to_dat8(ev)
     dat = torch.from_numpy(dat_h.view(np.uint8).reshape(-1, 8)).cuda()
     state = torch.full((H, W, 2, K), -6000.0, device="cuda")
+    use_fast = n >= er.FAST_MIN_EVENTS
 
-    def step():
-        return er.encode_taf_dat(dat, (H, W), state, 0, win_us, n_win, K, want_view=False, want_u8=True,
-                                 flip_k=True, check=False)
+    def step(fast=use_fast):
+        return er.encode_taf_dat(dat, (H, W), state, 0, win_us, n_win, K, want_view=False, want_u8=True, flip_k=True,
+                                 check=False, fast=fast)
 
-    sync_all = fd.barrier_sync
-
-    # correctness guard: data-dependent status of the first encode must be clean
-    u8, _ = er.encode_taf_dat(dat, (H, W), state, 0, win_us, n_win, K, check=True)
-    for _ in range(args.warmup):
-        step()
-    sync_all()
-    e0 = torch.cuda.Event(enable_timing=True)
-    e1 = torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record()
-    for _ in range(args.steps):
-        step()
-    e1.record()
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    dev_ms = e0.elapsed_time(e1) / args.steps  # HIP events on the launch stream (torch's current stream)
-    elapsed, dev_ms = fd.max_over_ranks([elapsed, dev_ms])
-
-    ms_per_step = elapsed / args.steps * 1e3
-    value = n_gpus * n / (elapsed / args.steps) / 1e6
+    # correctness guard: data-dependent status of the first encode must be clean (and the fast path must have taken it)
+    if use_fast:
+        er.encode_taf_batch(dat, [0, n], (H, W), state.view(1, H, W, 2, K), 0, win_us, n_win, K, check=True)
+    else:
+        er.encode_taf_dat(dat, (H, W), state, 0, win_us, n_win, K, check=True, fast=False)
+    per_step, dev_ms = timer.run(step, args.steps, args.warmup)
     alg_bytes = taf_algorithmic_bytes(n, H, W, K)
-    achieved = alg_bytes / (dev_ms * 1e-3) / 1e9
-
+    kernels = ("frlw_taf_encode_batch = kf_hist + kf_slabscan + kf_tilescan + kf_scatter + kf_split_whole + kf_split_place + "
+               "kf_taf_walk (dominant: kf_taf_walk)") if use_fast else \
+        "frlw_taf_encode = k_hist + k_slabscan + k_tilescan + k_scatter + k_taf_tile (dominant: k_taf_tile)"
     result = {
         "metric": "TAF encode throughput (Mevents/s)",
-        "value": round(value, 2),
+        "value": round(n_gpus * n / per_step / 1e6, 2),
         "unit": "Mevents/s",
         "n_gpus": n_gpus,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 4),
+        "ms_per_step": round(per_step * 1e3, 4),
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -123,103 +196,222 @@ def main():
                         f"TAF K={K} encode + leaky transform + uint8, {n} events, {W}x{H}, "
                         f"{n_win} windows x {win_us} us, raw 8-byte DAT records resident in HBM"
                         + (", hotspot" if args.hotspot else ""),
+            "path": "fast (csrc/taf_fast.hip)" if use_fast else "general (csrc/encoders.hip)",
             "events_per_step_per_gpu": n,
             "parallelism": f"sequence-sharded x{n_gpus} (no collective)",
         },
-        "roofline": {
-            "bound": "hbm",
-            "kernel": "frlw_taf_encode = k_hist + k_slabscan + k_tilescan + k_scatter + k_taf_tile (dominant: k_taf_tile)",
-            "achieved": round(achieved, 1),
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "algorithmic_bytes": alg_bytes,
-            "device_ms_per_encode": round(dev_ms, 4),
-            "traffic": None,
-        },
+        "roofline": roofline(alg_bytes, dev_ms, kernels, copy_gbs, f"{n} events"),
     }
-    traffic_file = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
-    if os.path.exists(traffic_file):  # PMC passes are separate runs (tools/profile.sh); per-encode HBM bytes
+    traffic_file = os.path.join(ROOT, "profiles", f"traffic_{args.workload}{'_hotspot' if args.hotspot else ''}.json")
+    if os.path.exists(traffic_file):  # PMC passes are separate runs (tools/pmc_cmd.sh): per-encode HBM bytes
         with open(traffic_file) as f:
-            result["roofline"]["traffic"] = json.load(f).get("hbm_bytes_per_encode")
+            tr = json.load(f)
+        if tr.get("kernel_source_sha") == kernel_source_sha():
+            result["roofline"]["traffic"] = tr.get("hbm_bytes_per_encode")
+            result["roofline"]["traffic_source"] = f"{os.path.relpath(traffic_file, ROOT)} (separate rocprofv3 --pmc passes, {tr.get('source')})"
+        else:
+            result["roofline"]["traffic_note"] = "kernel sources changed since the PMC pass in profiles/: not reported"
+    if use_fast:  # the general path on the same workload, for comparison
+        st2 = state.clone()
+        per2, dev2 = timer.run(lambda: er.encode_taf_dat(dat, (H, W), st2, 0, win_us, n_win, K, check=False, fast=False),
+                               max(5, args.steps // 5), 2)
+        result["general_path"] = {"value": round(n_gpus * n / per2 / 1e6, 2), "unit": "Mevents/s", "device_ms": round(dev2, 4)}
 
     if args.workload == "taf_mpx" and not args.no_also:
-        # the same encoder at the GEN1 sensor shape BASELINE.json's metric names (304x240, 1 M events): launch /
-        # latency bound at this size, reported next to the headline number
-        s2, n2, H2, W2, t2, nw2, wu2, K2 = WORKLOADS["taf_gen1"]
-        ev2 = synth.synth_events(s2 + 7919 * rank, n2, W2, H2, t2)
-        dat2 = torch.from_numpy(synth.to_dat8(ev2).view(np.uint8).reshape(-1, 8)).cuda()
-        st2 = torch.full((H2, W2, 2, K2), -6000.0, device="cuda")
-        for _ in range(3):
-            er.encode_taf_dat(dat2, (H2, W2), st2, 0, wu2, nw2, K2, check=False)
-        sync_all()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            er.encode_taf_dat(dat2, (H2, W2), st2, 0, wu2, nw2, K2, check=False)
-        sync_all()
-        dt2, = fd.max_over_ranks([time.perf_counter() - t0])
-        result["also"] = [{"workload": "taf_gen1 (the GEN1 304x240 shape BASELINE.json's metric names): TAF K=8 encode + leaky + "
-                                       "uint8, 1000000 events, 304x240, 8 windows",
-                           "value": round(n_gpus * n2 / (dt2 / args.steps) / 1e6, 2), "unit": "Mevents/s",
-                           "ms_per_step": round(dt2 / args.steps * 1e3, 4)}]
-        # BASELINE.json configs[1]: Event Volume, 1 M events, 304x240, 5 bins (bit-exactness is the tests' job; this is its rate)
-        ev4 = synth.synth_events(1002 + 7919 * rank, 1_000_000, W2, H2, 250_000)
-        dat4 = torch.from_numpy(synth.to_dat8(ev4).view(np.uint8).reshape(-1, 8)).cuda()
-        for _ in range(3):
-            er.encode_ev_dat(dat4, (H2, W2), 250_000, 250_000, volume_bins=5, check=False)
-        sync_all()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            er.encode_ev_dat(dat4, (H2, W2), 250_000, 250_000, volume_bins=5, check=False)
-        sync_all()
-        dt4, = fd.max_over_ranks([time.perf_counter() - t0])
-        result["also"].append({"workload": "ev_gen1 (BASELINE.json configs[1]): Event Volume 5 bins, 1000000 events, 304x240",
-                               "value": round(n_gpus * 1_000_000 / (dt4 / args.steps) / 1e6, 2), "unit": "Mevents/s",
-                               "ms_per_step": round(dt4 / args.steps * 1e3, 4)})
-        if not args.hotspot:
-            # SURVEY.md section 8d "report both": the contention variant of the headline workload (25 % of the events in
-            # a sigma = 8 px blob -> a few tiles hold most of them; hot tiles are split over workgroups)
-            ev3 = synth.synth_events(seed + 7919 * rank, n, W, H, t_span, hotspot=True)
-            dat3 = torch.from_numpy(synth.to_dat8(ev3).view(np.uint8).reshape(-1, 8)).cuda()
-            st3 = torch.full((H, W, 2, K), -6000.0, device="cuda")
-            hs = max(3, min(10, args.steps))
-            for _ in range(2):
-                er.encode_taf_dat(dat3, (H, W), st3, 0, win_us, n_win, K, check=False)
-            sync_all()
-            t0 = time.perf_counter()
-            for _ in range(hs):
-                er.encode_taf_dat(dat3, (H, W), st3, 0, win_us, n_win, K, check=False)
-            sync_all()
-            dt3, = fd.max_over_ranks([time.perf_counter() - t0])
-            result["also"].append({"workload": f"{args.workload}, hotspot variant (25 % of the events in a sigma = 8 px blob)",
-                                   "value": round(n_gpus * n / (dt3 / hs) / 1e6, 2), "unit": "Mevents/s",
-                                   "ms_per_step": round(dt3 / hs * 1e3, 4)})
-            del dat3, st3, ev3
+        result["also"] = bench_also(args, torch, synth, er, timer, rank, n_gpus, copy_gbs)
     if not args.no_detector:
-        result["detector"] = bench_detector(args, torch, dist, world, rank, sync_all)
+        result["detector"] = bench_detector(args, torch, world, rank, timer)
     if not args.no_train:
         try:
-            result["train"] = bench_train(args, torch, world, rank, local_rank, sync_all)
+            result["train"] = bench_train(args, torch, world, rank, local_rank, timer)
         except Exception as e:  # never lose the headline line to the extra leg
             result["train"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(dat_h, n, H, W, K, n_win, win_us)
+        result["cpu_baseline"] = cpu_baseline_taf(dat_h, n, H, W, K, n_win, win_us)
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
 
 
-def bench_train(args, torch, world, rank, local_rank, sync_all):
-    """SURVEY.md section 8d cfg 5 without the encode: YOLOX (16-channel TAF input) train step -- forward, batched
-    SimOTA assignment (frlw_simota_assign) + losses, backward, Adam -- under DDP over RCCL when N > 1, per-GPU batch
-    fixed (weak scaling).  Convolution forward/backward of this leg are torch/MIOpen autograd; the assignment is ours."""
+def bench_also(args, torch, synth, er, timer, rank, n_gpus, copy_gbs):
+    """The other encoder rows of SURVEY.md 8(d): the GEN1 shape BASELINE.json's metric names (single stream and 64
+    sequences per launch), Event Volume cfg 2 (single and batched), and the contention variant of the headline."""
+    out = []
+    steps = max(5, min(args.steps, 20))
+    s2, n2, H2, W2, t2, nw2, wu2, K2 = WORKLOADS["taf_gen1"]
+    # ---- TAF, GEN1 shape, one stream (launch / latency bound at this size)
+    ev2 = synth.synth_events(s2 + 7919 * rank, n2, W2, H2, t2)
+    rec2 = synth.to_dat8(ev2)
+    dat2 = torch.from_numpy(rec2.view(np.uint8).reshape(-1, 8)).cuda()
+    st2 = torch.full((H2, W2, 2, K2), -6000.0, device="cuda")
+    per, dev = timer.run(lambda: er.encode_taf_dat(dat2, (H2, W2), st2, 0, wu2, nw2, K2, check=False), steps, 3)
+    row = {"workload": "taf_gen1 (the GEN1 304x240 shape BASELINE.json's metric names): TAF K=8 encode + leaky + uint8, "
+                       "1000000 events, 304x240, 8 windows, ONE stream per launch sequence",
+           "value": round(n_gpus * n2 / per / 1e6, 2), "unit": "Mevents/s", "ms_per_step": round(per * 1e3, 4),
+           "roofline": roofline(taf_algorithmic_bytes(n2, H2, W2, K2), dev, "frlw_taf_encode (k_taf_tile dominant)", copy_gbs,
+                                f"{n2} events")}
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+        row["cpu_baseline"] = cpu_baseline_taf(rec2, n2, H2, W2, K2, nw2, wu2, all_cores=False)
+    out.append(row)
+    # ---- TAF, GEN1 shape, 64 sequences per launch sequence (frlw_taf_encode_batch)
+    B = 64
+    recs = [synth.to_dat8(synth.synth_events(s2 + 100 + j + 7919 * rank, n2, W2, H2, t2)) for j in range(B)]
+    offs = np.concatenate([[0], np.cumsum([len(r) for r in recs])])
+    datb = torch.from_numpy(np.concatenate(recs).view(np.uint8).reshape(-1, 8)).cuda()
+    del recs
+    stb = torch.full((B, H2, W2, 2, K2), -6000.0, device="cuda")
+    per, dev = timer.run(lambda: er.encode_taf_batch(datb, offs, (H2, W2), stb, 0, wu2, nw2, K2, check=False), steps, 3)
+    out.append({"workload": f"taf_gen1 x{B}: {B} independent GEN1-shaped streams of 1000000 events in ONE launch sequence "
+                            "(frlw_taf_encode_batch: own FIFO state and window rule per sequence)",
+                "value": round(n_gpus * B * n2 / per / 1e6, 2), "unit": "Mevents/s", "ms_per_step": round(per * 1e3, 4),
+                "roofline": roofline(B * taf_algorithmic_bytes(n2, H2, W2, K2), dev, "frlw_taf_encode_batch (kf_taf_walk dominant)",
+                                     copy_gbs, f"{B} x {n2} events")})
+    del datb, stb
+    # ---- Event Volume cfg 2: 1 M events, 304x240, 5 bins -- one stream, then 64 streams as two launches of 32 stacked
+    ev4 = synth.synth_events(1002 + 7919 * rank, 1_000_000, W2, H2, 250_000)
+    rec4 = synth.to_dat8(ev4)
+    dat4 = torch.from_numpy(rec4.view(np.uint8).reshape(-1, 8)).cuda()
+    per, dev = timer.run(lambda: er.encode_ev_dat(dat4, (H2, W2), 250_000, 250_000, volume_bins=5, check=False), steps, 3)
+    row = {"workload": "ev_gen1 (BASELINE.json configs[1]): Event Volume 5 bins, 1000000 events, 304x240, ONE stream",
+           "value": round(n_gpus * 1_000_000 / per / 1e6, 2), "unit": "Mevents/s", "ms_per_step": round(per * 1e3, 4),
+           "roofline": roofline(ev_algorithmic_bytes(1_000_000, H2, W2, 5), dev, "frlw_ev_encode (k_ev_tile dominant)", copy_gbs,
+                                "1000000 events")}
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+        row["cpu_baseline"] = cpu_baseline_ev(rec4, H2, W2)
+    out.append(row)
+    G = 32  # sequences stacked along y per launch (the general partition holds 2048 tiles); 64 = two launches
+    parts = []
+    for j in range(G):
+        e = dict(synth.synth_events(1002 + 50 + j + 7919 * rank, 1_000_000, W2, H2, 250_000))
+        e["y"] = e["y"] + j * H2
+        parts.append(synth.to_dat8(e))
+    dat5 = torch.from_numpy(np.concatenate(parts).view(np.uint8).reshape(-1, 8)).cuda()
+    del parts
+
+    def ev_batched():
+        for _ in range(2):
+            er.encode_ev_dat(dat5, (G * H2, W2), 250_000, 250_000, volume_bins=5, check=False)
+    per, dev = timer.run(ev_batched, steps, 2)
+    out.append({"workload": f"ev_gen1 x64: 64 GEN1-shaped streams of 1000000 events as two launch sequences of {G} sequences "
+                            "stacked along y (Event Volume has no per-sequence rule, so stacking is exact)",
+                "value": round(n_gpus * 2 * G * 1_000_000 / per / 1e6, 2), "unit": "Mevents/s", "ms_per_step": round(per * 1e3, 4),
+                "roofline": roofline(2 * G * ev_algorithmic_bytes(1_000_000, H2, W2, 5), dev, "frlw_ev_encode (k_ev_tile dominant)",
+                                     copy_gbs, f"2 x {G} x 1000000 events")})
+    del dat5
+    if not args.hotspot:
+        # SURVEY.md 8(d) "report both": the contention variant of the headline workload (25 % of the events in a
+        # sigma = 8 px blob -> a few tiles hold most of them; skewed tiles are split by segments, DESIGN.md 3)
+        seed, n, H, W, t_span, n_win, win_us, K = WORKLOADS["taf_mpx"]
+        ev3 = synth.synth_events(seed + 7919 * rank, n, W, H, t_span, hotspot=True)
+        dat3 = torch.from_numpy(synth.to_dat8(ev3).view(np.uint8).reshape(-1, 8)).cuda()
+        st3 = torch.full((H, W, 2, K), -6000.0, device="cuda")
+        per, dev = timer.run(lambda: er.encode_taf_dat(dat3, (H, W), st3, 0, win_us, n_win, K, check=False), steps, 2)
+        out.append({"workload": "taf_mpx, hotspot variant (25 % of the events in a sigma = 8 px blob)",
+                    "value": round(n_gpus * n / per / 1e6, 2), "unit": "Mevents/s", "ms_per_step": round(per * 1e3, 4),
+                    "roofline": roofline(taf_algorithmic_bytes(n, H, W, K), dev, "frlw_taf_encode_batch", copy_gbs, f"{n} events")})
+    return out
+
+
+def mfma_sustained(torch):
+    """What a bare v_mfma_f32_32x32x2_f32 loop sustains on this chip (random operands), TFLOP/s."""
+    import ctypes as C
+    from frlw_evd_amd import _lib
+    lib = _lib.load()
+    seed = torch.randn(256, device="cuda")
+    sink = torch.zeros(4, device="cuda")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    blocks, iters = 256 * 5, 2000
+    lib.frlw_selftest_mfma_f32_rate(blocks, iters, seed.data_ptr(), sink.data_ptr(), st)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        lib.frlw_selftest_mfma_f32_rate(blocks, iters, seed.data_ptr(), sink.data_ptr(), st)
+    e1.record()
+    torch.cuda.synchronize()
+    return blocks * 4 * iters * 32 * 4096 / (e0.elapsed_time(e1) / 3) / 1e9
+
+
+def bench_detector(args, torch, world, rank, timer):
+    """Second half of BASELINE.json's metric: YOLOX forward frames/s (SURVEY.md 8(d) cfg 4): B = 32, (10, 256, 320) f32
+    input (the detector shape of a 304x240 sensor), recipe weights, eval mode, forward to the pre-NMS tensor (B, 1680, 7);
+    decode + NMS timed separately; then the 1 Mpx detector shape (10, 512, 640), 4x the FLOPs per image."""
+    from frlw_evd_amd.yolox import build_yolox
+    from frlw_evd_amd.yolox.model import recipe_state_dict
+    out = None
+    sustained = mfma_sustained(torch)
+    for tag, B, Hd, Wd in (("gen1", args.det_batch, 256, 320), ("1mpx", max(1, args.det_batch // 4), 512, 640)):
+        net = build_yolox(10, 2 if tag == "gen1" else 7, radius=5.0 if tag == "gen1" else 2.5)
+        net.load_state_dict(recipe_state_dict(net, seed=1004))
+        net.eval()
+        rng = np.random.default_rng(1004 + rank)
+        x_h = torch.from_numpy(rng.integers(0, 256, size=(B, 10, Hd, Wd)).astype(np.float32) / np.float32(255))
+        x = x_h.cuda()
+        eng = net.engine()
+        steps = max(5, min(args.steps, 30))
+        per, dev_ms = timer.run(lambda: eng.raw_outputs(x), steps, 3)
+        tflops = eng.flops_per_image * B / (dev_ms * 1e-3) / 1e12
+        row = {
+            "value": round(world * B / per, 1), "unit": "frames/s", "batch_per_gpu": B,
+            "input": f"(B, 10, {Hd}, {Wd}) f32, recipe weights", "steps": steps, "ms_per_batch": round(per * 1e3, 3), "dtype": "f32",
+            "roofline": {"bound": "mfma", "kernel": f"k_conv_mfma ({eng.n_conv} launches per forward)", "achieved": round(tflops, 2),
+                         "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / FP32_MFMA_PEAK_TFLOPS, 4),
+                         "bare_mfma_loop_TFLOPs": round(sustained, 1), "frac_of_bare_loop": round(tflops / sustained, 4),
+                         "flops_per_image": eng.flops_per_image, "device_ms_per_batch": round(dev_ms, 3),
+                         "mfma": "v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate)"},
+        }
+        for _ in range(2):
+            eng.detect(x)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            eng.detect(x)
+        torch.cuda.synchronize()
+        row["fwd_plus_decode_nms_ms"] = round((time.perf_counter() - t1) / 5 * 1e3, 3)
+        if tag == "gen1":
+            out = dict({"metric": "YOLOX-S (CSPDarknet + PAFPN + decoupled head) eval forward to the pre-NMS tensor "
+                                  "(BASELINE.json configs[3])"}, **row)
+            if rank == 0 and world == 1 and not args.no_cpu_baseline:
+                # PyTorch-CPU forward of the same module definition (BASELINE.md section 3 item 2): all cores and 1
+                xb = x_h[:8, ..., None]
+                cpu = {}
+                for nthreads in (min(os.cpu_count() or 1, 64), 1):
+                    torch.set_num_threads(nthreads)
+                    xs = xb if nthreads > 1 else xb[:1]
+                    with torch.no_grad():
+                        net.reference_outputs(xs)
+                        best = None
+                        for _ in range(3 if nthreads > 1 else 1):
+                            t2 = time.perf_counter()
+                            net.reference_outputs(xs)
+                            dt = time.perf_counter() - t2
+                            best = dt if best is None else min(best, dt)
+                    cpu[nthreads] = (len(xs) / best, best, len(xs))
+                many = max(cpu)
+                out["cpu_baseline"] = {"value": round(cpu[many][0], 1), "unit": "frames/s", "cores": many, "kind": "port",
+                                       "one_thread_frames_per_s": round(cpu[1][0], 2), "cpu": cpu_model(),
+                                       "sample": f"PyTorch-CPU fp32 forward of the same modules, batch {cpu[many][2]} on {many} threads "
+                                                 f"(best of 3, {cpu[many][1]:.3f} s), batch 1 on 1 thread ({cpu[1][1]:.3f} s)"}
+        else:
+            out["shape_1mpx"] = dict({"workload": "the 1 Mpx detector shape of SURVEY.md 8(d) cfg 4: (B, 10, 512, 640), 7 classes, "
+                                                  "6720 anchors, 4x the FLOPs per image"}, **row)
+        del eng, net, x
+    return out
+
+
+def bench_train(args, torch, world, rank, local_rank, timer):
+    """SURVEY.md 8(d) cfg 5: YOLOX (16-channel TAF input) train step -- forward, batched SimOTA assignment
+    (frlw_simota_assign) + losses, backward, Adam -- under DDP over RCCL when N > 1, per-GPU batch fixed (weak scaling).
+    Every BaseConv runs forward and backward in the gfx950 kernels of csrc/train_ops.hip; the same step with torch
+    autograd / MIOpen convolutions is timed beside it."""
     from frlw_evd_amd import dist as fd
     from frlw_evd_amd import e2e
     from frlw_evd_amd.trainer import Trainer
     B = args.train_batch
     m = e2e.build_model(in_channels=16, num_classes=2)
-    tr = Trainer(m, global_batch=B * world, nodes=world, iters_per_epoch=100, local_rank=local_rank, ddp=world > 1)
+    tr = Trainer(m, global_batch=B * world, nodes=world, iters_per_epoch=100, local_rank=local_rank, ddp=world > 1,
+                 comm_hook="timed" if world > 1 else None)
     rng = np.random.default_rng(1005 + rank)
     x = torch.from_numpy(rng.integers(0, 256, size=(B, 16, 256, 320, 1, 1), dtype=np.uint8)).float().div(255).cuda()
     lab = torch.zeros(B, 80, 5, dtype=torch.float64)
@@ -227,144 +419,118 @@ def bench_train(args, torch, world, rank, local_rank, sync_all):
     lab[:, 1] = torch.tensor([1, 220, 150, 50, 80.0])
     lab = lab.cuda()
     steps = 5
+    state = {"i": 0, "loss": None}
 
-    def timed():
-        for i in range(3):
-            tr.train_step(x, lab, i)
-        sync_all()
-        t0 = time.perf_counter()
-        for i in range(steps):
-            loss, _ = tr.train_step(x, lab, 3 + i)
-        sync_all()
-        dt, = fd.max_over_ranks([time.perf_counter() - t0])
-        return dt, loss
+    def one():
+        state["loss"], _ = tr.train_step(x, lab, state["i"])
+        state["i"] += 1
 
-    dt, loss = timed()  # BaseConv forward / backward in the gfx950 kernels of csrc/train_ops.hip (the default)
+    per, dev_ms = timer.run(one, steps, 3)
+    loss = state["loss"]
+    from frlw_evd_amd.detector import DetectorEngine
+    probe = DetectorEngine(e2e.build_model(16, 2, device="cpu").eval(), device="cpu")
+    probe.build((16, 256, 320))  # the plan builder counts the convolution MACs of the 16-channel network
+    flops = 3 * probe.flops_per_image * B
+    tflops = flops / (dev_ms * 1e-3) / 1e12
+    out = {"metric": "YOLOX train step (frames/s)", "value": round(world * B / per, 1), "unit": "frames/s",
+           "ms_per_step": round(per * 1e3, 3), "per_gpu_batch": B, "steps": steps, "loss": round(loss, 4),
+           "parallelism": f"ddp{world}" if world > 1 else "single", "scaling": "weak",
+           "convolutions": "csrc/train_ops.hip (fp32 MFMA fwd / dgrad / wgrad, BatchNorm + SiLU fwd / bwd), SimOTA csrc/simota.hip",
+           "roofline": {"bound": "mfma", "kernel": "k_conv_mfma (fwd + dgrad) + k_wgrad_mfma", "achieved": round(tflops, 2),
+                        "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / FP32_MFMA_PEAK_TFLOPS, 4),
+                        "flops_per_step": flops, "flops_model": "3 x (conv MACs x 2 of the 16-channel forward) x batch: forward + data "
+                        "gradient + weight gradient", "device_ms_per_step": round(dev_ms, 3)}}
+    if world > 1:
+        # how much of the gradient all-reduce is hidden behind the backward: the same step inside no_sync() has no
+        # collective at all; the difference is what the all-reduce adds to the step = its exposed part
+        hook = tr.comm_hook.summary() if tr.comm_hook is not None else {}
+
+        plain = Trainer(m, global_batch=B * world, nodes=world, iters_per_epoch=100, local_rank=local_rank, ddp=False)
+
+        def nosync():  # the bare module behind the DDP wrapper: same kernels, no gradient hooks, no collective
+            plain.train_step(x, lab, 0)
+        per_ns, _ = timer.run(nosync, steps, 2)
+        out["allreduce"] = {"gradient_bytes": int(sum(p.numel() for p in m.parameters()) * 4), "buckets_per_step": None,
+                            "bucket_bytes": hook.get("bucket_bytes"), "mean_bucket_ms": round(hook.get("mean_bucket_ms", 0.0), 3),
+                            "allreduce_total_ms_per_step": round(hook.get("total_ms", 0.0) / max(steps + 3, 1), 3),
+                            "step_ms_without_collective": round(per_ns * 1e3, 3),
+                            "allreduce_exposed_ms": round(max(0.0, (per - per_ns) * 1e3), 3),
+                            "ddp": "gradient_as_bucket_view, static_graph, 25 MB buckets (frlw_evd_amd.dist.ddp_kwargs)"}
+        if hook.get("buckets"):
+            out["allreduce"]["buckets_per_step"] = hook["buckets"] // (steps + 3)
     # BASELINE.json configs[4]: the same step fed by the TAF encode of its batch (B GEN1-shaped streams of 8 x 125 000
-    # events -> TAF K=8 -> leaky -> uint8 -> nearest 256x320 -> /255), everything on this GPU
+    # events -> frlw_taf_encode_batch -> uint8 -> nearest 256x320 -> /255), everything on this GPU
     src = e2e.SyntheticTafSource(B, seed=1005 + 1000 * rank)
     idx = list(range(B))
-    for i in range(2):
-        tr.train_step(src.encode_batch(idx), lab, i)
-    sync_all()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        tr.train_step(src.encode_batch(idx), lab, 2 + i)
-    sync_all()
-    dt_e2e, = fd.max_over_ranks([time.perf_counter() - t0])
-    t0 = time.perf_counter()
-    for i in range(steps):
-        src.encode_batch(idx)
-    sync_all()
-    dt_enc, = fd.max_over_ranks([time.perf_counter() - t0])
-    prev = os.environ.get("FRLW_NATIVE_TRAIN")
-    os.environ["FRLW_NATIVE_TRAIN"] = "0"  # the same step with torch autograd / MIOpen convolutions, for comparison
-    try:
-        dt_t, _ = timed()
-    finally:
-        if prev is None:
-            os.environ.pop("FRLW_NATIVE_TRAIN", None)
-        else:
-            os.environ["FRLW_NATIVE_TRAIN"] = prev
-    return {"metric": "YOLOX train step (frames/s)", "value": round(world * B * steps / dt, 1), "unit": "frames/s",
-            "ms_per_step": round(dt / steps * 1e3, 3), "per_gpu_batch": B, "steps": steps, "loss": round(loss, 4),
-            "parallelism": f"ddp{world}" if world > 1 else "single", "scaling": "weak",
-            "convolutions": "csrc/train_ops.hip (fp32 MFMA fwd / dgrad / wgrad, BatchNorm + SiLU fwd / bwd), SimOTA csrc/simota.hip",
-            "same_step_with_miopen_convs": {"value": round(world * B * steps / dt_t, 1), "ms_per_step": round(dt_t / steps * 1e3, 3)},
-            "encode_plus_train_step": {"workload": "BASELINE.json configs[4]: TAF encode of the batch (8 x 125 000 events per "
-                                                   "304x240 sample) + train step", "value": round(world * B * steps / dt_e2e, 1),
-                                       "unit": "frames/s", "ms_per_step": round(dt_e2e / steps * 1e3, 3),
-                                       "encode_ms_per_batch": round(dt_enc / steps * 1e3, 3)}}
 
-
-FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, f32 in / f32 accumulate
-
-
-def bench_detector(args, torch, dist, world, rank, sync_all):
-    """Second half of BASELINE.json's metric: YOLOX forward frames/s (SURVEY.md section 8d cfg 4):
-    B = 32, (10, 256, 320) f32 input (the detector shape of a 304x240 sensor), recipe weights, eval mode,
-    forward to the pre-NMS tensor (B, 1680, 7); decode + NMS timed separately."""
-    from frlw_evd_amd.yolox import build_yolox
-    from frlw_evd_amd.yolox.model import recipe_state_dict
-    B = args.det_batch
-    net = build_yolox(10, 2)
-    net.load_state_dict(recipe_state_dict(net, seed=1004))
-    net.eval()
-    rng = np.random.default_rng(1004 + rank)
-    x_h = torch.from_numpy(rng.integers(0, 256, size=(B, 10, 256, 320)).astype(np.float32) / np.float32(255))
-    x = x_h.cuda()
-    eng = net.engine()
-    steps = max(5, min(args.steps, 30))
-    for _ in range(3):
-        eng.raw_outputs(x)
-    sync_all()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record()
-    for _ in range(steps):
-        eng.raw_outputs(x)
-    e1.record()
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    dev_ms = e0.elapsed_time(e1) / steps
-    for _ in range(2):
-        eng.detect(x)
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    for _ in range(5):
-        eng.detect(x)
-    torch.cuda.synchronize()
-    full_ms = (time.perf_counter() - t1) / 5 * 1e3
-    from frlw_evd_amd import dist as fd
-    elapsed, dev_ms = fd.max_over_ranks([elapsed, dev_ms])
-    tflops = eng.flops_per_image * B / (dev_ms * 1e-3) / 1e12
-    out = {
-        "metric": "YOLOX-S (CSPDarknet + PAFPN + decoupled head) eval forward to the pre-NMS tensor (BASELINE.json configs[3])",
-        "value": round(world * B / (elapsed / steps), 1), "unit": "frames/s", "batch_per_gpu": B,
-        "input": "(B, 10, 256, 320) f32, recipe weights", "steps": steps, "ms_per_batch": round(elapsed / steps * 1e3, 3),
-        "dtype": "f32", "fwd_plus_decode_nms_ms": round(full_ms, 3),
-        "roofline": {"bound": "mfma", "kernel": "k_conv_mfma (80 launches per forward)", "achieved": round(tflops, 2),
-                     "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / FP32_MFMA_PEAK_TFLOPS, 4),
-                     "flops_per_image": eng.flops_per_image, "device_ms_per_batch": round(dev_ms, 3),
-                     "mfma": "v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate)"},
-    }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        # PyTorch-CPU forward of the same module definition (BASELINE.md section 3 item 2)
-        nthreads = min(os.cpu_count() or 1, 64)
-        torch.set_num_threads(nthreads)
-        xb = x_h[:8, ..., None]
-        with torch.no_grad():
-            net.reference_outputs(xb)
-            best = None
-            for _ in range(3):
-                t2 = time.perf_counter()
-                net.reference_outputs(xb)
-                dt = time.perf_counter() - t2
-                best = dt if best is None else min(best, dt)
-        out["cpu_baseline"] = {"value": round(8 / best, 1), "unit": "frames/s", "cores": nthreads, "kind": "port",
-                               "sample": f"PyTorch-CPU fp32 forward of the same modules, batch 8, best of 3 ({best:.3f} s)"}
+    def e2e_step():
+        state["loss"], _ = tr.train_step(src.encode_batch(idx), lab, state["i"])
+        state["i"] += 1
+    per_e2e, _ = timer.run(e2e_step, steps, 2)
+    per_enc, _ = timer.run(lambda: src.encode_batch(idx), steps, 1)
+    out["encode_plus_train_step"] = {"workload": "BASELINE.json configs[4]: TAF encode of the batch (8 x 125 000 events per "
+                                                 "304x240 sample, one frlw_taf_encode_batch call) + train step",
+                                     "value": round(world * B / per_e2e, 1), "unit": "frames/s",
+                                     "ms_per_step": round(per_e2e * 1e3, 3), "encode_ms_per_batch": round(per_enc * 1e3, 3)}
+    if world == 1:
+        prev = os.environ.get("FRLW_NATIVE_TRAIN")
+        os.environ["FRLW_NATIVE_TRAIN"] = "0"  # the same step with torch autograd / MIOpen convolutions, for comparison
+        try:
+            per_t, _ = timer.run(one, steps, 3)
+        finally:
+            if prev is None:
+                os.environ.pop("FRLW_NATIVE_TRAIN", None)
+            else:
+                os.environ["FRLW_NATIVE_TRAIN"] = prev
+        out["same_step_with_miopen_convs"] = {"value": round(world * B / per_t, 1), "ms_per_step": round(per_t * 1e3, 3),
+                                              "native_speedup": round(per_t / per, 3)}
     return out
 
 
-def cpu_baseline(dat_h, n, H, W, K, n_win, win_us, budget_s=20.0):
-    """The CPU oracle (a 1-thread C port of generate_taf.py:19-76 + harness) on the same stream."""
-    from oracle import oracle as orc
-    orc.build()
-    st0 = np.full((H, W, 2, K), -6000, np.float32)
-    best = None
-    spent = 0.0
-    runs = 0
-    while runs < 3 and spent < budget_s:
+def _best_of(fn, budget_s, max_runs=3):
+    best, spent, runs = None, 0.0, 0
+    while runs < max_runs and spent < budget_s:
         t0 = time.perf_counter()
-        view, st = orc.taf_stream_dat8(dat_h, (H, W), (H, W), K, 0, win_us, n_win, st0)
-        u8 = orc.quantize_u8(orc.leaky_transform(view))
+        fn()
         dt = time.perf_counter() - t0
         spent += dt
         runs += 1
         best = dt if best is None else min(best, dt)
-    return {"value": round(n / best / 1e6, 3), "unit": "Mevents/s", "cores": 1, "kind": "port",
-            "sample": f"the full workload ({n} events, {n_win} windows), best of {runs} runs, {best:.3f} s each",
-            "host_cpus": os.cpu_count()}
+    return best, runs
+
+
+def cpu_baseline_taf(dat_h, n, H, W, K, n_win, win_us, all_cores=True, budget_s=12.0):
+    """The CPU oracle (a C port of generate_taf.py:19-76 + harness) on the same stream: one thread, and -- the path
+    shards by sequence -- one independent copy of the stream per host thread on all cores (ctypes releases the GIL)."""
+    from oracle import oracle as orc
+    orc.build()
+    st0 = np.full((H, W, 2, K), -6000, np.float32)
+
+    def one():
+        view, _ = orc.taf_stream_dat8(dat_h, (H, W), (H, W), K, 0, win_us, n_win, st0)
+        orc.quantize_u8(orc.leaky_transform(view))
+
+    best, runs = _best_of(one, budget_s)
+    out = {"value": round(n / best / 1e6, 3), "unit": "Mevents/s", "cores": 1, "kind": "port",
+           "sample": f"the full workload ({n} events, {n_win} windows), best of {runs} runs, {best:.3f} s each",
+           "host_cpus": os.cpu_count(), "cpu": cpu_model()}
+    if all_cores:
+        threads = min(os.cpu_count() or 1, 64)
+        with ThreadPoolExecutor(threads) as pool:
+            t0 = time.perf_counter()
+            list(pool.map(lambda _i: one(), range(threads)))
+            dt = time.perf_counter() - t0
+        out["all_cores"] = {"value": round(threads * n / dt / 1e6, 3), "unit": "Mevents/s", "cores": threads,
+                            "sample": f"{threads} threads, each the full workload on its own copy of the state ({dt:.3f} s)"}
+    return out
+
+
+def cpu_baseline_ev(rec, H, W, budget_s=6.0):
+    from oracle import oracle as orc
+    orc.build()
+    best, runs = _best_of(lambda: orc.ev_stream_dat8(rec, (H, W), (H, W), 5, 250_000, 250_000), budget_s, 5)
+    return {"value": round(len(rec) / best / 1e6, 3), "unit": "Mevents/s", "cores": 1, "kind": "port",
+            "sample": f"the full workload ({len(rec)} events), best of {runs} runs, {best:.4f} s each", "cpu": cpu_model()}
 
 
 if __name__ == "__main__":

@@ -147,7 +147,7 @@ class TimedAllreduce:
         self.group = group
         self.events = []  # (bytes, start event, end event)
 
-    def __call__(self, state, bucket):
+    def record(self, bucket):
         group = self.group if self.group is not None else dist.group.WORLD
         world = dist.get_world_size(group)
         buf = bucket.buffer()
@@ -179,6 +179,11 @@ class TimedAllreduce:
         return out
 
 
+def timed_allreduce_hook(state, bucket):
+    """The function DDP calls (it wants a plain function with a ``__name__``); ``state`` is the TimedAllreduce."""
+    return state.record(bucket)
+
+
 def install_comm_hook(ddp_model, kind=None):
     """``kind``: None / "default" (DDP's all-reduce), "rs_ag" (reduce-scatter + all-gather), "timed" (default + timing;
     returns the TimedAllreduce object).  ``FRLW_DDP_HOOK`` supplies the default."""
@@ -188,6 +193,6 @@ def install_comm_hook(ddp_model, kind=None):
         return None
     if kind == "timed":
         hook = TimedAllreduce()
-        ddp_model.register_comm_hook(None, hook)
+        ddp_model.register_comm_hook(hook, timed_allreduce_hook)
         return hook
     return None

@@ -40,7 +40,7 @@ def _build():
     return m.cuda().train()
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, hook="default"):
     two_gpus = torch.cuda.device_count() >= world  # device_count() does not initialise the GPU
     dev = rank if two_gpus else 0
     backend = "nccl" if two_gpus else "gloo"
@@ -51,7 +51,7 @@ def _worker(rank, world, port, out_dir):
     fd.init_from_env(backend)
     torch.cuda.set_device(dev)
     ddp = DistributedDataParallel(_build(), device_ids=[dev], broadcast_buffers=False, **fd.ddp_kwargs())  # core/exp.py:391
-    fd.install_comm_hook(ddp, os.environ.get("FRLW_TEST_HOOK", "default"))
+    timed = fd.install_comm_hook(ddp, hook)
     x, lab = _inputs(rank)
     loss = ddp(x.cuda(), lab.cuda(), None, None)
     loss.backward()
@@ -59,14 +59,20 @@ def _worker(rank, world, port, out_dir):
     g = torch.cat([p.grad.flatten().double().cpu() for p in ddp.module.parameters()])
     np.save(os.path.join(out_dir, f"g{rank}.npy"), g.numpy())
     np.save(os.path.join(out_dir, f"l{rank}.npy"), np.array(float(loss.detach())))
+    if hook == "timed":  # the timing hook is the default all-reduce plus device events around every bucket
+        summary = timed.summary()
+        assert summary["buckets"] >= 1 and summary["total_ms"] > 0 and sum(summary["bucket_bytes"]) > 0, summary
     torch.distributed.destroy_process_group()
 
 
-def test_two_ddp_ranks_native_train_ops(tmp_path):
+@pytest.mark.parametrize("hook", ["default", "timed", "rs_ag"])
+def test_two_ddp_ranks_native_train_ops(tmp_path, hook):
+    """hook: DDP's own all-reduce, the same with per-bucket timing (what bench.py --gpus N reports), and the
+    reduce-scatter + all-gather hook -- all three must deliver the averaged gradient."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), hook), nprocs=world, join=True)
     g0, g1 = (np.load(tmp_path / f"g{r}.npy") for r in range(world))
     assert np.array_equal(g0, g1)  # the all-reduced (averaged) gradient is the same on both ranks
     # single process: mean of the two per-rank gradients (each rank normalises its loss by its own foreground count)
