@@ -10,11 +10,14 @@
 //   * the stable partition ranks a batch of 64 consecutive events with ONE returning LDS atomic per event: gfx950
 //     serves the lanes of a wave-instruction that hit one LDS address in ascending lane order (tools/lds_order_test.hip,
 //     tests/test_taf_fast_gpu.py::test_lds_atomic_lane_order), so the returned value IS the stream rank.
-//   * the tile kernel never sorts.  A chunk of the tile's records is split (stably, the same atomic) over the 16
-//     wavefronts of the workgroup by sub-tile: wavefront v owns cells [256 v, 256 v + 256) and their FIFO state in
-//     registers.  It then walks ITS records 64 at a time, wave-synchronously: count by returning LDS atomic, and the
-//     f32 sums of the lanes that share a cell are applied in rank order (one round per multiplicity) -- the reference's
-//     sequential index_add_.  Windows are closed per wavefront (FIFO step in registers), no workgroup barrier inside.
+//   * the records of a tile (4096 cells) are split once more, stably, by sub-tile of 256 cells (kf_split_whole; tiles
+//     that hold a large share of the stream are cut into segments of 8192 records with one workgroup each,
+//     kf_split_place), so skew costs more workgroups, not a longer critical path.
+//   * the sums of different windows do not depend on each other -- only the FIFO steps that consume them are
+//     sequential.  kf_taf_walk gives a sub-tile to eight wavefronts that take ONE WINDOW EACH: tickets from per-cell
+//     LDS counters (the same lane-ordered atomic) turn the window's records into per-cell segments without any
+//     ordering pass, owner lanes add each segment front to back (the reference's sequential index_add_), and the FIFO
+//     steps follow with one cell per lane.
 //   * sequences of a batch are independent problems in one launch sequence: own tiles, own window mask
 //     (generate_taf.py:40-41 is a per-sequence rule), own t_start.
 //
