@@ -31,6 +31,7 @@ struct ConvArgs {
     float *partial;    // [splits][M][Npad] when splits > 1
     int tstride;       // 0 / 1: ordinary gather; 2: transposed gather (dgrad of a stride-2 convolution)
     int kw;            // taps per tap row when the window is not square (0: k); K = rows * kw * Cin
+    uint32_t x_bytes, w_bytes; // extents of the x view and of w for the buffer descriptors (set by launch_conv)
     int y_rp;          // output row pitch in floats (0: dense, pixel p at p * y_cs); else pixel (oy, ox) at oy * y_rp + ox * y_cs
 };
 
@@ -51,14 +52,41 @@ __device__ __forceinline__ float act_apply(float v, int act)
     return v;
 }
 
+#ifdef CONV_LAB_PROBE
+__device__ uint32_t *g_probe;
+__device__ unsigned long long *g_probe_t, *g_probe_e, *g_probe_ph;
+#define PROBE_PH(i) do { if (probe_end.on && threadIdx.x == 0) g_probe_ph[probe_end.idx * 8 + (i)] = wall_clock64(); } while (0)
+struct ProbeEnd { // writes the workgroup's end time when the kernel body is left
+    int idx; bool on;
+    __device__ ~ProbeEnd() { if (on) { __syncthreads(); if (threadIdx.x == 0) g_probe_e[idx] = wall_clock64(); } }
+};
+#else
+#define PROBE_PH(i) do { } while (0)
+#endif
+// Operand loads go through buffer descriptors: a lane whose element is padding, outside the tensor or past K carries
+// the offset kOob, the range check of the descriptor answers zeros -- no branch and no select around any load.
+constexpr uint32_t kOob = 0xF0000000u;        // no operand view reaches this byte offset (launch_conv splits the batch otherwise)
+constexpr long long kMaxViewBytes = 0xE0000000ll;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t conv_rsrc(const void *p, uint32_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 conv_load16(__amdgpu_buffer_rsrc_t r, uint32_t byte_off)
+{
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
+}
+
 // BM x BN output tile, 4 wavefronts arranged WROWS x WCOLS, each owning TM x TN MFMA tiles of 32 x 32.
-template <int BM, int BN, int WROWS, int WCOLS, int BK>
+// UT ("uniform taps"): Cin % BK == 0, so a k-tile lies inside one filter tap and the tap changes for the whole
+// workgroup at once: the gather offsets are recomputed only then, a k-tile costs one add per load.
+template <int BM, int BN, int WROWS, int WCOLS, int BK, bool UT>
 __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
 {
     constexpr int TM = BM / (32 * WROWS), TN = BN / (32 * WCOLS);
     constexpr int KQ = BK / 4;        // float4 per A row of the k-tile
     constexpr int RPP = 256 / KQ;     // A rows staged per pass of the 256 threads
-    constexpr int LDA = BM + 4, LDB = BN + 4; // +4 floats: k rows land on different banks for the staging writes
+    constexpr int LDA = BM + 4; // +4 floats: k rows land on different banks for the staging writes
+    constexpr int LDB = BN;     // the weight tile arrives by LDS-DMA: lane-linear, [BK][BN] without padding
     constexpr int A_F4 = BM * BK / 4 / 256;   // float4 loads per thread for the A tile
     constexpr int B_F4 = (BN * BK / 4 + 255) / 256;
     constexpr int EPLD = 36;                          // row pitch of the epilogue staging (16-byte aligned rows)
@@ -70,50 +98,99 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wr = wv / WCOLS, wc = wv % WCOLS;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+#ifdef CONV_LAB_PROBE
+    if (tid == 0 && g_probe) {
+        const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        g_probe[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = ((xcc & 15) << 8) | (((hw >> 13) & 7) << 4) | ((hw >> 8) & 15);
+        g_probe_t[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = wall_clock64();
+    }
+    ProbeEnd probe_end{(int)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x), g_probe != nullptr};
+#endif
+    const __amdgpu_buffer_rsrc_t rx = conv_rsrc(a.x, a.x_bytes), rw = conv_rsrc(a.w, a.w_bytes);
 
     // ---- A staging: thread -> A_F4 rows m, one float4 of 4 consecutive k
     const int a_k4 = (tid % KQ) * 4;
     int a_iy0[A_F4], a_ix0[A_F4];
-    long long a_base[A_F4];
-    bool a_ok[A_F4];
+    uint32_t a_base[A_F4]; // byte offset of the row's image (+ channel offset); kOob for rows past M
 #pragma unroll
     for (int i = 0; i < A_F4; ++i) {
         const int m = m0 + tid / KQ + RPP * i;
-        a_ok[i] = m < a.M;
-        const int mm = a_ok[i] ? m : 0;
+        const int mm = m < a.M ? m : 0;
         const int b = mm / (a.Ho * a.Wo), pix = mm - b * (a.Ho * a.Wo);
         const int oy = pix / a.Wo, ox = pix - oy * a.Wo;
         a_iy0[i] = oy * a.stride - a.pad;
         a_ix0[i] = ox * a.stride - a.pad;
-        a_base[i] = (long long)b * a.x_bs + a.x_co;
+        a_base[i] = m < a.M ? (uint32_t)(((long long)b * a.x_bs + a.x_co) * 4) : kOob;
     }
+    const int kw = a.kw ? a.kw : a.k;
+    const int x_cs4 = a.x_cs * 4;
+    auto gather_off = [&](int i, int ky, int kx) -> uint32_t { // byte offset of row i's pixel under tap (ky, kx)
+        int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
+        bool ok = a_base[i] != kOob;
+        if (a.tstride == 2) { ok = ok && !((iy | ix) & 1); iy >>= 1; ix >>= 1; }
+        ok = ok && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        return ok ? a_base[i] + (uint32_t)((iy * a.W + ix) * x_cs4) : kOob;
+    };
     // ---- B staging: thread -> rows k, one float4 of 4 consecutive n
     constexpr int BN4 = BN / 4;
-    float4 ra[A_F4], rb[B_F4];
+    uint32_t b_off[B_F4]; // byte offset of this thread's float4 in the NEXT k-tile to load; rows past K fail the range check
+    float4 ra[A_F4];
 
-    // (ky, kx, ci) of this thread's float4 in the CURRENT k-tile to be loaded; advanced by BK per tile
-    int t_ci = 0, t_ky = 0, t_kx = 0;
-    const int kw = a.kw ? a.kw : a.k;
-    auto load_tiles = [&](int kt) {
-        const int k = kt * BK + a_k4;
+    const int nk_all = (a.K + BK - 1) / BK;
+    const int kt0 = (int)((long long)nk_all * blockIdx.z / a.splits), kt1 = (int)((long long)nk_all * (blockIdx.z + 1) / a.splits);
+    const int nk = kt1 - kt0;
 #pragma unroll
-        for (int i = 0; i < A_F4; ++i) {
-            int iy = a_iy0[i] + t_ky, ix = a_ix0[i] + t_kx;
-            bool even = true;
-            if (a.tstride == 2) { even = !((iy | ix) & 1); iy >>= 1; ix >>= 1; }
-            const bool ok = even && a_ok[i] && k < a.K && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            ra[i] = ok ? *(const float4 *)(a.x + a_base[i] + ((long long)iy * a.W + ix) * a.x_cs + t_ci)
-                       : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < B_F4; ++i) {
+        const int e = tid + 256 * i;
+        const int kr = e / BN4, n4 = (e - kr * BN4) * 4;
+        b_off[i] = (kr < BK && n0 + n4 < a.Npad) ? (uint32_t)((((long long)kt0 * BK + kr) * a.Npad + n0 + n4) * 4) : kOob;
+    }
+    // tap tracker of the NEXT k-tile to load.  UT: (s_ky, s_kx, s_ci) are workgroup-uniform, a_pix[] holds the rows'
+    // offsets under that tap.  Otherwise every thread tracks the tap of its own float4.
+    int s_ci, s_ky, s_kx;
+    uint32_t a_pix[A_F4];
+    {
+        const int k = kt0 * BK + (UT ? 0 : a_k4);
+        const int tap = k / a.Cin;
+        s_ci = k - tap * a.Cin;
+        s_ky = tap / kw;
+        s_kx = tap - s_ky * kw;
+    }
+    if (UT) {
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) a_pix[i] = gather_off(i, s_ky, s_kx);
+    }
+    // The weight tile goes global -> LDS directly (buffer_load ... lds: no registers, no ds_write; wave-instruction i of
+    // wavefront wv fills the 1 KB at float offset (wv * 64 + 256 i) * 4 of the tile).  The gathered A tile is staged
+    // through registers: its LDS image is k-major, which no lane-linear DMA can produce.
+    auto load_tiles = [&](int kt, int nbuf) {
+        if (UT) {
+            const uint32_t cib = (uint32_t)(s_ci + a_k4) * 4;
+#pragma unroll
+            for (int i = 0; i < A_F4; ++i) ra[i] = conv_load16(rx, a_pix[i] + cib); // kOob + cib stays out of range
+            s_ci += BK;
+            if (s_ci == a.Cin) { // next tap (uniform branch, once per Cin / BK tiles)
+                s_ci = 0;
+                if (++s_kx == kw) { s_kx = 0; ++s_ky; }
+#pragma unroll
+                for (int i = 0; i < A_F4; ++i) a_pix[i] = gather_off(i, s_ky, s_kx);
+            }
+        } else {
+            const bool in_k = kt * BK + a_k4 < a.K;
+#pragma unroll
+            for (int i = 0; i < A_F4; ++i) {
+                const uint32_t o = gather_off(i, s_ky, s_kx);
+                ra[i] = conv_load16(rx, in_k ? o + (uint32_t)s_ci * 4 : kOob);
+            }
+            s_ci += BK; // Cin % 4 == 0: a float4 never straddles taps
+            while (s_ci >= a.Cin) { s_ci -= a.Cin; if (++s_kx == kw) { s_kx = 0; ++s_ky; } }
         }
-        t_ci += BK; // Cin % 4 == 0: a float4 never straddles taps
-        while (t_ci >= a.Cin) { t_ci -= a.Cin; if (++t_kx == kw) { t_kx = 0; ++t_ky; } }
 #pragma unroll
         for (int i = 0; i < B_F4; ++i) {
-            const int e = tid + 256 * i;
-            const int kr = e / BN4, n4 = (e - kr * BN4) * 4;
-            const int kk = kt * BK + kr;
-            const bool ok = kr < BK && kk < a.K && n0 + n4 < a.Npad;
-            rb[i] = ok ? *(const float4 *)(a.w + (long long)kk * a.Npad + n0 + n4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((BN * BK / 4) % 256 == 0 || wv * 64 + 256 * i < BN * BK / 4) // wave-uniform
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void *)(&Bs[nbuf][0][0] + (wv * 64 + 256 * i) * 4),
+                                                         16, (int)b_off[i], 0, 0, 0);
+            b_off[i] += (uint32_t)(BK * 4) * (uint32_t)a.Npad;
         }
     };
     auto store_tiles = [&](int buf) {
@@ -125,12 +202,6 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
             As[buf][a_k4 + 2][ml] = ra[i].z;
             As[buf][a_k4 + 3][ml] = ra[i].w;
         }
-#pragma unroll
-        for (int i = 0; i < B_F4; ++i) {
-            const int e = tid + 256 * i;
-            const int kr = e / BN4, n4 = (e - kr * BN4) * 4;
-            if (kr < BK) *(float4 *)&Bs[buf][kr][n4] = rb[i];
-        }
     };
 
     f32x16 acc[TM][TN];
@@ -141,51 +212,53 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    const int nk_all = (a.K + BK - 1) / BK;
-    const int kt0 = (int)((long long)nk_all * blockIdx.z / a.splits), kt1 = (int)((long long)nk_all * (blockIdx.z + 1) / a.splits);
-    const int nk = kt1 - kt0;
-    {   // position the tap tracker on this split's first k-tile
-        const int k = kt0 * BK + a_k4;
-        const int tap = k / a.Cin;
-        t_ci = k - tap * a.Cin;
-        t_ky = tap / kw;
-        t_kx = tap - t_ky * kw;
-    }
-    load_tiles(kt0);
+    PROBE_PH(0);
+    load_tiles(kt0, 0);
+    PROBE_PH(1);
     store_tiles(0);
     __syncthreads();
+    PROBE_PH(2);
     const int fm = wr * TM * 32 + (lane & 31), fn = wc * TN * 32 + (lane & 31), fk = lane >> 5;
+#if defined(CONV_EXP) && CONV_EXP >= 4
+    float fa[2][TM], fb[2][TN];
+#endif
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
 #if !defined(CONV_EXP) || CONV_EXP < 1
-        if (kt + 1 < nk) load_tiles(kt0 + kt + 1);
+        if (kt + 1 < nk) load_tiles(kt0 + kt + 1, buf ^ 1);
 #endif
-        // all operand fragments of the k-tile are requested up front, into their own registers: the LDS answers in
-        // order, so the first MFMAs start as soon as their fragments are there while the rest is still in flight
-        // (fragment reads issued one k-step at a time leave every wavefront waiting a full LDS round trip per step:
-        // measured 117 -> see DESIGN.md section 4)
-        float fa[BK / 2][TM], fb[BK / 2][TN];
-#if defined(CONV_EXP) && CONV_EXP == 4
-        if (kt == 0)
+        // Fragment reads run one k-step ahead of the MFMAs that consume them (two register sets): the matrix pipe never
+        // waits for a full LDS round trip once the first pair has arrived.  The group barriers pin that order.
+#if !defined(CONV_EXP) || CONV_EXP < 4
+        float fa[2][TM], fb[2][TN];
 #endif
-#pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) fa[kk / 2][i] = As[buf][kk + fk][fm + 32 * i];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) fb[kk / 2][j] = Bs[buf][kk + fk][fn + 32 * j];
-        }
-#if defined(CONV_EXP) && CONV_EXP >= 5
-        __builtin_amdgcn_sched_barrier(0);
+        auto read_frags = [&](int st) {
+#if defined(CONV_EXP) && CONV_EXP >= 4
+            if (kt) return;
 #endif
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
+            for (int i = 0; i < TM; ++i) fa[st & 1][i] = As[buf][2 * st + fk][fm + 32 * i];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[st & 1][j] = Bs[buf][2 * st + fk][fn + 32 * j];
+        };
+        read_frags(0);
+#pragma unroll
+        for (int st = 0; st < BK / 2; ++st) {
+            if (st + 1 < BK / 2) read_frags(st + 1);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk / 2][i], fb[kk / 2][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[st & 1][i], fb[st & 1][j], acc[i][j], 0, 0, 0);
         }
+#ifndef CONV_NO_SGB
+        __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+#pragma unroll
+        for (int st = 0; st < BK / 2; ++st) {
+            if (st + 1 < BK / 2) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+        }
+#endif
 #if !defined(CONV_EXP) || CONV_EXP < 2
         if (kt + 1 < nk) store_tiles(buf ^ 1);
 #endif
@@ -194,19 +267,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
 #endif
     }
 
-#if defined(CONV_EXP) && CONV_EXP == 6
-    {   // experiment: no epilogue at all (a never-taken store keeps the accumulators alive)
-        float t = 0.f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) t += acc[i][j][r];
-        if (t == 123.456f) a.y[0] = t;
-        return;
-    }
-#endif
+    PROBE_PH(3);
     // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     if (a.splits > 1) { // raw partial sums; k_splitk_reduce applies bias / activation / residual
         float *dst = a.partial + (long long)blockIdx.z * a.M * a.Npad;
@@ -321,9 +382,33 @@ __global__ void k_splitk_reduce(ConvArgs a)
 
 inline int conv_grid_1d(long long n) { long long g = (n + 255) / 256; if (g > 4096) g = 4096; if (g < 1) g = 1; return (int)g; }
 
+template <int BM, int BN, int WROWS, int WCOLS, int BK>
+inline void launch_conv_tile(const ConvArgs &c, dim3 grid, hipStream_t s)
+{
+    if (c.Cin % BK == 0) hipLaunchKernelGGL((k_conv_mfma<BM, BN, WROWS, WCOLS, BK, true>), grid, dim3(256), 0, s, c);
+    else hipLaunchKernelGGL((k_conv_mfma<BM, BN, WROWS, WCOLS, BK, false>), grid, dim3(256), 0, s, c);
+}
+
 // Tile choice and split-K for one convolution; `scratch` (scratch_floats floats, may be NULL) holds split-K partials.
 inline void launch_conv(ConvArgs &c, float *scratch, long long scratch_floats, hipStream_t s)
 {
+    const int howo = c.Ho * c.Wo, nb = c.M / howo;
+    const long long x_bytes = (((long long)(nb - 1) * c.x_bs) + ((long long)c.H * c.W - 1) * c.x_cs + c.x_co + c.Cin) * 4;
+    if (x_bytes > kMaxViewBytes && nb > 1 && c.M == nb * howo) { // 32-bit buffer offsets: run the batch in two halves
+        ConvArgs h = c;
+        const int b0 = nb / 2;
+        h.M = b0 * howo;
+        launch_conv(h, scratch, scratch_floats, s);
+        h = c;
+        h.M = (nb - b0) * howo;
+        h.x = c.x + (long long)b0 * c.x_bs;
+        h.y = c.y + (long long)b0 * c.y_bs;
+        if (c.res) h.res = c.res + (long long)b0 * c.r_bs;
+        launch_conv(h, scratch, scratch_floats, s);
+        return;
+    }
+    c.x_bytes = (uint32_t)(x_bytes < kMaxViewBytes ? x_bytes : kMaxViewBytes);
+    c.w_bytes = (uint32_t)((long long)c.K * c.Npad * 4);
     c.splits = 1;
     c.partial = nullptr;
     const long long big = (long long)((c.M + 127) / 128) * ((c.Npad + 127) / 128);
@@ -332,12 +417,12 @@ inline void launch_conv(ConvArgs &c, float *scratch, long long scratch_floats, h
     static const long long big_min = dev_knob("FRLW_CONV_BIG_MIN", 1000000ll);
     static const long long wide_min = dev_knob("FRLW_CONV_WIDE_MIN", 1200ll);
     if (c.Npad <= 32) { // small N (prediction convs, the stem's data gradient)
-        hipLaunchKernelGGL((k_conv_mfma<128, 32, 4, 1, 16>), dim3((c.M + 127) / 128, 1), dim3(256), 0, s, c);
+        launch_conv_tile<128, 32, 4, 1, 16>(c, dim3((c.M + 127) / 128, 1), s);
     } else if (big >= big_min && c.Npad >= 128) {
-        hipLaunchKernelGGL((k_conv_mfma<128, 128, 2, 2, CONV_BK_BIG>), dim3((c.M + 127) / 128, (c.Npad + 127) / 128), dim3(256), 0, s, c);
+        launch_conv_tile<128, 128, 2, 2, CONV_BK_BIG>(c, dim3((c.M + 127) / 128, (c.Npad + 127) / 128), s);
     } else if (c.Npad >= 128 && (long long)((c.M + 63) / 64) * ((c.Npad + 127) / 128) >= wide_min) {
         // 64 x 128: half the im2col gathers per output of the 64 x 64 tile, still > 4 workgroups per CU
-        hipLaunchKernelGGL((k_conv_mfma<64, 128, 2, 2, 16>), dim3((c.M + 63) / 64, (c.Npad + 127) / 128), dim3(256), 0, s, c);
+        launch_conv_tile<64, 128, 2, 2, 16>(c, dim3((c.M + 63) / 64, (c.Npad + 127) / 128), s);
     } else {
         const long long wgs = (long long)((c.M + 63) / 64) * ((c.Npad + 63) / 64);
         const int nk = (c.K + kSplitBK - 1) / kSplitBK;
@@ -348,7 +433,7 @@ inline void launch_conv(ConvArgs &c, float *scratch, long long scratch_floats, h
             if (sp > nk / 8) sp = nk / 8;
             if (sp > 1 && (long long)sp * c.M * c.Npad <= scratch_floats) { c.splits = sp; c.partial = scratch; }
         }
-        hipLaunchKernelGGL((k_conv_mfma<64, 64, 2, 2, CONV_BK_SMALL>), dim3((c.M + 63) / 64, (c.Npad + 63) / 64, c.splits), dim3(256), 0, s, c);
+        launch_conv_tile<64, 64, 2, 2, CONV_BK_SMALL>(c, dim3((c.M + 63) / 64, (c.Npad + 63) / 64, c.splits), s);
         if (c.splits > 1)
             hipLaunchKernelGGL(k_splitk_reduce, dim3(conv_grid_1d((long long)c.M * c.Cout)), dim3(256), 0, s, c);
     }
