@@ -7,6 +7,8 @@
 // (no #includes here: the including file has <hip/hip_runtime.h>, <math.h>, <stdint.h>, <stdlib.h> already)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int V> struct ConvIC { static constexpr int value = V; }; // compile-time step index for asm immediates
 
 // Launch heuristics are compile-time constants in the product library: it reads no environment and prints nothing.  A
 // developer build (-DFRLW_DEV_BUILD) lets the environment override them for A/B runs and logs HIP errors.
@@ -85,16 +87,22 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
     constexpr int TM = BM / (32 * WROWS), TN = BN / (32 * WCOLS);
     constexpr int KQ = BK / 4;        // float4 per A row of the k-tile
     constexpr int RPP = 256 / KQ;     // A rows staged per pass of the 256 threads
-    constexpr int LDA = BM + 4; // +4 floats: k rows land on different banks for the staging writes
-    constexpr int LDB = BN;     // the weight tile arrives by LDS-DMA: lane-linear, [BK][BN] without padding
+    // Both operand tiles arrive by LDS-DMA (buffer_load ... lds: no registers, no ds_write), so their LDS images are
+    // lane-linear: weights [BK][BN], gathered rows [BM][BK] with the four 16-byte quads of a row XOR-swizzled by
+    // (row >> 2) & 3 on the SOURCE side, which makes the ds_read_b128 fragment reads conflict-free.
+    static_assert(BK == 16, "the A image is four quads per row");
+    constexpr int LDB = BN;
     constexpr int A_F4 = BM * BK / 4 / 256;   // float4 loads per thread for the A tile
     constexpr int B_F4 = (BN * BK / 4 + 255) / 256;
     constexpr int EPLD = 36;                          // row pitch of the epilogue staging (16-byte aligned rows)
-    constexpr int kTileFloats = 2 * BK * (LDA + LDB);
+    // LDS rings.  The gathered operand streams from HBM / the far L2: its tile t + 2 is requested while tile t is
+    // computed (three slots).  The weights are L2-resident and shared by every workgroup: one tile ahead (two slots).
+    constexpr int NA = 3, NB = 2;
+    constexpr int kTileFloats = BK * (NA * BM + NB * LDB);
     constexpr int kEpiFloats = 4 * 32 * EPLD;         // one 32 x 32 MFMA tile per wavefront
     __shared__ __attribute__((aligned(16))) float smem[kTileFloats > kEpiFloats ? kTileFloats : kEpiFloats];
-    float (*As)[BK][LDA] = (float (*)[BK][LDA])smem;
-    float (*Bs)[BK][LDB] = (float (*)[BK][LDB])(smem + 2 * BK * LDA);
+    float (*As)[BM][BK] = (float (*)[BM][BK])smem;
+    float (*Bs)[BK][LDB] = (float (*)[BK][LDB])(smem + NA * BK * BM);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wr = wv / WCOLS, wc = wv % WCOLS;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
@@ -109,7 +117,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
     const __amdgpu_buffer_rsrc_t rx = conv_rsrc(a.x, a.x_bytes), rw = conv_rsrc(a.w, a.w_bytes);
 
     // ---- A staging: thread -> A_F4 rows m, one float4 of 4 consecutive k
-    const int a_k4 = (tid % KQ) * 4;
+    const int a_k4 = ((tid & 3) ^ ((tid >> 4) & 3)) * 4; // the quad this lane FETCHES; it lands in slot tid & 3 of its row
     int a_iy0[A_F4], a_ix0[A_F4];
     uint32_t a_base[A_F4]; // byte offset of the row's image (+ channel offset); kOob for rows past M
 #pragma unroll
@@ -134,7 +142,6 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
     // ---- B staging: thread -> rows k, one float4 of 4 consecutive n
     constexpr int BN4 = BN / 4;
     uint32_t b_off[B_F4]; // byte offset of this thread's float4 in the NEXT k-tile to load; rows past K fail the range check
-    float4 ra[A_F4];
 
     const int nk_all = (a.K + BK - 1) / BK;
     const int kt0 = (int)((long long)nk_all * blockIdx.z / a.splits), kt1 = (int)((long long)nk_all * (blockIdx.z + 1) / a.splits);
@@ -160,14 +167,14 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) a_pix[i] = gather_off(i, s_ky, s_kx);
     }
-    // The weight tile goes global -> LDS directly (buffer_load ... lds: no registers, no ds_write; wave-instruction i of
-    // wavefront wv fills the 1 KB at float offset (wv * 64 + 256 i) * 4 of the tile).  The gathered A tile is staged
-    // through registers: its LDS image is k-major, which no lane-linear DMA can produce.
-    auto load_tiles = [&](int kt, int nbuf) {
+    // wave-instruction i of wavefront wv fills the 1 KB at float offset (wv * 64 + 256 i) * 4 of a tile
+    auto load_a = [&](int kt, int nbuf) {
         if (UT) {
             const uint32_t cib = (uint32_t)(s_ci + a_k4) * 4;
 #pragma unroll
-            for (int i = 0; i < A_F4; ++i) ra[i] = conv_load16(rx, a_pix[i] + cib); // kOob + cib stays out of range
+            for (int i = 0; i < A_F4; ++i) // kOob + cib stays out of range: zeros land in LDS
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void *)(&As[nbuf][0][0] + (wv * 64 + 256 * i) * 4),
+                                                         16, (int)(a_pix[i] + cib), 0, 0, 0);
             s_ci += BK;
             if (s_ci == a.Cin) { // next tap (uniform branch, once per Cin / BK tiles)
                 s_ci = 0;
@@ -180,27 +187,20 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
 #pragma unroll
             for (int i = 0; i < A_F4; ++i) {
                 const uint32_t o = gather_off(i, s_ky, s_kx);
-                ra[i] = conv_load16(rx, in_k ? o + (uint32_t)s_ci * 4 : kOob);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void *)(&As[nbuf][0][0] + (wv * 64 + 256 * i) * 4),
+                                                         16, (int)(in_k ? o + (uint32_t)s_ci * 4 : kOob), 0, 0, 0);
             }
             s_ci += BK; // Cin % 4 == 0: a float4 never straddles taps
             while (s_ci >= a.Cin) { s_ci -= a.Cin; if (++s_kx == kw) { s_kx = 0; ++s_ky; } }
         }
+    };
+    auto load_b = [&](int nbuf) {
 #pragma unroll
         for (int i = 0; i < B_F4; ++i) {
             if ((BN * BK / 4) % 256 == 0 || wv * 64 + 256 * i < BN * BK / 4) // wave-uniform
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void *)(&Bs[nbuf][0][0] + (wv * 64 + 256 * i) * 4),
                                                          16, (int)b_off[i], 0, 0, 0);
             b_off[i] += (uint32_t)(BK * 4) * (uint32_t)a.Npad;
-        }
-    };
-    auto store_tiles = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < A_F4; ++i) {
-            const int ml = tid / KQ + RPP * i;
-            As[buf][a_k4 + 0][ml] = ra[i].x;
-            As[buf][a_k4 + 1][ml] = ra[i].y;
-            As[buf][a_k4 + 2][ml] = ra[i].z;
-            As[buf][a_k4 + 3][ml] = ra[i].w;
         }
     };
 
@@ -212,74 +212,116 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
+    // Issue order inside an iteration: weights of tile t + 1 first, gathered rows of tile t + 2 last -- "all but my
+    // newest A_F4 DMA instructions have landed" (a counted vmcnt) is then exactly "tile t + 1 is complete".
+    auto wait_next_tile = [&](bool a_in_flight) { // wave-uniform
+        if (a_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_F4) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
     PROBE_PH(0);
-    load_tiles(kt0, 0);
+    load_a(kt0, 0);
+    load_b(0);
+    if (nk > 1) load_a(kt0 + 1, 1);
     PROBE_PH(1);
-    store_tiles(0);
-    __syncthreads();
+    wait_next_tile(nk > 1);
+    __builtin_amdgcn_s_barrier(); // raw barrier: __syncthreads() would drain the DMA of the tile in flight
     PROBE_PH(2);
-    const int fm = wr * TM * 32 + (lane & 31), fn = wc * TN * 32 + (lane & 31), fk = lane >> 5;
-#if defined(CONV_EXP) && CONV_EXP >= 4
-    float fa[2][TM], fb[2][TN];
-#endif
+    // MFMA k-step (j, t), j = 0..1, t = 0..3: lane half h supplies k = 8 j + 4 h + t -- any pairing of the tile's 16 k
+    // works as long as both operands use it; this one lets a lane take its four A values of a j from ONE 16-byte read.
+    static_assert(TM <= 2 && TN <= 2, "fragment reads are written out for at most two tiles per direction");
+    const int fh = lane >> 5, fsw = ((lane & 31) >> 2) & 3;
+    const int fm = wr * TM * 32 + (lane & 31), fn = wc * TN * 32 + (lane & 31);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float *)smem;
+    // byte addresses in ring slot 0: A quad (2 j + h) ^ swizzle of row fm (second tile: + 32 rows = 2048 B), B row 4 h
+    const uint32_t a_lds[2] = {lds0 + (uint32_t)(fm * BK + ((0 + fh) ^ fsw) * 4) * 4, lds0 + (uint32_t)(fm * BK + ((2 + fh) ^ fsw) * 4) * 4};
+    const uint32_t b_lds = lds0 + (uint32_t)(NA * BK * BM + 4 * fh * LDB + fn) * 4;
+    int buf = 0; // A ring slot of tile kt; the B slot is kt & 1
     for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
 #if !defined(CONV_EXP) || CONV_EXP < 1
-        if (kt + 1 < nk) load_tiles(kt0 + kt + 1, buf ^ 1);
+        if (kt + 1 < nk) load_b((kt + 1) & 1);                               // slot read last in iteration kt - 1
+        if (kt + 2 < nk) load_a(kt0 + kt + 2, buf == 0 ? 2 : buf - 1);       // (buf + 2) % 3: likewise
 #endif
-        // Fragment reads run one k-step ahead of the MFMAs that consume them (two register sets): the matrix pipe never
-        // waits for a full LDS round trip once the first pair has arrived.  The group barriers pin that order.
-#if !defined(CONV_EXP) || CONV_EXP < 4
-        float fa[2][TM], fb[2][TN];
-#endif
-        auto read_frags = [&](int st) {
-#if defined(CONV_EXP) && CONV_EXP >= 4
-            if (kt) return;
-#endif
-#pragma unroll
-            for (int i = 0; i < TM; ++i) fa[st & 1][i] = As[buf][2 * st + fk][fm + 32 * i];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) fb[st & 1][j] = Bs[buf][2 * st + fk][fn + 32 * j];
+        // Fragment reads run ahead of the MFMAs that consume them (B one k-step, A one j).  They are issued as asm
+        // statements with hand-counted lgkmcnt waits: the compiler puts `s_waitcnt vmcnt(0)` in front of every LDS read
+        // it can see while an LDS-DMA is in flight (it cannot tell that the DMA writes another ring slot), which would
+        // drain the prefetch.  LDS returns in order, so "all but the newest N reads" is exactly lgkmcnt(N); the empty asm
+        // statements after a wait make the consuming MFMAs depend on it.
+        f32x4 fa[2][TM];
+        float fb[2][TN];
+        const uint32_t a_addr0 = a_lds[0] + (uint32_t)buf * (BM * BK * 4), a_addr1 = a_lds[1] + (uint32_t)buf * (BM * BK * 4);
+        const uint32_t b_addr = b_lds + (uint32_t)(kt & 1) * (BK * LDB * 4);
+        auto read_a = [&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            asm volatile("ds_read_b128 %0, %1" : "=v"(fa[j][0]) : "v"(j ? a_addr1 : a_addr0));
+            if (TM > 1) asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(fa[j][TM - 1]) : "v"(j ? a_addr1 : a_addr0));
         };
-        read_frags(0);
+        auto read_b = [&](auto stc) {
+            constexpr int st = decltype(stc)::value;
+            constexpr int off = (8 * (st >> 2) + (st & 3)) * LDB * 4;
+            asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(fb[st & 1][0]) : "v"(b_addr), "n"(off));
+            if (TN > 1) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(fb[st & 1][TN - 1]) : "v"(b_addr), "n"(off + 128));
+        };
+        auto step = [&](auto stc) {
+            constexpr int st = decltype(stc)::value;
+            if (st + 1 < 8) {
+                read_b(ConvIC<(st + 1 < 8 ? st + 1 : 7)>{});
+                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(st == 0 ? TM + TN : TN) : "memory");
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
 #pragma unroll
-        for (int st = 0; st < BK / 2; ++st) {
-            if (st + 1 < BK / 2) read_frags(st + 1);
+            for (int jn = 0; jn < TN; ++jn) asm volatile("" : "+v"(fb[st & 1][jn]));
+            if ((st & 3) == 0) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(fa[st >> 2][i]));
+            }
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[st & 1][i], fb[st & 1][j], acc[i][j], 0, 0, 0);
-        }
-#ifndef CONV_NO_SGB
-        __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+            for (int i = 0; i < TM; ++i) {
+                const float af = fa[st >> 2][i][st & 3];
 #pragma unroll
-        for (int st = 0; st < BK / 2; ++st) {
-            if (st + 1 < BK / 2) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
-        }
-#endif
-#if !defined(CONV_EXP) || CONV_EXP < 2
-        if (kt + 1 < nk) store_tiles(buf ^ 1);
-#endif
+                for (int jn = 0; jn < TN; ++jn)
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, fb[st & 1][jn], acc[i][jn], 0, 0, 0);
+            }
+        };
+        read_a(ConvIC<0>{});
+        read_b(ConvIC<0>{});
+        read_a(ConvIC<1>{});
+        step(ConvIC<0>{});
+        step(ConvIC<1>{});
+        step(ConvIC<2>{});
+        step(ConvIC<3>{});
+        step(ConvIC<4>{});
+        step(ConvIC<5>{});
+        step(ConvIC<6>{});
+        step(ConvIC<7>{});
 #if !defined(CONV_EXP) || CONV_EXP < 3
-        __syncthreads();
+        wait_next_tile(kt + 2 < nk);            // tile kt + 1 has landed (this wavefront's pieces) ...
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();           // ... everybody's have, and everybody is done reading tile kt
 #endif
+        buf = buf == 2 ? 0 : buf + 1;
     }
 
     PROBE_PH(3);
     // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-    if (a.splits > 1) { // raw partial sums; k_splitk_reduce applies bias / activation / residual
+    if (a.splits > 1) { // raw partial sums (k_splitk_reduce applies bias / activation / residual), as 16-byte rows
         float *dst = a.partial + (long long)blockIdx.z * a.M * a.Npad;
+        float *epw = smem + wv * 32 * EPLD;
+        const int er = lane >> 3, ec = (lane & 7) * 4;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int n = n0 + wc * TN * 32 + 32 * j + (lane & 31);
+                asm volatile("" ::: "memory");
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + wr * TM * 32 + 32 * i + 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2);
-                    if (m < a.M && n < a.Npad) dst[(long long)m * a.Npad + n] = acc[i][j][r];
+                for (int r = 0; r < 16; ++r)
+                    epw[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EPLD + (lane & 31)] = acc[i][j][r];
+                asm volatile("" ::: "memory");
+                const int n = n0 + wc * TN * 32 + 32 * j + ec;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int m = m0 + wr * TM * 32 + 32 * i + er + 8 * t;
+                    if (m < a.M && n < a.Npad) *(float4 *)(dst + (long long)m * a.Npad + n) = *(const float4 *)&epw[(er + 8 * t) * EPLD + ec];
                 }
             }
         return;
@@ -360,23 +402,52 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
     }
 }
 
-// y = act(sum over splits of partial + bias) [+ res]
-__global__ void k_splitk_reduce(ConvArgs a)
+// y = act(sum over splits of partial + bias) [+ res].  VEC: four consecutive channels per thread (16-byte loads of every
+// split's partial row, one 16-byte store); the partial sums are added in split order, as the scalar form does.
+template <bool VEC>
+__global__ __launch_bounds__(256) void k_splitk_reduce(ConvArgs a)
 {
-    const long long total = (long long)a.M * a.Cout;
+    constexpr int V = VEC ? 4 : 1;
+    const int cv = a.Cout / V;
+    const long long total = (long long)a.M * cv;
     const int howo = a.Ho * a.Wo;
+    const long long zstride = (long long)a.M * a.Npad;
     for (long long o = blockIdx.x * (long long)blockDim.x + threadIdx.x; o < total; o += (long long)gridDim.x * blockDim.x) {
-        const int n = (int)(o % a.Cout);
-        const int m = (int)(o / a.Cout);
-        float v = 0.0f;
-        for (int z = 0; z < a.splits; ++z) v += a.partial[((long long)z * a.M + m) * a.Npad + n];
-        const int act = (a.act == ACT_SIGMOID && n < a.sig_from) ? ACT_NONE : a.act;
-        v = act_apply(v + (a.bias ? a.bias[n] : 0.0f), act);
+        const int m = (int)(o / cv);
+        const int n = (int)(o - (long long)m * cv) * V;
+        const float *p = a.partial + (long long)m * a.Npad + n;
+        float v[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) v[e] = 0.0f;
+        if (VEC) {
+            float4 t[8];
+#pragma unroll
+            for (int z = 0; z < 8; ++z)
+                if (z < a.splits) t[z] = *(const float4 *)(p + z * zstride);
+#pragma unroll
+            for (int z = 0; z < 8; ++z)
+                if (z < a.splits) { v[0] += t[z].x; v[1 % V] += t[z].y; v[2 % V] += t[z].z; v[3 % V] += t[z].w; }
+        } else {
+            for (int z = 0; z < a.splits; ++z) v[0] += p[z * zstride];
+        }
         const int b = m / howo, pix = m - b * howo;
-        if (a.res) v = v + a.res[(long long)b * a.r_bs + (long long)pix * a.r_cs + a.r_co + n];
         long long yo = (long long)pix * a.y_cs;
         if (a.y_rp) { const int oy = pix / a.Wo; yo = (long long)oy * a.y_rp + (long long)(pix - oy * a.Wo) * a.y_cs; }
-        a.y[(long long)b * a.y_bs + yo + a.y_co + n] = v;
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const int act = (a.act == ACT_SIGMOID && n + e < a.sig_from) ? ACT_NONE : a.act;
+            v[e] = act_apply(v[e] + (a.bias ? a.bias[n + e] : 0.0f), act);
+        }
+        if (VEC) {
+            if (a.res) {
+                const float4 rr = *(const float4 *)(a.res + (long long)b * a.r_bs + (long long)pix * a.r_cs + a.r_co + n);
+                v[0] += rr.x; v[1 % V] += rr.y; v[2 % V] += rr.z; v[3 % V] += rr.w;
+            }
+            *(float4 *)(a.y + (long long)b * a.y_bs + yo + a.y_co + n) = make_float4(v[0], v[1 % V], v[2 % V], v[3 % V]);
+        } else {
+            if (a.res) v[0] += a.res[(long long)b * a.r_bs + (long long)pix * a.r_cs + a.r_co + n];
+            a.y[(long long)b * a.y_bs + yo + a.y_co + n] = v[0];
+        }
     }
 }
 
@@ -434,7 +505,10 @@ inline void launch_conv(ConvArgs &c, float *scratch, long long scratch_floats, h
             if (sp > 1 && (long long)sp * c.M * c.Npad <= scratch_floats) { c.splits = sp; c.partial = scratch; }
         }
         launch_conv_tile<64, 64, 2, 2, CONV_BK_SMALL>(c, dim3((c.M + 63) / 64, (c.Npad + 63) / 64, c.splits), s);
-        if (c.splits > 1)
-            hipLaunchKernelGGL(k_splitk_reduce, dim3(conv_grid_1d((long long)c.M * c.Cout)), dim3(256), 0, s, c);
+        if (c.splits > 1) {
+            const bool vec = ((c.Cout | c.Npad | c.y_cs | c.y_co | c.r_cs | c.r_co | c.y_rp) & 3) == 0 && (c.y_bs & 3) == 0 && (c.r_bs & 3) == 0;
+            if (vec) hipLaunchKernelGGL(k_splitk_reduce<true>, dim3(conv_grid_1d((long long)c.M * c.Cout / 4)), dim3(256), 0, s, c);
+            else hipLaunchKernelGGL(k_splitk_reduce<false>, dim3(conv_grid_1d((long long)c.M * c.Cout)), dim3(256), 0, s, c);
+        }
     }
 }

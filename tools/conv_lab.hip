@@ -84,6 +84,12 @@ int main(int argc, char **argv)
             printf("   probe: %d workgroups on %d CUs, per CU min %d max %d, start spread %.1f us, span %.1f us, workgroup mean %.1f max %.1f us; histogram:", n, cus, mn, mx, (tmax - tmin) / 100.0, (emax - tmin) / 100.0, dsum / n / 100.0, dmax / 100.0);
             for (int i = 0; i < 64; ++i) if (hist[i]) printf(" %dx%d", hist[i], i);
             printf("\n");
+            { // per CU: when does its first / last workgroup finish (relative to the launch's first start)
+              static unsigned long long cmin[4096], cmax[4096]; for (int i = 0; i < 4096; ++i) { cmin[i] = ~0ull; cmax[i] = 0; }
+              for (int i = 0; i < maxwg; ++i) if (hp[i] != 0xFFFFFFFFu) { const int c2 = hp[i] & 4095; if (he[i] < cmin[c2]) cmin[c2] = he[i]; if (he[i] > cmax[c2]) cmax[c2] = he[i]; }
+              double sfirst = 0, slast = 0, lo = 1e30, hi = 0; int nc = 0;
+              for (int i = 0; i < 4096; ++i) if (cmax[i]) { ++nc; sfirst += cmin[i] - tmin; slast += cmax[i] - tmin; if (cmax[i] - tmin < lo) lo = cmax[i] - tmin; if (cmax[i] - tmin > hi) hi = cmax[i] - tmin; }
+              printf("   per CU: first workgroup done at %.1f us (mean), last at %.1f us (mean; min %.1f max %.1f over CUs)\n", sfirst / nc / 100, slast / nc / 100, lo / 100, hi / 100); }
             { double a[5] = {0}; for (int i = 0; i < maxwg; ++i) if (hp[i] != 0xFFFFFFFFu) { a[0] += hph[i * 8] - ht[i]; a[1] += hph[i * 8 + 1] - hph[i * 8]; a[2] += hph[i * 8 + 2] - hph[i * 8 + 1]; a[3] += hph[i * 8 + 3] - hph[i * 8 + 2]; a[4] += he[i] - hph[i * 8 + 3]; }
               printf("   phases (mean us): index setup %.2f, first loads issued %.2f, first tile in LDS %.2f, k-loop %.2f, epilogue %.2f\n", a[0] / n / 100, a[1] / n / 100, a[2] / n / 100, a[3] / n / 100, a[4] / n / 100); }
             CK(hipFree(ph));
