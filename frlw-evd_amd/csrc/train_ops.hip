@@ -73,128 +73,7 @@ __global__ void k_weight_layouts(const float *w, int Cout, int Cin, int k, float
 // dW[r = (ky, kx, ci)][co] = sum over pixels m of x[m shifted by the tap][ci] * dz[m][co].
 // 64 x 64 tile of (r, co) per workgroup, 4 wavefronts 2 x 2, k-tiles of 16 pixels, blockIdx.z owns a slice of the
 // pixels and writes a partial tile (always: the reduction kernel also converts to torch's layout).
-struct WgradArgs {
-    const float *x; int H, W, Cin; long long x_bs; int x_cs;     // input NHWC
-    const float *dz; int Ho, Wo, Cout; long long dz_bs; int dz_cs;
-    int k, stride, pad;
-    int R;          // k * k * Cin
-    int M;          // B * Ho * Wo
-    int splits;
-    float *partial; // [splits][R][Cout]
-};
-
-// BM = 64 or 128 rows (r) x BN = 64 or 128 columns (co) per workgroup; the 4 wavefronts are 2 x 2, each
-// TM x TN = (BM / 64) x (BN / 64) MFMA tiles of 32 x 32.
-template <int BM, int BN>
-__global__ __launch_bounds__(256) void k_wgrad_mfma(WgradArgs a)
-{
-    constexpr int BK = 16, LDA = BM + 4, LDB = BN + 4, TM = BM / 64, TN = BN / 64;
-    __shared__ float As[2][BK][LDA]; // [pixel][r]
-    __shared__ float Bs[2][BK][LDB]; // [pixel][co]
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int wr = wv >> 1, wc = wv & 1;
-    const int r0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    // staging: thread -> pixel (tid / 16) of the k-tile, float4 #(tid % 16) of each 64-wide group of r / co columns
-    const int pk = tid >> 4, q4 = (tid & 15) * 4;
-    bool r_ok[TM], n_ok[TN];
-    int ci[TM], ky[TM], kx[TM];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) { // the (tap, ci) of this thread's float4 in r-group i (Cin % 4 == 0: one tap per float4)
-        const int r = r0 + 64 * i + q4;
-        r_ok[i] = r < a.R;
-        const int tap = r_ok[i] ? r / a.Cin : 0;
-        ci[i] = r_ok[i] ? r - tap * a.Cin : 0;
-        ky[i] = tap / a.k;
-        kx[i] = tap - ky[i] * a.k;
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) n_ok[j] = n0 + 64 * j + q4 < a.Cout;
-    const int howo = a.Ho * a.Wo;
-    const int nk_all = (a.M + BK - 1) / BK;
-    const int kt0 = (int)((long long)nk_all * blockIdx.z / a.splits), kt1 = (int)((long long)nk_all * (blockIdx.z + 1) / a.splits);
-    // this thread's pixel of the current k-tile as (image, oy, ox); advanced by BK pixels per tile without divisions
-    int pb, poy, pox;
-    {
-        const long long m = (long long)kt0 * BK + pk;
-        pb = (int)(m / howo);
-        const int pix = (int)(m - (long long)pb * howo);
-        poy = pix / a.Wo;
-        pox = pix - poy * a.Wo;
-    }
-    float4 ra[TM], rb[TN];
-    auto load_tiles = [&]() {
-        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int i = 0; i < TM; ++i) ra[i] = zero;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) rb[j] = zero;
-        if (pb * howo + poy * a.Wo + pox < a.M) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int iy = poy * a.stride - a.pad + ky[i], ix = pox * a.stride - a.pad + kx[i];
-                if (r_ok[i] && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
-                    ra[i] = *(const float4 *)(a.x + (long long)pb * a.x_bs + ((long long)iy * a.W + ix) * a.x_cs + ci[i]);
-            }
-            const float *dzp = a.dz + (long long)pb * a.dz_bs + ((long long)poy * a.Wo + pox) * a.dz_cs + n0 + q4;
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                if (n_ok[j]) rb[j] = *(const float4 *)(dzp + 64 * j);
-        }
-        pox += BK;
-        while (pox >= a.Wo) { pox -= a.Wo; if (++poy == a.Ho) { poy = 0; ++pb; } }
-    };
-    auto store_tiles = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) *(float4 *)&As[buf][pk][64 * i + q4] = ra[i];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) *(float4 *)&Bs[buf][pk][64 * j + q4] = rb[j];
-    };
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-    const int nk = kt1 - kt0;
-    if (nk > 0) {
-        load_tiles();
-        store_tiles(0);
-    }
-    __syncthreads();
-    const int fm = wr * 32 * TM + (lane & 31), fn = wc * 32 * TN + (lane & 31), fk = lane >> 5;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) load_tiles();
-#pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            float fa[TM], fb[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = As[buf][kk + fk][fm + 32 * i];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = Bs[buf][kk + fk][fn + 32 * j];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
-        }
-        if (kt + 1 < nk) store_tiles(buf ^ 1);
-        __syncthreads();
-    }
-    float *dst = a.partial + (long long)blockIdx.z * a.R * a.Cout;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wc * 32 * TN + 32 * j + (lane & 31);
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int rr = r0 + wr * 32 * TM + 32 * i + 4 * (lane >> 5) + (e & 3) + 8 * (e >> 2);
-                if (rr < a.R && n < a.Cout) dst[(long long)rr * a.Cout + n] = acc[i][j][e];
-            }
-        }
-}
+#include "wgrad_mfma.h"
 
 // Thin layers have few output tiles and therefore many pixel splits: first add groups of kWgradGroup partial tiles
 // in parallel (same layout), then the final pass below runs over the group sums.  Fixed order -> deterministic.
@@ -544,22 +423,11 @@ int frlw_conv2d_dgrad(const float *dz, int B, int Ho, int Wo, int Cout, const fl
                        (hipStream_t)stream);
 }
 
-// 128 x 128 tiles (half the x gathers and half the dz reads per output) when that still leaves >= 32 output tiles
-static bool wgrad_wide(long long R, int Cout)
-{
-    static const long long min_tiles = dev_knob("FRLW_WGRAD_WIDE_TILES", 32ll);
-    return Cout >= 128 && R >= 128 && ((R + 127) / 128) * ((Cout + 127) / 128) >= min_tiles;
-}
-
 int64_t frlw_conv2d_wgrad_scratch_floats(int B, int Ho, int Wo, int Cin, int Cout, int k)
 {
-    const long long R = (long long)k * k * Cin, bm = R > 64 ? 128 : 64, bn = wgrad_wide(R, Cout) ? 128 : 64;
-    const long long tiles = ((R + bm - 1) / bm) * ((Cout + bn - 1) / bn);
-    const long long nk = ((long long)B * Ho * Wo + 15) / 16;
-    long long sp = (1024 + tiles - 1) / tiles; // ~1024 workgroups
-    if (sp > 256) sp = 256;                    // (more than 64 partial tiles per output tile: two-stage reduction)
-    if (sp > nk / 4) sp = nk / 4;
-    if (sp < 1) sp = 1;
+    const long long R = (long long)k * k * Cin;
+    static const long long target = dev_knob("FRLW_WGRAD_TARGET", 1024ll);
+    const long long sp = wgrad_want_splits(R, Cout, (long long)B * Ho * Wo, target);
     const long long groups = sp > 64 ? (sp + kWgradGroup - 1) / kWgradGroup : 0;
     return (sp + groups) * R * Cout;
 }
@@ -594,12 +462,7 @@ int frlw_conv2d_wgrad(const float *x, int B, int H, int W, int Cin, const float 
     a.splits = (int)sp;
     a.partial = scratch;
     hipStream_t s = (hipStream_t)stream;
-    if (wgrad_wide(a.R, Cout))
-        hipLaunchKernelGGL((k_wgrad_mfma<128, 128>), dim3((a.R + 127) / 128, (Cout + 127) / 128, a.splits), dim3(256), 0, s, a);
-    else if (a.R > 64)
-        hipLaunchKernelGGL((k_wgrad_mfma<128, 64>), dim3((a.R + 127) / 128, (Cout + 63) / 64, a.splits), dim3(256), 0, s, a);
-    else
-        hipLaunchKernelGGL((k_wgrad_mfma<64, 64>), dim3((a.R + 63) / 64, (Cout + 63) / 64, a.splits), dim3(256), 0, s, a);
+    launch_wgrad_tiles(a, s);
     const float *final_src = scratch;
     int final_n = a.splits;
     if (a.splits > 64) { // group sums go behind the partial tiles (the scratch query reserves the room)
