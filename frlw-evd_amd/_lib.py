@@ -104,9 +104,12 @@ SYMBOLS = {
     "frlw_baseconv_weight_cache_floats": (_I64, [_I, _I, _I]),
     "frlw_baseconv_train_scratch_bytes": (_I64, [_I, _I, _I, _I, _I, _I, _I]),
     "frlw_baseconv_train_fwd": (_I, [_P, _P, _P, _P, C.c_float, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P,
-                                    C.c_float, _P, _P, _I64, _P]),
+                                    C.c_float, _P, _P, _P, _I64, _P]),
     "frlw_baseconv_train_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P,
                                     _P, _I64, _P]),
+    "frlw_pred_bwd_scratch_floats": (_I64, [_I64, _I, _I]),
+    "frlw_pred_fwd": (_I, [_P, _P, _I64, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "frlw_pred_bwd": (_I, [_P, _P, _P, _I64, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
     "frlw_simota_workspace_bytes": (_SZ, [_I, _I, _I]),
     "frlw_simota_assign": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, C.c_float, _P, _P, _P, _P, _P, _P, _SZ, _P]),
 }

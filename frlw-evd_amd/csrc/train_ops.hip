@@ -242,10 +242,11 @@ __device__ __forceinline__ void bn_sum_partials(const double *partial, int n_wg,
 // (+ the running statistics of nn.BatchNorm2d when given: momentum update with the unbiased variance)
 __global__ __launch_bounds__(256) void k_bn_stats_final(const double *partial, int n_wg, int C, long long M, float eps,
                                                         float *mean, float *var, float *invstd, float *run_mean,
-                                                        float *run_var, float momentum)
+                                                        float *run_var, float momentum, long long *batches_tracked)
 {
     double s, ss;
     int c;
+    if (batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *batches_tracked += 1; // nn.BatchNorm2d.num_batches_tracked
     bn_sum_partials(partial, n_wg, C, s, ss, c);
     if (c < 0) return;
     const double mu = s / (double)M;
@@ -484,16 +485,18 @@ int64_t frlw_bn_scratch_doubles(int64_t M, int C)
 }
 
 static int bn_stats_impl(const float *z, int64_t M, int C, float eps, float *mean, float *var, float *invstd,
-                         double *scratch, float *run_mean, float *run_var, float momentum, frlw_stream_t stream);
+                         double *scratch, float *run_mean, float *run_var, float momentum, long long *batches_tracked,
+                         frlw_stream_t stream);
 
 int frlw_bn_stats(const float *z, int64_t M, int C, float eps, float *mean, float *var, float *invstd, double *scratch,
                   frlw_stream_t stream)
 {
-    return bn_stats_impl(z, M, C, eps, mean, var, invstd, scratch, nullptr, nullptr, 0.0f, stream);
+    return bn_stats_impl(z, M, C, eps, mean, var, invstd, scratch, nullptr, nullptr, 0.0f, nullptr, stream);
 }
 
 static int bn_stats_impl(const float *z, int64_t M, int C, float eps, float *mean, float *var, float *invstd,
-                         double *scratch, float *run_mean, float *run_var, float momentum, frlw_stream_t stream)
+                         double *scratch, float *run_mean, float *run_var, float momentum, long long *batches_tracked,
+                         frlw_stream_t stream)
 {
     (void)hipGetLastError(); // other libraries in the process (torch's BLAS look-ups) leave stale errors behind
     if (!z || !mean || !var || !invstd || !scratch || M < 1 || C < 4 || (C & 3)) return FRLW_ERR_ARG;
@@ -501,7 +504,7 @@ static int bn_stats_impl(const float *z, int64_t M, int C, float eps, float *mea
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(k_bn_stats_partial, dim3(n_wg), dim3(256), 0, s, z, (long long)M, C, scratch);
     hipLaunchKernelGGL(k_bn_stats_final, dim3((C + kFinCh - 1) / kFinCh), dim3(256), 0, s, scratch, n_wg, C, (long long)M, eps, mean,
-                       var, invstd, run_mean, run_var, momentum);
+                       var, invstd, run_mean, run_var, momentum, batches_tracked);
     TRY_HIP(hipGetLastError());
     return FRLW_OK;
 }
@@ -581,8 +584,9 @@ inline TrainScratch carve(void *scratch, int B, int Ho, int Wo, int Cin, int Cou
  * the backward needs.  scratch: frlw_baseconv_train_scratch_bytes bytes, contents not needed afterwards. */
 int frlw_baseconv_train_fwd(const float *x, const float *w, const float *gamma, const float *beta, float eps, int B, int H,
                             int W, int Cin, int Cout, int k, int stride, float *z, float *y, float *mean, float *var,
-                            float *invstd, float *running_mean, float *running_var, float momentum, float *w_cache,
-                            void *scratch, int64_t scratch_bytes, frlw_stream_t stream)
+                            float *invstd, float *running_mean, float *running_var, float momentum,
+                            int64_t *num_batches_tracked, float *w_cache, void *scratch, int64_t scratch_bytes,
+                            frlw_stream_t stream)
 {
     if (!x || !w || !gamma || !beta || !z || !y || !mean || !var || !invstd || !scratch) return FRLW_ERR_ARG;
     if (scratch_bytes < frlw_baseconv_train_scratch_bytes(B, H, W, Cin, Cout, k, stride)) return FRLW_ERR_WORKSPACE;
@@ -599,7 +603,7 @@ int frlw_baseconv_train_fwd(const float *x, const float *w, const float *gamma, 
     } else if ((rc = frlw_conv_weight_layouts(w, Cout, Cin, k, 0, t.w_fwd, nullptr, stream)) != FRLW_OK) return rc;
     if ((rc = frlw_conv2d_fwd(x, B, H, W, Cin, w_fwd, Cout, k, stride, z, t.splitk, t.splitk_floats, stream)) != FRLW_OK) return rc;
     if ((rc = bn_stats_impl(z, M, Cout, eps, mean, var, invstd, t.red, running_mean, running_mean ? running_var : nullptr,
-                            momentum, stream)) != FRLW_OK) return rc;
+                            momentum, (long long *)num_batches_tracked, stream)) != FRLW_OK) return rc;
     return frlw_bn_silu_fwd(z, M, Cout, gamma, beta, mean, invstd, y, stream);
 }
 

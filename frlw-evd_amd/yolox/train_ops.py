@@ -60,7 +60,7 @@ def native_enabled():
 
 class _BaseConvTrain(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, stride, eps, run_mean, run_var, momentum):
+    def forward(ctx, x, weight, gamma, beta, stride, eps, run_mean, run_var, momentum, tracked=None):
         ctx.set_materialize_grads(False)
         lib = _lib.load()
         dev = x.device
@@ -82,6 +82,7 @@ class _BaseConvTrain(torch.autograd.Function):
                                                stats[1].data_ptr(), stats[2].data_ptr(),
                                                run_mean.data_ptr() if run_mean is not None else None,
                                                run_var.data_ptr() if run_var is not None else None, C.c_float(momentum),
+                                               tracked.data_ptr() if tracked is not None else None,
                                                wc.data_ptr(), sc.data_ptr(), sc.numel(), _stream(dev)), "baseconv_train_fwd")
         ctx.wcache = wc
         ctx.wversion = weight._version
@@ -113,7 +114,7 @@ class _BaseConvTrain(torch.autograd.Function):
                                                dw.data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(),
                                                ctx.wcache.data_ptr() if fresh else None, sc.data_ptr(),
                                                sc.numel(), _stream(dev)), "baseconv_train_bwd")
-        return dx, dw, dgb[0], dgb[1], None, None, None, None, None
+        return dx, dw, dgb[0], dgb[1], None, None, None, None, None, None
 
 
 def base_conv_train(x, conv, bn):
@@ -121,11 +122,73 @@ def base_conv_train(x, conv, bn):
     nn.BatchNorm2d.forward does (momentum, unbiased variance, num_batches_tracked)."""
     track = bn.track_running_stats and bn.running_mean is not None
     momentum = 0.0
+    tracked = None
     if track:
-        bn.num_batches_tracked += 1
-        momentum = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+        if bn.momentum is None:  # cumulative average: the factor needs the counter's value on the host (one sync)
+            bn.num_batches_tracked += 1
+            momentum = 1.0 / float(bn.num_batches_tracked)
+        else:  # the counter is bumped on the device by the statistics kernel: no extra launch per layer
+            momentum = bn.momentum
+            tracked = bn.num_batches_tracked if bn.num_batches_tracked.is_cuda else None
+            if tracked is None:
+                bn.num_batches_tracked += 1
     return _BaseConvTrain.apply(x, conv.weight, bn.weight, bn.bias, conv.stride[0], bn.eps,
-                                bn.running_mean if track else None, bn.running_var if track else None, float(momentum))
+                                bn.running_mean if track else None, bn.running_var if track else None, float(momentum), tracked)
+
+
+class _PredLevel(torch.autograd.Function):
+    """cat[reg_pred(reg_feat), obj_pred(reg_feat), cls_pred(cls_feat)] of one head level (yolo_head.py:160-186, training
+    branch) and its gradients in csrc/pred_ops.hip: one streaming pass forward, one backward."""
+
+    @staticmethod
+    def forward(ctx, reg_feat, cls_feat, w_reg, b_reg, w_obj, b_obj, w_cls, b_cls):
+        lib = _lib.load()
+        dev = reg_feat.device
+        reg_feat, cls_feat = _nhwc(reg_feat.float()), _nhwc(cls_feat.float())
+        B, Cc, H, W = reg_feat.shape
+        nc = w_cls.shape[0]
+        ws = [t.detach().float().contiguous() for t in (w_reg, b_reg, w_obj, b_obj, w_cls, b_cls)]
+        out = torch.empty((B, H, W, 5 + nc), dtype=torch.float32, device=dev)
+        _lib.check(lib.frlw_pred_fwd(reg_feat.data_ptr(), cls_feat.data_ptr(), B * H * W, Cc, nc, ws[0].data_ptr(), ws[1].data_ptr(),
+                                     ws[2].data_ptr(), ws[3].data_ptr(), ws[4].data_ptr(), ws[5].data_ptr(), out.data_ptr(),
+                                     _stream(dev)), "pred_fwd")
+        ctx.save_for_backward(reg_feat, cls_feat, ws[0], ws[2], ws[4])
+        ctx.shapes = (w_reg.shape, b_reg.shape, w_obj.shape, b_obj.shape, w_cls.shape, b_cls.shape)
+        return out.permute(0, 3, 1, 2)  # (B, 5 + nc, H, W) view
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        reg_feat, cls_feat, w_reg, w_obj, w_cls = ctx.saved_tensors
+        dev = reg_feat.device
+        B, Cc, H, W = reg_feat.shape
+        nc = w_cls.shape[0]
+        M = B * H * W
+        g = dout.float().permute(0, 2, 3, 1).contiguous()  # (B, H, W, 5 + nc) rows
+        d_reg = torch.empty_like(reg_feat, memory_format=torch.channels_last)
+        d_cls = torch.empty_like(cls_feat, memory_format=torch.channels_last)
+        dw = [torch.empty(sh, dtype=torch.float32, device=dev) for sh in ctx.shapes]
+        n = lib.frlw_pred_bwd_scratch_floats(M, Cc, nc)
+        sc = _scratch(dev, "pred", n, torch.float32)
+        _lib.check(lib.frlw_pred_bwd(reg_feat.data_ptr(), cls_feat.data_ptr(), g.data_ptr(), M, Cc, nc, w_reg.data_ptr(),
+                                     w_obj.data_ptr(), w_cls.data_ptr(), d_reg.data_ptr(), d_cls.data_ptr(), dw[0].data_ptr(),
+                                     dw[1].data_ptr(), dw[2].data_ptr(), dw[3].data_ptr(), dw[4].data_ptr(), dw[5].data_ptr(),
+                                     sc.data_ptr(), sc.numel(), _stream(dev)), "pred_bwd")
+        return d_reg, d_cls, dw[0], dw[1], dw[2], dw[3], dw[4], dw[5]
+
+
+def pred_level(reg_feat, cls_feat, reg_pred, obj_pred, cls_pred):
+    """The three prediction convolutions of a level, concatenated along channels (native kernels)."""
+    return _PredLevel.apply(reg_feat, cls_feat, reg_pred.weight, reg_pred.bias, obj_pred.weight, obj_pred.bias,
+                            cls_pred.weight, cls_pred.bias)
+
+
+def pred_eligible(reg_feat, cls_feat, reg_pred, obj_pred, cls_pred):
+    c = reg_feat.shape[1]
+    return (native_enabled() and reg_feat.is_cuda and reg_feat.dim() == 4 and reg_feat.shape == cls_feat.shape
+            and c % 4 == 0 and c <= 512 and 1 <= cls_pred.out_channels <= 11 and reg_pred.out_channels == 4
+            and obj_pred.out_channels == 1 and all(p.kernel_size == (1, 1) and p.bias is not None and p.stride == (1, 1)
+                                                   for p in (reg_pred, obj_pred, cls_pred)))
 
 
 def eligible(x, conv, bn, act):

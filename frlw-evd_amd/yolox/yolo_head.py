@@ -94,6 +94,10 @@ class YOLOXHead(nn.Module):
             x = self.stems[k](x)
             cls_feat = self.cls_convs[k](x)
             reg_feat = self.reg_convs[k](x)
+            from . import train_ops
+            if train_ops.pred_eligible(reg_feat, cls_feat, self.reg_preds[k], self.obj_preds[k], self.cls_preds[k]):
+                outs.append(train_ops.pred_level(reg_feat, cls_feat, self.reg_preds[k], self.obj_preds[k], self.cls_preds[k]))
+                continue
             outs.append(torch.cat([self._pred(self.reg_preds[k], reg_feat), self._pred(self.obj_preds[k], reg_feat),
                                    self._pred(self.cls_preds[k], cls_feat)], 1))
         return outs

@@ -275,6 +275,21 @@ int frlw_det_add_decode_nms(frlw_detector_t *d, int raw_buf, int A, int nc, int 
 int frlw_det_run(const frlw_detector_t *d, int B, void *const *bufs, int n_bufs, int first, int last,
                  frlw_stream_t stream);
 
+/* The three biased 1x1 prediction convolutions of ONE head level in training mode and their gradients (csrc/pred_ops.hip)
+ * -- replaces torch.cat([reg_preds[k](reg_feat), obj_preds[k](reg_feat), cls_preds[k](cls_feat)], 1) of
+ * core/yolox/models/yolo_head.py:160-186 (training branch, no sigmoid) and its autograd.
+ *   reg_feat, cls_feat (M = B*H*W, C) NHWC rows; w_reg (4, C), w_obj (1, C), w_cls (nc, C) as torch stores the 1x1 weights;
+ *   out / dout (M, 5 + nc) rows [reg 0:4 | obj | cls]; C % 4 == 0, C <= 512, 1 <= nc <= 11.
+ * Deterministic (fixed summation order for the weight and bias gradients). */
+int64_t frlw_pred_bwd_scratch_floats(int64_t M, int C, int nc);
+int frlw_pred_fwd(const float *reg_feat, const float *cls_feat, int64_t M, int C, int nc, const float *w_reg,
+                  const float *b_reg, const float *w_obj, const float *b_obj, const float *w_cls, const float *b_cls,
+                  float *out, frlw_stream_t stream);
+int frlw_pred_bwd(const float *reg_feat, const float *cls_feat, const float *dout, int64_t M, int C, int nc,
+                  const float *w_reg, const float *w_obj, const float *w_cls, float *d_reg_feat, float *d_cls_feat,
+                  float *dw_reg, float *db_reg, float *dw_obj, float *db_obj, float *dw_cls, float *db_cls, float *scratch,
+                  int64_t scratch_floats, frlw_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * SimOTA label assignment of the YOLOX training branch, whole batch, no host round trips.
  * Replaces the per-image Python of core/yolox/models/yolo_head.py:482-584 (get_assignments),
@@ -353,7 +368,8 @@ int frlw_bn_silu_bwd(const float *dy, const float *z, int64_t M, int C, const fl
  * convolution + batch statistics + BatchNorm/SiLU; backward = BatchNorm/SiLU backward + data gradient (dx may be NULL)
  * + weight gradient.  x (B, H, W, Cin), z / y / dy / dz (B, Ho, Wo, Cout) NHWC; w and dw in torch's (Cout, Cin, k, k).
  * mean / var (biased) / invstd: (Cout).  running_mean / running_var (may be NULL) are updated in place like
- * nn.BatchNorm2d: r = (1 - momentum) r + momentum * {mean, unbiased variance}.
+ * nn.BatchNorm2d: r = (1 - momentum) r + momentum * {mean, unbiased variance}; num_batches_tracked (device int64, may be
+ * NULL) is incremented by one in the same launch sequence.
  * scratch: frlw_baseconv_train_scratch_bytes(...) bytes, reusable between calls.
  * w_cache (may be NULL): frlw_baseconv_weight_cache_floats(Cin, Cout, k) floats owned by the caller, one per layer: the
  * forward then lays the weight out for itself AND for the data gradient in one launch, and the backward of the same
@@ -362,8 +378,9 @@ int64_t frlw_baseconv_weight_cache_floats(int Cin, int Cout, int k);
 int64_t frlw_baseconv_train_scratch_bytes(int B, int H, int W, int Cin, int Cout, int k, int stride);
 int frlw_baseconv_train_fwd(const float *x, const float *w, const float *gamma, const float *beta, float eps, int B, int H,
                             int W, int Cin, int Cout, int k, int stride, float *z, float *y, float *mean, float *var,
-                            float *invstd, float *running_mean, float *running_var, float momentum, float *w_cache,
-                            void *scratch, int64_t scratch_bytes, frlw_stream_t stream);
+                            float *invstd, float *running_mean, float *running_var, float momentum,
+                            int64_t *num_batches_tracked, float *w_cache, void *scratch, int64_t scratch_bytes,
+                            frlw_stream_t stream);
 int frlw_baseconv_train_bwd(const float *dy, const float *x, const float *z, const float *w, const float *gamma,
                             const float *beta, const float *mean, const float *invstd, int B, int H, int W, int Cin,
                             int Cout, int k, int stride, float *dz, float *dx, float *dw, float *dgamma, float *dbeta,

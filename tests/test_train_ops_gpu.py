@@ -57,3 +57,39 @@ def test_base_conv_train_vs_torch(B, Cin, H, W, Cout, k, stride):
     assert max(errs) <= TOL, errs
     assert int(mine.bn.num_batches_tracked) == 1
     assert max(errs) <= 2e-5, errs  # observed accuracy (exact-f32 contraction, float64 statistics)
+
+
+@pytest.mark.parametrize("B,C,H,W,nc", [(2, 256, 8, 10, 2), (3, 128, 16, 20, 7), (1, 64, 5, 7, 1), (2, 512, 4, 5, 11), (64, 256, 8, 10, 2)])
+def test_pred_level_vs_torch(B, C, H, W, nc):
+    """csrc/pred_ops.hip (the three biased 1x1 prediction convolutions of a head level + their gradients) against the
+    float64 torch modules; run twice: bit-identical (fixed summation order)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from frlw_evd_amd.yolox import train_ops
+    torch.manual_seed(C + nc)
+    convs = [torch.nn.Conv2d(C, n, 1).cuda() for n in (4, 1, nc)]
+    reg = torch.randn(B, C, H, W, device="cuda").contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    cls = torch.randn(B, C, H, W, device="cuda").contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    assert train_ops.pred_eligible(reg, cls, *convs)
+    gout = torch.randn(B, 5 + nc, H, W, device="cuda")
+
+    def native():
+        for t in (reg, cls, *[p for c in convs for p in c.parameters()]):
+            t.grad = None
+        out = train_ops.pred_level(reg, cls, *convs)
+        out.backward(gout)
+        return [out.detach().clone(), reg.grad.clone(), cls.grad.clone()] + [p.grad.clone() for c in convs for p in c.parameters()]
+    got = native()
+    again = native()
+    for a, b in zip(got, again):
+        assert torch.equal(a, b)
+    r64, c64 = reg.detach().double().requires_grad_(True), cls.detach().double().requires_grad_(True)
+    convs64 = [torch.nn.Conv2d(C, n, 1).cuda().double() for n in (4, 1, nc)]
+    for c64m, c32m in zip(convs64, convs):
+        c64m.load_state_dict({k: v.double() for k, v in c32m.state_dict().items()})
+    ref = torch.cat([convs64[0](r64), convs64[1](r64), convs64[2](c64)], 1)
+    ref.backward(gout.double())
+    want = [ref.detach(), r64.grad, c64.grad] + [p.grad for c in convs64 for p in c.parameters()]
+    for a, b in zip(got, want):
+        assert a.shape == b.shape
+        assert rel(a.double(), b) < TOL, (a.shape, rel(a.double(), b))
