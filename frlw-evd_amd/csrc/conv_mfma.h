@@ -34,6 +34,7 @@ struct ConvArgs {
     int tstride;       // 0 / 1: ordinary gather; 2: transposed gather (dgrad of a stride-2 convolution)
     int kw;            // taps per tap row when the window is not square (0: k); K = rows * kw * Cin
     uint32_t x_bytes, w_bytes; // extents of the x view and of w for the buffer descriptors (set by launch_conv)
+    int group_n;       // grouped convolution: output columns [g * group_n, (g + 1) * group_n) read input channels x_co + g * Cin ...; 0: one group
     int y_rp;          // output row pitch in floats (0: dense, pixel p at p * y_cs); else pixel (oy, ox) at oy * y_rp + ox * y_cs
 };
 
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
         const int oy = pix / a.Wo, ox = pix - oy * a.Wo;
         a_iy0[i] = oy * a.stride - a.pad;
         a_ix0[i] = ox * a.stride - a.pad;
-        a_base[i] = m < a.M ? (uint32_t)(((long long)b * a.x_bs + a.x_co) * 4) : kOob;
+        a_base[i] = m < a.M ? (uint32_t)(((long long)b * a.x_bs + a.x_co + (a.group_n ? (n0 / a.group_n) * a.Cin : 0)) * 4) : kOob;
     }
     const int kw = a.kw ? a.kw : a.k;
     const int x_cs4 = a.x_cs * 4;
@@ -464,7 +465,8 @@ inline void launch_conv_tile(const ConvArgs &c, dim3 grid, hipStream_t s)
 inline void launch_conv(ConvArgs &c, float *scratch, long long scratch_floats, hipStream_t s)
 {
     const int howo = c.Ho * c.Wo, nb = c.M / howo;
-    const long long x_bytes = (((long long)(nb - 1) * c.x_bs) + ((long long)c.H * c.W - 1) * c.x_cs + c.x_co + c.Cin) * 4;
+    const int n_groups = c.group_n ? (c.Npad + c.group_n - 1) / c.group_n : 1;
+    const long long x_bytes = (((long long)(nb - 1) * c.x_bs) + ((long long)c.H * c.W - 1) * c.x_cs + c.x_co + (long long)c.Cin * n_groups) * 4;
     if (x_bytes > kMaxViewBytes && nb > 1 && c.M == nb * howo) { // 32-bit buffer offsets: run the batch in two halves
         ConvArgs h = c;
         const int b0 = nb / 2;

@@ -372,8 +372,15 @@ __global__ __launch_bounds__(1024) void k_decode_nms(DecodeArgs a, int cap)
 }
 
 // ---- plan ------------------------------------------------------------------------------------------
-enum OpType : int { OP_CONV = 0, OP_FOCUS = 1, OP_UPSAMPLE = 2, OP_SPP = 3, OP_DECODE = 4, OP_FORK = 5, OP_JOIN = 6, OP_BFM = 7 };
+enum OpType : int { OP_CONV = 0, OP_FOCUS = 1, OP_UPSAMPLE = 2, OP_SPP = 3, OP_DECODE = 4, OP_FORK = 5, OP_JOIN = 6, OP_BFM = 7, OP_PRED = 8 };
 constexpr int kSideLanes = 2; // independent sub-graphs (the head levels) run on side streams
+
+struct PredInferArgs {
+    const float *x; int cs, co, C; // feature buffer: pixel stride, channel offset of reg_feat (cls_feat follows at + C)
+    const float *w, *bias;         // (F, C) rows as above, (F)
+    float *out; int F, hw, off; long long out_bs; // F = 5 + nc; anchors of this level per image, first anchor, image stride
+    long long M;
+};
 
 struct Op {
     int type;
@@ -383,7 +390,69 @@ struct Op {
     int C, H, W, cs_src, co_src, cs_dst, co_dst;
     DecodeArgs dec; int decoded_buf, dets_buf, counts_buf;
     const float *bfm_w;     // OP_BFM: packed weights (device)
+    PredInferArgs pred;     // OP_PRED
 };
+
+// ---- prediction convolutions of one head level (yolo_head.py:205-231, eval branch) ------------------------------------
+// out[b][off + p][j] = f_j(feat[b][p] . w[j] + bias[j]): rows j < 5 (reg, obj) read the first C channels of the level's
+// [reg_feat | cls_feat] buffer, rows j >= 5 (cls) the second C; f = sigmoid for j >= 4.  5 + nc outputs per 2 C inputs is no
+// work for a matrix pipe: one wavefront owns whole rows (lane l holds float4 chunk l of a row and of every weight row), the
+// partial dots are folded over the lanes with a halving butterfly, and the row leaves as 5 + nc consecutive floats of the
+// (B, A, 5 + nc) head tensor.  HBM-bound: 2 C * 4 bytes per anchor.
+
+template <int NG>
+__global__ __launch_bounds__(256) void k_pred_infer(PredInferArgs a)
+{
+    const int lane = threadIdx.x & 63, wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
+    const int c4n = a.C / 4;
+    const bool has = lane < c4n;
+    float4 w[NG * 8];
+#pragma unroll
+    for (int j = 0; j < NG * 8; ++j) w[j] = (j < a.F && has) ? *(const float4 *)(a.w + (long long)j * a.C + 4 * lane) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int sel = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1); // output index this lane ends up with
+    float bias[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) bias[g] = g * 8 + sel < a.F ? a.bias[g * 8 + sel] : 0.0f;
+    for (long long m = wave; m < a.M; m += n_waves) {
+        const float *row = a.x + m * a.cs + a.co + 4 * lane;
+        const float4 xr = has ? *(const float4 *)row : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 xc = has ? *(const float4 *)(row + a.C) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float res[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            float v[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int j = g * 8 + t;
+                const float4 x = j < 5 ? xr : xc;
+                v[t] = x.x * w[j].x + x.y * w[j].y + x.z * w[j].z + x.w * w[j].w;
+            }
+            float q[4], r2[2];
+            const bool h1 = lane & 32, h2 = lane & 16, h3 = lane & 8;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) q[t] = (h1 ? v[4 + t] : v[t]) + __shfl_xor(h1 ? v[t] : v[4 + t], 32, 64);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) r2[t] = (h2 ? q[2 + t] : q[t]) + __shfl_xor(h2 ? q[t] : q[2 + t], 16, 64);
+            float c = (h3 ? r2[1] : r2[0]) + __shfl_xor(h3 ? r2[0] : r2[1], 8, 64);
+            c += __shfl_xor(c, 4, 64);
+            c += __shfl_xor(c, 2, 64);
+            c += __shfl_xor(c, 1, 64);
+            res[g] = c;
+        }
+        if ((lane & 7) == 0) {
+            const long long b = m / a.hw, p = m - b * a.hw;
+            float *o = a.out + b * a.out_bs + (a.off + p) * a.F;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const int j = g * 8 + sel;
+                if (j < a.F) {
+                    const float t = res[g] + bias[g];
+                    o[j] = j >= 4 ? act_apply(t, ACT_SIGMOID) : t;
+                }
+            }
+        }
+    }
+}
 
 int grid_1d(long long n) { long long g = (n + 255) / 256; if (g > 4096) g = 4096; if (g < 1) g = 1; return (int)g; }
 
@@ -555,11 +624,11 @@ int frlw_det_add_spp_pool(frlw_detector_t *d, int buf, int cs, int C, int H, int
 int frlw_det_add_conv(frlw_detector_t *d, int src_buf, int src_cs, int src_co, int Cin, int H, int W,
                       const float *w_dev, const float *bias_dev, int Cout, int Npad, int k, int stride,
                       int dst_buf, int dst_cs, int dst_co, int64_t dst_bs, int res_buf, int res_cs, int res_co,
-                      int act, int sig_from)
+                      int act, int sig_from, int group_n)
 {
     if (!d || !w_dev || (k != 1 && k != 3) || (stride != 1 && stride != 2) || (Cin & 3) || (Npad & 31) ||
-        Npad < Cout || (src_cs & 3) || (src_co & 3))
-        return FRLW_ERR_ARG;
+        Npad < Cout || (src_cs & 3) || (src_co & 3) || group_n < 0 || (group_n & 127))
+        return FRLW_ERR_ARG; // groups: whole 128-column tiles per group
     Op op = {};
     op.type = OP_CONV; op.src = src_buf; op.dst = dst_buf; op.res = res_buf;
     ConvArgs &c = op.conv;
@@ -568,7 +637,21 @@ int frlw_det_add_conv(frlw_detector_t *d, int src_buf, int src_cs, int src_co, i
     c.Ho = (H + 2 * c.pad - k) / stride + 1; c.Wo = (W + 2 * c.pad - k) / stride + 1;
     c.y_cs = dst_cs; c.y_co = dst_co; c.y_bs = dst_bs > 0 ? dst_bs : (long long)c.Ho * c.Wo * dst_cs;
     c.r_cs = res_cs; c.r_co = res_co; c.r_bs = (long long)c.Ho * c.Wo * res_cs;
-    c.act = act; c.sig_from = sig_from; c.K = k * k * Cin;
+    c.act = act; c.sig_from = sig_from; c.K = k * k * Cin; c.group_n = group_n;
+    op.lane = d->cur_lane;
+    d->ops.push_back(op);
+    return FRLW_OK;
+}
+
+int frlw_det_add_pred(frlw_detector_t *d, int src_buf, int src_cs, int src_co, int C, int hw, const float *w_dev,
+                      const float *bias_dev, int F, int dst_buf, int first_anchor, int64_t dst_bs)
+{
+    if (!d || !w_dev || !bias_dev || hw < 1 || F < 6 || dst_bs < 1) return FRLW_ERR_ARG;
+    if (C < 4 || (C & 3) || C > 256 || F > 16 || (src_cs & 3) || (src_co & 3)) return FRLW_ERR_UNSUPPORTED;
+    Op op = {};
+    op.type = OP_PRED; op.src = src_buf; op.dst = dst_buf;
+    PredInferArgs &a = op.pred;
+    a.cs = src_cs; a.co = src_co; a.C = C; a.w = w_dev; a.bias = bias_dev; a.F = F; a.hw = hw; a.off = first_anchor; a.out_bs = dst_bs;
     op.lane = d->cur_lane;
     d->ops.push_back(op);
     return FRLW_OK;
@@ -657,6 +740,17 @@ int frlw_det_run(const frlw_detector_t *d, int B, void *const *bufs, int n_bufs,
             c.M = B * c.Ho * c.Wo;
             launch_conv(c, d->scratch_buf >= 0 ? buf(d->scratch_buf) + (long long)op.lane * d->scratch_floats : nullptr,
                         d->scratch_buf >= 0 ? d->scratch_floats : 0, s);
+            break;
+        }
+        case OP_PRED: {
+            PredInferArgs a = op.pred;
+            a.x = buf(op.src); a.out = buf(op.dst);
+            if (!a.x || !a.out) return FRLW_ERR_ARG;
+            a.M = (long long)B * a.hw;
+            long long wg = (a.M + 31) / 32; // >= 8 rows per wavefront
+            if (wg > 2048) wg = 2048;
+            if (a.F <= 8) hipLaunchKernelGGL(k_pred_infer<1>, dim3((int)wg), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL(k_pred_infer<2>, dim3((int)wg), dim3(256), 0, s, a);
             break;
         }
         case OP_DECODE: {

@@ -252,11 +252,13 @@ int frlw_det_add_spp_pool(frlw_detector_t *d, int buf, int cs, int C, int H, int
  *             convs write straight into the (B, A, 5 + nc) head tensor (yolo_head.py:229-231)
  *   res_buf : < 0 for none; Bottleneck shortcut added AFTER the activation (network_blocks.py:108-110)
  *   act     : FRLW_ACT_*; with FRLW_ACT_SIGMOID only channels >= sig_from are squashed (yolo_head.py:209-211)
+ *   group_n : 0, or a multiple of 128: grouped convolution -- output channels [g * group_n, (g + 1) * group_n) read the Cin
+ *             input channels starting at src_co + g * Cin (two towers of the head in one launch)
  */
 int frlw_det_add_conv(frlw_detector_t *d, int src_buf, int src_cs, int src_co, int Cin, int H, int W,
                       const float *w_dev, const float *bias_dev, int Cout, int Npad, int k, int stride,
                       int dst_buf, int dst_cs, int dst_co, int64_t dst_bs, int res_buf, int res_cs,
-                      int res_co, int act, int sig_from);
+                      int res_co, int act, int sig_from, int group_n);
 
 /*
  * decode_outputs (yolo_head.py:258-303): xy = (xy + grid) * stride, wh = square(wh) * stride, keep
@@ -267,6 +269,14 @@ int frlw_det_add_conv(frlw_detector_t *d, int src_buf, int src_cs, int src_co, i
  *                passed (the reference then returns one all-zero row), -1 = more than 8192 candidates (only reachable
  *                with A > 8192; not handled on device); [b][1..] = scratch (the candidates' anchors in score order)
  */
+/* The three biased 1x1 prediction convolutions of one head level in eval mode (yolo_head.py:205-231) as ONE streaming
+ * pass: rows 0..4 of w_dev (F = 5 + nc rows of C floats: reg x4, obj, cls x nc) read channels [src_co, src_co + C) of the
+ * level's feature buffer, rows 5.. read [src_co + C, src_co + 2 C); sigmoid on outputs >= 4; the result lands at anchors
+ * [first_anchor, first_anchor + hw) of the (B, A, F) head tensor (dst_bs = A * F).  C <= 256, F <= 16, else
+ * FRLW_ERR_UNSUPPORTED (use frlw_det_add_conv with the block weight matrix). */
+int frlw_det_add_pred(frlw_detector_t *d, int src_buf, int src_cs, int src_co, int C, int hw, const float *w_dev,
+                      const float *bias_dev, int F, int dst_buf, int first_anchor, int64_t dst_bs);
+
 int frlw_det_add_decode_nms(frlw_detector_t *d, int raw_buf, int A, int nc, int n_levels, const int *lvl_h,
                             const int *lvl_w, const int *lvl_stride, float obj_thr, float iou_thr,
                             int decoded_buf, int dets_buf, int counts_buf);
