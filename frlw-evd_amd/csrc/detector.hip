@@ -55,6 +55,95 @@ __global__ __launch_bounds__(256) void k_focus(const float *x, int B, int C, int
     for (int i = threadIdx.x; i < Wo * C4; i += 256) dst[i] = frow[(i / C4) * LD + (i % C4)];
 }
 
+// Focus + stem convolution in one kernel (network_blocks.py:205-217 followed by the 3x3 BaseConv of darknet.py:292):
+// the space-to-depth image is never written.  A persistent workgroup keeps the whole weight operand (9 * 4 C0 rows of 32
+// output channels) in LDS and walks 8 x 16 output tiles: the 10 x 18 halo patch of the Focus image is built in LDS straight
+// from the NCHW input (zero outside the frame), and the nine taps are shifted views of that patch -- every input value is
+// fetched once instead of nine times.  k pairing as in k_conv_mfma: lane half h supplies ci = 8 j + 4 h + e of a tap.
+struct FocusStemArgs {
+    const float *x; int H, W;            // (B, C0, H, W)
+    const float *w, *bias;               // (9 * 4 C0, 32) rows (tap * 4 C0 + q * C0 + c), q = py + 2 px as in k_focus; bias (Cout)
+    float *y; int Cout, y_cs, y_co;      // NHWC view of the output, Ho = H / 2, Wo = W / 2
+    int tiles_x, tiles_y, n_tiles;
+};
+
+template <int C0>
+__global__ __launch_bounds__(256) void k_focus_stem(FocusStemArgs a)
+{
+    constexpr int CF = 4 * C0, PS = CF + 4, TH = 8, TW = 16, PH = TH + 2, PW = TW + 2, KT = 9 * CF;
+    static_assert(C0 % 2 == 0, "quads are paired");
+    extern __shared__ __attribute__((aligned(16))) float fs_lds[];
+    float *Ws = fs_lds, *patch = fs_lds + KT * 32;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int i = tid; i < KT * 8; i += 256) ((float4 *)Ws)[i] = ((const float4 *)a.w)[i];
+    const int Ho = a.H / 2, Wo = a.W / 2;
+    const int fh = lane >> 5, m = lane & 31, n = lane & 31;
+    const int pp0 = (2 * wv + (m >> 4)) * PW + (m & 15);
+    const float bias = n < a.Cout ? a.bias[n] : 0.0f;
+    // This thread's share of a patch fill: items i = tid + 256 u -> (c, input row iy, column pair jx).  Everything but the
+    // tile origin is fixed, so the decomposition is done once; the NEXT tile's values are fetched into registers while the
+    // current tile is multiplied and written to LDS after it.
+    constexpr int NI = (C0 * 2 * PH * PW + 255) / 256;
+    int it_src[NI], it_dst[NI], it_yx[NI];
+#pragma unroll
+    for (int u = 0; u < NI; ++u) {
+        const int i = tid + 256 * u;
+        const int jx = i % PW, r = i / PW, iy = r % (2 * PH), c = r / (2 * PH);
+        it_src[u] = (c * a.H + iy) * a.W + 2 * jx;
+        it_dst[u] = ((iy >> 1) * PW + jx) * PS + (iy & 1) * C0 + c;
+        it_yx[u] = i < C0 * 2 * PH * PW ? (iy << 16) | (2 * jx) : -1;
+    }
+    float2 pv[NI];
+    auto fetch = [&](int tile) {
+        const int b = tile / (a.tiles_x * a.tiles_y), tr = tile - b * (a.tiles_x * a.tiles_y);
+        const int y0 = 2 * ((tr / a.tiles_x) * TH - 1), x0 = 2 * ((tr % a.tiles_x) * TW - 1);
+        const float *base = a.x + ((long long)b * C0 * a.H + y0) * a.W + x0;
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+            const int y = y0 + (it_yx[u] >> 16), xc = x0 + (it_yx[u] & 0xFFFF);
+            pv[u] = make_float2(0.f, 0.f);
+            if (it_yx[u] >= 0 && (unsigned)y < (unsigned)a.H && (unsigned)xc < (unsigned)a.W) pv[u] = *(const float2 *)(base + it_src[u]);
+        }
+    };
+    if ((int)blockIdx.x < a.n_tiles) fetch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+        const int b = tile / (a.tiles_x * a.tiles_y), tr = tile - b * (a.tiles_x * a.tiles_y);
+        const int fy0 = (tr / a.tiles_x) * TH, fx0 = (tr % a.tiles_x) * TW;
+        __syncthreads(); // the previous tile's reads of the patch are done (first pass: the weights are in LDS)
+#pragma unroll
+        for (int u = 0; u < NI; ++u)
+            if (it_yx[u] >= 0) { patch[it_dst[u]] = pv[u].x; patch[it_dst[u] + 2 * C0] = pv[u].y; } // px = 0: q = py; px = 1: q = py + 2
+        __syncthreads();
+        if (tile + (int)gridDim.x < a.n_tiles) fetch(tile + gridDim.x);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float *prow = patch + (pp0 + (t / 3) * PW + (t % 3)) * PS + fh * 4;
+            const float *wrow = Ws + (t * CF + 4 * fh) * 32 + n;
+#pragma unroll
+            for (int j = 0; j < C0 / 2; ++j) {
+                const float4 av = *(const float4 *)(prow + 8 * j);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, wrow[(8 * j + 0) * 32], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, wrow[(8 * j + 1) * 32], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, wrow[(8 * j + 2) * 32], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, wrow[(8 * j + 3) * 32], acc, 0, 0, 0);
+            }
+        }
+        // C/D layout of the 32x32 MFMA: col = lane & 31 (channel), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) (pixel of the wave)
+        if (n < a.Cout) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int pm = (r & 3) + 8 * (r >> 2) + 4 * fh;
+                const int oy = fy0 + 2 * wv + (pm >> 4), ox = fx0 + (pm & 15);
+                if (oy < Ho && ox < Wo)
+                    a.y[(((long long)b * Ho + oy) * Wo + ox) * a.y_cs + a.y_co + n] = act_apply(acc[r] + bias, ACT_SILU);
+            }
+        }
+    }
+}
+
 // BFM stem, per-pixel part (core/Others/Temporal_Active_Focus.py:62-127, Temporal_Active_Focus_connect.forward
 // up to `self.patch`): log2(TC) grouped 1x1 convolutions (weight norm already applied) + ReLU, the first 4
 // channels of every stage concatenated (ER = 4 log2(TC) channels), residual MLP ER -> 4 ER -> ER with SiLU
@@ -372,7 +461,7 @@ __global__ __launch_bounds__(1024) void k_decode_nms(DecodeArgs a, int cap)
 }
 
 // ---- plan ------------------------------------------------------------------------------------------
-enum OpType : int { OP_CONV = 0, OP_FOCUS = 1, OP_UPSAMPLE = 2, OP_SPP = 3, OP_DECODE = 4, OP_FORK = 5, OP_JOIN = 6, OP_BFM = 7, OP_PRED = 8 };
+enum OpType : int { OP_CONV = 0, OP_FOCUS = 1, OP_UPSAMPLE = 2, OP_SPP = 3, OP_DECODE = 4, OP_FORK = 5, OP_JOIN = 6, OP_BFM = 7, OP_PRED = 8, OP_FOCUS_STEM = 9 };
 constexpr int kSideLanes = 2; // independent sub-graphs (the head levels) run on side streams
 
 struct PredInferArgs {
@@ -391,6 +480,7 @@ struct Op {
     DecodeArgs dec; int decoded_buf, dets_buf, counts_buf;
     const float *bfm_w;     // OP_BFM: packed weights (device)
     PredInferArgs pred;     // OP_PRED
+    FocusStemArgs fstem;    // OP_FOCUS_STEM
 };
 
 // ---- prediction convolutions of one head level (yolo_head.py:205-231, eval branch) ------------------------------------
@@ -574,6 +664,21 @@ int frlw_det_add_focus(frlw_detector_t *d, int src_buf, int C, int H, int W, int
     return FRLW_OK;
 }
 
+int frlw_det_add_focus_stem(frlw_detector_t *d, int src_buf, int C, int H, int W, const float *w_dev, const float *bias_dev,
+                            int Cout, int dst_buf, int dst_cs, int dst_co)
+{
+    if (!d || !w_dev || !bias_dev || (H & 1) || (W & 1) || Cout < 1) return FRLW_ERR_ARG;
+    if ((C != 10 && C != 16) || Cout > 32) return FRLW_ERR_UNSUPPORTED; // other stems: frlw_det_add_focus + frlw_det_add_conv
+    Op op = {};
+    op.type = OP_FOCUS_STEM; op.src = src_buf; op.dst = dst_buf; op.C = C;
+    FocusStemArgs &a = op.fstem;
+    a.H = H; a.W = W; a.w = w_dev; a.bias = bias_dev; a.Cout = Cout; a.y_cs = dst_cs; a.y_co = dst_co;
+    a.tiles_x = (W / 2 + 15) / 16; a.tiles_y = (H / 2 + 7) / 8;
+    op.lane = d->cur_lane;
+    d->ops.push_back(op);
+    return FRLW_OK;
+}
+
 int frlw_det_bfm_weight_count(int C)
 {
     switch (C) {
@@ -711,6 +816,24 @@ int frlw_det_run(const frlw_detector_t *d, int B, void *const *bufs, int n_bufs,
             const size_t lds = (size_t)(op.W / 2) * (4 * op.C + 1) * sizeof(float);
             if (lds > 150 * 1024) return FRLW_ERR_UNSUPPORTED;
             hipLaunchKernelGGL(k_focus, dim3(B * (op.H / 2)), dim3(256), lds, s, buf(op.src), B, op.C, op.H, op.W, buf(op.dst));
+            break;
+        }
+        case OP_FOCUS_STEM: {
+            FocusStemArgs a = op.fstem;
+            a.x = buf(op.src); a.y = buf(op.dst);
+            if (!a.x || !a.y) return FRLW_ERR_ARG;
+            a.n_tiles = B * a.tiles_x * a.tiles_y;
+            const int cf = 4 * op.C;
+            const size_t lds = ((size_t)9 * cf * 32 + (size_t)180 * (cf + 4)) * sizeof(float);
+            const int per_cu = lds <= 80 * 1024 ? 2 : 1;
+            const int grid = a.n_tiles < 256 * per_cu ? a.n_tiles : 256 * per_cu;
+            if (op.C == 10) {
+                (void)hipFuncSetAttribute((const void *)k_focus_stem<10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipLaunchKernelGGL(k_focus_stem<10>, dim3(grid), dim3(256), lds, s, a);
+            } else {
+                (void)hipFuncSetAttribute((const void *)k_focus_stem<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipLaunchKernelGGL(k_focus_stem<16>, dim3(grid), dim3(256), lds, s, a);
+            }
             break;
         }
         case OP_BFM: {

@@ -162,12 +162,31 @@ class DetectorEngine:
         if hasattr(bb.stem, "trans_up"):  # BFM stem (yolox_taf_bfm): fused per-pixel mix, Focus layout out
             f = self._bfm_front(bb.stem, x_in, cin, H, W)
         else:
-            f = self._new_buf(H // 2, W // 2, 4 * cin)
-            _lib.check(lib.frlw_det_add_focus(self.handle, x_in, cin, H, W, f.buf), "focus")
-            self.ops_meta.append(("focus", H * W // 4, 4 * cin, 0, 0))
+            f = None
         c = bb.stem.conv.conv.out_channels
         stem = self._new_buf(H // 2, W // 2, c)
-        self._baseconv(bb.stem.conv, f, stem)
+        fused = False
+        if f is None:  # Focus + stem convolution as one kernel (the space-to-depth image is never written)
+            sc = bb.stem.conv
+            if isinstance(sc.act, torch.nn.SiLU) and sc.conv.kernel_size == (3, 3) and sc.conv.stride == (1, 1):
+                w, b = fold_bn(sc.conv, sc.bn)
+                wm, npad = gemm_weight(w)
+                if npad == 32:
+                    rc = lib.frlw_det_add_focus_stem(self.handle, x_in, cin, H, W, self._dev(wm), self._dev(b), c, stem.buf,
+                                                     stem.cs, stem.co)
+                    if rc != _lib.FRLW_ERR_UNSUPPORTED:
+                        _lib.check(rc, "focus_stem")
+                        fused = True
+                        fl = 2 * (H // 2) * (W // 2) * c * 4 * cin * 9
+                        self.n_conv += 1
+                        self.flops_per_image += fl
+                        self.ops_meta.append(("fstem", H * W // 4, c, 36 * cin, fl))
+            if not fused:
+                f = self._new_buf(H // 2, W // 2, 4 * cin)
+                _lib.check(lib.frlw_det_add_focus(self.handle, x_in, cin, H, W, f.buf), "focus")
+                self.ops_meta.append(("focus", H * W // 4, 4 * cin, 0, 0))
+        if not fused:
+            self._baseconv(bb.stem.conv, f, stem)
         h2, w2 = H // 4, W // 4
         d2a = self._new_buf(h2, w2, 2 * c)
         self._baseconv(bb.dark2[0], stem, d2a)

@@ -232,6 +232,11 @@ int frlw_det_add_focus(frlw_detector_t *d, int src_buf, int C, int H, int W, int
  * `weights` (device, kept by reference): for every stage i its effective grouped 1x1 weight g * v / |v| as
  * (out_channels_i, in_channels_per_group_i) row-major then its bias; then trans_up weight (4E, E) + bias and
  * trans_down weight (E, 4E) + bias, E = 4 log2(T).  frlw_det_bfm_weight_count(C) floats (0: unsupported C). */
+/* Focus + the stem's 3x3 BaseConv (darknet.py:292) fused: the space-to-depth image stays in LDS.  w_dev / bias_dev as for
+ * frlw_det_add_conv with Cin = 4 C, k = 3, Npad = 32.  C in {10, 16} (TAF K = 5 / 8), Cout <= 32, else
+ * FRLW_ERR_UNSUPPORTED (use frlw_det_add_focus + frlw_det_add_conv). */
+int frlw_det_add_focus_stem(frlw_detector_t *d, int src_buf, int C, int H, int W, const float *w_dev, const float *bias_dev,
+                            int Cout, int dst_buf, int dst_cs, int dst_co);
 int frlw_det_bfm_weight_count(int C);
 int frlw_det_add_bfm_stem(frlw_detector_t *d, int src_buf, int C, int H, int W, const float *weights, int n_weights,
                           int dst_buf);

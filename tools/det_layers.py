@@ -8,7 +8,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "parse":
     B = int(os.environ.get("B", "32"))
     e = DetectorEngine(build_yolox(10, 2).eval(), device="cpu"); e.build((10, 256, 320))
     meta = e.ops_meta
-    rows = [r for r in csv.DictReader(open(sys.argv[2])) if "k_conv_mfma" in r["Kernel_Name"] or "k_focus" in r["Kernel_Name"] or "k_spp" in r["Kernel_Name"] or "k_upsample" in r["Kernel_Name"] or "k_pred_infer" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(sys.argv[2])) if "k_conv_mfma" in r["Kernel_Name"] or "k_focus" in r["Kernel_Name"] or "k_spp" in r["Kernel_Name"] or "k_upsample" in r["Kernel_Name"] or "k_pred_infer" in r["Kernel_Name"] or "k_focus_stem" in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     n = len(meta)
     assert len(rows) % n == 0, (len(rows), n)
