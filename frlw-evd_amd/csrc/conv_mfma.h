@@ -238,10 +238,8 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
     const uint32_t b_lds = lds0 + (uint32_t)(NA * BK * BM + 4 * fh * LDB + fn) * 4;
     int buf = 0; // A ring slot of tile kt; the B slot is kt & 1
     for (int kt = 0; kt < nk; ++kt) {
-#if !defined(CONV_EXP) || CONV_EXP < 1
         if (kt + 1 < nk) load_b((kt + 1) & 1);                               // slot read last in iteration kt - 1
         if (kt + 2 < nk) load_a(kt0 + kt + 2, buf == 0 ? 2 : buf - 1);       // (buf + 2) % 3: likewise
-#endif
         // Fragment reads run ahead of the MFMAs that consume them (B one k-step, A one j).  They are issued as asm
         // statements with hand-counted lgkmcnt waits: the compiler puts `s_waitcnt vmcnt(0)` in front of every LDS read
         // it can see while an LDS-DMA is in flight (it cannot tell that the DMA writes another ring slot), which would
@@ -295,11 +293,9 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
         step(ConvIC<5>{});
         step(ConvIC<6>{});
         step(ConvIC<7>{});
-#if !defined(CONV_EXP) || CONV_EXP < 3
         wait_next_tile(kt + 2 < nk);            // tile kt + 1 has landed (this wavefront's pieces) ...
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();           // ... everybody's have, and everybody is done reading tile kt
-#endif
         buf = buf == 2 ? 0 : buf + 1;
     }
 
@@ -462,7 +458,8 @@ inline void launch_conv_tile(const ConvArgs &c, dim3 grid, hipStream_t s)
 }
 
 // Tile choice and split-K for one convolution; `scratch` (scratch_floats floats, may be NULL) holds split-K partials.
-inline void launch_conv(ConvArgs &c, float *scratch, long long scratch_floats, hipStream_t s)
+// Returns false (nothing launched) when a single image's view exceeds the 32-bit buffer offsets.
+inline bool launch_conv(ConvArgs &c, float *scratch, long long scratch_floats, hipStream_t s)
 {
     const int howo = c.Ho * c.Wo, nb = c.M / howo;
     const int n_groups = c.group_n ? (c.Npad + c.group_n - 1) / c.group_n : 1;
@@ -471,22 +468,22 @@ inline void launch_conv(ConvArgs &c, float *scratch, long long scratch_floats, h
         ConvArgs h = c;
         const int b0 = nb / 2;
         h.M = b0 * howo;
-        launch_conv(h, scratch, scratch_floats, s);
+        if (!launch_conv(h, scratch, scratch_floats, s)) return false;
         h = c;
         h.M = (nb - b0) * howo;
         h.x = c.x + (long long)b0 * c.x_bs;
         h.y = c.y + (long long)b0 * c.y_bs;
         if (c.res) h.res = c.res + (long long)b0 * c.r_bs;
-        launch_conv(h, scratch, scratch_floats, s);
-        return;
+        return launch_conv(h, scratch, scratch_floats, s);
     }
-    c.x_bytes = (uint32_t)(x_bytes < kMaxViewBytes ? x_bytes : kMaxViewBytes);
+    if (x_bytes > kMaxViewBytes || (long long)c.K * c.Npad * 4 > kMaxViewBytes) return false;
+    c.x_bytes = (uint32_t)x_bytes;
     c.w_bytes = (uint32_t)((long long)c.K * c.Npad * 4);
     c.splits = 1;
     c.partial = nullptr;
     const long long big = (long long)((c.M + 127) / 128) * ((c.Npad + 127) / 128);
     static const long long split_below = dev_knob("FRLW_CONV_SPLIT_BELOW", 700ll);
-    static const long long split_target = dev_knob("FRLW_CONV_SPLIT_TARGET", 1024ll);
+    static const long long split_target = dev_knob("FRLW_CONV_SPLIT_TARGET", 1280ll);
     static const long long big_min = dev_knob("FRLW_CONV_BIG_MIN", 1000000ll);
     static const long long wide_min = dev_knob("FRLW_CONV_WIDE_MIN", 1200ll);
     if (c.Npad <= 32) { // small N (prediction convs, the stem's data gradient)
@@ -500,7 +497,7 @@ inline void launch_conv(ConvArgs &c, float *scratch, long long scratch_floats, h
         const long long wgs = (long long)((c.M + 63) / 64) * ((c.Npad + 63) / 64);
         const int nk = (c.K + kSplitBK - 1) / kSplitBK;
         // small feature maps leave most CUs idle: split the contraction over blockIdx.z
-        if (wgs < split_below && nk >= 32 && scratch) {
+        if (wgs < split_below && nk >= 64 && scratch) { // (contractions shorter than 1024 gained nothing from splitting: measured)
             int sp = (int)((split_target + wgs - 1) / wgs);
             if (sp > 8) sp = 8;
             if (sp > nk / 8) sp = nk / 8;
@@ -513,4 +510,5 @@ inline void launch_conv(ConvArgs &c, float *scratch, long long scratch_floats, h
             else hipLaunchKernelGGL(k_splitk_reduce<false>, dim3(conv_grid_1d((long long)c.M * c.Cout)), dim3(256), 0, s, c);
         }
     }
+    return true;
 }

@@ -861,8 +861,9 @@ int frlw_det_run(const frlw_detector_t *d, int B, void *const *bufs, int n_bufs,
             c.x = buf(op.src); c.y = buf(op.dst); c.res = buf(op.res);
             if (!c.x || !c.y) return FRLW_ERR_ARG;
             c.M = B * c.Ho * c.Wo;
-            launch_conv(c, d->scratch_buf >= 0 ? buf(d->scratch_buf) + (long long)op.lane * d->scratch_floats : nullptr,
-                        d->scratch_buf >= 0 ? d->scratch_floats : 0, s);
+            if (!launch_conv(c, d->scratch_buf >= 0 ? buf(d->scratch_buf) + (long long)op.lane * d->scratch_floats : nullptr,
+                             d->scratch_buf >= 0 ? d->scratch_floats : 0, s))
+                return FRLW_ERR_UNSUPPORTED;
             break;
         }
         case OP_PRED: {

@@ -377,7 +377,7 @@ static int conv_common(const float *x, int B, int H, int W, int Cin, const float
     c.res = nullptr; c.act = ACT_NONE; c.sig_from = 0;
     c.M = B * Ho * Wo; c.K = k * k * Cin;
     c.tstride = tstride;
-    launch_conv(c, scratch, scratch ? scratch_floats : 0, s);
+    if (!launch_conv(c, scratch, scratch ? scratch_floats : 0, s)) return FRLW_ERR_UNSUPPORTED;
     if (hipGetLastError() != hipSuccess) return FRLW_ERR_HIP;
     return FRLW_OK;
 }
@@ -415,7 +415,7 @@ int frlw_conv2d_dgrad(const float *dz, int B, int Ho, int Wo, int Cout, const fl
             c.y_bs = (long long)H * W * Cin;
             c.res = nullptr; c.act = ACT_NONE;
             c.M = B * Ho * Wo; c.K = kh * kwc * Cout;
-            launch_conv(c, scratch, scratch ? scratch_floats : 0, (hipStream_t)stream);
+            if (!launch_conv(c, scratch, scratch ? scratch_floats : 0, (hipStream_t)stream)) return FRLW_ERR_UNSUPPORTED;
         }
         if (hipGetLastError() != hipSuccess) return FRLW_ERR_HIP;
         return FRLW_OK;
@@ -463,7 +463,7 @@ int frlw_conv2d_wgrad(const float *x, int B, int H, int W, int Cin, const float 
     a.splits = (int)sp;
     a.partial = scratch;
     hipStream_t s = (hipStream_t)stream;
-    launch_wgrad_tiles(a, s);
+    if (!launch_wgrad_tiles(a, s)) return FRLW_ERR_UNSUPPORTED; // a tensor beyond 3.7 GB: split the batch
     const float *final_src = scratch;
     int final_n = a.splits;
     if (a.splits > 64) { // group sums go behind the partial tiles (the scratch query reserves the room)

@@ -176,19 +176,21 @@ inline bool wgrad_wide(long long R, int Cout)
 #ifndef WGRAD_NBUF
 #define WGRAD_NBUF 2
 #endif
-inline void launch_wgrad_tiles(WgradArgs &a, hipStream_t s) // a.splits and a.partial are set by the caller
+inline bool launch_wgrad_tiles(WgradArgs &a, hipStream_t s) // a.splits and a.partial are set by the caller; false: too large
 {
     const int nimg = a.M / (a.Ho * a.Wo);
     const long long xb = ((long long)(nimg - 1) * a.x_bs + ((long long)a.H * a.W - 1) * a.x_cs + a.Cin) * 4;
     const long long zb = ((long long)(nimg - 1) * a.dz_bs + ((long long)a.Ho * a.Wo - 1) * a.dz_cs + a.Cout) * 4;
-    a.x_bytes = (uint32_t)(xb < kMaxViewBytes ? xb : kMaxViewBytes);
-    a.dz_bytes = (uint32_t)(zb < kMaxViewBytes ? zb : kMaxViewBytes);
+    if (xb > kMaxViewBytes || zb > kMaxViewBytes) return false; // 32-bit buffer offsets
+    a.x_bytes = (uint32_t)xb;
+    a.dz_bytes = (uint32_t)zb;
     if (wgrad_wide(a.R, a.Cout))
         hipLaunchKernelGGL((k_wgrad_mfma<128, 128, WGRAD_NBUF>), dim3((a.R + 127) / 128, (a.Cout + 127) / 128, a.splits), dim3(256), 0, s, a);
     else if (a.R > 64)
         hipLaunchKernelGGL((k_wgrad_mfma<128, 64, WGRAD_NBUF>), dim3((a.R + 127) / 128, (a.Cout + 63) / 64, a.splits), dim3(256), 0, s, a);
     else
         hipLaunchKernelGGL((k_wgrad_mfma<64, 64, WGRAD_NBUF>), dim3((a.R + 63) / 64, (a.Cout + 63) / 64, a.splits), dim3(256), 0, s, a);
+    return true;
 }
 
 inline long long wgrad_want_splits(long long R, int Cout, long long M, long long target)
