@@ -225,35 +225,48 @@ __global__ __launch_bounds__(64 * kPredWaves) void k_pred_bwd(PredArgs a)
     }
 }
 
-// dw[j][c] = sum over workgroups (in workgroup order) of the partials; db likewise.
-__global__ __launch_bounds__(256) void k_pred_bwd_final(const float *partial, int n_waves, int nout, int C, float *dw_reg,
+// dw[j][c] = sum over workgroups of the partials; db likewise.  16 elements x 16 segments of the workgroup range per block:
+// every thread adds its segment front to back, the 16 segment sums are added in segment order -- a fixed order.
+__global__ __launch_bounds__(256) void k_pred_bwd_final(const float *partial, int n_wg, int nout, int C, float *dw_reg,
                                                         float *dw_obj, float *dw_cls, float *db_reg, float *db_obj, float *db_cls)
 {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    const int per = nout * C;
+    __shared__ float seg_sum[16][17];
+    const int el = threadIdx.x & 15, seg = threadIdx.x >> 4;
+    const int e = blockIdx.x * 16 + el;
+    const int per = nout * C, total = per + nout;
+    const int len = (n_wg + 15) / 16, w0 = seg * len, w1 = w0 + len < n_wg ? w0 + len : n_wg;
+    float s = 0.0f;
     if (e < per) {
-        float s = 0.0f;
-        int wv = 0;
-        for (; wv + 8 <= n_waves; wv += 8) {
-            float t[8];
+        int wv = w0;
+        for (; wv + 4 <= w1; wv += 4) {
+            float t[4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) t[u] = partial[(long long)(wv + u) * per + e];
+            for (int u = 0; u < 4; ++u) t[u] = partial[(long long)(wv + u) * per + e];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) s += t[u];
+            for (int u = 0; u < 4; ++u) s += t[u];
         }
-        for (; wv < n_waves; ++wv) s += partial[(long long)wv * per + e];
-        const int j = e / C, c = e - j * C;
-        if (j < 4) dw_reg[j * C + c] = s;
-        else if (j == 4) dw_obj[c] = s;
-        else dw_cls[(j - 5) * C + c] = s;
-    } else if (e < per + nout) {
-        const int j = e - per;
-        const float *pb = partial + (long long)n_waves * per;
-        float s = 0.0f;
-        for (int wv = 0; wv < n_waves; ++wv) s += pb[(long long)wv * 16 + j];
-        if (j < 4) db_reg[j] = s;
-        else if (j == 4) db_obj[0] = s;
-        else db_cls[j - 5] = s;
+        for (; wv < w1; ++wv) s += partial[(long long)wv * per + e];
+    } else if (e < total) {
+        const float *pb = partial + (long long)n_wg * per;
+        for (int wv = w0; wv < w1; ++wv) s += pb[(long long)wv * 16 + (e - per)];
+    }
+    seg_sum[seg][el] = s;
+    __syncthreads();
+    if (seg == 0 && e < total) {
+        float t = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += seg_sum[q][el];
+        if (e < per) {
+            const int j = e / C, c = e - j * C;
+            if (j < 4) dw_reg[j * C + c] = t;
+            else if (j == 4) dw_obj[c] = t;
+            else dw_cls[(j - 5) * C + c] = t;
+        } else {
+            const int j = e - per;
+            if (j < 4) db_reg[j] = t;
+            else if (j == 4) db_obj[0] = t;
+            else db_cls[j - 5] = t;
+        }
     }
 }
 
@@ -319,7 +332,7 @@ int frlw_pred_bwd(const float *reg_feat, const float *cls_feat, const float *dou
     else if (!two_c) hipLaunchKernelGGL((k_pred_bwd<1, 2>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((k_pred_bwd<2, 2>), grid, block, 0, s, a);
     const int nout = 5 + nc, total = nout * C + nout;
-    hipLaunchKernelGGL(k_pred_bwd_final, dim3((total + 255) / 256), dim3(256), 0, s, scratch, a.n_waves / kPredWaves, nout, C, dw_reg, dw_obj,
+    hipLaunchKernelGGL(k_pred_bwd_final, dim3((total + 15) / 16), dim3(256), 0, s, scratch, a.n_waves / kPredWaves, nout, C, dw_reg, dw_obj,
                        dw_cls, db_reg, db_obj, db_cls);
     return hipGetLastError() == hipSuccess ? FRLW_OK : FRLW_ERR_HIP;
 }
