@@ -82,6 +82,7 @@ SYMBOLS = {
     "frlw_det_add_focus": (_I, [_P, _I, _I, _I, _I, _I]),
     "frlw_det_add_upsample": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I]),
     "frlw_det_add_spp_pool": (_I, [_P, _I, _I, _I, _I, _I]),
+    "frlw_focus_nhwc": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "frlw_det_add_focus_stem": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I]),
     "frlw_det_add_pred": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I64]),
     "frlw_det_add_conv": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I64, _I, _I, _I, _I, _I, _I]),

@@ -664,6 +664,17 @@ int frlw_det_add_focus(frlw_detector_t *d, int src_buf, int C, int H, int W, int
     return FRLW_OK;
 }
 
+int frlw_focus_nhwc(const float *x, int B, int C, int H, int W, float *y, frlw_stream_t stream)
+{
+    (void)hipGetLastError();
+    if (!x || !y || B < 1 || C < 1 || (H & 1) || (W & 1)) return FRLW_ERR_ARG;
+    const size_t lds = (size_t)(W / 2) * (4 * C + 1) * sizeof(float);
+    if (lds > 150 * 1024) return FRLW_ERR_UNSUPPORTED;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_focus, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_focus, dim3(B * (H / 2)), dim3(256), lds, (hipStream_t)stream, x, B, C, H, W, y);
+    return hipGetLastError() == hipSuccess ? FRLW_OK : FRLW_ERR_HIP;
+}
+
 int frlw_det_add_focus_stem(frlw_detector_t *d, int src_buf, int C, int H, int W, const float *w_dev, const float *bias_dev,
                             int Cout, int dst_buf, int dst_cs, int dst_co)
 {

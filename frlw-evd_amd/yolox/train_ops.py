@@ -177,6 +177,21 @@ class _PredLevel(torch.autograd.Function):
         return d_reg, d_cls, dw[0], dw[1], dw[2], dw[3], dw[4], dw[5]
 
 
+def focus_nhwc(x):
+    """Focus space-to-depth (network_blocks.py:205-217) of an input that needs no gradient: (B, C, H, W) ->
+    (B, 4C, H/2, W/2) logical tensor with NHWC storage, channel blocks TL, BL, TR, BR."""
+    lib = _lib.load()
+    x = x.contiguous()
+    B, Cc, H, W = x.shape
+    out = torch.empty((B, H // 2, W // 2, 4 * Cc), dtype=torch.float32, device=x.device)
+    rc = lib.frlw_focus_nhwc(x.data_ptr(), B, Cc, H, W, out.data_ptr(), _stream(x.device))
+    if rc == _lib.FRLW_ERR_UNSUPPORTED:  # very wide frames: the row does not fit the LDS transpose
+        from .network_blocks import Focus
+        return Focus.space_to_depth(x)
+    _lib.check(rc, "focus_nhwc")
+    return out.permute(0, 3, 1, 2)
+
+
 def pred_level(reg_feat, cls_feat, reg_pred, obj_pred, cls_pred):
     """The three prediction convolutions of a level, concatenated along channels (native kernels)."""
     return _PredLevel.apply(reg_feat, cls_feat, reg_pred.weight, reg_pred.bias, obj_pred.weight, obj_pred.bias,

@@ -232,6 +232,11 @@ int frlw_det_add_focus(frlw_detector_t *d, int src_buf, int C, int H, int W, int
  * `weights` (device, kept by reference): for every stage i its effective grouped 1x1 weight g * v / |v| as
  * (out_channels_i, in_channels_per_group_i) row-major then its bias; then trans_up weight (4E, E) + bias and
  * trans_down weight (E, 4E) + bias, E = 4 log2(T).  frlw_det_bfm_weight_count(C) floats (0: unsupported C). */
+/* Focus space-to-depth (network_blocks.py:205-217) as a stand-alone call: (B, C, H, W) NCHW -> (B, H/2, W/2, 4C) NHWC with
+ * the channel blocks TL, BL, TR, BR -- what the train step feeds its first BaseConv (the torch.cat + layout copy it
+ * replaces cost 0.55 ms per step at batch 64). */
+int frlw_focus_nhwc(const float *x, int B, int C, int H, int W, float *y, frlw_stream_t stream);
+
 /* Focus + the stem's 3x3 BaseConv (darknet.py:292) fused: the space-to-depth image stays in LDS.  w_dev / bias_dev as for
  * frlw_det_add_conv with Cin = 4 C, k = 3, Npad = 32.  C in {10, 16} (TAF K = 5 / 8), Cout <= 32, else
  * FRLW_ERR_UNSUPPORTED (use frlw_det_add_focus + frlw_det_add_conv). */

@@ -93,3 +93,14 @@ def test_pred_level_vs_torch(B, C, H, W, nc):
     for a, b in zip(got, want):
         assert a.shape == b.shape
         assert rel(a.double(), b) < TOL, (a.shape, rel(a.double(), b))
+
+
+def test_focus_nhwc_matches_space_to_depth():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from frlw_evd_amd.yolox import train_ops
+    from frlw_evd_amd.yolox.network_blocks import Focus
+    x = torch.randn(3, 10, 32, 48, device="cuda")
+    got = train_ops.focus_nhwc(x)
+    assert got.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(got, Focus.space_to_depth(x))
