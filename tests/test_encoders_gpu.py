@@ -396,3 +396,23 @@ def test_workspace_reuse_across_shapes_and_kinds(er, orc):
         st = dev(st0)
         er.encode_taf_dat(dat_dev(ev), (H, W), st, 0, 10_000, 8, 8)
         assert_bitexact(host(st), ost, "taf")
+
+
+@pytest.mark.parametrize("n", [0, 3000])
+def test_taf_u8_with_mostly_empty_tiles(er, orc, n):
+    """A wide frame (W > 512: 1024-thread tile workgroups) whose events sit in one corner, and a stream with no events
+    at all: the uint8 planes of the empty tiles come from the threshold table alone, which every wavefront must see
+    complete before the write-out (the barrier after the table fill in taf_tile_body)."""
+    H, W, K, n_windows, window_us = 64, 640, 8, 4, 10_000
+    ev = synth.synth_events(77, n, 40, 16, n_windows * window_us, t_offset=0)  # n = 0: empty arrays
+    st0 = np.random.default_rng(9).uniform(-300, 0, size=(H, W, 2, K)).astype(np.float32)
+    dat = synth.to_dat8(ev)
+    oview, ost = orc.taf_stream_dat8(dat, (H, W), (H, W), K, 0, window_us, n_windows, st0)
+    want_u8 = orc.quantize_u8(orc.leaky_transform(oview.reshape(K, 2, H, W)))
+    d = torch.from_numpy(dat.view(np.uint8).reshape(-1, 8).copy()).cuda()
+    for _ in range(3):  # timing-dependent bugs need more than one try
+        st = dev(st0)
+        u8, view = er.encode_taf_dat(d, (H, W), st, 0, window_us, n_windows, K, want_view=True, flip_k=False, fast=False)
+        assert_bitexact(host(st), ost, "taf state")
+        assert_bitexact(host(view), oview, "taf view")
+        assert_u8_budget(host(u8), want_u8, 1e-4, "taf u8")
