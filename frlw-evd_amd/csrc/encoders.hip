@@ -139,12 +139,7 @@ __device__ __forceinline__ void slice_sort(const uint2 *rec, uint32_t s0, uint32
     uint32_t tot = 0;
 #pragma unroll
     for (int j = 0; j < C; ++j) { c[j] = cnt[t + NT * j]; tot += c[j]; }
-    uint32_t inc = tot;
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-        const uint32_t v = __shfl_up(inc, off);
-        if (lane >= off) inc += v;
-    }
+    const uint32_t inc = wave_incl_scan(tot);
     if (lane == kWave - 1) red[16 + wv] = inc;
     __syncthreads();
     uint32_t run = inc - tot;

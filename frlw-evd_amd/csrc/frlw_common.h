@@ -11,6 +11,20 @@
 namespace frlw {
 
 constexpr int kWave = 64;
+
+// Inclusive prefix sum over the 64 lanes of a wavefront in the vector ALU (DPP row shifts inside the rows of 16 lanes, then
+// the row totals by row_bcast15 / row_bcast31): six adds, no LDS crossbar round trips (a __shfl_up scan is six dependent
+// ds_bpermute).  All lanes must be active.
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false); // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false); // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false); // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false); // row_bcast15 into rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false); // row_bcast31 into rows 2 and 3
+    return v;
+}
 // A tile is (1 << twl) pixels wide and 8 rows high; twl = 8 for frames wider than 512 px, else 6
 // (measured best on MI355X; frlw_tuning_t::tile_width_log2 overrides for experiments).
 // One tile = one workgroup of the tile kernels = NT = 4 << twl threads owning 4 cells each

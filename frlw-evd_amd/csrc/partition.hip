@@ -162,12 +162,7 @@ __global__ __launch_bounds__(1024) void k_tilescan(uint32_t *slabtot, int slabs,
     if (b1 > n) b1 = n;
     uint32_t s = 0;
     for (int b = b0; b < b1; ++b) s += tot[b];
-    uint32_t inc = s; // inclusive scan inside the wave
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-        const uint32_t v = __shfl_up(inc, off);
-        if (lane >= off) inc += v;
-    }
+    const uint32_t inc = wave_incl_scan(s); // inclusive scan inside the wave
     if (lane == kWave - 1) wsum[wv] = inc;
     __syncthreads();
     uint32_t pre = 0;
@@ -329,12 +324,7 @@ __global__ __launch_bounds__(kPartThreads, 8) void k_scatter(Decode P, int bpw, 
         uint32_t a0 = 0, a1 = 0;
         if (2 * tid < P.n_tiles) a0 = loff[2 * tid];
         if (2 * tid + 1 < P.n_tiles) a1 = loff[2 * tid + 1];
-        uint32_t inc = a0 + a1;
-#pragma unroll
-        for (int off = 1; off < kWave; off <<= 1) {
-            const uint32_t v = __shfl_up(inc, off);
-            if (lane >= off) inc += v;
-        }
+        const uint32_t inc = wave_incl_scan(a0 + a1);
         if (lane == kWave - 1) wtot[wv] = inc;
         __syncthreads();
         uint32_t pre = 0, total = 0;

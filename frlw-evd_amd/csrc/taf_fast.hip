@@ -42,7 +42,10 @@ constexpr int kMaxPairs = 8192;           // (sequence, tile) pairs per call (LD
 constexpr int kFastSlab = 32;             // chunks per slab of the two-level column scan
 constexpr int ST_MULBAD = 8;              // per-chunk flag next to the ST_* error bits (not an error)
 constexpr int kSplitSeg = 8192;           // records one workgroup of the sub-tile split handles
-constexpr int kSplitWhole = 8 * kSplitSeg; // tiles up to this many records are split by ONE workgroup (kf_split_whole)
+#ifndef FRLW_SPLIT_WHOLE_SEGS
+#define FRLW_SPLIT_WHOLE_SEGS 8
+#endif
+constexpr int kSplitWhole = FRLW_SPLIT_WHOLE_SEGS * kSplitSeg; // tiles up to this many records are split by ONE workgroup (kf_split_whole)
 __host__ __device__ inline uint32_t split_segments(uint32_t n) { return n > (uint32_t)kSplitWhole ? (n + kSplitSeg - 1) / kSplitSeg : 0u; }
 
 struct SeqTab { // kernel argument, built on the host
@@ -423,12 +426,7 @@ __global__ __launch_bounds__(kFT) void kf_scatter(FastGeom G, SeqTab S, const ui
         }
         mine = run;
     }
-    uint32_t inc = mine;
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-        const uint32_t v = __shfl_up(inc, off);
-        if (lane >= off) inc += v;
-    }
+    const uint32_t inc = wave_incl_scan(mine);
     if (lane == kWave - 1) wtot[wv] = inc;
     __syncthreads();
     uint32_t pre = 0, total = 0;
@@ -594,12 +592,7 @@ __global__ __launch_bounds__(kFT) void kf_split_whole(TileP q)
             const int e0 = 2 * lane, e1 = 2 * lane + 1;
             if (e0 < NE) v0 = scnt[e0 / kFW][e0 % kFW][wv];
             if (e1 < NE) v1 = scnt[e1 / kFW][e1 % kFW][wv];
-            uint32_t inc = v0 + v1;
-#pragma unroll
-            for (int o2 = 1; o2 < kWave; o2 <<= 1) {
-                const uint32_t t = __shfl_up(inc, o2);
-                if (lane >= o2) inc += t;
-            }
+            const uint32_t inc = wave_incl_scan(v0 + v1);
             const uint32_t ex = inc - (v0 + v1);
             if (e0 < NE) scnt[e0 / kFW][e0 % kFW][wv] = ex;
             if (e1 < NE) scnt[e1 / kFW][e1 % kFW][wv] = ex + v0;
@@ -679,12 +672,7 @@ __global__ __launch_bounds__(kFT) void kf_split_place(TileP q)
         const int e0 = 2 * lane, e1 = 2 * lane + 1;
         if (e0 < NE) v0 = scnt[e0 / kFW][e0 % kFW][wv];
         if (e1 < NE) v1 = scnt[e1 / kFW][e1 % kFW][wv];
-        uint32_t inc = v0 + v1;
-#pragma unroll
-        for (int o2 = 1; o2 < kWave; o2 <<= 1) {
-            const uint32_t t = __shfl_up(inc, o2);
-            if (lane >= o2) inc += t;
-        }
+        const uint32_t inc = wave_incl_scan(v0 + v1);
         const uint32_t ex = inc - (v0 + v1) + vstart + before;
         if (e0 < NE) scnt[e0 / kFW][e0 % kFW][wv] = ex;
         if (e1 < NE) scnt[e1 / kFW][e1 % kFW][wv] = ex + v0;
@@ -830,12 +818,7 @@ __global__ __launch_bounds__(kWalkThreads) void kf_taf_walk(TileP q)
                     if (!(lane & 1)) cnt[32 * j + (lane >> 1)] = 0u; // after both lanes of the word have read it
                 {
                     const uint32_t tl = n[0] + n[1] + n[2] + n[3];
-                    uint32_t inc = tl;
-#pragma unroll
-                    for (int o2 = 1; o2 < kWave; o2 <<= 1) {
-                        const uint32_t t = __shfl_up(inc, o2);
-                        if (lane >= o2) inc += t;
-                    }
+                    const uint32_t inc = wave_incl_scan(tl);
                     o[0] = inc - tl; o[1] = o[0] + n[0]; o[2] = o[1] + n[1]; o[3] = o[2] + n[2];
                 }
 #pragma unroll
