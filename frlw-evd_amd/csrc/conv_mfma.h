@@ -82,7 +82,7 @@ __device__ __forceinline__ float4 conv_load16(__amdgpu_buffer_rsrc_t r, uint32_t
 // BM x BN output tile, 4 wavefronts arranged WROWS x WCOLS, each owning TM x TN MFMA tiles of 32 x 32.
 // UT ("uniform taps"): Cin % BK == 0, so a k-tile lies inside one filter tap and the tap changes for the whole
 // workgroup at once: the gather offsets are recomputed only then, a k-tile costs one add per load.
-template <int BM, int BN, int WROWS, int WCOLS, int BK, bool UT>
+template <int BM, int BN, int WROWS, int WCOLS, int BK, bool UT, int D = 2>
 __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
 {
     constexpr int TM = BM / (32 * WROWS), TN = BN / (32 * WCOLS);
@@ -96,9 +96,12 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
     constexpr int A_F4 = BM * BK / 4 / 256;   // float4 loads per thread for the A tile
     constexpr int B_F4 = (BN * BK / 4 + 255) / 256;
     constexpr int EPLD = 36;                          // row pitch of the epilogue staging (16-byte aligned rows)
-    // LDS rings.  The gathered operand streams from HBM / the far L2: its tile t + 2 is requested while tile t is
-    // computed (three slots).  The weights are L2-resident and shared by every workgroup: one tile ahead (two slots).
-    constexpr int NA = 3, NB = 2;
+    // LDS rings.  The gathered operand streams from HBM / the far L2: its tile t + D is requested while tile t is
+    // computed (D + 1 slots).  The weights are L2-resident and shared by every workgroup: D - 1 tiles ahead (D slots).
+    // D = 2 where many workgroups share a CU (they hide each other's latency and LDS is what limits their number);
+    // D = 4 for launches that leave a workgroup alone on its CU: its k-tile then costs latency / D, not latency / 2.
+    constexpr int NA = D + 1, NB = D;
+    static_assert(D == 2 || (BN * BK / 4) % 256 == 0, "deeper rings count on every wavefront issuing the same DMAs");
     constexpr int kTileFloats = BK * (NA * BM + NB * LDB);
     constexpr int kEpiFloats = 4 * 32 * EPLD;         // one 32 x 32 MFMA tile per wavefront
     __shared__ __attribute__((aligned(16))) float smem[kTileFloats > kEpiFloats ? kTileFloats : kEpiFloats];
@@ -213,19 +216,24 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    // Issue order inside an iteration: weights of tile t + 1 first, gathered rows of tile t + 2 last -- "all but my
-    // newest A_F4 DMA instructions have landed" (a counted vmcnt) is then exactly "tile t + 1 is complete".
-    auto wait_next_tile = [&](bool a_in_flight) { // wave-uniform
-        if (a_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_F4) : "memory");
+    // Issue order inside an iteration: weights of tile t + D - 1 first, gathered rows of tile t + D last.  The newest
+    // instructions behind the weights of tile t + 1 are then A(t + 2) and D - 2 whole (B, A) pairs: "all but my newest
+    // kInFlight DMA instructions have landed" (a counted vmcnt) is exactly "tile t + 1 is complete".
+    constexpr int kInFlight = A_F4 + (D - 2) * (A_F4 + B_F4);
+    auto wait_next_tile = [&](bool steady) { // wave-uniform
+        if (steady) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kInFlight) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
     PROBE_PH(0);
     load_a(kt0, 0);
-    load_b(0);
-    if (nk > 1) load_a(kt0 + 1, 1);
+#pragma unroll
+    for (int i = 0; i < D - 1; ++i) { // the issue order of the iterations -(D - 1) .. -1
+        if (i < nk) load_b(i);
+        if (i + 1 < nk) load_a(kt0 + i + 1, i + 1);
+    }
     PROBE_PH(1);
-    wait_next_tile(nk > 1);
-    __builtin_amdgcn_s_barrier(); // raw barrier: __syncthreads() would drain the DMA of the tile in flight
+    wait_next_tile(nk >= D);
+    __builtin_amdgcn_s_barrier(); // raw barrier: __syncthreads() would drain the DMA of the tiles in flight
     PROBE_PH(2);
     // MFMA k-step (j, t), j = 0..1, t = 0..3: lane half h supplies k = 8 j + 4 h + t -- any pairing of the tile's 16 k
     // works as long as both operands use it; this one lets a lane take its four A values of a j from ONE 16-byte read.
@@ -236,10 +244,10 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
     // byte addresses in ring slot 0: A quad (2 j + h) ^ swizzle of row fm (second tile: + 32 rows = 2048 B), B row 4 h
     const uint32_t a_lds[2] = {lds0 + (uint32_t)(fm * BK + ((0 + fh) ^ fsw) * 4) * 4, lds0 + (uint32_t)(fm * BK + ((2 + fh) ^ fsw) * 4) * 4};
     const uint32_t b_lds = lds0 + (uint32_t)(NA * BK * BM + 4 * fh * LDB + fn) * 4;
-    int buf = 0; // A ring slot of tile kt; the B slot is kt & 1
+    int buf = 0, bufb = 0; // ring slots of tile kt: A (kt % NA), B (kt % NB)
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) load_b((kt + 1) & 1);                               // slot read last in iteration kt - 1
-        if (kt + 2 < nk) load_a(kt0 + kt + 2, buf == 0 ? 2 : buf - 1);       // (buf + 2) % 3: likewise
+        if (kt + D - 1 < nk) load_b(bufb == 0 ? NB - 1 : bufb - 1);          // (kt + D - 1) % NB: read last in iteration kt - 1
+        if (kt + D < nk) load_a(kt0 + kt + D, buf == 0 ? NA - 1 : buf - 1);  // (kt + D) % NA: likewise
         // Fragment reads run ahead of the MFMAs that consume them (B one k-step, A one j).  They are issued as asm
         // statements with hand-counted lgkmcnt waits: the compiler puts `s_waitcnt vmcnt(0)` in front of every LDS read
         // it can see while an LDS-DMA is in flight (it cannot tell that the DMA writes another ring slot), which would
@@ -248,7 +256,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
         f32x4 fa[2][TM];
         float fb[2][TN];
         const uint32_t a_addr0 = a_lds[0] + (uint32_t)buf * (BM * BK * 4), a_addr1 = a_lds[1] + (uint32_t)buf * (BM * BK * 4);
-        const uint32_t b_addr = b_lds + (uint32_t)(kt & 1) * (BK * LDB * 4);
+        const uint32_t b_addr = b_lds + (uint32_t)bufb * (BK * LDB * 4);
         auto read_a = [&](auto jc) {
             constexpr int j = decltype(jc)::value;
             asm volatile("ds_read_b128 %0, %1" : "=v"(fa[j][0]) : "v"(j ? a_addr1 : a_addr0));
@@ -293,10 +301,11 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
         step(ConvIC<5>{});
         step(ConvIC<6>{});
         step(ConvIC<7>{});
-        wait_next_tile(kt + 2 < nk);            // tile kt + 1 has landed (this wavefront's pieces) ...
+        wait_next_tile(kt + D < nk);            // tile kt + 1 has landed (this wavefront's pieces) ...
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();           // ... everybody's have, and everybody is done reading tile kt
-        buf = buf == 2 ? 0 : buf + 1;
+        buf = buf == NA - 1 ? 0 : buf + 1;
+        bufb = bufb == NB - 1 ? 0 : bufb + 1;
     }
 
     PROBE_PH(3);
@@ -450,11 +459,11 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(ConvArgs a)
 
 inline int conv_grid_1d(long long n) { long long g = (n + 255) / 256; if (g > 4096) g = 4096; if (g < 1) g = 1; return (int)g; }
 
-template <int BM, int BN, int WROWS, int WCOLS, int BK>
+template <int BM, int BN, int WROWS, int WCOLS, int BK, int D = 2>
 inline void launch_conv_tile(const ConvArgs &c, dim3 grid, hipStream_t s)
 {
-    if (c.Cin % BK == 0) hipLaunchKernelGGL((k_conv_mfma<BM, BN, WROWS, WCOLS, BK, true>), grid, dim3(256), 0, s, c);
-    else hipLaunchKernelGGL((k_conv_mfma<BM, BN, WROWS, WCOLS, BK, false>), grid, dim3(256), 0, s, c);
+    if (c.Cin % BK == 0) hipLaunchKernelGGL((k_conv_mfma<BM, BN, WROWS, WCOLS, BK, true, D>), grid, dim3(256), 0, s, c);
+    else hipLaunchKernelGGL((k_conv_mfma<BM, BN, WROWS, WCOLS, BK, false, D>), grid, dim3(256), 0, s, c);
 }
 
 // Tile choice and split-K for one convolution; `scratch` (scratch_floats floats, may be NULL) holds split-K partials.
@@ -503,6 +512,8 @@ inline bool launch_conv(ConvArgs &c, float *scratch, long long scratch_floats, h
             if (sp > nk / 8) sp = nk / 8;
             if (sp > 1 && (long long)sp * c.M * c.Npad <= scratch_floats) { c.splits = sp; c.partial = scratch; }
         }
+        // (a deeper ring, D = 4, for launches that leave a workgroup alone on its CU was measured: no gain -- such
+        // workgroups are bound by the issue cost of their own DMA and fragment instructions, not by prefetch distance)
         launch_conv_tile<64, 64, 2, 2, CONV_BK_SMALL>(c, dim3((c.M + 63) / 64, (c.Npad + 63) / 64, c.splits), s);
         if (c.splits > 1) {
             const bool vec = ((c.Cout | c.Npad | c.y_cs | c.y_co | c.r_cs | c.r_co | c.y_rp) & 3) == 0 && (c.y_bs & 3) == 0 && (c.r_bs & 3) == 0;
