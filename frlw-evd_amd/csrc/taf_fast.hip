@@ -500,6 +500,23 @@ __device__ __forceinline__ void fifo_step(float (&st)[kMaxK], int K, bool has, u
     }
 }
 
+// The same step for K = 8 with TWO lanes per cell: the even lane holds slots 0..3, the odd lane slots 4..7 of the row
+// (the whole workgroup works in phase 2, and a lane moves 16 bytes of the row).  Slot 3 takes over slot 4 from the
+// partner lane through a DPP row shift; the float operations per slot are those of fifo_step.
+__device__ __forceinline__ void fifo_step_half(float (&st)[4], bool upper, bool has, uint32_t n, float sum)
+{
+    const bool hit = n != 0u;
+    const float mean = sum / ((float)n + 1e-8f);
+    const float up = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, st[0]), 0x101, 0xf, 0xf, false)); // row_shl:1: lane l reads lane l + 1
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float nxt = k < 3 ? st[k + 1] : (upper ? 0.0f : up);
+        const float v = (hit ? nxt : st[k]) - 1.0f;
+        const float nv = (hit && upper && k == 3) ? mean : v;
+        st[k] = has ? nv : st[k];
+    }
+}
+
 #define LDS_FENCE() asm volatile("" ::: "memory")
 
 __device__ __forceinline__ int pair_of_segment(const uint32_t *seg0, int pairs, uint32_t seg)
@@ -712,7 +729,7 @@ constexpr int kWalkRpt = 4;                 // records per lane and pass
 constexpr int kWalkChunk = kWalkRpt * kWave;
 
 template <bool K8>
-__global__ __launch_bounds__(kWalkThreads) void kf_taf_walk(TileP q)
+__global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void kf_taf_walk(TileP q)
 {
     __shared__ uint32_t s_cnt[kWalkWaves][kSubCells / 2];   // two 16-bit ticket counters per word
     __shared__ uint16_t s_off[kWalkWaves][kSubCells];
@@ -756,22 +773,25 @@ __global__ __launch_bounds__(kWalkThreads) void kf_taf_walk(TileP q)
     }
     __syncthreads();
 
-    // phase-2 ownership: cell = tid (< 256): pixel 128 sub + tid / 2 of the tile, polarity tid & 1
+    // phase-2 ownership.  K = 8: cell = tid / 2, lane half tid & 1 holds slots 4 (tid & 1) .. + 3 (all 512 threads work);
+    // other K: cell = tid (< 256), the whole row in one lane.  Cell c: pixel 128 sub + c / 2 of the tile, polarity c & 1.
     const int ty = tile / q.tiles_x, tx = tile - ty * q.tiles_x;
     const int x0 = tx << q.twl, y0 = ty << q.thl, tw1 = (1 << q.twl) - 1;
     const long long plane = (long long)q.H * q.W;
-    const int pol = tid & 1;
-    const int pt = sub * (kSubCells / 2) + ((tid & (kSubCells - 1)) >> 1);
+    const int cell = K8 ? tid >> 1 : tid & (kSubCells - 1);
+    const int half = K8 ? tid & 1 : 0;
+    const int pol = cell & 1;
+    const int pt = sub * (kSubCells / 2) + (cell >> 1);
     const int py = y0 + (pt >> q.twl), px = x0 + (pt & tw1);
-    const bool owner = tid < kSubCells, ok = owner && py < q.H && px < q.W;
-    float *srow = q.state + (((long long)s * plane + (long long)py * q.W + px) * 2 + pol) * K;
-    float st[kMaxK];
+    const bool owner = K8 || tid < kSubCells, ok = owner && py < q.H && px < q.W;
+    float *srow = q.state + (((long long)s * plane + (long long)py * q.W + px) * 2 + pol) * K + 4 * half;
+    float st[kMaxK]; // K = 8: st[0..3] only
 #pragma unroll
     for (int k = 0; k < kMaxK; ++k) st[k] = 0.0f;
     if (ok) {
         if (K8) {
-            const float4 a = ((const float4 *)srow)[0], b = ((const float4 *)srow)[1];
-            st[0] = a.x; st[1] = a.y; st[2] = a.z; st[3] = a.w; st[4] = b.x; st[5] = b.y; st[6] = b.z; st[7] = b.w;
+            const float4 a = ((const float4 *)srow)[0];
+            st[0] = a.x; st[1] = a.y; st[2] = a.z; st[3] = a.w;
         } else {
 #pragma unroll
             for (int k = 0; k < kMaxK; ++k)
@@ -864,7 +884,12 @@ __global__ __launch_bounds__(kWalkThreads) void kf_taf_walk(TileP q)
         for (int j = 0; j < 4; ++j) { res_sum[wv][64 * j + lane] = sum[j]; res_cnt[wv][64 * j + lane] = num[j]; }
         __syncthreads();
         // ---- phase 2: one cell per lane, the FIFO steps of this round's windows in order
-        if (owner) {
+        if (K8) {
+            float (&h4)[4] = reinterpret_cast<float (&)[4]>(st);
+#pragma nounroll
+            for (int ws = 0; ws < kWalkWaves && g0 + ws < NW; ++ws) // (wave-uniform condition: every lane runs the DPP move)
+                if ((wmask >> (g0 + ws)) & 1ull) fifo_step_half(h4, half != 0, true, res_cnt[ws][cell], res_sum[ws][cell]);
+        } else if (owner) {
 #pragma nounroll
             for (int ws = 0; ws < kWalkWaves && g0 + ws < NW; ++ws)
                 if ((wmask >> (g0 + ws)) & 1ull) fifo_step(st, K, true, res_cnt[ws][tid], res_sum[ws][tid]);
@@ -874,10 +899,10 @@ __global__ __launch_bounds__(kWalkThreads) void kf_taf_walk(TileP q)
 
     // ---- write-out: state, optional f32 view (2K, H, W), optional uint8 leaky transform (K, 2, H, W)
     uint8_t *ob = (uint8_t *)&res_sum[0][0]; // [2K planes][128 pixels of the sub-tile]
+    const int nslot = K8 ? 4 : kMaxK, slot0 = 4 * half; // this lane's slots: slot0 .. slot0 + nslot - 1
     if (ok) {
         if (K8) {
             ((float4 *)srow)[0] = make_float4(st[0], st[1], st[2], st[3]);
-            ((float4 *)srow)[1] = make_float4(st[4], st[5], st[6], st[7]);
         } else {
 #pragma unroll
             for (int k = 0; k < kMaxK; ++k)
@@ -887,18 +912,29 @@ __global__ __launch_bounds__(kWalkThreads) void kf_taf_walk(TileP q)
             float *vw = q.view_f32 + (long long)s * 2 * K * plane + (long long)py * q.W + px;
 #pragma unroll
             for (int k = 0; k < kMaxK; ++k)
-                if (k < K) vw[(long long)(2 * k + pol) * plane] = st[k]; // generate_taf.py:55
+                if (k < nslot && slot0 + k < K) vw[(long long)(2 * (slot0 + k) + pol) * plane] = st[k]; // generate_taf.py:55
         }
     }
     if (q.out_u8) {
         if (owner) {
-            uint8_t lv[kMaxK];
-            leaky_u8_lookup_n<kMaxK>(st, thr, lv); // the eight table look-ups in flight together
+            if (K8) {
+                const float (&h4)[4] = reinterpret_cast<const float (&)[4]>(st);
+                uint8_t lv[4];
+                leaky_u8_lookup_n<4>(h4, thr, lv);
 #pragma unroll
-            for (int k = 0; k < kMaxK; ++k) {
-                if (k < K) {
-                    const int ko = q.flip ? (K - 1 - k) : k;
-                    ob[(2 * ko + pol) * (kSubCells / 2) + (tid >> 1)] = lv[k];
+                for (int k = 0; k < 4; ++k) {
+                    const int ko = q.flip ? (7 - (slot0 + k)) : slot0 + k;
+                    ob[(2 * ko + pol) * (kSubCells / 2) + (cell >> 1)] = lv[k];
+                }
+            } else {
+                uint8_t lv[kMaxK];
+                leaky_u8_lookup_n<kMaxK>(st, thr, lv); // the eight table look-ups in flight together
+#pragma unroll
+                for (int k = 0; k < kMaxK; ++k) {
+                    if (k < K) {
+                        const int ko = q.flip ? (K - 1 - k) : k;
+                        ob[(2 * ko + pol) * (kSubCells / 2) + (tid >> 1)] = lv[k];
+                    }
                 }
             }
         }
