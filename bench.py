@@ -280,24 +280,29 @@ def bench_also(args, torch, synth, er, timer, rank, n_gpus, copy_gbs):
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         row["cpu_baseline"] = cpu_baseline_ev(rec4, H2, W2)
     out.append(row)
-    G = 32  # sequences stacked along y per launch (the general partition holds 2048 tiles); 64 = two launches
+    # 64 streams as four launch sequences of 16 samples laid out 2 across x 8 down (608 x 1920: the 256-pixel-wide tiles of
+    # the wide-frame kernels; measured best of the layouts in tools/ev_layouts.py: 1 x 32 28 Gev/s, 4 x 8 33, 2 x 8 40)
+    G, across = 16, 2
     parts = []
     for j in range(G):
         e = dict(synth.synth_events(1002 + 50 + j + 7919 * rank, 1_000_000, W2, H2, 250_000))
-        e["y"] = e["y"] + j * H2
+        e["x"] = e["x"] + (j % across) * W2
+        e["y"] = e["y"] + (j // across) * H2
         parts.append(synth.to_dat8(e))
     dat5 = torch.from_numpy(np.concatenate(parts).view(np.uint8).reshape(-1, 8)).cuda()
     del parts
+    launches = 64 // G
 
     def ev_batched():
-        for _ in range(2):
-            er.encode_ev_dat(dat5, (G * H2, W2), 250_000, 250_000, volume_bins=5, check=False)
+        for _ in range(launches):
+            er.encode_ev_dat(dat5, ((G // across) * H2, across * W2), 250_000, 250_000, volume_bins=5, check=False)
     per, dev = timer.run(ev_batched, steps, 2)
-    out.append({"workload": f"ev_gen1 x64: 64 GEN1-shaped streams of 1000000 events as two launch sequences of {G} sequences "
-                            "stacked along y (Event Volume has no per-sequence rule, so stacking is exact)",
-                "value": round(n_gpus * 2 * G * 1_000_000 / per / 1e6, 2), "unit": "Mevents/s", "ms_per_step": round(per * 1e3, 4),
-                "roofline": roofline(2 * G * ev_algorithmic_bytes(1_000_000, H2, W2, 5), dev, "frlw_ev_encode (k_ev_tile dominant)",
-                                     copy_gbs, f"2 x {G} x 1000000 events")})
+    out.append({"workload": f"ev_gen1 x64: 64 GEN1-shaped streams of 1000000 events as {launches} launch sequences of {G} samples laid "
+                            f"out {across} across x {G // across} down in one frame (Event Volume has no per-sequence rule, so any "
+                            "layout is exact: every sample's planes equal its own encode, tools/ev_layouts.py)",
+                "value": round(n_gpus * launches * G * 1_000_000 / per / 1e6, 2), "unit": "Mevents/s", "ms_per_step": round(per * 1e3, 4),
+                "roofline": roofline(launches * G * ev_algorithmic_bytes(1_000_000, H2, W2, 5), dev, "frlw_ev_encode (k_scatter / k_ev_tile)",
+                                     copy_gbs, f"{launches} x {G} x 1000000 events")})
     del dat5
     if not args.hotspot:
         # SURVEY.md 8(d) "report both": the contention variant of the headline workload (25 % of the events in a

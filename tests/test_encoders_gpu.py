@@ -416,3 +416,22 @@ def test_taf_u8_with_mostly_empty_tiles(er, orc, n):
         assert_bitexact(host(st), ost, "taf state")
         assert_bitexact(host(view), oview, "taf view")
         assert_u8_budget(host(u8), want_u8, 1e-4, "taf u8")
+
+
+def test_ev_samples_laid_out_in_one_frame_equal_their_own_encodes(er):
+    """Event Volume has no per-sequence rule: independent samples placed side by side (2 across x 2 down here, the layout
+    of bench.py's ev_gen1 x64 row) come out of ONE encode bit-identical to their own encodes."""
+    H, W, n, span = 40, 72, 30_000, 250_000
+    parts, singles = [], []
+    for j in range(4):
+        e = dict(synth.synth_events(300 + j, n, W, H, span, hotspot=bool(j & 1)))
+        out, _ = er.encode_ev_dat(dat_dev(e), (H, W), span, span, volume_bins=5)
+        singles.append(out)
+        e["x"] = e["x"] + (j % 2) * W
+        e["y"] = e["y"] + (j // 2) * H
+        parts.append(synth.to_dat8(e))
+    dat = torch.from_numpy(np.concatenate(parts).view(np.uint8).reshape(-1, 8).copy()).cuda()
+    both, _ = er.encode_ev_dat(dat, (2 * H, 2 * W), span, span, volume_bins=5)
+    for j in range(4):
+        r0, c0 = (j // 2) * H, (j % 2) * W
+        assert torch.equal(both[:, r0:r0 + H, c0:c0 + W], singles[j]), j
