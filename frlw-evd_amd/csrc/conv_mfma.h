@@ -493,7 +493,7 @@ inline bool launch_conv(ConvArgs &c, float *scratch, long long scratch_floats, h
     const long long big = (long long)((c.M + 127) / 128) * ((c.Npad + 127) / 128);
     static const long long split_below = dev_knob("FRLW_CONV_SPLIT_BELOW", 700ll);
     static const long long split_target = dev_knob("FRLW_CONV_SPLIT_TARGET", 1280ll);
-    static const long long big_min = dev_knob("FRLW_CONV_BIG_MIN", 1000000ll);
+    static const long long big_min = dev_knob("FRLW_CONV_BIG_MIN", 1200ll);
     static const long long wide_min = dev_knob("FRLW_CONV_WIDE_MIN", 1200ll);
     if (c.Npad <= 32) { // small N (prediction convs, the stem's data gradient)
         launch_conv_tile<128, 32, 4, 1, 16>(c, dim3((c.M + 127) / 128, 1), s);

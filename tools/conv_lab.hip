@@ -39,7 +39,8 @@ int main(int argc, char **argv)
                             {32, 40, 64, 64, 3, 1}, {16, 20, 256, 256, 1, 1}, {32, 40, 128, 128, 1, 1}, {64, 80, 64, 64, 1, 1},
                             {16, 20, 128, 128, 1, 1}, {32, 40, 64, 64, 1, 1}, {8, 10, 256, 256, 1, 1}, {8, 10, 512, 512, 1, 1},
                             {32, 40, 512, 7, 1, 1}, {16, 20, 512, 7, 1, 1}, {8, 10, 512, 7, 1, 1},
-                            {16, 20, 16, 128, 1, 1}, {8, 10, 16, 64, 1, 1}}; // (the last two: one k-tile -- the floor of a launch)
+                            {16, 20, 16, 128, 1, 1}, {8, 10, 16, 64, 1, 1}, // (these two: one k-tile -- the floor of a launch)
+                            {64, 80, 64, 128, 3, 1}, {64, 80, 128, 128, 1, 1}, {32, 40, 256, 128, 1, 1}}; // wide-M layers of the train step
     hipStream_t st; CK(hipStreamCreate(&st));
     float *scratch; const long long scratch_floats = 64ll << 20; CK(hipMalloc(&scratch, scratch_floats * 4));
     double *cs; CK(hipMalloc(&cs, 8));
