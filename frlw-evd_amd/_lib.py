@@ -110,6 +110,8 @@ SYMBOLS = {
                                     C.c_float, _P, _P, _P, _I64, _P]),
     "frlw_baseconv_train_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P,
                                     _P, _I64, _P]),
+    "frlw_spp_train_fwd": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
+    "frlw_spp_train_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
     "frlw_pred_bwd_scratch_floats": (_I64, [_I64, _I, _I]),
     "frlw_pred_fwd": (_I, [_P, _P, _I64, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "frlw_pred_bwd": (_I, [_P, _P, _P, _I64, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),

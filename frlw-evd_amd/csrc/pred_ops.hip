@@ -338,3 +338,110 @@ int frlw_pred_bwd(const float *reg_feat, const float *cls_feat, const float *dou
 }
 
 } // extern "C"
+
+// ---- SPP max-pools of the train step ---------------------------------------------------------------------------------
+// SPPBottleneck (network_blocks.py:139-151): cat[x, maxpool5(x), maxpool9(x), maxpool13(x)] (stride 1, "same" padding) and
+// its gradient, NHWC.  ATen's channels_last max-pool backward costs 0.11 ms per pool on these 8 x 10 maps (measured); here
+// the maps of 64 channels sit in LDS, every output scans its window row-major with torch's update rule
+// (`v > best || isnan(v)`: the FIRST maximum wins a tie) and remembers the arg-max pixel; the backward GATHERS (every input
+// pixel looks at the outputs whose window holds it, k = 5, 9, 13, row-major) -- a fixed summation order, no float atomics.
+namespace {
+
+// channels per workgroup: the widest of 64 / 32 / 16 whose maps (backward: 3 x (float + uint16) per element) fit the LDS
+inline int spp_train_ch(int HW, int per_elem_bytes)
+{
+    for (int ch = 64; ch >= 16; ch >>= 1)
+        if ((size_t)HW * ch * per_elem_bytes <= 144 * 1024) return ch;
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void k_spp_train_fwd(const float *x, int H, int W, int C, int ch, float *out, uint16_t *arg)
+{
+    extern __shared__ float sp_x[]; // [H * W][ch]
+    const int b = blockIdx.y, c0 = blockIdx.x * ch, HW = H * W;
+    const int cl = threadIdx.x % ch, prow = threadIdx.x / ch, pstep = 256 / ch;
+    const bool c_ok = c0 + cl < C;
+    for (int p = prow; p < HW; p += pstep) sp_x[p * ch + cl] = c_ok ? x[((long long)b * HW + p) * C + c0 + cl] : 0.0f;
+    __syncthreads();
+    if (!c_ok) return;
+    for (int p = prow; p < HW; p += pstep) {
+        const int y = p / W, xx = p - y * W;
+        float *o = out + ((long long)b * HW + p) * 4 * C + c0 + cl;
+        o[0] = sp_x[p * ch + cl];
+#pragma unroll
+        for (int ki = 0; ki < 3; ++ki) {
+            const int r = 2 + 2 * ki; // window radius 2, 4, 6
+            float best = -INFINITY;
+            int at = -1;
+            for (int yy = y - r > 0 ? y - r : 0; yy <= (y + r < H - 1 ? y + r : H - 1); ++yy)
+                for (int xc = xx - r > 0 ? xx - r : 0; xc <= (xx + r < W - 1 ? xx + r : W - 1); ++xc) {
+                    const float v = sp_x[(yy * W + xc) * ch + cl];
+                    if (v > best || v != v || at < 0) { best = v; at = yy * W + xc; } // (at < 0: the first element, like ATen)
+                }
+            o[(ki + 1) * C] = best;
+            arg[(((long long)b * HW + p) * 3 + ki) * C + c0 + cl] = (uint16_t)at;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_spp_train_bwd(const float *g, const uint16_t *arg, int H, int W, int C, int ch, float *dx)
+{
+    extern __shared__ float sp_lds[];
+    const int b = blockIdx.y, c0 = blockIdx.x * ch, HW = H * W;
+    float *sg = sp_lds;                               // [3][H * W][ch] gradients of the three pools
+    uint16_t *sa = (uint16_t *)(sg + 3 * HW * ch);    // [3][H * W][ch] their arg-max pixels
+    const int cl = threadIdx.x % ch, prow = threadIdx.x / ch, pstep = 256 / ch;
+    const bool c_ok = c0 + cl < C;
+    for (int p = prow; p < HW; p += pstep)
+#pragma unroll
+        for (int ki = 0; ki < 3; ++ki) {
+            sg[(ki * HW + p) * ch + cl] = c_ok ? g[((long long)b * HW + p) * 4 * C + (ki + 1) * C + c0 + cl] : 0.0f;
+            sa[(ki * HW + p) * ch + cl] = c_ok ? arg[(((long long)b * HW + p) * 3 + ki) * C + c0 + cl] : (uint16_t)0xffff;
+        }
+    __syncthreads();
+    if (!c_ok) return;
+    for (int p = prow; p < HW; p += pstep) {
+        const int y = p / W, xx = p - y * W;
+        float s = g[((long long)b * HW + p) * 4 * C + c0 + cl]; // the identity branch
+#pragma unroll
+        for (int ki = 0; ki < 3; ++ki) {
+            const int r = 2 + 2 * ki;
+            for (int yy = y - r > 0 ? y - r : 0; yy <= (y + r < H - 1 ? y + r : H - 1); ++yy)
+                for (int xc = xx - r > 0 ? xx - r : 0; xc <= (xx + r < W - 1 ? xx + r : W - 1); ++xc) {
+                    const int q = yy * W + xc;
+                    if (sa[(ki * HW + q) * ch + cl] == (uint16_t)p) s += sg[(ki * HW + q) * ch + cl];
+                }
+        }
+        dx[((long long)b * HW + p) * C + c0 + cl] = s;
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+int frlw_spp_train_fwd(const float *x, int B, int H, int W, int C, float *out, uint16_t *argmax, frlw_stream_t stream)
+{
+    (void)hipGetLastError();
+    if (!x || !out || !argmax || B < 1 || H < 1 || W < 1 || C < 1) return FRLW_ERR_ARG;
+    const int ch = spp_train_ch(H * W, 3 * 6); // the same chunking as the backward, which needs the most LDS
+    if (H * W > 65535 || ch == 0) return FRLW_ERR_UNSUPPORTED;
+    const size_t lds = (size_t)H * W * ch * sizeof(float);
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_spp_train_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_spp_train_fwd, dim3((C + ch - 1) / ch, B), dim3(256), lds, (hipStream_t)stream, x, H, W, C, ch, out, argmax);
+    return hipGetLastError() == hipSuccess ? FRLW_OK : FRLW_ERR_HIP;
+}
+
+int frlw_spp_train_bwd(const float *dout, const uint16_t *argmax, int B, int H, int W, int C, float *dx, frlw_stream_t stream)
+{
+    (void)hipGetLastError();
+    if (!dout || !argmax || !dx || B < 1 || H < 1 || W < 1 || C < 1) return FRLW_ERR_ARG;
+    const int ch = spp_train_ch(H * W, 3 * 6);
+    if (H * W > 65535 || ch == 0) return FRLW_ERR_UNSUPPORTED;
+    const size_t lds = (size_t)3 * H * W * ch * (sizeof(float) + sizeof(uint16_t));
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_spp_train_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_spp_train_bwd, dim3((C + ch - 1) / ch, B), dim3(256), lds, (hipStream_t)stream, dout, argmax, H, W, C, ch, dx);
+    return hipGetLastError() == hipSuccess ? FRLW_OK : FRLW_ERR_HIP;
+}
+
+} // extern "C"

@@ -177,6 +177,42 @@ class _PredLevel(torch.autograd.Function):
         return d_reg, d_cls, dw[0], dw[1], dw[2], dw[3], dw[4], dw[5]
 
 
+class _SppPools(torch.autograd.Function):
+    """cat[x, maxpool5(x), maxpool9(x), maxpool13(x)] of SPPBottleneck (network_blocks.py:139-151) and its gradient in
+    csrc/pred_ops.hip (arg-max kept from the forward, gather backward: deterministic)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        x = _nhwc(x.float())
+        B, Cc, H, W = x.shape
+        out = torch.empty((B, H, W, 4 * Cc), dtype=torch.float32, device=x.device)
+        arg = torch.empty((B, H, W, 3, Cc), dtype=torch.int16, device=x.device)
+        _lib.check(lib.frlw_spp_train_fwd(x.data_ptr(), B, H, W, Cc, out.data_ptr(), arg.data_ptr(), _stream(x.device)), "spp_fwd")
+        ctx.save_for_backward(arg)
+        ctx.geom = (B, Cc, H, W)
+        return out.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        (arg,) = ctx.saved_tensors
+        B, Cc, H, W = ctx.geom
+        g = _nhwc(dout.float())
+        dx = torch.empty((B, H, W, Cc), dtype=torch.float32, device=g.device)
+        _lib.check(lib.frlw_spp_train_bwd(g.data_ptr(), arg.data_ptr(), B, H, W, Cc, dx.data_ptr(), _stream(g.device)), "spp_bwd")
+        return dx.permute(0, 3, 1, 2)
+
+
+def spp_pools_eligible(x, pools):
+    return (native_enabled() and x.is_cuda and x.dim() == 4 and x.shape[2] * x.shape[3] <= 512
+            and [(m.kernel_size, m.stride, m.padding) for m in pools] == [(5, 1, 2), (9, 1, 4), (13, 1, 6)])
+
+
+def spp_pools(x):
+    return _SppPools.apply(x)
+
+
 def focus_nhwc(x):
     """Focus space-to-depth (network_blocks.py:205-217) of an input that needs no gradient: (B, C, H, W) ->
     (B, 4C, H/2, W/2) logical tensor with NHWC storage, channel blocks TL, BL, TR, BR."""

@@ -310,6 +310,13 @@ int frlw_pred_bwd(const float *reg_feat, const float *cls_feat, const float *dou
                   float *dw_reg, float *db_reg, float *dw_obj, float *db_obj, float *dw_cls, float *db_cls, float *scratch,
                   int64_t scratch_floats, frlw_stream_t stream);
 
+/* The pools of SPPBottleneck in training mode (network_blocks.py:139-151): out (B, H, W, 4C) NHWC = cat[x, maxpool5, maxpool9,
+ * maxpool13] (stride 1, "same" padding, ATen's tie rule: the first maximum in row-major window order), argmax (B, H, W, 3, C)
+ * uint16 input pixel of every pooled value; the backward gathers dx (B, H, W, C) from dout (B, H, W, 4C) in a fixed order.
+ * The maps of 64, 32 or 16 channels must fit the LDS (H * W <= 512), else FRLW_ERR_UNSUPPORTED. */
+int frlw_spp_train_fwd(const float *x, int B, int H, int W, int C, float *out, uint16_t *argmax, frlw_stream_t stream);
+int frlw_spp_train_bwd(const float *dout, const uint16_t *argmax, int B, int H, int W, int C, float *dx, frlw_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * SimOTA label assignment of the YOLOX training branch, whole batch, no host round trips.
  * Replaces the per-image Python of core/yolox/models/yolo_head.py:482-584 (get_assignments),

@@ -104,3 +104,25 @@ def test_focus_nhwc_matches_space_to_depth():
     got = train_ops.focus_nhwc(x)
     assert got.is_contiguous(memory_format=torch.channels_last)
     assert torch.equal(got, Focus.space_to_depth(x))
+
+
+@pytest.mark.parametrize("B,C,H,W", [(2, 256, 8, 10), (3, 96, 16, 20), (1, 40, 5, 7), (64, 256, 8, 10)])
+def test_spp_pools_vs_torch(B, C, H, W):
+    """csrc/pred_ops.hip SPP pools (forward + gather backward) against torch's MaxPool2d + cat, incl. exact ties."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from frlw_evd_amd.yolox import train_ops
+    torch.manual_seed(C)
+    x0 = torch.randn(B, C, H, W, device="cuda")
+    x0[:, : C // 4] = torch.round(x0[:, : C // 4] * 2) / 2   # many exact ties: the first maximum must win
+    pools = [torch.nn.MaxPool2d(k, 1, k // 2) for k in (5, 9, 13)]
+    xa = x0.clone().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    assert train_ops.spp_pools_eligible(xa, pools)
+    ya = train_ops.spp_pools(xa)
+    xb = x0.clone().requires_grad_(True)
+    yb = torch.cat([xb] + [m(xb) for m in pools], 1)
+    assert torch.equal(ya, yb)
+    g = torch.randn_like(yb)
+    ya.backward(g)
+    yb.backward(g)
+    assert rel(xa.grad.double(), xb.grad.double()) < 1e-5
