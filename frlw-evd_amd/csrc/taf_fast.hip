@@ -42,11 +42,12 @@ constexpr int kMaxPairs = 8192;           // (sequence, tile) pairs per call (LD
 constexpr int kFastSlab = 32;             // chunks per slab of the two-level column scan
 constexpr int ST_MULBAD = 8;              // per-chunk flag next to the ST_* error bits (not an error)
 constexpr int kSplitSeg = 8192;           // records one workgroup of the sub-tile split handles
-#ifndef FRLW_SPLIT_WHOLE_SEGS
-#define FRLW_SPLIT_WHOLE_SEGS 8
-#endif
-constexpr int kSplitWhole = FRLW_SPLIT_WHOLE_SEGS * kSplitSeg; // tiles up to this many records are split by ONE workgroup (kf_split_whole)
-__host__ __device__ inline uint32_t split_segments(uint32_t n) { return n > (uint32_t)kSplitWhole ? (n + kSplitSeg - 1) / kSplitSeg : 0u; }
+constexpr int kSplitWhole = 8 * kSplitSeg; // tiles up to this many records are split by ONE workgroup (kf_split_whole) ...
+constexpr int kFewPairs = 256;             // ... unless the call has fewer (sequence, tile) pairs than this: one workgroup per
+                                           // tile would leave most CUs idle (one GEN1 stream: 20 tiles of 50 000 records took
+                                           // 31 us), so every tile above one segment goes through the segment kernels
+__host__ __device__ inline uint32_t whole_max_of(int pairs) { return pairs < kFewPairs ? (uint32_t)kSplitSeg : (uint32_t)kSplitWhole; }
+__host__ __device__ inline uint32_t split_segments(uint32_t n, uint32_t whole_max) { return n > whole_max ? (n + kSplitSeg - 1) / kSplitSeg : 0u; }
 
 struct SeqTab { // kernel argument, built on the host
     int n_seq;
@@ -135,7 +136,7 @@ bool fast_layout(const int64_t *seq_offsets, const int64_t *t_start, int n_seq, 
     p.off_slabtot = off; off = align_up(off + (size_t)(sl > 0 ? sl : 1) * p.T * 4, 256);
     p.off_base = off;    off = align_up(off + (size_t)(p.pairs + 1) * 4, 256);
     p.off_sub = off;     off = align_up(off + ((size_t)p.pairs * kFW + 1) * 4, 256);
-    p.max_segs = (int)(n / kSplitSeg) + (int)(n / kSplitWhole) + 1; // only tiles above kSplitWhole: full + one partial each
+    p.max_segs = 2 * (int)(n / kSplitSeg) + 1; // tiles above the whole-tile limit (>= one segment): full segments + one partial each
     p.off_seg0 = off;    off = align_up(off + (size_t)(p.pairs + 1) * 4, 256);
     p.off_segcnt = off;  off = align_up(off + (size_t)p.max_segs * kFW * 4, 256);
     p.off_errs = off;    off = align_up(off + (size_t)(c > 0 ? c : 1) * 4, 256);
@@ -324,7 +325,8 @@ __global__ __launch_bounds__(kFT) void kf_tilescan(SeqTab S, uint32_t *slabtot, 
     // two exclusive scans over the (sequence, tile) pairs: records -> base[], split segments (kSplitSeg records each,
     // at least one per pair) -> seg0[]
     uint32_t sum = 0, ssum = 0;
-    for (int b = b0; b < b1; ++b) { sum += tot[b]; ssum += split_segments(tot[b]); }
+    const uint32_t whole_max = whole_max_of(pairs);
+    for (int b = b0; b < b1; ++b) { sum += tot[b]; ssum += split_segments(tot[b], whole_max); }
     uint32_t inc = sum, sinc = ssum;
 #pragma unroll
     for (int off = 1; off < kWave; off <<= 1) {
@@ -340,7 +342,7 @@ __global__ __launch_bounds__(kFT) void kf_tilescan(SeqTab S, uint32_t *slabtot, 
         base[b] = run;
         seg0[b] = srun;
         run += tot[b];
-        srun += split_segments(tot[b]);
+        srun += split_segments(tot[b], whole_max);
     }
     if (tid == kFT - 1) { base[pairs] = pre + inc; seg0[pairs] = spre + sinc; }
 }
@@ -568,7 +570,7 @@ __global__ __launch_bounds__(kFT) void kf_split_whole(TileP q)
     const int g = blockIdx.x;
     const uint32_t beg = q.base[g], end = q.base[g + 1];
     if (g == q.pairs - 1 && tid == 0) q.sub[(long long)q.pairs * kFW] = end; // end of the last sub-tile's list
-    if (end - beg > (uint32_t)kSplitWhole) return; // a skewed tile: left to the segment kernels below
+    if (end - beg > whole_max_of(q.pairs)) return; // a skewed tile (or a call with few tiles): left to the segment kernels below
     if (tid < kFW * kFW) (&wtot[0][0])[tid] = 0u;
     __syncthreads();
     for (uint32_t i = beg + tid; i < end; i += kFT) atomicAdd(&wtot[wv][(q.rec[i] & (kCells - 1)) >> 8], 1u);
@@ -1052,7 +1054,7 @@ size_t frlw_taf_batch_workspace_bytes(int64_t n_events, int n_seq, int H, int W,
     off = align_up(off + (size_t)(p.pairs + 1) * 4, 256);
     off = align_up(off + ((size_t)p.pairs * kFW + 1) * 4, 256);
     off = align_up(off + (size_t)(p.pairs + 1) * 4, 256);
-    off = align_up(off + ((size_t)(n_events / kSplitSeg) + (size_t)(n_events / kSplitWhole) + 1) * kFW * 4, 256);
+    off = align_up(off + (2 * (size_t)(n_events / kSplitSeg) + 1) * kFW * 4, 256);
     off = align_up(off + chunks * 4, 256);
     off = align_up(off + (size_t)(window_us + 1) * 4, 256);
     off = align_up(off + (size_t)kLeakyLevels * 4, 256);
