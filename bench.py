@@ -249,7 +249,7 @@ def bench_also(args, torch, synth, er, timer, rank, n_gpus, copy_gbs):
     row = {"workload": "taf_gen1 (the GEN1 304x240 shape BASELINE.json's metric names): TAF K=8 encode + leaky + uint8, "
                        "1000000 events, 304x240, 8 windows, ONE stream per launch sequence",
            "value": round(n_gpus * n2 / per / 1e6, 2), "unit": "Mevents/s", "ms_per_step": round(per * 1e3, 4),
-           "roofline": roofline(taf_algorithmic_bytes(n2, H2, W2, K2), dev, "frlw_taf_encode (k_taf_tile dominant)", copy_gbs,
+           "roofline": roofline(taf_algorithmic_bytes(n2, H2, W2, K2), dev, "frlw_taf_encode_batch, one sequence (launch-bound: 6 launches)" if n2 >= er.FAST_MIN_EVENTS else "frlw_taf_encode (k_taf_tile dominant)", copy_gbs,
                                 f"{n2} events")}
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         row["cpu_baseline"] = cpu_baseline_taf(rec2, n2, H2, W2, K2, nw2, wu2, all_cores=False)

@@ -259,11 +259,8 @@ __global__ __launch_bounds__(kFT) void kf_hist(FastGeom G, SeqTab S, uint32_t *c
 
 // ---- 2. scans ----------------------------------------------------------------------------------------
 // counts[c][b], c in one slab of 32 chunks of ONE sequence -> exclusive prefix over c (in place), slabtot[slab][b]
-__global__ __launch_bounds__(kWave) void kf_slabscan(SeqTab S, uint32_t *counts, int T, uint32_t *slabtot)
+__device__ __forceinline__ void slabscan_one(const SeqTab &S, uint32_t *counts, int T, uint32_t *slabtot, int slab, int b)
 {
-    const int b = blockIdx.x * kWave + threadIdx.x;
-    const int slab = blockIdx.y;
-    if (b >= T) return;
     int s = 0;
     while (s + 1 < S.n_seq && slab >= S.slab0[s + 1]) ++s;
     const int c0 = S.chunk0[s] + (slab - S.slab0[s]) * kFastSlab, cend = S.chunk0[s + 1];
@@ -282,12 +279,24 @@ __global__ __launch_bounds__(kWave) void kf_slabscan(SeqTab S, uint32_t *counts,
         if (c0 + k < cend) counts[(long long)(c0 + k) * T + b] = v[k];
     slabtot[(long long)slab * T + b] = run;
 }
+__global__ __launch_bounds__(kWave) void kf_slabscan(SeqTab S, uint32_t *counts, int T, uint32_t *slabtot)
+{
+    const int b = blockIdx.x * kWave + threadIdx.x;
+    if (b < T) slabscan_one(S, counts, T, slabtot, blockIdx.y, b);
+}
 
 // slabtot[slab][b] -> exclusive prefix over the slabs of each sequence (in place); exclusive scan over the
 // (sequence, tile) pairs -> base[0..pairs]; resets the header and folds the per-chunk error flags into it.
+// (small calls -- at most kInlineSlabScan (slab, tile) columns -- run the slab scan here too: one launch less)
+constexpr int kInlineSlabScan = 8192;
 __global__ __launch_bounds__(kFT) void kf_tilescan(SeqTab S, uint32_t *slabtot, int T, uint32_t *base, uint32_t *seg0,
-                                                   FastHeader *hdr, const int32_t *errs, int chunks)
+                                                   FastHeader *hdr, const int32_t *errs, int chunks, uint32_t *counts_inline,
+                                                   int slabs_inline)
 {
+    if (counts_inline) {
+        for (int i = threadIdx.x; i < slabs_inline * T; i += kFT) slabscan_one(S, counts_inline, T, slabtot, i / T, i % T);
+        __syncthreads(); // the totals are read back below by other threads of this workgroup
+    }
     __shared__ uint32_t tot[kMaxPairs];
     __shared__ uint32_t wsum[kFW], wsum2[kFW];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -1018,9 +1027,11 @@ void launch_fast(const FastGeom &G, const SeqTab &S, const FastPlan &p, char *w8
     if (lds_sc > 64 * 1024)
         (void)hipFuncSetAttribute((const void *)kf_scatter<HAS_MAP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc);
     hipLaunchKernelGGL((kf_hist<HAS_MAP>), dim3(p.chunks), dim3(kFT), (size_t)p.T * 4, st, G, S, counts, errs, tlut, leaky);
-    hipLaunchKernelGGL(kf_slabscan, dim3((p.T + kWave - 1) / kWave, p.slabs), dim3(kWave), 0, st, S, counts, p.T, slabtot);
+    const bool inline_slabs = (long long)p.slabs * p.T <= kInlineSlabScan;
+    if (!inline_slabs)
+        hipLaunchKernelGGL(kf_slabscan, dim3((p.T + kWave - 1) / kWave, p.slabs), dim3(kWave), 0, st, S, counts, p.T, slabtot);
     hipLaunchKernelGGL(kf_tilescan, dim3(1), dim3(kFT), 0, st, S, slabtot, p.T, base, (uint32_t *)(w8 + p.off_seg0), hdr, errs,
-                       p.chunks);
+                       p.chunks, inline_slabs ? counts : (uint32_t *)nullptr, p.slabs);
     hipLaunchKernelGGL((kf_scatter<HAS_MAP>), dim3(p.chunks), dim3(kFT), lds_sc, st, G, S, counts, slabtot, base, records, hdr);
 }
 

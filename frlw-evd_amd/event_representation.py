@@ -29,7 +29,7 @@ from . import _lib
 _WORKSPACES = {}
 TUNING = None  # a _lib.FrlwTuning to attach to every encoder call (experiments / tests forcing a path); None = defaults
 TUNING = None  # a _lib.FrlwTuning to attach to every encoder call (experiments / tests forcing a path); None = defaults
-FAST_MIN_EVENTS = 3_000_000  # single streams shorter than this take the general TAF path (encode_taf_dat, fast="auto")
+FAST_MIN_EVENTS = 1_000_000  # single streams shorter than this take the general TAF path (encode_taf_dat, fast="auto")
 
 
 def _stream():
@@ -257,8 +257,8 @@ def encode_taf_dat(dat, shape, state, t_start, window_us=10000, n_windows=8, vol
     newest-slot-first like ``np.flip(ecd, axis=0)`` (:229): ``u8[:4]`` is the bins4 file, ``u8[4:]`` bins8.
 
     ``fast``: run the batched fast path with one sequence (csrc/taf_fast.hip); ``"auto"`` = for streams of at least
-    ``FAST_MIN_EVENTS`` events (below that its two extra launches cost more than they save: measured 94 vs 65 us at
-    1 M events).  It needs every event inside ``[t_start, t_start + n_windows * window_us]``; if the device check says
+    ``FAST_MIN_EVENTS`` events (below that its extra launch costs more than it saves: 61 vs 64 us at 1 M events, the
+    break-even).  It needs every event inside ``[t_start, t_start + n_windows * window_us]``; if the device check says
     otherwise (only seen with ``check``), or the window does not fit its 4-byte records, the general path
     (csrc/encoders.hip) runs -- same bits either way.
     """
