@@ -78,8 +78,8 @@ def cpu_model():
 class Timer:
     """K timed steps between barrier + synchronize on both sides; device time by HIP events on the launch stream."""
 
-    def __init__(self, torch, fd):
-        self.torch, self.fd = torch, fd
+    def __init__(self, torch, fd, er=None):
+        self.torch, self.fd, self.er = torch, fd, er
 
     def run(self, fn, steps, warmup):
         torch = self.torch
@@ -95,6 +95,8 @@ class Timer:
         self.fd.barrier_sync()
         wall = time.perf_counter() - t0
         wall, dev_ms = self.fd.max_over_ranks([wall, e0.elapsed_time(e1) / steps])
+        if self.er is not None:
+            self.er.raise_deferred("bench.py timed region")  # unchecked encoder calls: their status, outside the timed region
         return wall / steps, dev_ms
 
 
@@ -126,9 +128,88 @@ def dev_records(torch, synth, ev):
     return torch.from_numpy(synth.to_dat8(ev).view(np.uint8).reshape(-1, 8)).cuda()
 
 
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """``python bench.py --gpus N`` without a launcher around it (no WORLD_SIZE in the environment): start N FRESH child
+    processes of this script, one rank per GPU (the reference's launch, README.md:160-170: one process per GPU with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment), forward rank 0's JSON line, and return non-zero when any
+    rank fails.  This parent never touches HIP (it does not even import torch): nothing re-execs or forks a process
+    that has initialised the GPU."""
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=os.environ.get("MASTER_PORT") or str(free_port()), FRLW_BENCH_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=e,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    rc, out0 = 0, b""
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                p = procs[r]
+                if r == 0 and p.stdout is not None:  # rank 0 prints one line at the very end; communicate() drains it
+                    try:
+                        o, _ = p.communicate(timeout=0.2)
+                        out0 += o or b""
+                    except subprocess.TimeoutExpired:
+                        continue
+                elif p.poll() is None:
+                    continue
+                pending.discard(r)
+                if p.returncode != 0:
+                    rc = rc or p.returncode or 1
+                    print(f"bench.py: rank {r} exited with code {p.returncode}", file=sys.stderr)
+            if rc:
+                break
+            time.sleep(0.05)
+    finally:
+        for p in procs:  # exactly the children started here, by PID
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    sys.stdout.write(out0.decode(errors="replace"))
+    sys.stdout.flush()
+    return rc
+
+
+def launch_only(args):
+    """--launch-only: the rendezvous of a --gpus N run and nothing else (tests/test_dist_cpu.py runs it with
+    FRLW_DIST_BACKEND=gloo on CPU): every rank joins the process group, the ranks are summed and the barrier-bracketed
+    MAX-over-ranks reduction of bench.py is exercised; rank 0 prints one JSON line."""
+    import torch.distributed as dist
+    from frlw_evd_amd import dist as fd
+    if os.environ.get("FRLW_BENCH_TEST_FAIL_RANK") == os.environ.get("RANK", "0"):  # the launcher's failure path, under test
+        raise SystemExit(3)
+    rank, world, local_rank = fd.init_from_env(None, args.local_rank)
+    fd.barrier_sync()
+    ranks = fd.sum_over_ranks([rank + 1])[0]
+    slowest = fd.max_over_ranks([0.5 + rank])[0]
+    fd.barrier_sync()
+    if rank == 0:
+        print(json.dumps({"launch_only": True, "n_gpus": world, "gpus_flag": args.gpus, "rank_sum": ranks,
+                          "max_over_ranks": slowest, "backend": dist.get_backend() if dist.is_initialized() else None,
+                          "launched_by": "bench.py" if os.environ.get("FRLW_BENCH_LAUNCHED") else "external launcher"}))
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs of this node (default: WORLD_SIZE, else 1)")
+    ap.add_argument("--launch-only", action="store_true", help="rendezvous of the N ranks only (CPU test of the launcher)")
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="taf_mpx", choices=sorted(WORKLOADS))
@@ -141,10 +222,23 @@ def main():
     ap.add_argument("--train-batch", type=int, default=64, help="per-GPU batch of the train-step leg")
     ap.add_argument("--local_rank", "--local-rank", type=int, default=None)
     args = ap.parse_args()
+    if args.gpus is None:
+        args.gpus = int(os.environ.get("WORLD_SIZE", "1"))
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: be the launcher (before anything imports torch or touches HIP in this process)
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks")
+    if args.launch_only:
+        return launch_only(args)
 
     import torch
     import torch.distributed as dist
 
+    if os.environ.get("FRLW_DIST_BACKEND", "nccl") == "nccl" and args.gpus > torch.cuda.device_count():
+        raise SystemExit(f"bench.py: --gpus {args.gpus} needs {args.gpus} GPUs, this box has {torch.cuda.device_count()} "
+                         "(one process per GPU over RCCL)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     from frlw_evd_amd import _lib, synth
@@ -154,7 +248,7 @@ def main():
     torch.cuda.set_device(local_rank)
     n_gpus = world
     _lib.load()
-    timer = Timer(torch, fd)
+    timer = Timer(torch, fd, er)
     copy_gbs = copy_bandwidth(torch)
 
     seed, n, H, W, t_span, n_win, win_us, K = WORKLOADS[args.workload]
@@ -245,7 +339,8 @@ def bench_also(args, torch, synth, er, timer, rank, n_gpus, copy_gbs):
     rec2 = synth.to_dat8(ev2)
     dat2 = torch.from_numpy(rec2.view(np.uint8).reshape(-1, 8)).cuda()
     st2 = torch.full((H2, W2, 2, K2), -6000.0, device="cuda")
-    per, dev = timer.run(lambda: er.encode_taf_dat(dat2, (H2, W2), st2, 0, wu2, nw2, K2, check=False), steps, 3)
+    per, dev = timer.run(lambda: er.encode_taf_dat(dat2, (H2, W2), st2, 0, wu2, nw2, K2, check=False,
+                                                     fast=n2 >= er.FAST_MIN_EVENTS), steps, 3)
     row = {"workload": "taf_gen1 (the GEN1 304x240 shape BASELINE.json's metric names): TAF K=8 encode + leaky + uint8, "
                        "1000000 events, 304x240, 8 windows, ONE stream per launch sequence",
            "value": round(n_gpus * n2 / per / 1e6, 2), "unit": "Mevents/s", "ms_per_step": round(per * 1e3, 4),
@@ -311,7 +406,7 @@ def bench_also(args, torch, synth, er, timer, rank, n_gpus, copy_gbs):
         ev3 = synth.synth_events(seed + 7919 * rank, n, W, H, t_span, hotspot=True)
         dat3 = torch.from_numpy(synth.to_dat8(ev3).view(np.uint8).reshape(-1, 8)).cuda()
         st3 = torch.full((H, W, 2, K), -6000.0, device="cuda")
-        per, dev = timer.run(lambda: er.encode_taf_dat(dat3, (H, W), st3, 0, win_us, n_win, K, check=False), steps, 2)
+        per, dev = timer.run(lambda: er.encode_taf_dat(dat3, (H, W), st3, 0, win_us, n_win, K, check=False, fast=True), steps, 2)
         out.append({"workload": "taf_mpx, hotspot variant (25 % of the events in a sigma = 8 px blob)",
                     "value": round(n_gpus * n / per / 1e6, 2), "unit": "Mevents/s", "ms_per_step": round(per * 1e3, 4),
                     "roofline": roofline(taf_algorithmic_bytes(n, H, W, K), dev, "frlw_taf_encode_batch", copy_gbs, f"{n} events")})
@@ -405,64 +500,87 @@ def bench_detector(args, torch, world, rank, timer):
     return out
 
 
-def bench_train(args, torch, world, rank, local_rank, timer):
-    """SURVEY.md 8(d) cfg 5: YOLOX (16-channel TAF input) train step -- forward, batched SimOTA assignment
-    (frlw_simota_assign) + losses, backward, Adam -- under DDP over RCCL when N > 1, per-GPU batch fixed (weak scaling).
-    Every BaseConv runs forward and backward in the gfx950 kernels of csrc/train_ops.hip; the same step with torch
-    autograd / MIOpen convolutions is timed beside it."""
-    from frlw_evd_amd import dist as fd
-    from frlw_evd_amd import e2e
-    from frlw_evd_amd.trainer import Trainer
-    B = args.train_batch
-    m = e2e.build_model(in_channels=16, num_classes=2)
-    tr = Trainer(m, global_batch=B * world, nodes=world, iters_per_epoch=100, local_rank=local_rank, ddp=world > 1,
-                 comm_hook="timed" if world > 1 else None)
+def _train_inputs(torch, B, rank):
     rng = np.random.default_rng(1005 + rank)
     x = torch.from_numpy(rng.integers(0, 256, size=(B, 16, 256, 320, 1, 1), dtype=np.uint8)).float().div(255).cuda()
     lab = torch.zeros(B, 80, 5, dtype=torch.float64)
     lab[:, 0] = torch.tensor([0, 100, 90, 60, 40.0])
     lab[:, 1] = torch.tensor([1, 220, 150, 50, 80.0])
-    lab = lab.cuda()
-    steps = 5
+    return x, lab.cuda()
+
+
+def _train_variant(torch, timer, world, rank, local_rank, per_gpu_batch, ddp, hook, steps=5, warmup=3):
+    """One configuration of the train step on a fresh model: (seconds per step, device ms per step, Trainer, last loss)."""
+    from frlw_evd_amd import e2e
+    from frlw_evd_amd.trainer import Trainer
+    m = e2e.build_model(in_channels=16, num_classes=2)
+    tr = Trainer(m, global_batch=per_gpu_batch * world, nodes=world, iters_per_epoch=100, local_rank=local_rank,
+                 ddp=ddp, comm_hook=hook)
+    x, lab = _train_inputs(torch, per_gpu_batch, rank)
     state = {"i": 0, "loss": None}
 
     def one():
         state["loss"], _ = tr.train_step(x, lab, state["i"])
         state["i"] += 1
 
-    per, dev_ms = timer.run(one, steps, 3)
+    per, dev_ms = timer.run(one, steps, warmup)
+    return per, dev_ms, tr, state, one, (x, lab)
+
+
+def _allreduce_rows(torch, timer, world, rank, local_rank, per_gpu_batch, per_default, steps):
+    """How much of the gradient exchange is exposed (not hidden behind the backward), per communication hook: the DDP
+    step minus the same step on the bare module (same kernels, no gradient hooks, no collective)."""
+    per_ns, _, tr_ns, *_ = _train_variant(torch, timer, world, rank, local_rank, per_gpu_batch, False, None, steps, 2)
+    grad_bytes = int(sum(p.numel() for p in tr_ns.model.parameters()) * 4)
+    del tr_ns
+    per_rs, _, tr_rs, *_ = _train_variant(torch, timer, world, rank, local_rank, per_gpu_batch, True, "rs_ag", steps, 3)
+    del tr_rs
+    per_t, _, tr_t, *_ = _train_variant(torch, timer, world, rank, local_rank, per_gpu_batch, True, "timed", steps, 3)
+    hook = tr_t.comm_hook.summary() if tr_t.comm_hook is not None else {}
+    del tr_t
+    torch.cuda.empty_cache()
+    out = {"gradient_bytes": grad_bytes, "step_ms_without_collective": round(per_ns * 1e3, 3),
+           "allreduce_exposed_ms": round(max(0.0, (per_default - per_ns) * 1e3), 3),
+           "exposed_ms_by_hook": {"default": round(max(0.0, (per_default - per_ns) * 1e3), 3),
+                                  "rs_ag": round(max(0.0, (per_rs - per_ns) * 1e3), 3)},
+           "step_ms_by_hook": {"default": round(per_default * 1e3, 3), "rs_ag": round(per_rs * 1e3, 3),
+                               "timed": round(per_t * 1e3, 3)},
+           "bucket_bytes": hook.get("bucket_bytes"), "mean_bucket_ms": round(hook.get("mean_bucket_ms", 0.0), 3),
+           "buckets_per_step": (hook["buckets"] // (steps + 3)) if hook.get("buckets") else None,
+           "collective_ms_per_step": round(hook.get("total_ms", 0.0) / max(steps + 3, 1), 3),
+           "hooks": "default = DDP's bucketed RCCL all-reduce; rs_ag = reduce-scatter + all-gather per bucket "
+                    "(frlw_evd_amd.dist); timed = default + HIP events around each bucket's collective",
+           "ddp": "gradient_as_bucket_view, static_graph, 25 MB buckets (frlw_evd_amd.dist.ddp_kwargs)"}
+    return out
+
+
+def bench_train(args, torch, world, rank, local_rank, timer):
+    """SURVEY.md 8(d) cfg 5: YOLOX (16-channel TAF input) train step -- forward, batched SimOTA assignment
+    (frlw_simota_assign) + losses, backward, Adam -- under DDP over RCCL when N > 1.  Two rows: per-GPU batch fixed at 64
+    (weak scaling, global 64 * N) and the reference's own semantics, global batch 64 = 64 / N per GPU (settings.py:41;
+    strong scaling, ``global64``).  Every BaseConv runs forward and backward in the gfx950 kernels of csrc/train_ops.hip;
+    the same step with torch autograd / MIOpen convolutions is timed beside it at N = 1."""
+    from frlw_evd_amd import e2e
+    B = args.train_batch
+    steps = 5
+    per, dev_ms, tr, state, one, (x, lab) = _train_variant(torch, timer, world, rank, local_rank, B, world > 1, None, steps)
     loss = state["loss"]
     from frlw_evd_amd.detector import DetectorEngine
     probe = DetectorEngine(e2e.build_model(16, 2, device="cpu").eval(), device="cpu")
     probe.build((16, 256, 320))  # the plan builder counts the convolution MACs of the 16-channel network
-    flops = 3 * probe.flops_per_image * B
+    flops_img = 3 * probe.flops_per_image
+    flops = flops_img * B
     tflops = flops / (dev_ms * 1e-3) / 1e12
     out = {"metric": "YOLOX train step (frames/s)", "value": round(world * B / per, 1), "unit": "frames/s",
-           "ms_per_step": round(per * 1e3, 3), "per_gpu_batch": B, "steps": steps, "loss": round(loss, 4),
-           "parallelism": f"ddp{world}" if world > 1 else "single", "scaling": "weak",
+           "ms_per_step": round(per * 1e3, 3), "per_gpu_batch": B, "global_batch": B * world, "steps": steps,
+           "loss": round(loss, 4), "parallelism": f"ddp{world}" if world > 1 else "single", "scaling": "weak",
            "convolutions": "csrc/train_ops.hip (fp32 MFMA fwd / dgrad / wgrad, BatchNorm + SiLU fwd / bwd), SimOTA csrc/simota.hip",
            "roofline": {"bound": "mfma", "kernel": "k_conv_mfma (fwd + dgrad) + k_wgrad_mfma", "achieved": round(tflops, 2),
                         "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / FP32_MFMA_PEAK_TFLOPS, 4),
                         "flops_per_step": flops, "flops_model": "3 x (conv MACs x 2 of the 16-channel forward) x batch: forward + data "
                         "gradient + weight gradient", "device_ms_per_step": round(dev_ms, 3)}}
     if world > 1:
-        # how much of the gradient all-reduce is hidden behind the backward: the same step inside no_sync() has no
-        # collective at all; the difference is what the all-reduce adds to the step = its exposed part
-        hook = tr.comm_hook.summary() if tr.comm_hook is not None else {}
-
-        plain = Trainer(m, global_batch=B * world, nodes=world, iters_per_epoch=100, local_rank=local_rank, ddp=False)
-
-        def nosync():  # the bare module behind the DDP wrapper: same kernels, no gradient hooks, no collective
-            plain.train_step(x, lab, 0)
-        per_ns, _ = timer.run(nosync, steps, 2)
-        out["allreduce"] = {"gradient_bytes": int(sum(p.numel() for p in m.parameters()) * 4), "buckets_per_step": None,
-                            "bucket_bytes": hook.get("bucket_bytes"), "mean_bucket_ms": round(hook.get("mean_bucket_ms", 0.0), 3),
-                            "allreduce_total_ms_per_step": round(hook.get("total_ms", 0.0) / max(steps + 3, 1), 3),
-                            "step_ms_without_collective": round(per_ns * 1e3, 3),
-                            "allreduce_exposed_ms": round(max(0.0, (per - per_ns) * 1e3), 3),
-                            "ddp": "gradient_as_bucket_view, static_graph, 25 MB buckets (frlw_evd_amd.dist.ddp_kwargs)"}
-        if hook.get("buckets"):
-            out["allreduce"]["buckets_per_step"] = hook["buckets"] // (steps + 3)
+        out["allreduce"] = _allreduce_rows(torch, timer, world, rank, local_rank, B, per, steps)
     # BASELINE.json configs[4]: the same step fed by the TAF encode of its batch (B GEN1-shaped streams of 8 x 125 000
     # events -> frlw_taf_encode_batch -> uint8 -> nearest 256x320 -> /255), everything on this GPU
     src = e2e.SyntheticTafSource(B, seed=1005 + 1000 * rank)
@@ -477,6 +595,7 @@ def bench_train(args, torch, world, rank, local_rank, timer):
                                                  "304x240 sample, one frlw_taf_encode_batch call) + train step",
                                      "value": round(world * B / per_e2e, 1), "unit": "frames/s",
                                      "ms_per_step": round(per_e2e * 1e3, 3), "encode_ms_per_batch": round(per_enc * 1e3, 3)}
+    del src
     if world == 1:
         prev = os.environ.get("FRLW_NATIVE_TRAIN")
         os.environ["FRLW_NATIVE_TRAIN"] = "0"  # the same step with torch autograd / MIOpen convolutions, for comparison
@@ -489,6 +608,27 @@ def bench_train(args, torch, world, rank, local_rank, timer):
                 os.environ["FRLW_NATIVE_TRAIN"] = prev
         out["same_step_with_miopen_convs"] = {"value": round(world * B / per_t, 1), "ms_per_step": round(per_t * 1e3, 3),
                                               "native_speedup": round(per_t / per, 3)}
+    del tr, one, x, lab
+    torch.cuda.empty_cache()
+    # ---- the reference's semantics: GLOBAL batch 64 (settings.py:41: 64 / nodes per GPU) -> strong scaling over N
+    G = 64
+    if G % world == 0:
+        b = G // world
+        if world == 1 and b == B:
+            g64 = {"value": out["value"], "ms_per_step": out["ms_per_step"], "device_ms_per_step": round(dev_ms, 3),
+                   "note": "N = 1: the same step as the weak row"}
+        else:
+            per_g, dev_g, tr_g, *_ = _train_variant(torch, timer, world, rank, local_rank, b, world > 1, None, steps)
+            del tr_g
+            g64 = {"value": round(G / per_g, 1), "ms_per_step": round(per_g * 1e3, 3), "device_ms_per_step": round(dev_g, 3)}
+            tf = flops_img * b / (dev_g * 1e-3) / 1e12
+            g64["roofline"] = {"bound": "mfma", "achieved": round(tf, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4)}
+            if world > 1:
+                g64["allreduce"] = _allreduce_rows(torch, timer, world, rank, local_rank, b, per_g, steps)
+        out["global64"] = dict({"workload": f"global batch {G} over {world} GPU(s) = {b} per GPU (settings.py:41), DDP "
+                                            "(core/exp.py:391)", "unit": "frames/s", "per_gpu_batch": b, "global_batch": G,
+                                "scaling": "strong"}, **g64)
     return out
 
 

@@ -59,6 +59,9 @@ SYMBOLS = {
     "frlw_version": (C.c_char_p, []),
     "frlw_encoder_workspace_bytes": (_SZ, [_I64, _I, _I]),
     "frlw_encoder_status": (_I, [_P, _P, C.POINTER(C.c_int)]),
+    "frlw_workspace_init": (_I, [_P, _SZ, _P]),
+    "frlw_encoder_deferred_status": (_I, [_P, _P, C.POINTER(C.c_int)]),
+    "frlw_debug_force_lds_order": (_I, [_I]),
     "frlw_eci_encode": (_I, [_EV, _I, _I, _P, _P, _P, _SZ, _P]),
     "frlw_ev_encode": (_I, [_EV, _I, _I, _I, _I64, _I64, _P, _P, _P, _SZ, _P]),
     "frlw_sae_encode": (_I, [_EV, _I, _I, C.POINTER(C.c_double), _I, _P, _P, _I64, _I64, _P, _P, _P, _SZ, _P]),

@@ -688,6 +688,25 @@ int frlw_encoder_status(const void *workspace, frlw_stream_t stream, int *status
     return FRLW_OK;
 }
 
+int frlw_workspace_init(void *workspace, size_t workspace_bytes, frlw_stream_t stream)
+{
+    if (!workspace || workspace_bytes < kHeaderBytes) return FRLW_ERR_ARG;
+    HIP_TRY(hipMemsetAsync(workspace, 0, kHeaderBytes, (hipStream_t)stream));
+    return FRLW_OK;
+}
+
+int frlw_encoder_deferred_status(void *workspace, frlw_stream_t stream, int *status_out)
+{
+    if (!workspace || !status_out) return FRLW_ERR_ARG;
+    int32_t st = 0;
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(&st, (char *)workspace + kStickyOffset, sizeof(st), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemsetAsync((char *)workspace + kStickyOffset, 0, sizeof(st), s));
+    HIP_TRY(hipStreamSynchronize(s));
+    *status_out = (st & ST_INDEX) ? FRLW_ERR_INDEX : (st & ST_POLARITY) ? FRLW_ERR_POLARITY : (st & ST_SPAN) ? FRLW_ERR_SPAN : FRLW_OK;
+    return FRLW_OK;
+}
+
 int frlw_eci_encode(const frlw_events_t *ev, int H, int W, float *out_f32, uint8_t *out_u8,
                     void *workspace, size_t workspace_bytes, frlw_stream_t stream)
 {

@@ -56,6 +56,16 @@ struct WsHeader {
 };
 constexpr size_t kHeaderBytes = 1024;
 static_assert(sizeof(WsHeader) <= kHeaderBytes, "header");
+// Two words at the end of the header outlive the per-call reset: `sticky` is the OR of the status of every encoder call
+// since frlw_workspace_init / the last frlw_encoder_deferred_status (unchecked callers read it once per batch or epoch
+// instead of synchronising after every call); the 24 bytes in front of it receive the one-time LDS self-test result.
+constexpr size_t kStickyOffset = kHeaderBytes - 8;
+constexpr size_t kSelftestOffset = kHeaderBytes - 64;
+static_assert(sizeof(WsHeader) <= kSelftestOffset, "header tail");
+__device__ __forceinline__ void fold_sticky_status(void *hdr, int status)
+{
+    if (status) atomicOr((int *)((char *)hdr + kStickyOffset), status);
+}
 
 // How one event becomes (tile, cell, window, value).  Passed by value to the kernels.
 struct Decode {

@@ -173,6 +173,7 @@ __global__ __launch_bounds__(1024) void k_tilescan(uint32_t *slabtot, int slabs,
         run += tot[b];
     }
     if (tid == 1023) base[n] = pre + inc;
+    if (tid == 0) fold_sticky_status(hdr, hdr->status); // every error flag was OR-ed in before the first barrier above
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -26,6 +26,8 @@
 
 #include "frlw_common.h"
 
+#include <atomic>
+
 using namespace frlw;
 
 namespace {
@@ -73,7 +75,7 @@ struct FastHeader {
     unsigned long long wmask[kMaxSeq]; // bit w set <=> window w of the sequence holds at least one event
     uint32_t mul_bad; // != 0: float(r * (1 / den)) differs from float(r / den) for some r in [0, win]: use the table
 };
-static_assert(sizeof(FastHeader) <= kHeaderBytes, "header");
+static_assert(sizeof(FastHeader) <= kSelftestOffset, "header");
 
 struct FastPlan {
     int twl, thl, tiles_x, tiles_y, T;
@@ -354,6 +356,7 @@ __global__ __launch_bounds__(kFT) void kf_tilescan(SeqTab S, uint32_t *slabtot, 
         srun += split_segments(tot[b], whole_max);
     }
     if (tid == kFT - 1) { base[pairs] = pre + inc; seg0[pairs] = spre + sinc; }
+    if (tid == 0) fold_sticky_status(hdr, hdr->status); // all error flags are in since the barrier behind the fold above
 }
 
 // ---- 3. stable scatter ---------------------------------------------------------------------------------
@@ -1035,9 +1038,46 @@ void launch_fast(const FastGeom &G, const SeqTab &S, const FastPlan &p, char *w8
     hipLaunchKernelGGL((kf_scatter<HAS_MAP>), dim3(p.chunks), dim3(kFT), lds_sc, st, G, S, counts, slabtot, base, records, hdr);
 }
 
+// ---- one-time check of the hardware property this file rests on ------------------------------------------------------
+// 0 = not yet tested on this device, 1 = lanes of one returning LDS atomic are served in lane order, 2 = they are not
+// (a new stepping / compiler): the fast path then refuses (FRLW_ERR_UNSUPPORTED) and callers take the general path.
+constexpr int kMaxDevices = 64;
+std::atomic<int> g_lds_order[kMaxDevices];
+
+int lds_order_ok(char *w8, hipStream_t st)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return FRLW_ERR_HIP;
+    int have = g_lds_order[dev].load(std::memory_order_acquire);
+    if (have == 0) {
+        // first fast-path call on this device: 256 workgroups x 64 rounds of conflicting lanes (~3e5 conflicting lane
+        // pairs), result into the spare bytes of the workspace header, ONE host synchronisation for the process lifetime
+        unsigned long long *out = (unsigned long long *)(w8 + kSelftestOffset);
+        unsigned long long host[3] = {1ull, 0ull, 0ull};
+        (void)hipFuncSetAttribute((const void *)kf_selftest_lane_order, hipFuncAttributeMaxDynamicSharedMemorySize, kFW * 512 * 12);
+        HIP_TRY(hipMemsetAsync(out, 0, 24, st));
+        hipLaunchKernelGGL(kf_selftest_lane_order, dim3(256), dim3(kFT), (size_t)kFW * 40 * 12, st, 40, 64, out);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(host, out, 24, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        have = (host[0] == 0ull && host[1] > 0ull) ? 1 : 2; // no rank violation among > 0 conflicting pairs
+        g_lds_order[dev].store(have, std::memory_order_release);
+    }
+    return have == 1 ? FRLW_OK : FRLW_ERR_UNSUPPORTED;
+}
+
 } // namespace
 
 extern "C" {
+
+int frlw_debug_force_lds_order(int value)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return FRLW_ERR_HIP;
+    if (value < -1 || value > 1) return FRLW_ERR_ARG;
+    g_lds_order[dev].store(value < 0 ? 0 : (value == 1 ? 1 : 2), std::memory_order_release);
+    return FRLW_OK;
+}
 
 int frlw_selftest_lds_atomic_order(int n_addr, int iters, unsigned long long *out_dev, frlw_stream_t stream)
 {
@@ -1109,6 +1149,10 @@ int frlw_taf_encode_batch(const frlw_events_t *ev, const int64_t *seq_offsets, c
     hipStream_t st = (hipStream_t)stream;
     char *w8 = (char *)workspace;
     (void)hipGetLastError();
+    {
+        const int ok = lds_order_ok(w8, st); // cached per device after the first call
+        if (ok != FRLW_OK) return ok;
+    }
     if (ev->xmap) launch_fast<true>(G, S, p, w8, st);
     else launch_fast<false>(G, S, p, w8, st);
     TileP q;

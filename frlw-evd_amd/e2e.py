@@ -74,6 +74,7 @@ class SyntheticTafSource:
                                           fast=False)
                 out[pos] = u8.reshape(2 * self.K, H, W)
             pos += run
+        er.raise_deferred("SyntheticTafSource.encode_u8")  # one sync per batch: never train on a stale / unwritten state
         return out
 
     def encode_batch(self, idx, batched=True):

@@ -28,7 +28,6 @@ from . import _lib
 
 _WORKSPACES = {}
 TUNING = None  # a _lib.FrlwTuning to attach to every encoder call (experiments / tests forcing a path); None = defaults
-TUNING = None  # a _lib.FrlwTuning to attach to every encoder call (experiments / tests forcing a path); None = defaults
 FAST_MIN_EVENTS = 1_000_000  # single streams shorter than this take the general TAF path (encode_taf_dat, fast="auto")
 
 
@@ -44,9 +43,36 @@ def _workspace(n, H, W, device):
     key = (device.index, torch.cuda.current_stream().cuda_stream)
     ws = _WORKSPACES.get(key)
     if ws is None or ws.numel() < need:
-        ws = torch.empty(int(need * 1.25) + 4096, dtype=torch.uint8, device=device)
+        ws = _new_workspace(ws, need, device)
         _WORKSPACES[key] = ws
     return ws
+
+
+def _new_workspace(old, need, device):
+    """A fresh workspace with a zeroed header (``frlw_workspace_init``): the deferred status word starts clean.  An
+    outgrown workspace hands over what it has accumulated first."""
+    if old is not None:
+        _raise_deferred_of(old, "encoder call (workspace outgrown)")
+    ws = torch.empty(int(need * 1.25) + 4096, dtype=torch.uint8, device=device)
+    _lib.check(_lib.load().frlw_workspace_init(C.c_void_p(ws.data_ptr()), ws.numel(), _stream()), "frlw_workspace_init")
+    return ws
+
+
+def _raise_deferred_of(ws, what):
+    st = C.c_int(0)
+    _lib.check(_lib.load().frlw_encoder_deferred_status(C.c_void_p(ws.data_ptr()), _stream(), C.byref(st)), what)
+    _lib.check(st.value, what)
+
+
+def raise_deferred(what="encoder calls since the last check"):
+    """For callers that pass ``check=False``: ONE host synchronisation that surfaces the data-dependent status of every
+    encoder call made on the current stream since the last check (IndexError / ValueError like the checked calls).  An
+    unchecked fast-path call whose events leave the sequence span or the frame writes nothing -- call this before
+    trusting its state / outputs (``e2e.SyntheticTafSource.encode_u8`` does, once per batch)."""
+    stream = torch.cuda.current_stream().cuda_stream
+    for key, ws in list(_WORKSPACES.items()):
+        if key[-1] == stream and ws.device.index == torch.cuda.current_device():
+            _raise_deferred_of(ws, what)
 
 
 def _ptr(t):
@@ -153,10 +179,22 @@ def generate_taf_cuda(events, shape, past_volume=None, volume_bins=5):
     K = int(volume_bins)
     if past_volume is None:
         raise TypeError("past_volume is required (the reference concatenates it, generate_taf.py:44)")
-    if tuple(past_volume.shape) != (H, W, 2, K):
-        raise ValueError("past_volume must be (H, W, 2, volume_bins)")
     ev, desc = _events_f64(events)
-    state = past_volume.to(torch.float32).contiguous().clone()
+    if tuple(past_volume.shape) == (H, W, 2, K - 1) and K > 1:
+        # the K-growing branch, generate_taf.py:50-53: the concatenated FIFO [old..., mean] is not cut and slot 0 of the
+        # cells without events becomes -6000.  Same as a K-slot step on [-5999, old...]: cells with events drop slot 0,
+        # the others age it to -5999 - 1 = -6000 (exact in f32).  An entirely empty window returns the short volume and
+        # the reference's .view (:55) raises.
+        if ev.shape[0] == 0:
+            raise RuntimeError(f"shape '[{2 * K}, {H}, {W}]' is invalid for input of size {H * W * 2 * (K - 1)} "
+                               "(generate_taf.py:40-41,55: a window without events keeps the short past_volume)")
+        state = torch.cat([torch.full((H, W, 2, 1), -5999.0, dtype=torch.float32, device=ev.device),
+                           past_volume.to(torch.float32)], dim=3).contiguous()
+    elif tuple(past_volume.shape) != (H, W, 2, K):
+        raise RuntimeError("past_volume must be (H, W, 2, volume_bins) or (H, W, 2, volume_bins - 1): any other slot count "
+                           "fails the reference's .view (generate_taf.py:48-55)")
+    else:
+        state = past_volume.to(torch.float32).contiguous().clone()
     view = torch.empty((2 * K, H, W), dtype=torch.float32, device=ev.device)
     ws = _workspace(ev.shape[0], H, W, ev.device)
     _lib.check(_lib.load().frlw_taf_encode(C.byref(desc), H, W, K, 0, 1, 1, _ptr(state), _ptr(view), None, 0,
@@ -205,7 +243,7 @@ def _batch_workspace(n, n_seq, H, W, window_us, device):
     key = ("batch", device.index, torch.cuda.current_stream().cuda_stream)
     ws = _WORKSPACES.get(key)
     if ws is None or ws.numel() < need:
-        ws = torch.empty(int(need * 1.25) + 4096, dtype=torch.uint8, device=device)
+        ws = _new_workspace(ws, need, device)
         _WORKSPACES[key] = ws
     return ws
 
@@ -220,8 +258,11 @@ def encode_taf_batch(dat, seq_offsets, shape, state, t_start, window_us=10000, n
     ``(B, H, W, 2, K)`` is updated IN PLACE.  Returns ``(u8 (B, K, 2, H, W) or None, view (B, 2K, H, W) or None)``.
 
     Every event must lie inside its sequence's ``[t_start, t_start + n_windows * window_us]`` and inside the frame;
-    with ``check`` a violation raises ``ValueError`` / ``IndexError`` and ``state`` is untouched.  Raises
-    ``NotImplementedError`` if the shape / window does not fit the fast path's 4-byte records.
+    with ``check`` a violation raises ``ValueError`` / ``IndexError`` and ``state`` is untouched.  With ``check=False``
+    nothing synchronises and a violation leaves ``state`` AND the returned tensors unwritten: the caller owes one
+    ``raise_deferred()`` before it uses them (the status of every unchecked call accumulates in the workspace).  Raises
+    ``NotImplementedError`` if the shape / window does not fit the fast path's 4-byte records, or if the device failed
+    the LDS lane-order self-test the library runs on its first fast-path call (then use ``encode_taf_dat``).
     """
     H, W = int(shape[0]), int(shape[1])
     K = int(volume_bins)
@@ -256,18 +297,20 @@ def encode_taf_dat(dat, shape, state, t_start, window_us=10000, n_windows=8, vol
     Returns ``(u8 (K, 2, H, W) or None, view (2K, H, W) or None)``.  With ``flip_k`` the uint8 volume is
     newest-slot-first like ``np.flip(ecd, axis=0)`` (:229): ``u8[:4]`` is the bins4 file, ``u8[4:]`` bins8.
 
-    ``fast``: run the batched fast path with one sequence (csrc/taf_fast.hip); ``"auto"`` = for streams of at least
-    ``FAST_MIN_EVENTS`` events (below that its extra launch costs more than it saves: 61 vs 64 us at 1 M events, the
-    break-even).  It needs every event inside ``[t_start, t_start + n_windows * window_us]``; if the device check says
-    otherwise (only seen with ``check``), or the window does not fit its 4-byte records, the general path
-    (csrc/encoders.hip) runs -- same bits either way.
+    ``fast``: run the batched fast path with one sequence (csrc/taf_fast.hip); ``"auto"`` = for CHECKED calls on streams
+    of at least ``FAST_MIN_EVENTS`` events (below that its extra launch costs more than it saves: 61 vs 64 us at 1 M
+    events, the break-even).  It needs every event inside ``[t_start, t_start + n_windows * window_us]``; if the device
+    check says otherwise, or the window does not fit its 4-byte records, the general path (csrc/encoders.hip) runs -- same
+    bits either way.  An unchecked call cannot see that verdict, so ``"auto"`` keeps it on the general path, which places
+    such events like the reference does; ``fast=True`` with ``check=False`` is an explicit opt-in whose caller owes a
+    ``raise_deferred()`` (a violation leaves ``state`` and the outputs unwritten).
     """
     H, W = int(shape[0]), int(shape[1])
     K = int(volume_bins)
     assert state.dtype == torch.float32 and state.is_contiguous() and tuple(state.shape) == (H, W, 2, K)
     n = dat.numel() * dat.element_size() // 8
     if fast == "auto":
-        fast = n >= FAST_MIN_EVENTS
+        fast = bool(check) and n >= FAST_MIN_EVENTS
     if fast:
         try:
             u8, view = encode_taf_batch(dat, [0, n], (H, W), state.view(1, H, W, 2, K), t_start, window_us, n_windows, K,

@@ -97,6 +97,15 @@ size_t frlw_encoder_workspace_bytes(int64_t n_events, int H, int W);
  * `workspace`: FRLW_OK, FRLW_ERR_INDEX, FRLW_ERR_POLARITY or FRLW_ERR_SPAN. */
 int frlw_encoder_status(const void *workspace, frlw_stream_t stream, int *status_out);
 
+/* Callers that do not synchronise after every call (a training loop that encodes batch after batch) still must not
+ * train on a stale state: every encoder call also ORs its data-dependent status into a word of the workspace header
+ * that survives the next call.  frlw_workspace_init() zeroes the header once after the workspace is allocated;
+ * frlw_encoder_deferred_status() synchronises `stream`, returns the accumulated status of all calls since (FRLW_OK or
+ * the first of FRLW_ERR_INDEX / _POLARITY / _SPAN) and clears it.  The reference raises at the offending call
+ * (torch's IndexError in index_add_, generate_taf.py:24); this is the same information, one host sync per batch. */
+int frlw_workspace_init(void *workspace, size_t workspace_bytes, frlw_stream_t stream);
+int frlw_encoder_deferred_status(void *workspace, frlw_stream_t stream, int *status_out);
+
 /*
  * Event Count Image -- replaces generate_eventframe(events, shape),
  * generate_eventcountimage.py:19-41.  out_f32: (2, H, W), channel = polarity, value * 255.
@@ -179,6 +188,10 @@ int frlw_taf_encode_batch(const frlw_events_t *ev, const int64_t *seq_offsets, c
  * addresses in [0, n_addr <= 512); out_dev (device, 3 x uint64): [0] = rank mismatches (must be 0), [1] = lanes that
  * shared their address with a lower lane (the sample size), [2] = f32 sums that differ from the sequential sum (must be 0). */
 int frlw_selftest_lds_atomic_order(int n_addr, int iters, unsigned long long *out_dev, frlw_stream_t stream);
+/* frlw_taf_encode_batch runs that self-test by itself on its first call per device (one host synchronisation for the
+ * lifetime of the process, result cached) and returns FRLW_ERR_UNSUPPORTED from then on if the property does not hold, so
+ * that callers take frlw_taf_encode.  Tests force the outcome: value 0 = "does not hold", 1 = "holds", -1 = forget. */
+int frlw_debug_force_lds_order(int value);
 
 /* leaky_transform(ecd), generate_taf.py:69-76, on n floats; either output may be NULL. */
 int frlw_leaky_transform(const float *in, int64_t n, float *out_f32, uint8_t *out_u8,

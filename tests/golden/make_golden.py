@@ -334,8 +334,35 @@ def gen_mpx():
     save("mpx_downscale", d)
 
 
+def gen_taf_grow():
+    """The K-growing branch of taf_cuda (generate_taf.py:50-53): a ``past_volume`` with volume_bins - 1 slots.  The
+    concatenated FIFO is not cut; slot 0 of the cells without events becomes -6000 (:53).  Dead in the reference's harness
+    (it always passes volume_bins slots) but part of the function's contract.  Also what the reference does with other
+    slot counts: an entirely empty window returns the short volume and the ``.view`` of :55 raises, as it does for
+    fewer than volume_bins - 1 slots."""
+    H, W, ev = tiny_events()
+    d = {}
+    for K in (8, 4):
+        rng = np.random.default_rng(50 + K)
+        past = (-rng.integers(0, 40, size=(H, W, 2, K - 1))).astype(np.float32) - rng.random((H, W, 2, K - 1)).astype(np.float32)
+        w = ev[:150]
+        w5 = np.concatenate([w, np.zeros((len(w), 1))], axis=1)
+        view, state, _ = ref_taf.generate_taf_cuda(T(w5), (H, W), T(past.copy()), K)
+        d[f"k{K}_past"], d[f"k{K}_view"], d[f"k{K}_state"] = past, view.numpy().copy(), state.numpy().copy()
+        assert state.shape == (H, W, 2, K)
+        for bad, what in ((T(past.copy()), w5[:0]), (T(past[..., :K - 2].copy()), w5)):
+            try:
+                ref_taf.generate_taf_cuda(T(what), (H, W), bad, K)
+                raise SystemExit("the reference was expected to raise here")
+            except RuntimeError:
+                pass
+    save("tiny_taf_grow", d)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tiny", "gen1", "mpx"]
+    which = sys.argv[1:] or ["tiny", "gen1", "mpx", "grow"]
+    if "grow" in which:
+        gen_taf_grow()
     if "tiny" in which:
         gen_tiny()
     if "gen1" in which:

@@ -161,7 +161,91 @@ def main_bfm():
     print("detector_bfm.npz", os.path.getsize(os.path.join(HERE, "detector_bfm.npz")) // 1024, "KiB")
 
 
+def nms_primitive(boxes, scores, iou_threshold):
+    """Stand-in for the ONE call the image cannot run, ``torchvision.ops.nms`` (yolo_head.py:281; torchvision==0.5.0,
+    requirements.txt:48, is neither in the reference tree nor in this image).  Its documented contract, as a plain loop:
+    visit boxes by descending score (ties: lower index first, the order a stable sort gives), drop every later box whose
+    IoU with a kept one is > threshold, IoU = inter / (area_a + area_b - inter) on xyxy without +1, return the kept
+    indices in descending-score order.  Everything AROUND this call in the goldens below is the reference's own code."""
+    b = boxes.detach().cpu().numpy().astype(np.float32)
+    sc = scores.detach().cpu().numpy()
+    order = np.argsort(-sc, kind="stable")
+    area = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    dead = np.zeros(len(b), bool)
+    keep = []
+    for oi, i in enumerate(order):
+        if dead[i]:
+            continue
+        keep.append(i)
+        rest = order[oi + 1:]
+        w = np.maximum(np.float32(0), np.minimum(b[i, 2], b[rest, 2]) - np.maximum(b[i, 0], b[rest, 0]))
+        h = np.maximum(np.float32(0), np.minimum(b[i, 3], b[rest, 3]) - np.maximum(b[i, 1], b[rest, 1]))
+        inter = w * h
+        iou = inter / (area[i] + area[rest] - inter)
+        dead[rest[iou > np.float32(iou_threshold)]] = True
+    return torch.from_numpy(np.asarray(keep, dtype=np.int64))
+
+
+def crafted_raw(A=1680, F=7):
+    """(3, A, F) head tensors that exercise the post-processing: image 0 large overlapping boxes with tied objectness,
+    image 1 nothing above obj > 0.3 (-> the zeros((1, 8)) row, yolo_head.py:277-278), image 2 a handful of boxes with
+    exact duplicates (IoU = 1) and an objectness exactly at the 0.3 threshold (strict >)."""
+    rng = np.random.default_rng(20)
+    raw = np.zeros((3, A, F), np.float32)
+    raw[..., 0:2] = rng.uniform(-0.5, 0.5, (3, A, 2))
+    raw[..., 2:4] = rng.uniform(1.0, 3.0, (3, A, 2))
+    raw[..., 4] = rng.choice(np.array([0.1, 0.35, 0.5, 0.5, 0.9], np.float32), (3, A))
+    raw[..., 5:] = rng.uniform(0, 1, (3, A, F - 5))
+    raw[1, :, 4] = 0.1
+    raw[2, :, 4] = 0.05
+    raw[2, 10, 4], raw[2, 11, 4], raw[2, 12, 4], raw[2, 500, 4], raw[2, 1679, 4] = 0.8, 0.8, np.float32(0.3), 0.6, 0.31
+    raw[2, 11, 0:4] = raw[2, 10, 0:4]
+    raw[2, 11, 0] += 1.0  # anchor 11 sits one cell right of anchor 10: same decoded box up to the grid offset
+    return raw
+
+
+def main_nms():
+    """Post-threshold goldens of yolo_head.py:258-303 produced by the reference's OWN ``YOLOXHead.decode_outputs`` with only
+    ``torchvision.ops.nms`` replaced by ``nms_primitive``: the obj > 0.3 filter, the xyxy conversion, the zeros((1, 8)) row
+    and the [cx, cy, w, h, argmax cls, obj * max cls] emission are the reference's statements."""
+    import torchvision
+    torchvision.ops.nms = nms_primitive
+    out = {}
+    chans = [128, 256, 512]
+    ref = RefModel(CSPDarknet(10, 0.33, 0.5, stem=Focus),
+                   YOLOPAFPN(0.33, in_features=["dark3", "dark4", "dark5"], in_channels=chans, act="silu"), None,
+                   YOLOXHead(2, in_channels=chans, act="silu", strides=[8, 16, 32], radius=5))
+    ref.load_state_dict(recipe_state_dict(build_yolox(10, 2), seed=1004))
+    ref.eval()
+    x = detector_input(1004, 4, 10)
+    with torch.no_grad():
+        head = ref.head
+        fpn = ref.neck(ref.backbone(x[..., 0]))
+        head.decode_in_inference = False
+        raw = head(fpn).clone()
+        head.decode_in_inference = True
+        dets = head(fpn)                      # the reference's forward -> decode_outputs (yolo_head.py:232-233)
+        out["b4_raw"] = raw.numpy()
+        out["b4_counts"] = np.array([len(d) for d in dets])
+        out["b4_dets"] = torch.cat(dets).numpy()
+        assert all(d.shape[1] == 6 for d in dets)
+        craft = torch.from_numpy(crafted_raw())
+        head.hw = [(32, 40), (16, 20), (8, 10)]
+        dets = head.decode_outputs(craft.clone(), craft.type())
+        out["craft_raw"] = craft.numpy()
+        out["craft_counts"] = np.array([len(d) for d in dets])
+        out["craft_dets"] = torch.cat(dets).numpy()
+        assert dets[1].shape == (1, 6) and float(dets[1].abs().sum()) == 0.0
+        print("counts", out["b4_counts"], out["craft_counts"])
+    np.savez_compressed(os.path.join(HERE, "detector_nms.npz"), **out)
+    print("detector_nms.npz", os.path.getsize(os.path.join(HERE, "detector_nms.npz")) // 1024, "KiB")
+
+
 if __name__ == "__main__":
+    if "--nms-only" in sys.argv:
+        main_nms()
+        sys.exit(0)
     if "--bfm-only" not in sys.argv:
         main()
+        main_nms()
     main_bfm()

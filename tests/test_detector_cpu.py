@@ -140,3 +140,20 @@ def test_bfm_stem_matches_reference(golden_dir, tag, C):
     assert st == pytest.approx(g[f"{tag}_stem_stats"], rel=1e-5)
     want = g[f"{tag}_raw"]
     assert np.abs(raw.numpy() - want).max() <= 1e-5 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("case", ["b4", "craft"])
+def test_decode_outputs_vs_reference_postprocessing(golden_dir, case):
+    """yolo_head.py:258-303 pinned up to the NMS primitive: the goldens are the reference's own ``decode_outputs`` (obj > 0.3
+    filter, xyxy, zeros((1, 8)) row, 6-column emission) with only ``torchvision.ops.nms`` stubbed
+    (tests/golden/make_golden_detector.py::main_nms)."""
+    g = np.load(os.path.join(golden_dir, "detector_nms.npz"))
+    m = build_yolox(10, 2)
+    m.head.hw = [(32, 40), (16, 20), (8, 10)]
+    raw = torch.from_numpy(g[f"{case}_raw"])
+    dets = m.head.decode_outputs(raw)
+    counts = g[f"{case}_counts"]
+    assert [len(d) for d in dets] == counts.tolist()
+    assert np.array_equal(torch.cat(dets).numpy(), g[f"{case}_dets"])  # same f32 statements -> same bits
+    if case == "craft":
+        assert dets[1].shape == (1, 6) and float(dets[1].abs().sum()) == 0.0 and counts[2] == 3

@@ -137,6 +137,43 @@ def test_nms_kernel_on_crafted_boxes(gpu):
     assert torch.allclose(dets[0, :counts[0]], want[0], rtol=0, atol=1e-4)
 
 
+def _device_postprocess(m, raw, gpu):
+    """Run only the decode + NMS stage of the plan on a given head tensor."""
+    import ctypes as C
+    from frlw_evd_amd import _lib
+    eng = m.engine()
+    eng.build((10, 256, 320))
+    B = raw.shape[0]
+    bufs = eng._buffers(B)
+    bufs[eng.raw_buf].copy_(raw.reshape(-1).to(gpu))
+    ptrs = (C.c_void_p * len(bufs))(*[None] + [C.c_void_p(t.data_ptr()) for t in bufs[1:]])
+    _lib.check(eng.lib.frlw_det_run(eng.handle, B, ptrs, len(bufs), eng.n_forward_ops, -1,
+                                    C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    return bufs[eng.counts_buf].cpu().tolist(), bufs[eng.dets_buf].view(B, eng.A, 6).cpu()
+
+
+@pytest.mark.parametrize("case", ["b4", "craft"])
+def test_device_nms_vs_reference_postprocessing(gpu, golden_dir, case):
+    """k_decode_nms against the reference's own ``YOLOXHead.decode_outputs`` (yolo_head.py:258-303) run on the same head
+    tensor with only ``torchvision.ops.nms`` stubbed (tests/golden/detector_nms.npz): same survivors in the same order,
+    same six columns; an image without candidates has count 0 where the reference emits its one all-zero row."""
+    g = np.load(os.path.join(golden_dir, "detector_nms.npz"))
+    m = build_yolox(10, 2)
+    m.load_state_dict(recipe_state_dict(m, seed=1004))
+    m.eval().to(gpu)
+    counts, dets = _device_postprocess(m, torch.from_numpy(g[f"{case}_raw"]), gpu)
+    want_counts = g[f"{case}_counts"].tolist()
+    want = np.split(g[f"{case}_dets"], np.cumsum(want_counts)[:-1])
+    for b, w in enumerate(want):
+        if w.shape[0] == 1 and not np.any(w):  # the reference's zeros((1, 8)) row: nothing passed obj > 0.3
+            assert counts[b] == 0
+            continue
+        assert counts[b] == w.shape[0], (b, counts[b], w.shape)
+        got = dets[b, :counts[b]].numpy()
+        assert np.array_equal(got[:, 4], w[:, 4])                    # class ids
+        assert np.abs(got - w).max() <= 1e-4, np.abs(got - w).max()  # boxes / scores (f32 arithmetic order)
+
+
 # ---- training branch: whole-batch SimOTA assignment in HIP ----------------------------------------
 def _train_labels():
     lab = torch.zeros((4, 80, 5), dtype=torch.float64)

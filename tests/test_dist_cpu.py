@@ -98,3 +98,54 @@ def test_ddp_train_step_two_ranks(tmp_path):
     h0, h1 = (np.load(tmp_path / f"d{i}_rs_ag.npy") for i in range(world))
     assert h0[2] == h1[2] and h0[3] == h1[3]
     assert np.allclose(h0, d0, rtol=1e-6, atol=0) and np.allclose(h1, d1, rtol=1e-6, atol=0)
+
+
+# ---- bench.py --gpus N is its own launcher (the flag used to be dead) --------------------------------
+def _run_bench(args, env_extra, timeout=240):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True, text=True,
+                       timeout=timeout)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return p.returncode, (json.loads(lines[-1]) if lines else None), p.stderr
+
+
+def test_bench_gpus_flag_spawns_the_ranks():
+    """`python bench.py --gpus 2` with no launcher around it starts 2 fresh ranks that rendezvous (gloo here, RCCL on
+    the GPU box) and rank 0's single JSON line comes back through the parent."""
+    rc, line, err = _run_bench(["--gpus", "2", "--launch-only"], {"FRLW_DIST_BACKEND": "gloo"})
+    assert rc == 0, err
+    assert line["n_gpus"] == 2 and line["rank_sum"] == 3.0 and line["max_over_ranks"] == 1.5
+    assert line["launched_by"] == "bench.py" and line["backend"] == "gloo"
+
+
+def test_bench_single_rank_line_has_one_gpu():
+    rc, line, err = _run_bench(["--launch-only"], {})
+    assert rc == 0, err
+    assert line["n_gpus"] == 1 and line["launched_by"] == "external launcher"
+
+
+def test_bench_launcher_reports_a_failed_rank():
+    rc, line, err = _run_bench(["--gpus", "2", "--launch-only"], {"FRLW_DIST_BACKEND": "gloo", "FRLW_BENCH_TEST_FAIL_RANK": "1"})
+    assert rc != 0 and "rank 1 exited with code 3" in err
+
+
+def test_bench_under_an_external_launcher():
+    """The driver's form: torch.distributed.run starts the ranks, bench.py --gpus N joins them (and refuses a mismatch)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FRLW_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2",
+                        "--launch-only"], env=env, capture_output=True, text=True, timeout=240)
+    assert p.returncode == 0, p.stderr
+    assert '"n_gpus": 2' in p.stdout and '"launched_by": "external launcher"' in p.stdout
+    rc, _, err = _run_bench(["--gpus", "2", "--launch-only"], {"WORLD_SIZE": "3", "RANK": "0"})
+    assert rc != 0

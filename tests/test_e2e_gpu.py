@@ -61,7 +61,7 @@ def test_train_batch64_is_finite_and_deterministic():
         pytest.skip("no GPU")
     from frlw_evd_amd import e2e
     from frlw_evd_amd.trainer import Trainer
-    src = e2e.SyntheticTafSource(64, seed=77, events_per_window=30_000)
+    src = e2e.SyntheticTafSource(64, seed=77, events_per_window=125_000)  # the config's stated size
     x = src.encode_batch(list(range(64)))
     assert torch.equal(x[:4], src.encode_batch([0, 1, 2, 3], batched=False))
     losses = []

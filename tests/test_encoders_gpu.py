@@ -106,6 +106,25 @@ def test_tiny_taf(er, tiny, K):
         assert_bitexact(host(view), tiny["taf_k4_view"], "taf K=4 view")
 
 
+def test_taf_growing_branch(er, golden_dir):
+    """generate_taf.py:50-53: ``past_volume`` with volume_bins - 1 slots grows to volume_bins; goldens from the reference."""
+    g = np.load(os.path.join(golden_dir, "tiny_taf_grow.npz"))
+    tiny = np.load(os.path.join(golden_dir, "tiny.npz"))
+    H, W = (int(v) for v in tiny["shape"])
+    w = tiny["events"][:150]
+    w5 = np.concatenate([w, np.zeros((len(w), 1))], axis=1)
+    for K in (8, 4):
+        past = torch.from_numpy(g[f"k{K}_past"]).cuda()
+        view, st, _ = er.generate_taf_cuda(dev(w5), (H, W), past, K)
+        assert st.shape == (H, W, 2, K)
+        assert_bitexact(host(st), g[f"k{K}_state"], f"K={K} grown state")
+        assert_bitexact(host(view), g[f"k{K}_view"], f"K={K} grown view")
+        with pytest.raises(RuntimeError):  # an empty window keeps the short volume: the reference's .view raises
+            er.generate_taf_cuda(dev(w5[:0]), (H, W), past, K)
+        with pytest.raises(RuntimeError):  # any other slot count fails that .view as well
+            er.generate_taf_cuda(dev(w5), (H, W), past[..., :K - 2], K)
+
+
 def test_errors_like_torch(er):
     oob = dev(np.array([[0.0, 8.0, 0.5, 1.0]]))  # flat index past the end
     with pytest.raises(IndexError):

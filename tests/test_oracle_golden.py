@@ -68,6 +68,21 @@ def test_tiny_taf(tiny):
     assert_bitexact(v, tiny["taf_k4_view"], "taf K=4 view")
 
 
+def test_taf_growing_branch_is_a_padded_step(golden_dir):
+    """generate_taf.py:50-53 (past_volume with volume_bins - 1 slots): the reference's result equals an ordinary K-slot
+    step on [-5999, old...] -- the identity the product's ``generate_taf_cuda`` uses for that branch."""
+    g = np.load(os.path.join(golden_dir, "tiny_taf_grow.npz"))
+    tiny = np.load(os.path.join(golden_dir, "tiny.npz"))
+    H, W = (int(v) for v in tiny["shape"])
+    for K in (8, 4):
+        past = g[f"k{K}_past"]
+        padded = np.concatenate([np.full((H, W, 2, 1), -5999, np.float32), past], axis=3)
+        v, st = orc.taf_window(tiny["events"][:150], (H, W), padded, K)
+        assert_bitexact(st, g[f"k{K}_state"], f"K={K} grown state")
+        assert_bitexact(v, g[f"k{K}_view"], f"K={K} grown view")
+        assert np.any(st[..., 0] == -6000) and np.any(st[..., 0] != -6000)
+
+
 def test_out_of_range_raises():
     ev = np.array([[0.0, 8.0, 0.5, 1.0]])  # flat index past the end -> IndexError in torch
     for fn in (lambda: orc.eventframe(ev, (8, 12)), lambda: orc.event_volume(ev, (8, 12), 5),

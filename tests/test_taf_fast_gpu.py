@@ -197,3 +197,61 @@ def test_gen1_batch64_equals_per_sample(er):
         sj = torch.full((H, W, 2, K), -6000.0, device="cuda")
         uj, _ = er.encode_taf_dat(to_dev(recs[j]), (H, W), sj, 0, win, n_win, K, fast=False)
         assert torch.equal(sj, st[j]) and torch.equal(uj, u8[j]), f"sample {j}"
+
+
+def test_unchecked_calls_leave_a_deferred_status(er, orc):
+    """An unchecked fast-path call whose events leave the span writes nothing -- and must not go unnoticed: the status
+    accumulates in the workspace and ``raise_deferred`` surfaces it with ONE sync, then is clean again.  ``fast="auto"``
+    keeps unchecked calls on the general path, which places such events like the reference does (z = 0)."""
+    H, W, K = 64, 96, 8
+    ev = synth.synth_events(77, 40_000, W, H, 80_000)
+    rec = synth.to_dat8(ev)
+    bad = rec.copy()
+    bad["t"][-5:] += 1_000_000  # five events far behind the last window
+    st0 = np.full((H, W, 2, K), -6000, np.float32)
+    er.raise_deferred()  # whatever earlier tests left behind
+    st = torch.from_numpy(st0.copy()).cuda()
+    er.encode_taf_batch(to_dev(bad), [0, len(bad)], (H, W), st.view(1, H, W, 2, K), 0, 10_000, 8, K, check=False)
+    assert_bitexact(host(st), st0, "nothing was written")
+    er.encode_taf_batch(to_dev(rec), [0, len(rec)], (H, W), st.view(1, H, W, 2, K), 0, 10_000, 8, K, check=False)  # a clean call after it
+    with pytest.raises(ValueError):
+        er.raise_deferred()
+    er.raise_deferred()  # cleared by the read
+    # unchecked + fast="auto": the general path, same bits as the oracle (which places out-of-span events in window 0)
+    st = torch.from_numpy(st0.copy()).cuda()
+    big = synth.to_dat8(synth.synth_events(78, er.FAST_MIN_EVENTS + 10, W, H, 80_000))
+    big["t"][-3:] += 1_000_000
+    er.encode_taf_dat(to_dev(big), (H, W), st, 0, 10_000, 8, K, check=False)
+    er.raise_deferred()
+    _, ost, _ = oracle_taf(orc, big, (H, W), K, 0, 10_000, 8, st0)
+    assert_bitexact(host(st), ost, "general path on the out-of-span stream")
+    # an out-of-frame coordinate through the unchecked general path: IndexError at the deferred check
+    oob = rec[:100].copy()
+    oob["_"][7] = (oob["_"][7] & np.uint32(~(16383 << 14) & 0xFFFFFFFF)) | np.uint32((H + 3) << 14)  # y = H + 3: flat index beyond the frame
+    er.encode_taf_dat(to_dev(oob), (H, W), torch.from_numpy(st0.copy()).cuda(), 0, 10_000, 8, K, check=False, fast=False)
+    with pytest.raises(IndexError):
+        er.raise_deferred()
+
+
+def test_failed_lane_order_selftest_disables_the_fast_path(er, orc):
+    """The library checks the LDS lane-order property on its first fast-path call per device and caches the verdict; if it
+    does not hold the fast path refuses and ``encode_taf_dat`` runs the general path -- same bits."""
+    from frlw_evd_amd import _lib
+    lib = _lib.load()
+    H, W, K = 64, 96, 8
+    rec = synth.to_dat8(synth.synth_events(79, 30_000, W, H, 80_000))
+    st0 = np.full((H, W, 2, K), -6000, np.float32)
+    _, ost, _ = oracle_taf(orc, rec, (H, W), K, 0, 10_000, 8, st0)
+    try:
+        _lib.check(lib.frlw_debug_force_lds_order(0))  # "the property does not hold on this device"
+        st = torch.from_numpy(st0.copy()).cuda()
+        with pytest.raises(NotImplementedError):
+            er.encode_taf_batch(to_dev(rec), [0, len(rec)], (H, W), st.view(1, H, W, 2, K), 0, 10_000, 8, K)
+        assert_bitexact(host(st), st0, "refused before anything ran")
+        er.encode_taf_dat(to_dev(rec), (H, W), st, 0, 10_000, 8, K, fast=True)  # falls back to the general path
+        assert_bitexact(host(st), ost, "general path after the refusal")
+    finally:
+        _lib.check(lib.frlw_debug_force_lds_order(-1))  # forget: the next call runs the real self-test again
+    st = torch.from_numpy(st0.copy()).cuda()
+    er.encode_taf_batch(to_dev(rec), [0, len(rec)], (H, W), st.view(1, H, W, 2, K), 0, 10_000, 8, K)
+    assert_bitexact(host(st), ost, "fast path after the real self-test passed")
