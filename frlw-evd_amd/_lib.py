@@ -38,7 +38,8 @@ _ERR_TEXT = {
 class FrlwTuning(C.Structure):
     """frlw_tuning_t: per-call overrides of the launch heuristics, every field < 0 = the library's choice."""
     _fields_ = [("tile_width_log2", C.c_int32), ("batches_per_wave", C.c_int32), ("hot_tile_records", C.c_int32),
-                ("staged_scatter", C.c_int32), ("quarter_below", C.c_int32), ("no_value_table", C.c_int32)]
+                ("staged_scatter", C.c_int32), ("quarter_below", C.c_int32), ("no_value_table", C.c_int32),
+                ("taf_tile_walk", C.c_int32)]
 
     def __init__(self, **kw):
         super().__init__(*[int(kw.pop(name, -1)) for name, _ in self._fields_])
@@ -71,6 +72,8 @@ SYMBOLS = {
     "frlw_taf_batch_workspace_bytes": (_SZ, [_I64, _I, _I, _I, _I64]),
     "frlw_taf_encode_batch": (_I, [_EV, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _I, _I, _I, _I, _I64, _I, _P, _P, _P, _I,
                                   _P, _SZ, _P]),
+    "frlw_ev_batch_workspace_bytes": (_SZ, [_I64, _I, _I, _I, _I64]),
+    "frlw_ev_encode_batch": (_I, [_EV, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _I, _I, _I, _I, _I64, _P, _P, _P, _SZ, _P]),
     "frlw_leaky_transform": (_I, [_P, _I64, _P, _P, _P]),
     "frlw_resize_nearest_f32": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     "frlw_resize_nearest_u8": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),

@@ -25,6 +25,19 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false); // row_bcast31 into rows 2 and 3
     return v;
 }
+// Maximum over the 64 lanes of a wavefront, returned wave-uniform (same DPP ladder, v_max instead of v_add; the total
+// ends up in lane 63).  All lanes must be active.
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+{
+    auto mx = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false));
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false));
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false));
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false));
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
 // A tile is (1 << twl) pixels wide and 8 rows high; twl = 8 for frames wider than 512 px, else 6
 // (measured best on MI355X; frlw_tuning_t::tile_width_log2 overrides for experiments).
 // One tile = one workgroup of the tile kernels = NT = 4 << twl threads owning 4 cells each

@@ -27,11 +27,19 @@
 #include "frlw_common.h"
 
 #include <atomic>
+#include <string.h>
 
 using namespace frlw;
 
 namespace {
 
+// TAF through the tile walk (kf_taf_tile) instead of kf_split_whole + kf_taf_walk: bit-identical, 23 % less HBM traffic,
+// but measured SLOWER on MI355X (141 vs 121 us of tile work at 10 M events) -- so it is opt-in
+// (frlw_tuning_t::taf_tile_walk), and the Event Volume batch path, which has no other tile kernel, is its user.
+#ifndef FRLW_TAF_TILE_WALK
+#define FRLW_TAF_TILE_WALK 0
+#endif
+constexpr bool kTafTileWalk = FRLW_TAF_TILE_WALK != 0;
 constexpr int kFT = 1024;                 // threads of every workgroup here
 constexpr int kFW = kFT / kWave;          // 16 wavefronts
 constexpr int kCellBits = 12;
@@ -64,7 +72,11 @@ struct FastGeom {
     const uint16_t *xmap, *ymap;
     int map_w, map_h;
     int H, W, twl, thl, tiles_x, T;
-    int bpw; // batches of 64 events per wavefront of a partition workgroup
+    int bpw;      // batches of 64 events per wavefront of a partition workgroup = ceil(run / 64)
+    int chunk_ev; // events per chunk (one scatter workgroup), a multiple of 16, <= 8192
+    int run;      // events per wavefront of the scatter workgroup = chunk_ev / 16
+    long long n_total; // records in the array (loads never go past it)
+    int order_check;   // TAF: flag sequences whose window index ever decreases (only the tile walk needs to know)
     int n_windows, wb;
     uint32_t win, win_magic;
 };
@@ -74,6 +86,8 @@ struct FastHeader {
     uint32_t filtered_tiles; // diagnostic: sub-tiles whose records were not window-sorted (unsorted stream)
     unsigned long long wmask[kMaxSeq]; // bit w set <=> window w of the sequence holds at least one event
     uint32_t mul_bad; // != 0: float(r * (1 / den)) differs from float(r / den) for some r in [0, win]: use the table
+    uint32_t unsorted[kMaxSeq]; // != 0: somewhere in the sequence an event's window is lower than its predecessor's (the
+                                // tile walk needs window-sorted lists; such a sequence takes the split + sub-tile kernels)
 };
 static_assert(sizeof(FastHeader) <= kSelftestOffset, "header");
 
@@ -104,9 +118,18 @@ bool fast_plan(long long n, int n_seq, int H, int W, FastPlan &p)
     p.T = p.tiles_x * p.tiles_y;
     if (p.T > kMaxFastTiles || (long long)p.T * n_seq > kMaxPairs) return false;
     p.pairs = p.T * n_seq;
-    long long bpw = (n + 512ll * kFT - 1) / (512ll * kFT); // >= 2 workgroups per CU before the chunks grow
-    p.bpw = (int)(bpw < 1 ? 1 : (bpw > kMaxBpw ? kMaxBpw : bpw));
-    p.chunk = kFT * p.bpw;
+    // Chunk size: the partition kernels run two workgroups per CU (512 at a time), and a grid that is not a whole number
+    // of such rounds ends on a part-filled one (10 M events in chunks of 8192 = 2.4 rounds: the last one 38 % full).  So
+    // the stream is cut into 512 * k chunks with the smallest k whose chunks fit the 8192-event staging area.
+    const long long cap = (long long)kFT * kMaxBpw;
+    long long k = (n + 512 * cap - 1) / (512 * cap);
+    if (k < 1) k = 1;
+    long long ce = (n + 512 * k - 1) / (512 * k);
+    ce = (ce + 15) / 16 * 16;
+    if (ce < 1024) ce = 1024; // tiny calls: keep whole 64-event batches per wavefront
+    if (ce > cap) ce = cap;
+    p.chunk = (int)ce;
+    p.bpw = (p.chunk / kFW + kWave - 1) / kWave;
     return true;
 }
 
@@ -160,7 +183,10 @@ struct FastEv {
 
 // src/io/dat_events_tools.py:96-98 (bit fields), generate_taf.py:197-203 (window), :215-219 (coordinate scaling via the
 // maps); the flat index x + W * y of generate_taf.py:23 aliases x >= W into the next row like the general path.
-template <bool HAS_MAP>
+// EV (Event Volume, generate_eventvolume.py:139-141): t0 = t_end - window; events with t <= t0 are dropped like the
+// harness' `events_[:, 2] > end_time - time_window` filter, an event behind t_end is outside the contract (ST_SPAN);
+// word = (t - t0) << 12 | cell, one "window".
+template <bool HAS_MAP, bool EV = false>
 __device__ __forceinline__ FastEv fast_decode(const FastGeom &G, uint2 r, long long t0)
 {
     FastEv o;
@@ -179,6 +205,14 @@ __device__ __forceinline__ FastEv fast_decode(const FastGeom &G, uint2 r, long l
         x = (int)(flat - (long long)y * G.W);
     }
     const long long rel = (long long)r.x - t0;
+    if (EV) {
+        if (rel <= 0) return o; // generate_eventvolume.py:139: not an error, not encoded
+        if (rel > (long long)G.win) { o.err = ST_SPAN; return o; }
+        const int tw1e = (1 << G.twl) - 1, th1e = (1 << G.thl) - 1;
+        o.tile = (y >> G.thl) * G.tiles_x + (x >> G.twl);
+        o.word = ((uint32_t)rel << kCellBits) | (uint32_t)((((y & th1e) << G.twl) | (x & tw1e)) << 1) | p;
+        return o;
+    }
     if (rel < 0 || rel > (long long)G.n_windows * G.win) { o.err = ST_SPAN; return o; }
     const uint32_t relu = (uint32_t)rel;
     uint32_t z = __umulhi(relu, G.win_magic); // floor(rel / win) - {0, 1, 2}
@@ -202,61 +236,133 @@ __device__ __forceinline__ int seq_of_chunk(const SeqTab &S, int chunk)
 }
 
 // ---- 1. histogram ------------------------------------------------------------------------------------
-template <bool HAS_MAP>
-__global__ __launch_bounds__(kFT) void kf_hist(FastGeom G, SeqTab S, uint32_t *counts, int32_t *errs, float *tlut_w,
-                                               uint32_t *leaky_w)
+// Persistent workgroups (two per CU) walk the chunks grid-stride; a thread takes eight records of a chunk as four 16-byte
+// loads (the order inside a chunk does not matter for a histogram) and has the NEXT chunk's loads in flight while it
+// decodes and counts this one: the read of the 8-byte records runs at the copy rate instead of in bursts.
+struct HistSpan { // wave-uniform description of one chunk's records
+    long long first; // index of the first record the loads cover (a 16-byte boundary; may lie one record in front of the chunk)
+    long long begin, end;
+    long long t0;
+};
+
+__device__ __forceinline__ HistSpan hist_span(const FastGeom &G, const SeqTab &S, int chunk, int n_chunks)
+{
+    HistSpan L;
+    L.begin = L.end = L.first = 0;
+    L.t0 = 0;
+    if (chunk >= n_chunks) return L;
+    const int s = seq_of_chunk(S, chunk);
+    L.t0 = S.t0[s];
+    L.begin = S.ev0[s] + (long long)(chunk - S.chunk0[s]) * G.chunk_ev;
+    L.end = L.begin + G.chunk_ev < S.ev0[s + 1] ? L.begin + G.chunk_ev : S.ev0[s + 1];
+    if (L.end < L.begin) L.end = L.begin;
+    // record pairs on 16-byte boundaries: step one record back if the chunk starts on the odd half of a pair (stays
+    // inside the array unless the array itself starts there: then the loads are merely unaligned)
+    L.first = L.begin - (long long)((reinterpret_cast<uintptr_t>(G.data + L.begin) >> 3) & 1u);
+    if (L.first < 0) L.first = L.begin;
+    return L;
+}
+
+// Loads without branches (a load under a lane condition becomes its own basic block with its own s_waitcnt: eight
+// serialized round trips to HBM): every thread reads SOME pair of the chunk -- its own, or the chunk's last one -- and the
+// validity of the two records is decided afterwards from the indices.
+__device__ __forceinline__ uint32_t hist_pairs(const HistSpan &L) // whole pairs inside [first, end): both records exist
+{
+    long long cover = L.end - L.first;
+    if (cover > 2ll * (kMaxBpw / 2) * kFT) cover = 2ll * (kMaxBpw / 2) * kFT;
+    return (uint32_t)(cover >> 1);
+}
+
+__device__ __forceinline__ void hist_issue(const FastGeom &G, const HistSpan &L, uint4 (&v)[kMaxBpw / 2])
+{
+    const uint32_t pairs = hist_pairs(L);
+    if (pairs > 0) { // wave-uniform
+        const uint4 *src = (const uint4 *)(G.data + L.first);
+#pragma unroll
+        for (int j = 0; j < kMaxBpw / 2; ++j) {
+            const uint32_t pj = (uint32_t)(j * kFT) + threadIdx.x;
+            v[j] = src[pj < pairs ? pj : pairs - 1u];
+        }
+    }
+}
+
+template <bool HAS_MAP, bool EV = false>
+__global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(8, 8))) void kf_hist(FastGeom G, SeqTab S, uint32_t *counts,
+                                                                                         int32_t *errs, float *tlut_w,
+                                                                                         uint32_t *leaky_w, int n_chunks)
 {
     extern __shared__ uint32_t lds[];
     uint32_t *hist = lds; // [T]
     __shared__ int serr;
     const int tid = threadIdx.x;
-    const int chunk = (int)chunk_of_block(blockIdx.x, gridDim.x);
-    const int s = seq_of_chunk(S, chunk);
     for (int b = tid; b < G.T; b += kFT) hist[b] = 0;
     if (tid == 0) serr = 0;
-    __syncthreads();
     int mul_err = 0;
-    if (chunk == (int)gridDim.x - 1 && tid < kLeakyLevels) // generate_taf.py:69-76 as a 256-level threshold table
+    if (!EV && blockIdx.x == gridDim.x - 1 && tid < kLeakyLevels) // generate_taf.py:69-76 as a 256-level threshold table
         leaky_w[tid] = tid == 0 ? 0x7f800000u : leaky_threshold_bits(tid);
-    {
+    if (EV) {
+        // Event Volume: tlut[r] = float(r / window) (generate_eventvolume.py:141, :23: t.float()), r = t - (t_end - window);
+        // the same exhaustive check decides whether the tile kernels may multiply by 1 / window instead
+        const double den = (double)G.win, rcp = 1.0 / den;
+        for (long long r = (long long)blockIdx.x * kFT + tid; r <= (long long)G.win; r += (long long)gridDim.x * kFT) {
+            const float exact = (float)((double)r / den);
+            if ((float)((double)r * rcp) != exact) mul_err = ST_MULBAD;
+            tlut_w[r] = exact;
+        }
+    } else if (tlut_w) {
         // tlut[r] = float(r / (win + 1e-8)) - 1 (generate_taf.py:215, :26): one correctly rounded f64 division per
         // distinct in-window time instead of one per event
         // The walk kernel would rather multiply by 1 / den than gather from the table: allowed only if that gives the
         // same float for EVERY r of the domain, which is checked right here, exhaustively, per call.
         const double den = (double)G.win + 1e-8, rcp = 1.0 / den;
-        for (long long r = (long long)chunk * kFT + tid; r <= (long long)G.win; r += (long long)gridDim.x * kFT) {
+        for (long long r = (long long)blockIdx.x * kFT + tid; r <= (long long)G.win; r += (long long)gridDim.x * kFT) {
             const float exact = (float)((double)r / den);
             if ((float)((double)r * rcp) != exact) mul_err = ST_MULBAD;
             tlut_w[r] = exact - 1.0f;
         }
     }
-    const int chunk_ev = kFT * G.bpw;
-    const long long begin = S.ev0[s] + (long long)(chunk - S.chunk0[s]) * chunk_ev;
-    const long long left = S.ev0[s + 1] - begin;
-    const uint32_t nloc = left < chunk_ev ? (uint32_t)(left < 0 ? 0 : left) : (uint32_t)chunk_ev;
-    const uint2 *src = G.data + begin;
-    const long long t0 = S.t0[s];
-    uint2 q[kMaxBpw];
+    uint4 cur[kMaxBpw / 2], nxt[kMaxBpw / 2];
+    HistSpan Lc, Ln = hist_span(G, S, (int)blockIdx.x, n_chunks);
+    hist_issue(G, Ln, nxt);
+    if (mul_err) atomicOr(&serr, mul_err);
+    __syncthreads();
+    for (int chunk = (int)blockIdx.x; chunk < n_chunks; chunk += (int)gridDim.x) {
+        Lc = Ln;
 #pragma unroll
-    for (int j = 0; j < kMaxBpw; ++j) {
-        const uint32_t i = (uint32_t)(j * kFT + tid);
-        q[j] = i < nloc ? src[i] : make_uint2(0u, 0u);
-    }
-    int err = mul_err;
+        for (int j = 0; j < kMaxBpw / 2; ++j) cur[j] = nxt[j];
+        Ln = hist_span(G, S, chunk + (int)gridDim.x, n_chunks);
+        hist_issue(G, Ln, nxt);
+        int err = 0;
+        const uint32_t pairs = hist_pairs(Lc);
+        const bool skip_first = Lc.first != Lc.begin; // the first record of pair 0 lies in front of the chunk
 #pragma unroll
-    for (int j = 0; j < kMaxBpw; ++j) {
-        const uint32_t i = (uint32_t)(j * kFT + tid);
-        if (i < nloc) {
-            const FastEv o = fast_decode<HAS_MAP>(G, q[j], t0);
+        for (int j = 0; j < kMaxBpw / 2; ++j) {
+            const uint32_t pj = (uint32_t)(j * kFT + tid);
+            if (pj < pairs && !(skip_first && pj == 0u)) {
+                const FastEv o = fast_decode<HAS_MAP, EV>(G, make_uint2(cur[j].x, cur[j].y), Lc.t0);
+                err |= o.err;
+                if (o.tile >= 0) atomicAdd(&hist[o.tile], 1u);
+            }
+            if (pj < pairs) {
+                const FastEv o = fast_decode<HAS_MAP, EV>(G, make_uint2(cur[j].z, cur[j].w), Lc.t0);
+                err |= o.err;
+                if (o.tile >= 0) atomicAdd(&hist[o.tile], 1u);
+            }
+        }
+        // what the whole pairs leave over -- the odd record at the chunk's end (also when the chunk starts on the odd half of
+        // a pair and is covered from one record earlier): at most one, fetched by one thread
+        if (tid == 0 && Lc.end > Lc.begin && Lc.first + 2ll * pairs < Lc.end) { // (an EMPTY chunk covered from one record earlier has nothing left over)
+            const FastEv o = fast_decode<HAS_MAP, EV>(G, G.data[Lc.end - 1], Lc.t0);
             err |= o.err;
             if (o.tile >= 0) atomicAdd(&hist[o.tile], 1u);
         }
+        if (err) atomicOr(&serr, err);
+        __syncthreads();
+        uint32_t *row = counts + (long long)chunk * G.T;
+        for (int b = tid; b < G.T; b += kFT) { row[b] = hist[b]; hist[b] = 0u; }
+        if (tid == 0) { errs[chunk] = serr; serr = 0; }
+        __syncthreads();
     }
-    if (err) atomicOr(&serr, err);
-    __syncthreads();
-    uint32_t *row = counts + (long long)chunk * G.T;
-    for (int b = tid; b < G.T; b += kFT) row[b] = hist[b];
-    if (tid == 0) errs[chunk] = serr;
 }
 
 // ---- 2. scans ----------------------------------------------------------------------------------------
@@ -304,7 +410,7 @@ __global__ __launch_bounds__(kFT) void kf_tilescan(SeqTab S, uint32_t *slabtot, 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int pairs = S.n_seq * T;
     if (tid == 0) { hdr->status = 0; hdr->filtered_tiles = 0u; hdr->mul_bad = 0u; }
-    if (tid < kMaxSeq) hdr->wmask[tid] = 0ull;
+    if (tid < kMaxSeq) { hdr->wmask[tid] = 0ull; hdr->unsorted[tid] = 0u; }
     __syncthreads();
     {
         int e = 0;
@@ -367,7 +473,7 @@ __host__ __device__ inline size_t scatter_lds_bytes(int T, int chunk)
     return (size_t)kFW * T * 4 + (size_t)(T + 2) * 4 + (size_t)chunk * 4 + (size_t)chunk * 2 + 16;
 }
 
-template <bool HAS_MAP>
+template <bool HAS_MAP, bool EV = false>
 __global__ __launch_bounds__(kFT) void kf_scatter(FastGeom G, SeqTab S, const uint32_t *counts, const uint32_t *slabtot,
                                                   const uint32_t *base, uint32_t *records, FastHeader *hdr)
 {
@@ -377,10 +483,10 @@ __global__ __launch_bounds__(kFT) void kf_scatter(FastGeom G, SeqTab S, const ui
     uint32_t *loff = wcnt_all + (size_t)kFW * T; // [T + 1] slot of tile b's first record in the staged chunk; after
                                                  // the staging: global slot of that record MINUS its staged slot
     uint32_t *stage = loff + ((T + 2) & ~1);
-    uint16_t *stile = (uint16_t *)(stage + kFT * G.bpw);
+    uint16_t *stile = (uint16_t *)(stage + G.chunk_ev);
     __shared__ uint32_t wtot[kFW];
     __shared__ unsigned long long wg_seen;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6; // (NOT readfirstlane: with the wavefront index in an SGPR this kernel ran 60 % longer, measured)
     const int chunk = (int)chunk_of_block(blockIdx.x, gridDim.x);
     const int s = seq_of_chunk(S, chunk);
     uint32_t *wcnt = wcnt_all + (size_t)wv * T;
@@ -388,45 +494,79 @@ __global__ __launch_bounds__(kFT) void kf_scatter(FastGeom G, SeqTab S, const ui
     if (tid == 0) wg_seen = 0ull;
     __syncthreads();
 
-    const int chunk_ev = kFT * G.bpw;
-    const long long chunk_begin = S.ev0[s] + (long long)(chunk - S.chunk0[s]) * chunk_ev;
-    const long long wave_begin = chunk_begin + (long long)wv * kWave * G.bpw; // wavefront w owns the w-th run of the chunk
+    const long long chunk_begin = S.ev0[s] + (long long)(chunk - S.chunk0[s]) * G.chunk_ev;
+    const long long wave_begin = chunk_begin + (long long)wv * G.run; // wavefront w owns the w-th run of the chunk
     const long long left = S.ev0[s + 1] - wave_begin;
-    const uint32_t nloc = left < (long long)kWave * G.bpw ? (uint32_t)(left < 0 ? 0 : left) : (uint32_t)(kWave * G.bpw);
+    const uint32_t nloc = left < (long long)G.run ? (uint32_t)(left < 0 ? 0 : left) : (uint32_t)G.run;
     const long long t0 = S.t0[s];
-    const uint2 *src = G.data + wave_begin;
+    // the event in front of this wavefront's run (same sequence), for the window-order check below: requested first, so
+    // that it is back first (loads return in order)
+    uint2 qprev = make_uint2(0u, 0u);
+    const bool ORDER = !EV && G.order_check != 0; // (wave-uniform) the window-order check only matters to the tile walk
+    const bool has_prev = ORDER && nloc > 0 && wave_begin > S.ev0[s];
+    if (ORDER && nloc > 0) qprev = G.data[has_prev ? wave_begin - 1 : wave_begin];
     uint2 q[kMaxBpw];
+    if (nloc > 0) { // wave-uniform.  No load under a lane condition (each would wait for its own data: eight serialized round
+                    // trips): lanes behind the run's end re-read its last event and are masked by `i < nloc` below
+        const uint2 *src = G.data + wave_begin;
 #pragma unroll
-    for (int j = 0; j < kMaxBpw; ++j) {
-        const uint32_t i = (uint32_t)(j * kWave + lane);
-        q[j] = i < nloc ? src[i] : make_uint2(0u, 0u);
+        for (int j = 0; j < kMaxBpw; ++j) {
+            const uint32_t i = (uint32_t)(j * kWave + lane);
+            q[j] = src[i < nloc ? i : nloc - 1u];
+        }
     }
     // global slot of this chunk's run in every tile (needed after the ranks: issue the loads now)
     const int slab = S.slab0[s] + (chunk - S.chunk0[s]) / kFastSlab;
-    uint32_t gs_pre = 0;
-    if (tid < T) gs_pre = base[s * T + tid] + slabtot[(long long)slab * T + tid] + counts[(long long)chunk * T + tid];
+    // (three loads without a lane condition, summed only where the sum is needed: inside an `if (tid < T)` the compiler
+    // waits for them -- and for the event loads in front of them -- right here)
+    const int tcl = tid < T ? tid : 0;
+    const uint32_t gs_a = base[s * T + tcl], gs_b = slabtot[(long long)slab * T + tcl], gs_c = counts[(long long)chunk * T + tcl];
     // ---- phase A: stream rank of every event inside (wavefront, tile): batches of 64 consecutive events, one
     // returning LDS atomic each -- same-address lanes are served in lane order, and a wavefront's LDS instructions in
     // program order, so the returned count is the number of earlier events of the wavefront's run in the same tile.
     uint32_t where[kMaxBpw], word[kMaxBpw];
     unsigned long long wseen = 0ull;
+    // window of the event in front of this wavefront's run (same sequence), for the order check below
+    uint32_t carry = 0u;
+    if (has_prev) carry = fast_decode<HAS_MAP, EV>(G, qprev, t0).window;
+    bool backwards = false;
 #pragma unroll
     for (int j = 0; j < kMaxBpw; ++j) {
         where[j] = 0xffffffffu;
         word[j] = 0u;
         if (j < G.bpw) {
             const uint32_t i = (uint32_t)(j * kWave + lane);
+            uint32_t win_j = 0xffffffffu; // lanes behind the run's end: larger than any window
             if (i < nloc) {
-                const FastEv o = fast_decode<HAS_MAP>(G, q[j], t0);
+                const FastEv o = fast_decode<HAS_MAP, EV>(G, q[j], t0);
                 if (o.tile >= 0) {
                     const uint32_t r = atomicAdd(&wcnt[o.tile], 1u);
                     where[j] = ((uint32_t)o.tile << 16) | r;
                     word[j] = o.word;
                     wseen |= 1ull << o.window;
+                    win_j = o.window;
+                }
+            }
+            if (ORDER) { // does the stream ever step back into an earlier window?  (the tile walk relies on window-sorted lists)
+                // Usual case: the 64 events of the batch lie in ONE window that is not below the previous batch's last --
+                // two lane reads and a ballot.  Otherwise (a window boundary inside the batch, an event that was not
+                // encoded, the ragged end of a run) every lane looks at its left neighbour.
+                const uint32_t w_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)win_j);
+                if (__ballot(win_j != w_first) == 0ull) {
+                    if (w_first != 0xffffffffu) { backwards |= w_first < carry; carry = w_first; }
+                } else {
+                    uint32_t prev = (uint32_t)__shfl_up((int)win_j, 1);
+                    if (lane == 0) prev = carry;
+                    // lanes without an event (0xffffffff) neither compare nor serve as a neighbour: the ragged end of a run
+                    // only has them behind its last event, an error event voids the whole call anyway
+                    backwards |= win_j != 0xffffffffu && prev != 0xffffffffu && win_j < prev;
+                    const unsigned long long have = __ballot(win_j != 0xffffffffu);
+                    if (have) carry = (uint32_t)__builtin_amdgcn_readlane((int)win_j, 63 - __builtin_clzll(have));
                 }
             }
         }
     }
+    if (ORDER && __ballot(backwards) && lane == 0) atomicOr(&hdr->unsorted[s], 1u);
     __syncthreads();
     // ---- phase B: per tile, exclusive prefix of the 16 wavefront counts; chunk-local offsets of the tiles
     uint32_t mine = 0; // records of tile `tid` in this chunk
@@ -468,7 +608,7 @@ __global__ __launch_bounds__(kFT) void kf_scatter(FastGeom G, SeqTab S, const ui
     }
     if (lane == 0 && wseen) atomicOr(&wg_seen, wseen);
     __syncthreads();
-    if (tid < T) loff[tid] = gs_pre - loff[tid]; // wraps around harmlessly (mod 2^32)
+    if (tid < T) loff[tid] = (gs_a + gs_b + gs_c) - loff[tid]; // wraps around harmlessly (mod 2^32)
     __syncthreads();
     for (uint32_t qi = tid; qi < total; qi += kFT) records[loff[stile[qi]] + qi] = stage[qi];
     if (tid == 0) {
@@ -489,6 +629,10 @@ struct TileP {
     const uint32_t *seg0;  // [pairs + 1] first split segment of every (sequence, tile) pair
     uint32_t *segcnt;      // [segments][16] records of every sub-tile in a segment, then their offsets inside the sub-tile
     int pairs;
+    int skip_whole;        // 1: tiles up to the whole-tile limit are NOT re-sorted (a tile-walk kernel splits them in LDS) ...
+    int tile_walk;         // ... TAF: unless their sequence is not window-sorted (hdr->unsorted)
+    int first_block;       // kf_split_whole: block b does the work of block b + first_block
+    uint32_t tile_max;     // tiles with more records than this go through the segment split
     const float *tlut;
     const uint32_t *leaky_thr;
     FastHeader *hdr;
@@ -575,14 +719,17 @@ __global__ __launch_bounds__(kFT) void kf_split_whole(TileP q)
     __shared__ uint32_t btot[kFW];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (q.hdr->status != 0) return;
-    if ((int)blockIdx.x >= q.pairs) { // the blocks behind the tiles: one segment of a skewed tile each (4b, counting)
-        split_count_segment(q, blockIdx.x - (uint32_t)q.pairs, wtot);
+    const int blk = (int)blockIdx.x + q.first_block;
+    if (blk >= q.pairs) { // the blocks behind the tiles: one segment of a skewed tile each (4b, counting)
+        if (q.first_block && blk == q.pairs && tid == 0) q.sub[(long long)q.pairs * kFW] = q.base[q.pairs]; // (the last tile's block is not there to do it)
+        split_count_segment(q, (uint32_t)(blk - q.pairs), wtot);
         return;
     }
-    const int g = blockIdx.x;
+    const int g = blk;
     const uint32_t beg = q.base[g], end = q.base[g + 1];
     if (g == q.pairs - 1 && tid == 0) q.sub[(long long)q.pairs * kFW] = end; // end of the last sub-tile's list
-    if (end - beg > whole_max_of(q.pairs)) return; // a skewed tile (or a call with few tiles): left to the segment kernels below
+    if (end - beg > whole_max_of(q.pairs) || q.skip_whole) return; // a skewed tile (or a call with few tiles): left to the segment kernels below
+    if (q.tile_walk && q.hdr->unsorted[g / q.T] == 0u) return;     // split in LDS by kf_taf_tile
     if (tid < kFW * kFW) (&wtot[0][0])[tid] = 0u;
     __syncthreads();
     for (uint32_t i = beg + tid; i < end; i += kFT) atomicAdd(&wtot[wv][(q.rec[i] & (kCells - 1)) >> 8], 1u);
@@ -757,11 +904,13 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_waves_per_eu(8,
     const int sg = blockIdx.x, g = sg / kFW, sub = sg - g * kFW;
     const int s = g / q.T, tile = g - s * q.T;
     if (q.hdr->status != 0) return; // data-dependent error: nothing is written (the caller re-runs the general path)
+    if (q.tile_walk && q.hdr->unsorted[s] == 0u && q.base[g + 1] - q.base[g] <= q.tile_max) return; // done by kf_taf_tile
     const int K = K8 ? 8 : q.K;
     const int NW = q.n_windows;
     for (int i = tid; i < kLeakyLevels; i += kWalkThreads) thr[i] = q.leaky_thr[i];
     for (int i = lane; i < kSubCells / 2; i += kWave) s_cnt[wv][i] = 0u;
-    const uint32_t beg = q.sub[sg], end = q.sub[sg + 1];
+    // (sub[] of the NEXT pair is only written if that pair went through a split kernel: take the tile's own end)
+    const uint32_t beg = q.sub[sg], end = sub == kFW - 1 ? q.base[g + 1] : q.sub[sg + 1];
     for (int i = tid; i <= NW; i += kWalkThreads) wstart[i] = end;
     if (tid == 0) s_unsorted = 0;
     const unsigned long long wmask = q.hdr->wmask[s];
@@ -971,6 +1120,554 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_waves_per_eu(8,
     }
 }
 
+// =====================================================================================================================
+// Tile walk: the second-level split done in LDS by the kernel that consumes it
+// =====================================================================================================================
+// kf_split_whole re-sorts a tile's records sub-tile-major through HBM (75 MB read + 41 MB written per 10 M events) only so
+// that the sub-tile kernel finds its list contiguous.  A tile-walk workgroup instead streams the tile's list (tile-major,
+// stream order, written by kf_scatter) in chunks, splits every chunk STABLY by sub-tile inside LDS with the same
+// lane-ordered tickets, and hands each sub-tile's piece to the wavefront that owns the sub-tile.  NW wavefronts per
+// workgroup = NW sub-tiles; 16 / NW workgroups ("parts") share a tile and each reads the whole list (from the XCD's L2:
+// the parts of a tile are placed on one XCD) but keeps only its own sub-tiles.
+//
+// Wave-private pass (the core of kf_taf_walk's phase 1, factored out): up to 256 records of ONE sub-tile, in stream order,
+// become per-cell ordered segments -- a ticket per record from two-per-word 16-bit LDS counters (lane-ordered, so the
+// ticket is the stream rank inside the cell), a wave scan of the cell counts, values to sorted[offset(cell) + ticket] --
+// and every lane then walks the segments of its four cells (64 j + lane) front to back.
+struct WavePass {
+    uint32_t *cnt;  // [128]: two 16-bit tickets per word, all zero between passes
+    uint16_t *off;  // [256]
+    float *sorted;  // [256]
+};
+
+// m[u], u < 4: the lane's records of this pass (0xffffffff = none), record u * 64 + lane of the pass in stream order;
+// val(m) -> the f32 to sort.  Returns the lane's four cell counts n[] and segment starts o[] in sorted[]; the caller
+// walks the segments (wave_segments below) and ends the pass with LDS_FENCE().
+template <class Val>
+__device__ __forceinline__ void wave_sort(const WavePass &P, const uint32_t (&m)[4], int lane, Val val, uint32_t (&n)[4], uint32_t (&o)[4])
+{
+    uint32_t rk[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        rk[u] = 0xffffffffu;
+        if (m[u] != 0xffffffffu) {
+            const uint32_t lc = m[u] & 255u, sh = 16u * (lc & 1u);
+            rk[u] = (atomicAdd(&P.cnt[lc >> 1], 1u << sh) >> sh) & 0xffffu;
+        }
+    }
+    LDS_FENCE();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) n[j] = (P.cnt[32 * j + (lane >> 1)] >> (16 * (lane & 1))) & 0xffffu;
+    LDS_FENCE();
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (!(lane & 1)) P.cnt[32 * j + (lane >> 1)] = 0u; // after both lanes of the word have read it
+    {
+        const uint32_t tl = n[0] + n[1] + n[2] + n[3];
+        const uint32_t inc = wave_incl_scan(tl);
+        o[0] = inc - tl; o[1] = o[0] + n[0]; o[2] = o[1] + n[1]; o[3] = o[2] + n[2];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) P.off[64 * j + lane] = (uint16_t)o[j];
+    LDS_FENCE();
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (rk[u] != 0xffffffffu) P.sorted[(uint32_t)P.off[m[u] & 255u] + rk[u]] = val(m[u]);
+    LDS_FENCE();
+}
+
+// add(j, v, live): "cell j of this lane receives v next" when live -- a select, not a branch (divergent control flow
+// around the accumulators makes the compiler keep copies of all of them).
+template <class Add>
+__device__ __forceinline__ void wave_segments(const WavePass &P, const uint32_t (&n)[4], const uint32_t (&o)[4], Add add)
+{
+    uint32_t nmax = n[0] > n[1] ? n[0] : n[1];
+    nmax = n[2] > nmax ? n[2] : nmax;
+    nmax = n[3] > nmax ? n[3] : nmax;
+    const uint32_t nm = wave_max_u32(nmax); // the longest segment of the wavefront: a uniform trip count
+#pragma nounroll
+    for (uint32_t a = 0; a < nm; ++a) {
+        float e[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t at = o[j] + a;
+            e[j] = P.sorted[at < 255u ? at : 255u];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) add(j, e[j], a < n[j]);
+    }
+}
+
+// In-LDS stable split of one chunk of a tile's list.  NT threads, RPT records per thread: record u * NT + tid of the chunk
+// (stream order = (round u, wavefront, lane)).  Every record of one of this workgroup's NW sub-tiles takes a ticket from
+// the (round, wavefront, sub-tile) counter -- lane-ordered -- wavefront b scans sub-tile b's RPT * NW counters in stream
+// order, the sub-tile totals are scanned by every wavefront for itself, and the records land sub-tile-major in stage[].
+// Returns through sb / nb the start and length of THIS wavefront's sub-tile in stage[].  Four workgroup barriers.
+template <int NW, int RPT>
+struct TileSplit {
+    static constexpr int NT = NW * kWave;
+    static constexpr int CH = NT * RPT;
+    uint32_t scnt[RPT][NW][NW]; // [round][wavefront][sub-tile]
+    uint32_t btot[NW];
+    uint32_t stage[CH];
+};
+
+template <int NW, int RPT>
+__device__ __forceinline__ void tile_split(TileSplit<NW, RPT> &L, const uint32_t (&m)[RPT], const bool (&mine)[RPT], int part,
+                                           uint32_t &sb, uint32_t &nb)
+{
+    constexpr int NE = RPT * NW;
+    static_assert(NE <= kWave, "one wavefront scans a sub-tile's counters");
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    uint32_t rk[RPT];
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) {
+        rk[u] = 0u;
+        if (mine[u]) rk[u] = atomicAdd(&L.scnt[u][wv][((m[u] >> 8) & 15u) - (uint32_t)(part * NW)], 1u);
+    }
+    __syncthreads();
+    {
+        uint32_t v = 0;
+        if (lane < NE) v = L.scnt[lane / NW][lane % NW][wv];
+        const uint32_t inc = wave_incl_scan(v);
+        if (lane < NE) L.scnt[lane / NW][lane % NW][wv] = inc - v;
+        if (lane == kWave - 1) L.btot[wv] = inc;
+    }
+    __syncthreads();
+    uint32_t ex;
+    {
+        const uint32_t t = lane < NW ? L.btot[lane] : 0u;
+        ex = wave_incl_scan(t) - t; // lane b: first slot of sub-tile b
+    }
+    sb = (uint32_t)__shfl((int)ex, wv);
+    nb = L.btot[wv];
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) {
+        const uint32_t b = mine[u] ? ((m[u] >> 8) & 15u) - (uint32_t)(part * NW) : 0u;
+        const uint32_t base = (uint32_t)__shfl((int)ex, (int)b);
+        if (mine[u]) L.stage[base + L.scnt[u][wv][b] + rk[u]] = m[u];
+    }
+    __syncthreads();
+}
+
+// blockIdx -> (pair, part) with the parts of a pair on ONE XCD (blocks b and b + 8 share an XCD): the list is read from
+// HBM once and from that XCD's L2 by the other parts.
+template <int PARTS>
+__device__ __forceinline__ bool pair_part_of_block(int pairs, int &g, int &part)
+{
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    part = q % PARTS;
+    g = (q / PARTS) * 8 + xcd;
+    return g < pairs;
+}
+
+// ---- Temporal Active Focus ---------------------------------------------------------------------------------------------
+// One workgroup = NW sub-tiles of one (sequence, tile) pair of a WINDOW-SORTED sequence (kf_scatter flags the others).
+// The tile's list is streamed once, in stream order; wavefront v keeps the FIFO rows of its 256 cells (four per lane) in
+// registers together with the running (sum, count) of the window it is in, and closes windows -- one FIFO step per cell,
+// generate_taf.py:27-49 -- whenever its records move on to a later window.  Replaces kf_split_whole + kf_taf_walk for the
+// tiles it takes: the sub-tile-major copy of the records never exists.
+struct TafWaveLds {
+    uint32_t cnt[kSubCells / 2];
+    uint16_t off[kSubCells];
+    float sorted[kSubCells];
+}; // 2 KB; at the end the uint8 staging of the wavefront's sub-tile: 2K planes x 128 pixels
+
+template <int NW, bool K8>
+__global__ __launch_bounds__(NW *kWave) void kf_taf_tile(TileP q)
+{
+    constexpr int RPT = 4, NT = NW * kWave, CH = NT * RPT, PARTS = kFW / NW;
+    __shared__ TileSplit<NW, RPT> L;
+    __shared__ __attribute__((aligned(16))) TafWaveLds wl[NW];
+    __shared__ uint32_t thr[kLeakyLevels];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int g, part;
+    if (!pair_part_of_block<PARTS>(q.pairs, g, part)) return;
+    if (q.hdr->status != 0) return;
+    const int s = g / q.T, tile = g - s * q.T;
+    if (q.hdr->unsorted[s] != 0u) return; // kf_split_whole + kf_taf_walk
+    const uint32_t beg = q.base[g], end = q.base[g + 1];
+    if (end - beg > q.tile_max) return;   // skewed tile: segment split + kf_taf_walk
+    const int K = K8 ? 8 : q.K;
+    const int NWIN = q.n_windows;
+    for (int i = tid; i < kLeakyLevels; i += NT) thr[i] = q.leaky_thr[i];
+    for (int i = lane; i < kSubCells / 2; i += kWave) wl[wv].cnt[i] = 0u;
+    for (int i = tid; i < RPT * NW * NW; i += NT) (&L.scnt[0][0][0])[i] = 0u;
+    const WavePass P = {wl[wv].cnt, wl[wv].off, wl[wv].sorted};
+    const unsigned long long wmask = q.hdr->wmask[s];
+    const bool use_mul = q.hdr->mul_bad == 0u; // checked for every r of the domain by kf_hist
+    const double rcp = 1.0 / ((double)q.win + 1e-8);
+    const uint32_t wfield = (1u << q.wb) - 1u;
+    const int rshift = kCellBits + q.wb;
+    // the lane's four cells: cell 64 j + lane of sub-tile `sub` = pixel 128 sub + 32 j + lane / 2 of the tile, polarity lane & 1
+    const int sub = part * NW + wv;
+    const int ty = tile / q.tiles_x, tx = tile - ty * q.tiles_x;
+    const int x0 = tx << q.twl, y0 = ty << q.thl, tw1 = (1 << q.twl) - 1;
+    const long long plane = (long long)q.H * q.W;
+    const int pol = lane & 1;
+    float st[4][kMaxK], sum[4];
+    uint32_t num[4];
+    bool ok[4];
+    long long pix[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int pt = sub * (kSubCells / 2) + 32 * j + (lane >> 1);
+        const int py = y0 + (pt >> q.twl), px = x0 + (pt & tw1);
+        ok[j] = py < q.H && px < q.W;
+        pix[j] = (long long)py * q.W + px;
+        const float *srow = q.state + (((long long)s * plane + pix[j]) * 2 + pol) * K;
+#pragma unroll
+        for (int k = 0; k < kMaxK; ++k) st[j][k] = 0.0f;
+        if (ok[j]) {
+            if (K8) {
+                const float4 a = ((const float4 *)srow)[0], b = ((const float4 *)srow)[1];
+                st[j][0] = a.x; st[j][1] = a.y; st[j][2] = a.z; st[j][3] = a.w;
+                st[j][4] = b.x; st[j][5] = b.y; st[j][6] = b.z; st[j][7] = b.w;
+            } else {
+#pragma unroll
+                for (int k = 0; k < kMaxK; ++k)
+                    if (k < K) st[j][k] = srow[k];
+            }
+        }
+        sum[j] = 0.0f;
+        num[j] = 0u;
+    }
+    int cur_w = 0; // wave-uniform: windows below it are closed for this wavefront's cells
+    auto close_upto = [&](int w) { // FIFO steps of windows cur_w .. w - 1 (skipped when empty in the whole sequence, :40-41)
+#pragma nounroll
+        for (; cur_w < w; ++cur_w) {
+            const bool has = (wmask >> cur_w) & 1ull;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                fifo_step(st[j], K, has, num[j], sum[j]);
+                sum[j] = 0.0f;
+                num[j] = 0u;
+            }
+        }
+    };
+    uint32_t m[RPT], nx[RPT];
+    // (loads without lane conditions -- a conditional load waits for its own data: indices are clamped, values masked)
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) {
+        const uint32_t i = beg + (uint32_t)(u * NT + tid);
+        nx[u] = 0xffffffffu;
+        if (end > beg) { const uint32_t v = q.rec[i < end ? i : end - 1u]; nx[u] = i < end ? v : 0xffffffffu; }
+    }
+    __syncthreads();
+    for (uint32_t c0 = beg; c0 < end; c0 += CH) {
+        bool mine[RPT];
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) {
+            m[u] = nx[u];
+            mine[u] = m[u] != 0xffffffffu && (int)((m[u] >> 8) & 15u) / NW == part;
+            const uint32_t i = c0 + CH + (uint32_t)(u * NT + tid); // the next chunk's loads fly during this one's passes
+            const uint32_t v = q.rec[i < end ? i : end - 1u];
+            nx[u] = i < end ? v : 0xffffffffu;
+        }
+        uint32_t sb, nb;
+        tile_split<NW, RPT>(L, m, mine, part, sb, nb);
+        for (int i = tid; i < RPT * NW * NW; i += NT) (&L.scnt[0][0][0])[i] = 0u; // dead since the placement; next chunk's tickets
+        for (uint32_t p0 = 0; p0 < nb; p0 += 256) {
+            uint32_t pm[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t i = p0 + (uint32_t)(u * kWave + lane);
+                pm[u] = i < nb ? L.stage[sb + i] : 0xffffffffu;
+            }
+            // the pass's records are window-sorted: first and last record give its window range
+            const uint32_t last = nb - p0 < 256u ? nb - 1u : p0 + 255u;
+            const int wlo = (int)((L.stage[sb + p0] >> kCellBits) & wfield), whi = (int)((L.stage[sb + last] >> kCellBits) & wfield);
+#pragma nounroll
+            for (int w = wlo; w <= whi; ++w) {
+                close_upto(w);
+                uint32_t sel[4], n[4], o[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    sel[u] = (pm[u] != 0xffffffffu && (int)((pm[u] >> kCellBits) & wfield) == w) ? pm[u] : 0xffffffffu;
+                wave_sort(P, sel, lane,
+                          [&](uint32_t rw) {
+                              const uint32_t r = rw >> rshift; // t - 1 with t = (t - t_min) / (w + 1e-8) in f64 (generate_taf.py:215, :26)
+                              return use_mul ? (float)((double)r * rcp) - 1.0f : q.tlut[r];
+                          }, n, o);
+                wave_segments(P, n, o, [&](int j, float v, bool live) {
+                    const float t = sum[j] + v; // sum += t - 1 in stream order, generate_taf.py:26
+                    sum[j] = live ? t : sum[j];
+                });
+#pragma unroll
+                for (int j = 0; j < 4; ++j) num[j] += n[j];
+                LDS_FENCE();
+            }
+        }
+        __syncthreads(); // stage[] and scnt[] are reused by the next chunk
+    }
+    close_upto(NWIN);
+
+    // ---- write-out: state, optional f32 view (2K, H, W), optional uint8 leaky transform (K, 2, H, W)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (!ok[j]) continue;
+        float *srow = q.state + (((long long)s * plane + pix[j]) * 2 + pol) * K;
+        if (K8) {
+            ((float4 *)srow)[0] = make_float4(st[j][0], st[j][1], st[j][2], st[j][3]);
+            ((float4 *)srow)[1] = make_float4(st[j][4], st[j][5], st[j][6], st[j][7]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < kMaxK; ++k)
+                if (k < K) srow[k] = st[j][k];
+        }
+        if (q.view_f32) {
+            float *vw = q.view_f32 + (long long)s * 2 * K * plane + pix[j];
+#pragma unroll
+            for (int k = 0; k < kMaxK; ++k)
+                if (k < K) vw[(long long)(2 * k + pol) * plane] = st[j][k]; // generate_taf.py:55
+        }
+    }
+    if (q.out_u8) {
+        uint8_t *ob = (uint8_t *)&wl[wv]; // [2K planes][128 pixels of the sub-tile]; the wave's pass buffers are dead
+        LDS_FENCE();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint8_t lv[kMaxK];
+            leaky_u8_lookup_n<kMaxK>(st[j], thr, lv);
+#pragma unroll
+            for (int k = 0; k < kMaxK; ++k) {
+                if (k < K) {
+                    const int ko = q.flip ? (K - 1 - k) : k;
+                    ob[(2 * ko + pol) * (kSubCells / 2) + 32 * j + (lane >> 1)] = lv[k];
+                }
+            }
+        }
+        LDS_FENCE();
+        // the (K, 2, H, W) volume leaves plane by plane in 16-pixel pieces: one 16-byte store where the row allows
+        for (int c = lane; c < 2 * K * 8; c += kWave) {
+            const int pl = c >> 3, piece = c & 7;
+            const int p16 = sub * (kSubCells / 2) + 16 * piece;
+            const int y = y0 + (p16 >> q.twl), x = x0 + (p16 & tw1);
+            if (y >= q.H || x >= q.W) continue;
+            const uint8_t *src = ob + pl * (kSubCells / 2) + 16 * piece;
+            uint8_t *dst = q.out_u8 + ((long long)s * 2 * K + pl) * plane + (long long)y * q.W + x;
+            if (x + 16 <= q.W && (((uintptr_t)dst) & 15u) == 0) {
+                *(uint4 *)dst = *(const uint4 *)src;
+            } else {
+                const int nv = q.W - x < 16 ? q.W - x : 16;
+                for (int e = 0; e < nv; ++e) dst[e] = src[e];
+            }
+        }
+    }
+}
+
+// ---- Event Volume ------------------------------------------------------------------------------------------------------
+struct EvTileP {
+    int H, W, twl, thl, tiles_x, T, bins;
+    uint32_t win;
+    const uint32_t *rec;  // tile-major records (scatter output)
+    const uint32_t *rec2; // sub-tile-major (segment split), for the tiles the tile walk leaves alone
+    const uint32_t *base; // [pairs + 1]
+    const uint32_t *sub;  // [pairs * 16 + 1]
+    int pairs;
+    uint32_t tile_max;    // tiles with more records go through the segment split + kf_ev_sub
+    const float *tlut;    // tlut[r] = float(r / window)
+    FastHeader *hdr;
+    float *out_f32;       // (B, 2 * bins, H, W) or NULL
+    uint8_t *out_u8;      // (B, 2 * bins, H, W) or NULL
+};
+
+// generate_eventvolume.py:23-32 for one event of normalised time tn on one cell: t* = bins * float(t); bin k (1-based)
+// receives 1 - |k - t*| when that is not negative.  Only the two bins around t*, k0 = floor(t*) and k0 + 1, can: for the
+// others |k - t*| >= 1 already before rounding, so their weight is zero or dropped and changes no sum.
+template <int BINS>
+__device__ __forceinline__ void ev_add(float (&acc)[BINS], float binsf, float tn, bool live)
+{
+    const float ts = binsf * tn;
+#pragma unroll
+    for (int k = 0; k < BINS; ++k) {
+        const float d = (float)(k + 1) - ts;
+        const float w = 1.0f - fabsf(d); // :28
+        const float na = acc[k] + w;
+        acc[k] = (live && w > 0.0f) ? na : acc[k]; // :29 (w == 0 adds nothing either)
+    }
+}
+
+// The same when floor(t*) = K0 is known for every record of the pass (the usual case: a pass is 256 consecutive records of
+// one sub-tile of a time-sorted stream): two bins instead of BINS.
+template <int BINS, int K0>
+__device__ __forceinline__ void ev_add_at(float (&acc)[BINS], float binsf, float tn, bool live)
+{
+    const float ts = binsf * tn;
+#pragma unroll
+    for (int k = K0 - 1; k <= K0; ++k) { // 0-based bins K0 - 1 (weight 1 - (t* - K0)) and K0 (weight 1 - (K0 + 1 - t*))
+        if (k >= 0 && k < BINS) {
+            const float d = (float)(k + 1) - ts;
+            const float w = 1.0f - fabsf(d);
+            const float na = acc[k] + w;
+            acc[k] = (live && w > 0.0f) ? na : acc[k];
+        }
+    }
+}
+
+// One pass of up to 256 records of one sub-tile through the wave's accumulators.
+template <int BINS>
+__device__ __forceinline__ void ev_pass(const WavePass &P, const uint32_t (&pm)[4], int lane, const EvTileP &q, bool use_mul, double rcp,
+                                        float binsf, float (&acc)[4][BINS])
+{
+    uint32_t n[4], o[4];
+    // floor(t*) of the pass: the same for all its records?  Compared against the pass's first record (lane 0, u = 0: a
+    // pass is never empty) -- one ballot instead of a reduction.
+    const uint32_t r0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)pm[0]) >> kCellBits;
+    const int kfirst = (int)(binsf * (use_mul ? (float)((double)r0 * rcp) : q.tlut[r0]));
+    bool differs = false;
+    wave_sort(P, pm, lane,
+              [&](uint32_t w) {
+                  const uint32_t r = w >> kCellBits;
+                  const float tn = use_mul ? (float)((double)r * rcp) : q.tlut[r]; // float((t - t0) / window), :141, :23
+                  differs |= (int)(binsf * tn) != kfirst;
+                  return tn;
+              }, n, o);
+    const int k0 = __ballot(differs) ? -1 : kfirst;
+    switch (k0) {
+#define EV_CASE(K) case K: wave_segments(P, n, o, [&](int j, float tn, bool live) { ev_add_at<BINS, K>(acc[j], binsf, tn, live); }); break;
+        EV_CASE(0) EV_CASE(1) EV_CASE(2) EV_CASE(3) EV_CASE(4) EV_CASE(5) EV_CASE(6) EV_CASE(7) EV_CASE(8)
+#undef EV_CASE
+    default: wave_segments(P, n, o, [&](int j, float tn, bool live) { ev_add<BINS>(acc[j], binsf, tn, live); }); break;
+    }
+    LDS_FENCE();
+}
+
+template <int BINS>
+__device__ __forceinline__ void ev_store(const EvTileP &q, int s, int tile, int sub, int lane, const float (&acc)[4][BINS])
+{
+    const int ty = tile / q.tiles_x, tx = tile - ty * q.tiles_x;
+    const int x0 = tx << q.twl, y0 = ty << q.thl, tw1 = (1 << q.twl) - 1;
+    const long long plane = (long long)q.H * q.W;
+    const int pol = lane & 1, ch = pol ? 0 : 1; // weights [p, 1 - p]: channel 0 = p == 1
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int pt = sub * (kSubCells / 2) + 32 * j + (lane >> 1); // cell 64 j + lane = pixel 32 j + lane / 2, polarity lane & 1
+        const int py = y0 + (pt >> q.twl), px = x0 + (pt & tw1);
+        if (py >= q.H || px >= q.W) continue;
+#pragma unroll
+        for (int k = 0; k < BINS; ++k) {
+            if (k < q.bins) {
+                const float v = acc[j][k] / 5.0f * 255.0f; // generate_eventvolume.py:37
+                const long long idx = ((long long)s * 2 * q.bins + (2 * k + ch)) * plane + (long long)py * q.W + px;
+                if (q.out_f32) q.out_f32[idx] = v;
+                if (q.out_u8) q.out_u8[idx] = f32_to_u8(v > 255.0f ? 255.0f : v);
+            }
+        }
+    }
+}
+
+// One workgroup = NW sub-tiles of one (sequence, tile) pair; see the section header.
+template <int NW, int BINS>
+__global__ __launch_bounds__(NW *kWave) void kf_ev_tile(EvTileP q)
+{
+    constexpr int RPT = 4, NT = NW * kWave, CH = NT * RPT, PARTS = kFW / NW;
+    __shared__ TileSplit<NW, RPT> L;
+    __shared__ uint32_t s_cnt[NW][kSubCells / 2];
+    __shared__ uint16_t s_off[NW][kSubCells];
+    __shared__ float s_sorted[NW][kSubCells];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int g, part;
+    if (!pair_part_of_block<PARTS>(q.pairs, g, part)) return;
+    if (q.hdr->status != 0) return;
+    const uint32_t beg = q.base[g], end = q.base[g + 1];
+    if (end - beg > q.tile_max) return; // skewed tile: segment split + kf_ev_sub
+    const int s = g / q.T, tile = g - s * q.T;
+    for (int i = lane; i < kSubCells / 2; i += kWave) s_cnt[wv][i] = 0u;
+    for (int i = tid; i < RPT * NW * NW; i += NT) (&L.scnt[0][0][0])[i] = 0u;
+    const WavePass P = {s_cnt[wv], s_off[wv], s_sorted[wv]};
+    const bool use_mul = q.hdr->mul_bad == 0u;
+    const double rcp = 1.0 / (double)q.win;
+    const float binsf = (float)q.bins;
+    float acc[4][BINS];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int k = 0; k < BINS; ++k) acc[j][k] = 0.0f;
+    uint32_t m[RPT], nx[RPT];
+    // (loads without lane conditions -- a conditional load waits for its own data: indices are clamped, values masked)
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) {
+        const uint32_t i = beg + (uint32_t)(u * NT + tid);
+        nx[u] = 0xffffffffu;
+        if (end > beg) { const uint32_t v = q.rec[i < end ? i : end - 1u]; nx[u] = i < end ? v : 0xffffffffu; }
+    }
+    __syncthreads();
+    for (uint32_t c0 = beg; c0 < end; c0 += CH) {
+        bool mine[RPT];
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) {
+            m[u] = nx[u];
+            mine[u] = m[u] != 0xffffffffu && (int)((m[u] >> 8) & 15u) / NW == part;
+            const uint32_t i = c0 + CH + (uint32_t)(u * NT + tid); // the next chunk's loads fly during this one's passes
+            const uint32_t v = q.rec[i < end ? i : end - 1u];
+            nx[u] = i < end ? v : 0xffffffffu;
+        }
+        uint32_t sb, nb;
+        tile_split<NW, RPT>(L, m, mine, part, sb, nb);
+        for (int i = tid; i < RPT * NW * NW; i += NT) (&L.scnt[0][0][0])[i] = 0u; // dead since the placement; next chunk's tickets
+        for (uint32_t p0 = 0; p0 < nb; p0 += 256) {
+            uint32_t pm[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t i = p0 + (uint32_t)(u * kWave + lane);
+                pm[u] = i < nb ? L.stage[sb + i] : 0xffffffffu;
+            }
+            ev_pass<BINS>(P, pm, lane, q, use_mul, rcp, binsf, acc);
+        }
+        __syncthreads(); // stage[] and scnt[] are reused by the next chunk
+    }
+    ev_store<BINS>(q, s, tile, part * NW + wv, lane, acc);
+}
+
+// After the segment split (kf_split_whole's counting blocks + kf_split_place): one wavefront per sub-tile walks its own
+// contiguous list -- the skewed tiles of any call, and every tile of a call with few (sequence, tile) pairs.
+template <int BINS>
+__global__ __launch_bounds__(4 * kWave) void kf_ev_sub(EvTileP q, int all_tiles)
+{
+    __shared__ uint32_t s_cnt[4][kSubCells / 2];
+    __shared__ uint16_t s_off[4][kSubCells];
+    __shared__ float s_sorted[4][kSubCells];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int sg = blockIdx.x * 4 + wv;
+    if (sg >= q.pairs * kFW || q.hdr->status != 0) return;
+    const int g = sg / kFW, sub = sg - g * kFW;
+    if (!all_tiles && q.base[g + 1] - q.base[g] <= q.tile_max) return; // done by kf_ev_tile
+    const int s = g / q.T, tile = g - s * q.T;
+    for (int i = lane; i < kSubCells / 2; i += kWave) s_cnt[wv][i] = 0u;
+    const WavePass P = {s_cnt[wv], s_off[wv], s_sorted[wv]};
+    const bool use_mul = q.hdr->mul_bad == 0u;
+    const double rcp = 1.0 / (double)q.win;
+    const float binsf = (float)q.bins;
+    float acc[4][BINS];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int k = 0; k < BINS; ++k) acc[j][k] = 0.0f;
+    // (sub[] of the NEXT pair is only written if that pair went through a split kernel: take the tile's own end)
+    const uint32_t beg = q.sub[sg], end = sub == kFW - 1 ? q.base[g + 1] : q.sub[sg + 1];
+    uint32_t nx[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const uint32_t i = beg + (uint32_t)(u * kWave + lane);
+        nx[u] = 0xffffffffu;
+        if (end > beg) { const uint32_t v = q.rec2[i < end ? i : end - 1u]; nx[u] = i < end ? v : 0xffffffffu; }
+    }
+    LDS_FENCE();
+    for (uint32_t p0 = beg; p0 < end; p0 += 256) {
+        uint32_t pm[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            pm[u] = nx[u];
+            const uint32_t i = p0 + 256u + (uint32_t)(u * kWave + lane);
+            const uint32_t v = q.rec2[i < end ? i : end - 1u];
+            nx[u] = i < end ? v : 0xffffffffu;
+        }
+        ev_pass<BINS>(P, pm, lane, q, use_mul, rcp, binsf, acc);
+    }
+    ev_store<BINS>(q, s, tile, sub, lane, acc);
+}
+
 // Self-test of the two hardware properties this file rests on, for lanes of ONE wave-instruction that hit the same LDS
 // address: (1) a returning integer atomic serves them in ascending lane order (the returned count is the stream rank);
 // (2) ds_add_f32 applies them in ascending lane order with the rounding of v_add_f32, i.e. it IS the sequential
@@ -1015,7 +1712,7 @@ __global__ __launch_bounds__(kFT) void kf_selftest_lane_order(int n_addr, int it
     if (fbad) atomicAdd(&out[2], fbad);
 }
 
-template <bool HAS_MAP>
+template <bool HAS_MAP, bool EV = false>
 void launch_fast(const FastGeom &G, const SeqTab &S, const FastPlan &p, char *w8, hipStream_t st)
 {
     FastHeader *hdr = (FastHeader *)w8;
@@ -1028,14 +1725,15 @@ void launch_fast(const FastGeom &G, const SeqTab &S, const FastPlan &p, char *w8
     uint32_t *records = (uint32_t *)(w8 + p.off_records);
     const size_t lds_sc = scatter_lds_bytes(p.T, p.chunk);
     if (lds_sc > 64 * 1024)
-        (void)hipFuncSetAttribute((const void *)kf_scatter<HAS_MAP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc);
-    hipLaunchKernelGGL((kf_hist<HAS_MAP>), dim3(p.chunks), dim3(kFT), (size_t)p.T * 4, st, G, S, counts, errs, tlut, leaky);
+        (void)hipFuncSetAttribute((const void *)kf_scatter<HAS_MAP, EV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc);
+    const int hist_grid = p.chunks < 512 ? p.chunks : 512; // persistent: two workgroups per CU
+    hipLaunchKernelGGL((kf_hist<HAS_MAP, EV>), dim3(hist_grid), dim3(kFT), (size_t)p.T * 4, st, G, S, counts, errs, tlut, leaky, p.chunks);
     const bool inline_slabs = (long long)p.slabs * p.T <= kInlineSlabScan;
     if (!inline_slabs)
         hipLaunchKernelGGL(kf_slabscan, dim3((p.T + kWave - 1) / kWave, p.slabs), dim3(kWave), 0, st, S, counts, p.T, slabtot);
     hipLaunchKernelGGL(kf_tilescan, dim3(1), dim3(kFT), 0, st, S, slabtot, p.T, base, (uint32_t *)(w8 + p.off_seg0), hdr, errs,
                        p.chunks, inline_slabs ? counts : (uint32_t *)nullptr, p.slabs);
-    hipLaunchKernelGGL((kf_scatter<HAS_MAP>), dim3(p.chunks), dim3(kFT), lds_sc, st, G, S, counts, slabtot, base, records, hdr);
+    hipLaunchKernelGGL((kf_scatter<HAS_MAP, EV>), dim3(p.chunks), dim3(kFT), lds_sc, st, G, S, counts, slabtot, base, records, hdr);
 }
 
 // ---- one-time check of the hardware property this file rests on ------------------------------------------------------
@@ -1142,7 +1840,13 @@ int frlw_taf_encode_batch(const frlw_events_t *ev, const int64_t *seq_offsets, c
     G.data = (const uint2 *)ev->data;
     G.xmap = ev->xmap; G.ymap = ev->ymap; G.map_w = ev->map_w; G.map_h = ev->map_h;
     G.H = H; G.W = W; G.twl = p.twl; G.thl = p.thl; G.tiles_x = p.tiles_x; G.T = p.T; G.bpw = p.bpw;
+    G.chunk_ev = p.chunk; G.run = p.chunk / kFW; G.n_total = ev->n;
     G.n_windows = n_windows; G.wb = wb; G.win = (uint32_t)window_us;
+    {
+        const frlw_tuning_t *tu = ev->tuning;
+        const bool want = (tu && tu->taf_tile_walk >= 0) ? tu->taf_tile_walk != 0 : kTafTileWalk;
+        G.order_check = (want && p.pairs >= kFewPairs) ? 1 : 0;
+    }
     const unsigned long long magic = (1ull << 32) / (unsigned long long)window_us;
     G.win_magic = magic > 0xffffffffull ? 0xffffffffu : (uint32_t)magic;
 
@@ -1165,14 +1869,101 @@ int frlw_taf_encode_batch(const frlw_events_t *ev, const int64_t *seq_offsets, c
     q.seg0 = (const uint32_t *)(w8 + p.off_seg0);
     q.segcnt = (uint32_t *)(w8 + p.off_segcnt);
     q.pairs = p.pairs;
+    q.skip_whole = 0;
+    q.first_block = 0;
+    q.tile_walk = G.order_check;
+    q.tile_max = whole_max_of(p.pairs);
     q.tlut = (const float *)(w8 + p.off_tlut);
     q.leaky_thr = (const uint32_t *)(w8 + p.off_leaky);
     q.hdr = (FastHeader *)w8;
     q.state = state; q.view_f32 = view_f32; q.out_u8 = out_u8;
     hipLaunchKernelGGL(kf_split_whole, dim3(p.pairs + p.max_segs), dim3(kFT), 0, st, q); // tiles, then segment counts
     hipLaunchKernelGGL(kf_split_place, dim3(p.max_segs), dim3(kFT), 0, st, q);
+    if (q.tile_walk) { // tiles of window-sorted sequences below the skew limit: split in LDS by the kernel that consumes them
+        const int grid = (p.pairs + 7) / 8 * 8;
+        if (K == 8) hipLaunchKernelGGL((kf_taf_tile<kFW, true>), dim3(grid), dim3(kFT), 0, st, q);
+        else hipLaunchKernelGGL((kf_taf_tile<kFW, false>), dim3(grid), dim3(kFT), 0, st, q);
+    }
     if (K == 8) hipLaunchKernelGGL(kf_taf_walk<true>, dim3(p.pairs * kFW), dim3(kWalkThreads), 0, st, q);
     else hipLaunchKernelGGL(kf_taf_walk<false>, dim3(p.pairs * kFW), dim3(kWalkThreads), 0, st, q);
+    HIP_TRY(hipGetLastError());
+    return FRLW_OK;
+}
+
+size_t frlw_ev_batch_workspace_bytes(int64_t n_events, int n_seq, int H, int W, int64_t window_us)
+{
+    return frlw_taf_batch_workspace_bytes(n_events, n_seq, H, W, window_us); // same partition, same tables
+}
+
+int frlw_ev_encode_batch(const frlw_events_t *ev, const int64_t *seq_offsets, const int64_t *t_end, int n_seq, int H, int W,
+                         int bins, int64_t window_us, float *out_f32, uint8_t *out_u8, void *workspace,
+                         size_t workspace_bytes, frlw_stream_t stream)
+{
+    if (!ev || !seq_offsets || !t_end || !workspace || (!out_f32 && !out_u8)) return FRLW_ERR_ARG;
+    if (bins < 1 || bins > FRLW_MAX_BINS || window_us < 1 || n_seq < 1 || n_seq > kMaxSeq) return FRLW_ERR_ARG;
+    if (ev->layout != FRLW_LAYOUT_DAT8) return FRLW_ERR_UNSUPPORTED;
+    if ((ev->xmap == nullptr) != (ev->ymap == nullptr)) return FRLW_ERR_ARG;
+    if (seq_offsets[0] < 0 || seq_offsets[n_seq] > ev->n) return FRLW_ERR_ARG;
+    if (seq_offsets[n_seq] > seq_offsets[0] && !ev->data) return FRLW_ERR_ARG;
+    int rb = 0; // record = (t - t_begin) | cell in 32 bits
+    while ((1ll << rb) <= window_us) ++rb;
+    if (kCellBits + rb > 32) return FRLW_ERR_UNSUPPORTED;
+    const long long n = seq_offsets[n_seq] - seq_offsets[0];
+    FastPlan p;
+    if (!fast_plan(n, n_seq, H, W, p)) return FRLW_ERR_UNSUPPORTED;
+    SeqTab S;
+    int64_t t_begin[kMaxSeq];
+    for (int s = 0; s < n_seq; ++s) t_begin[s] = t_end[s] - window_us; // generate_eventvolume.py:139-141
+    if (!fast_layout(seq_offsets, t_begin, n_seq, p, S, (uint32_t)window_us)) return FRLW_ERR_ARG;
+    if (workspace_bytes < p.bytes) return FRLW_ERR_WORKSPACE;
+    if (scatter_lds_bytes(p.T, p.chunk) > 160 * 1024) return FRLW_ERR_UNSUPPORTED;
+
+    FastGeom G;
+    G.data = (const uint2 *)ev->data;
+    G.xmap = ev->xmap; G.ymap = ev->ymap; G.map_w = ev->map_w; G.map_h = ev->map_h;
+    G.H = H; G.W = W; G.twl = p.twl; G.thl = p.thl; G.tiles_x = p.tiles_x; G.T = p.T; G.bpw = p.bpw;
+    G.chunk_ev = p.chunk; G.run = p.chunk / kFW; G.n_total = ev->n;
+    G.n_windows = 1; G.wb = 0; G.win = (uint32_t)window_us; G.win_magic = 0u; G.order_check = 0;
+
+    hipStream_t st = (hipStream_t)stream;
+    char *w8 = (char *)workspace;
+    (void)hipGetLastError();
+    {
+        const int ok = lds_order_ok(w8, st); // cached per device after the first call
+        if (ok != FRLW_OK) return ok;
+    }
+    if (ev->xmap) launch_fast<true, true>(G, S, p, w8, st);
+    else launch_fast<false, true>(G, S, p, w8, st);
+    const bool tile_walk = p.pairs >= kFewPairs;
+    TileP q;
+    memset(&q, 0, sizeof(q));
+    q.T = p.T; q.pairs = p.pairs; q.skip_whole = tile_walk ? 1 : 0;
+    q.rec = (const uint32_t *)(w8 + p.off_records);
+    q.rec2 = (uint32_t *)(w8 + p.off_records2);
+    q.base = (const uint32_t *)(w8 + p.off_base);
+    q.sub = (uint32_t *)(w8 + p.off_sub);
+    q.seg0 = (const uint32_t *)(w8 + p.off_seg0);
+    q.segcnt = (uint32_t *)(w8 + p.off_segcnt);
+    q.hdr = (FastHeader *)w8;
+    q.first_block = tile_walk ? p.pairs : 0; // with the tile walk only the segment-counting blocks have work
+    hipLaunchKernelGGL(kf_split_whole, dim3(p.pairs + p.max_segs - q.first_block), dim3(kFT), 0, st, q); // tiles, then segment counts
+    hipLaunchKernelGGL(kf_split_place, dim3(p.max_segs), dim3(kFT), 0, st, q);
+    EvTileP e;
+    e.H = H; e.W = W; e.twl = p.twl; e.thl = p.thl; e.tiles_x = p.tiles_x; e.T = p.T; e.bins = bins; e.win = (uint32_t)window_us;
+    e.rec = q.rec; e.rec2 = q.rec2; e.base = q.base; e.sub = q.sub; e.pairs = p.pairs; e.tile_max = whole_max_of(p.pairs);
+    e.tlut = (const float *)(w8 + p.off_tlut); e.hdr = (FastHeader *)w8; e.out_f32 = out_f32; e.out_u8 = out_u8;
+    const int sub_grid = (p.pairs * kFW + 3) / 4;
+    if (tile_walk) {
+#ifndef FRLW_EV_NW
+#define FRLW_EV_NW 16
+#endif
+        constexpr int NW = FRLW_EV_NW, PARTS = kFW / NW;
+        const int grid = (p.pairs + 7) / 8 * 8 * PARTS;
+        if (bins <= 5) hipLaunchKernelGGL((kf_ev_tile<NW, 5>), dim3(grid), dim3(NW * kWave), 0, st, e);
+        else hipLaunchKernelGGL((kf_ev_tile<NW, kMaxK>), dim3(grid), dim3(NW * kWave), 0, st, e);
+    }
+    if (bins <= 5) hipLaunchKernelGGL((kf_ev_sub<5>), dim3(sub_grid), dim3(4 * kWave), 0, st, e, tile_walk ? 0 : 1);
+    else hipLaunchKernelGGL((kf_ev_sub<kMaxK>), dim3(sub_grid), dim3(4 * kWave), 0, st, e, tile_walk ? 0 : 1);
     HIP_TRY(hipGetLastError());
     return FRLW_OK;
 }

@@ -110,10 +110,9 @@ def _events_dat(dat, xmap=None, ymap=None):
 
 
 def _finish(ws, what):
-    """Synchronise and surface data-dependent errors the way torch would (IndexError)."""
-    st = C.c_int(0)
-    _lib.check(_lib.load().frlw_encoder_status(_ptr(ws), _stream(), C.byref(st)), what)
-    _lib.check(st.value, what)
+    """Synchronise and surface data-dependent errors the way torch would (IndexError): the status of this call and of any
+    unchecked call on the same workspace before it, read and cleared in one go (``frlw_encoder_deferred_status``)."""
+    _raise_deferred_of(ws, what)
 
 
 def coordinate_maps(sensor_shape, shape, device):
@@ -384,6 +383,36 @@ def encode_ev_dat(dat, shape, t_end, window_us, volume_bins=5, want_f32=True, wa
                                           _ptr(u8), _ptr(ws), ws.numel(), _stream()), "encode_ev_dat")
     if check:
         _finish(ws, "encode_ev_dat")
+    return out, u8
+
+
+def encode_ev_batch(dat, seq_offsets, shape, t_end, window_us, volume_bins=5, want_f32=True, want_u8=False, xmap=None, ymap=None,
+                    check=True):
+    """generate_eventvolume.py:139-157 for a batch of independent label windows in one launch sequence
+    (``frlw_ev_encode_batch``, csrc/taf_fast.hip): sequence ``s`` owns the records ``[seq_offsets[s], seq_offsets[s + 1])`` of
+    ``dat`` and ends at ``t_end[s]`` (an int applies to all); events with ``t <= t_end - window_us`` are dropped like the
+    harness does.  Returns ``(f32 (B, 2 * bins, H, W) or None, u8 or None)`` -- bit for bit what ``encode_ev_dat`` gives per
+    sequence.  An event behind its ``t_end`` is outside the contract: with ``check`` it raises ``ValueError`` (nothing is
+    written); unchecked callers owe a ``raise_deferred()``.  ``NotImplementedError``: shape / window outside the path."""
+    H, W = int(shape[0]), int(shape[1])
+    offs = [int(o) for o in seq_offsets]
+    B = len(offs) - 1
+    if B < 1 or B > _lib.MAX_SEQUENCES:
+        raise ValueError(f"1..{_lib.MAX_SEQUENCES} sequences per call")
+    te = [int(t_end)] * B if not hasattr(t_end, "__len__") else [int(t) for t in t_end]
+    d, desc = _events_dat(dat, xmap, ymap)
+    ws = _batch_workspace(offs[-1] - offs[0], B, H, W, window_us, d.device)
+    if ws is None:
+        raise NotImplementedError("shape outside the batched Event Volume path")
+    out = torch.empty((B, 2 * volume_bins, H, W), dtype=torch.float32, device=d.device) if want_f32 else None
+    u8 = torch.empty((B, 2 * volume_bins, H, W), dtype=torch.uint8, device=d.device) if want_u8 else None
+    rc = _lib.load().frlw_ev_encode_batch(C.byref(desc), (C.c_int64 * (B + 1))(*offs), (C.c_int64 * B)(*te), B, H, W,
+                                          int(volume_bins), int(window_us), _ptr(out), _ptr(u8), _ptr(ws), ws.numel(), _stream())
+    if rc == _lib.FRLW_ERR_UNSUPPORTED:
+        raise NotImplementedError("window / shape outside the batched Event Volume path")
+    _lib.check(rc, "encode_ev_batch")
+    if check:
+        _finish(ws, "encode_ev_batch")
     return out, u8
 
 

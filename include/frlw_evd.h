@@ -66,6 +66,8 @@ typedef struct frlw_tuning {
     int32_t staged_scatter;   /* 0 / 1: records leave the partition through an LDS staging area */
     int32_t quarter_below;    /* frames with at most this many wavefronts run every tile as four quarter workgroups */
     int32_t no_value_table;   /* 1: TAF DAT8 computes the f64 division per event instead of the per-call table */
+    int32_t taf_tile_walk;    /* frlw_taf_encode_batch: 1 = tiles are split in LDS by the kernel that walks them (kf_taf_tile:
+                               * less HBM traffic, measured slower), 0 = split pass + sub-tile kernel (the default) */
 } frlw_tuning_t;
 
 typedef struct frlw_events {
@@ -181,6 +183,21 @@ size_t frlw_taf_batch_workspace_bytes(int64_t n_events, int n_seq, int H, int W,
 int frlw_taf_encode_batch(const frlw_events_t *ev, const int64_t *seq_offsets, const int64_t *t_start, int n_seq, int H,
                           int W, int K, int64_t window_us, int n_windows, float *state, float *view_f32,
                           uint8_t *out_u8, int flags, void *workspace, size_t workspace_bytes, frlw_stream_t stream);
+
+/*
+ * Event Volume for a batch of independent streams -- the harness lines generate_eventvolume.py:139-157 (window cut,
+ * f64 normalisation) around generate_agile_event_volume_cuda (:15-42) for n_seq <= FRLW_MAX_SEQUENCES label windows in one
+ * launch sequence.  Sequence s owns the DAT8 records [seq_offsets[s], seq_offsets[s + 1]) and ends at t_end[s] (HOST
+ * arrays): events with t <= t_end[s] - window_us are dropped (:139), t <- (t - (t_end[s] - window_us)) / window_us in f64
+ * (:141).  out_f32 (n_seq, 2 * bins, H, W) and / or out_u8 (the same clipped at 255 and truncated, :155-157).
+ * Bit-identical to n_seq calls of frlw_ev_encode.  Differences in contract: DAT8 only; window_us < 2^20; an event with
+ * t > t_end[s] is reported by frlw_encoder_status() as FRLW_ERR_SPAN and NOTHING is written (frlw_ev_encode places it).
+ * Workspace: frlw_ev_batch_workspace_bytes(total events, n_seq, H, W, window_us); 0 = unsupported shape.
+ */
+size_t frlw_ev_batch_workspace_bytes(int64_t n_events, int n_seq, int H, int W, int64_t window_us);
+int frlw_ev_encode_batch(const frlw_events_t *ev, const int64_t *seq_offsets, const int64_t *t_end, int n_seq, int H, int W,
+                         int bins, int64_t window_us, float *out_f32, uint8_t *out_u8, void *workspace,
+                         size_t workspace_bytes, frlw_stream_t stream);
 
 /* Self-test of the gfx950 properties frlw_taf_encode_batch relies on, for the lanes of one LDS atomic instruction that
  * hit the same address: a returning integer add serves them in ascending lane order, and ds_add_f32 applies them in that

@@ -128,7 +128,7 @@ def test_nms_kernel_on_crafted_boxes(gpu):
     ptrs = (C.c_void_p * len(bufs))(*[None] + [C.c_void_p(t.data_ptr()) for t in bufs[1:]])
     _lib.check(eng.lib.frlw_det_run(eng.handle, B, ptrs, len(bufs), eng.n_forward_ops, -1,
                                     C.c_void_p(torch.cuda.current_stream().cuda_stream)))
-    counts = bufs[eng.counts_buf].cpu().tolist()
+    counts = bufs[eng.counts_buf].view(B, 1 + eng.A)[:, 0].cpu().tolist()  # per image: [count, A ints of scratch]
     dets = bufs[eng.dets_buf].view(B, A, 6)
     m.head.hw = [(32, 40), (16, 20), (8, 10)]
     want = m.head.decode_outputs(raw.to(gpu))
@@ -149,7 +149,7 @@ def _device_postprocess(m, raw, gpu):
     ptrs = (C.c_void_p * len(bufs))(*[None] + [C.c_void_p(t.data_ptr()) for t in bufs[1:]])
     _lib.check(eng.lib.frlw_det_run(eng.handle, B, ptrs, len(bufs), eng.n_forward_ops, -1,
                                     C.c_void_p(torch.cuda.current_stream().cuda_stream)))
-    return bufs[eng.counts_buf].cpu().tolist(), bufs[eng.dets_buf].view(B, eng.A, 6).cpu()
+    return bufs[eng.counts_buf].view(B, 1 + eng.A)[:, 0].cpu().tolist(), bufs[eng.dets_buf].view(B, eng.A, 6).cpu()
 
 
 @pytest.mark.parametrize("case", ["b4", "craft"])

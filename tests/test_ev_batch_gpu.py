@@ -1,0 +1,105 @@
+"""The batched Event Volume path (csrc/taf_fast.hip, ``frlw_ev_encode_batch``) against the CPU oracle (pinned to the
+reference's goldens, tests/test_oracle_golden.py), the reference-generated GEN1 goldens and the general path
+(``frlw_ev_encode``), bit for bit.  Harness semantics: generate_eventvolume.py:139-157 per label window."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from frlw_evd_amd import synth  # noqa: E402
+from golden_util import assert_bitexact  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def er():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from frlw_evd_amd import event_representation
+    return event_representation
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+    return oracle
+
+
+def to_dev(rec):
+    return torch.from_numpy(np.ascontiguousarray(rec).view(np.uint8).reshape(-1, 8).copy()).cuda()
+
+
+def host(t):
+    return t.cpu().numpy()
+
+
+@pytest.mark.parametrize("tag,hot", [("", False), ("hot_", True)])
+def test_gen1_golden_single_sequence(er, golden_dir, tag, hot):
+    """BASELINE.json configs[1] (1 M events, 304x240, 5 bins) through the batch entry point with one sequence: the sha256
+    of the reference's own output."""
+    g = np.load(os.path.join(golden_dir, "gen1_ev.npz"))
+    H, W = 240, 304
+    rec = synth.to_dat8(synth.synth_events(1002, 1_000_000, W, H, 250_000, hotspot=hot))
+    out, _ = er.encode_ev_batch(to_dev(rec), [0, len(rec)], (H, W), 250_000, 250_000, 5)
+    assert hashlib.sha256(host(out[0]).tobytes()).hexdigest() == str(g[tag + "native_sha"])
+
+
+@pytest.mark.parametrize("bins", [1, 2, 5, 8])
+def test_batch_vs_oracle_and_general_path(er, orc, bins):
+    """Eight label windows in one call (320 (sequence, tile) pairs -> the tile walk): own t_end each, a sparse one, an empty
+    one, one with a hot spot, one unsorted, one with events in front of its window (dropped like the harness' time filter)
+    and events exactly on t_end."""
+    H, W, B, win = 240, 304, 8, 50_000
+    t_end = [50_000, 50_000, 1_050_000, 50_000, 50_000, 80_000, 50_000, 50_000]
+    recs = []
+    for j in range(B):
+        n = 200_000 if j != 1 else 3_000
+        ev = synth.synth_events(700 + j, n, W, H, win, hotspot=(j == 3), t_offset=t_end[j] - win + 1)
+        ev["t"][-2:] = t_end[j]                      # exactly the end of the window: t* = bins
+        if j == 5:
+            ev["t"][:5000] -= 30_000                 # in front of the window: dropped (generate_eventvolume.py:139)
+        keep = np.ones(n, bool) if j != 2 else np.zeros(n, bool)
+        r = synth.to_dat8({k: v[keep] for k, v in ev.items()})
+        if j == 6:
+            r = r[np.random.default_rng(2).permutation(len(r))]
+        recs.append(r)
+    offs = np.concatenate([[0], np.cumsum([len(r) for r in recs])])
+    dat = to_dev(np.concatenate(recs))
+    out, u8 = er.encode_ev_batch(dat, offs, (H, W), t_end, win, bins, want_u8=True)
+    assert out.shape == (B, 2 * bins, H, W)
+    for j in range(B):
+        want = orc.ev_stream_dat8(recs[j], (H, W), (H, W), bins, t_end[j], win)
+        assert_bitexact(host(out[j]), want, f"sequence {j}")
+        if len(recs[j]):
+            oj, uj = er.encode_ev_dat(to_dev(recs[j]), (H, W), t_end[j], win, bins, want_u8=True)
+            assert torch.equal(oj, out[j]) and torch.equal(uj, u8[j]), f"general path, sequence {j}"
+    assert float(out[2].abs().sum()) == 0.0          # the empty sequence: an all-zero volume
+    assert float(out[0].max()) > 0
+
+
+def test_few_pairs_and_downscale_maps(er, orc):
+    """A single 1 Mpx stream down-scaled to 512 x 640 by the coordinate maps (generate_eventvolume.py:143-146): 90 pairs,
+    so every tile goes through the segment split + kf_ev_sub."""
+    Hs, Ws, H, W, win = 720, 1280, 512, 640, 80_000
+    xmap, ymap = er.coordinate_maps((Hs, Ws), (H, W), "cuda")
+    rec = synth.to_dat8(synth.synth_events(1013, 600_000, Ws, Hs, win, hotspot=True, t_offset=1))
+    out, _ = er.encode_ev_batch(to_dev(rec), [0, len(rec)], (H, W), win, win, 5, xmap=xmap, ymap=ymap)
+    assert_bitexact(host(out[0]), orc.ev_stream_dat8(rec, (Hs, Ws), (H, W), 5, win, win), "down-scaled volume")
+
+
+def test_event_behind_the_window_is_outside_the_contract(er):
+    H, W, win = 64, 96, 10_000
+    ev = synth.synth_events(5, 20_000, W, H, win, t_offset=1)
+    ev["t"][-1] = win + 7   # behind t_end
+    dat = to_dev(synth.to_dat8(ev))
+    with pytest.raises(ValueError):
+        er.encode_ev_batch(dat, [0, len(ev["t"])], (H, W), win, win, 5)
+    er.encode_ev_batch(dat, [0, len(ev["t"])], (H, W), win, win, 5, check=False)
+    with pytest.raises(ValueError):
+        er.raise_deferred()
+    with pytest.raises(NotImplementedError):  # window beyond the 20 bits of the 4-byte record
+        er.encode_ev_batch(dat, [0, len(ev["t"])], (H, W), 2_000_000, 2_000_000, 5)

@@ -255,3 +255,48 @@ def test_failed_lane_order_selftest_disables_the_fast_path(er, orc):
     st = torch.from_numpy(st0.copy()).cuda()
     er.encode_taf_batch(to_dev(rec), [0, len(rec)], (H, W), st.view(1, H, W, 2, K), 0, 10_000, 8, K)
     assert_bitexact(host(st), ost, "fast path after the real self-test passed")
+
+
+# ---- the tile walk (kf_taf_tile, frlw_tuning_t::taf_tile_walk = 1): same bits as the default split + sub-tile kernels ----
+def _batch(seed, B, n, H, W, span, hotspot=False):
+    recs = [synth.to_dat8(synth.synth_events(seed + j, n if j != 2 else n // 40, W, H, span, hotspot=hotspot)) for j in range(B)]
+    return recs, np.concatenate([[0], np.cumsum([len(r) for r in recs])])
+
+
+@pytest.mark.parametrize("K,n_win,win", [(8, 8, 10_000), (4, 3, 977), (5, 16, 5_000)])
+def test_tile_walk_equals_default_path(er, monkeypatch, K, n_win, win):
+    """A batch with >= 256 (sequence, tile) pairs, one sparse sequence, one sequence with an empty window and one whose
+    stream is NOT time-sorted (the tile walk needs window-sorted lists: kf_scatter flags it and it takes the default
+    kernels inside the same call), plus a hot spot that pushes tiles over the segment limit."""
+    from frlw_evd_amd import _lib
+    H, W, B = 240, 304, 8  # 40 tiles per sequence -> 320 pairs
+    recs, _ = _batch(4400 + K, B, 260_000, H, W, n_win * win, hotspot=True)
+    r4 = recs[4]
+    recs[4] = r4[(r4["t"] // win) != 1]                       # no event in window 1 of sequence 4
+    recs[5] = recs[5][np.random.default_rng(9).permutation(len(recs[5]))]  # unsorted sequence
+    recs[6] = np.concatenate([recs[6]] * 3)                   # time runs backwards twice, 3x the events
+    offs = np.concatenate([[0], np.cumsum([len(r) for r in recs])])
+    dat = to_dev(np.concatenate(recs))
+    init = torch.from_numpy(np.random.default_rng(3).uniform(-50, 0, (B, H, W, 2, K)).astype(np.float32)).cuda()
+    sa, sb = init.clone(), init.clone()
+    ua, va = er.encode_taf_batch(dat, offs, (H, W), sa, 0, win, n_win, K, want_view=True)
+    monkeypatch.setattr(er, "TUNING", _lib.FrlwTuning(taf_tile_walk=1))
+    ub, vb = er.encode_taf_batch(dat, offs, (H, W), sb, 0, win, n_win, K, want_view=True)
+    assert not torch.equal(sa, init)
+    assert torch.equal(sa, sb), "state"
+    assert torch.equal(va, vb), "view"
+    assert torch.equal(ua, ub), "uint8"
+
+
+def test_tile_walk_mpx_golden(er, monkeypatch, golden_dir):
+    """The reference's own 10 M-event 1280x720 state (sha256 golden) through the tile walk."""
+    import hashlib
+    import os
+    from frlw_evd_amd import _lib
+    g = np.load(os.path.join(golden_dir, "mpx_taf_native.npz"))
+    H, W, K = 720, 1280, 8
+    rec = synth.to_dat8(synth.synth_events(1003, 10_000_000, W, H, 80_000))
+    st = torch.full((1, H, W, 2, K), -6000.0, device="cuda")
+    monkeypatch.setattr(er, "TUNING", _lib.FrlwTuning(taf_tile_walk=1))
+    er.encode_taf_batch(to_dev(rec), [0, len(rec)], (H, W), st, 0, 10_000, 8, K)
+    assert hashlib.sha256(host(st[0]).tobytes()).hexdigest() == str(g["state_sha"])
