@@ -53,7 +53,10 @@ constexpr int kFastSlab = 32;             // chunks per slab of the two-level co
 constexpr int ST_MULBAD = 8;              // per-chunk flag next to the ST_* error bits (not an error)
 constexpr int kSplitSeg = 8192;           // records one workgroup of the sub-tile split handles
 constexpr int kSplitWhole = 8 * kSplitSeg; // tiles up to this many records are split by ONE workgroup (kf_split_whole) ...
-constexpr int kFewPairs = 256;             // ... unless the call has fewer (sequence, tile) pairs than this: one workgroup per
+#ifndef FRLW_FEW_PAIRS
+#define FRLW_FEW_PAIRS 256
+#endif
+constexpr int kFewPairs = FRLW_FEW_PAIRS;             // ... unless the call has fewer (sequence, tile) pairs than this: one workgroup per
                                            // tile would leave most CUs idle (one GEN1 stream: 20 tiles of 50 000 records took
                                            // 31 us), so every tile above one segment goes through the segment kernels
 __host__ __device__ inline uint32_t whole_max_of(int pairs) { return pairs < kFewPairs ? (uint32_t)kSplitSeg : (uint32_t)kSplitWhole; }
@@ -473,7 +476,8 @@ __host__ __device__ inline size_t scatter_lds_bytes(int T, int chunk)
     return (size_t)kFW * T * 4 + (size_t)(T + 2) * 4 + (size_t)chunk * 4 + (size_t)chunk * 2 + 16;
 }
 
-template <bool HAS_MAP, bool EV = false>
+template <bool HAS_MAP, bool EV = false, bool ORDER = false> // ORDER: flag sequences whose window index ever decreases (a
+// template parameter on purpose: as a run-time flag the mere presence of the check cost this kernel 35 %, measured)
 __global__ __launch_bounds__(kFT) void kf_scatter(FastGeom G, SeqTab S, const uint32_t *counts, const uint32_t *slabtot,
                                                   const uint32_t *base, uint32_t *records, FastHeader *hdr)
 {
@@ -502,7 +506,6 @@ __global__ __launch_bounds__(kFT) void kf_scatter(FastGeom G, SeqTab S, const ui
     // the event in front of this wavefront's run (same sequence), for the window-order check below: requested first, so
     // that it is back first (loads return in order)
     uint2 qprev = make_uint2(0u, 0u);
-    const bool ORDER = !EV && G.order_check != 0; // (wave-uniform) the window-order check only matters to the tile walk
     const bool has_prev = ORDER && nloc > 0 && wave_begin > S.ev0[s];
     if (ORDER && nloc > 0) qprev = G.data[has_prev ? wave_begin - 1 : wave_begin];
     uint2 q[kMaxBpw];
@@ -687,6 +690,25 @@ __device__ __forceinline__ int pair_of_segment(const uint32_t *seg0, int pairs, 
     return lo;
 }
 
+// Count the records of rec[beg, end) per (wavefront, sub-tile) into wtot: eight loads in flight per thread (indices
+// clamped, values masked -- a load under a lane condition, or one load per loop iteration, is one exposed round trip each:
+// a 22 000-record tile took 22 of them).
+__device__ __forceinline__ void count_subtiles(const uint32_t *rec, uint32_t beg, uint32_t end, uint32_t (*wtot)[kFW])
+{
+    const int tid = threadIdx.x, wv = tid >> 6;
+    for (uint32_t c0 = beg; c0 < end; c0 += 8 * kFT) {
+        uint32_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t i = c0 + (uint32_t)(u * kFT + tid);
+            v[u] = rec[i < end ? i : end - 1u];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (c0 + (uint32_t)(u * kFT + tid) < end) atomicAdd(&wtot[wv][(v[u] & (kCells - 1)) >> 8], 1u);
+    }
+}
+
 __device__ __forceinline__ void split_count_segment(const TileP &q, uint32_t seg, uint32_t (*wtot)[kFW])
 {
     const int tid = threadIdx.x, wv = tid >> 6;
@@ -696,7 +718,7 @@ __device__ __forceinline__ void split_count_segment(const TileP &q, uint32_t seg
     const uint32_t end = q.base[g + 1] - beg < (uint32_t)kSplitSeg ? q.base[g + 1] : beg + kSplitSeg;
     if (tid < kFW * kFW) (&wtot[0][0])[tid] = 0u;
     __syncthreads();
-    for (uint32_t i = beg + tid; i < end; i += kFT) atomicAdd(&wtot[wv][(q.rec[i] & (kCells - 1)) >> 8], 1u);
+    count_subtiles(q.rec, beg, end, wtot);
     __syncthreads();
     if (tid < kFW) {
         uint32_t t = 0;
@@ -732,7 +754,7 @@ __global__ __launch_bounds__(kFT) void kf_split_whole(TileP q)
     if (q.tile_walk && q.hdr->unsorted[g / q.T] == 0u) return;     // split in LDS by kf_taf_tile
     if (tid < kFW * kFW) (&wtot[0][0])[tid] = 0u;
     __syncthreads();
-    for (uint32_t i = beg + tid; i < end; i += kFT) atomicAdd(&wtot[wv][(q.rec[i] & (kCells - 1)) >> 8], 1u);
+    count_subtiles(q.rec, beg, end, wtot);
     __syncthreads();
     if (tid < kFW) {
         uint32_t t = 0;
@@ -920,12 +942,25 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_waves_per_eu(8,
     const int rshift = kCellBits + q.wb;
     __syncthreads();
     // ---- phase 0: first record of every window; a window index that decreases = not window-sorted
-    for (uint32_t i = beg + tid; i < end; i += kWalkThreads) {
-        const uint32_t w = (q.rec2[i] >> kCellBits) & wfield;
-        const uint32_t wp = i > beg ? (q.rec2[i - 1] >> kCellBits) & wfield : 0xffffffffu;
-        if (wp == 0xffffffffu || w != wp) {
-            if (wp != 0xffffffffu && w < wp) s_unsorted = 1;
-            atomicMin(&wstart[w], i);
+    for (uint32_t c0 = beg; c0 < end; c0 += 4 * kWalkThreads) { // (eight clamped loads in flight, then the compares)
+        uint32_t cw[4], pw[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t i = c0 + (uint32_t)(u * kWalkThreads + tid), ic = i < end ? i : end - 1u;
+            cw[u] = q.rec2[ic];
+            pw[u] = q.rec2[ic > beg ? ic - 1u : beg];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t i = c0 + (uint32_t)(u * kWalkThreads + tid);
+            if (i < end) {
+                const uint32_t w = (cw[u] >> kCellBits) & wfield;
+                const uint32_t wp = i > beg ? (pw[u] >> kCellBits) & wfield : 0xffffffffu;
+                if (wp == 0xffffffffu || w != wp) {
+                    if (wp != 0xffffffffu && w < wp) s_unsorted = 1;
+                    atomicMin(&wstart[w], i);
+                }
+            }
         }
     }
     __syncthreads();
@@ -1724,8 +1759,10 @@ void launch_fast(const FastGeom &G, const SeqTab &S, const FastPlan &p, char *w8
     uint32_t *leaky = (uint32_t *)(w8 + p.off_leaky);
     uint32_t *records = (uint32_t *)(w8 + p.off_records);
     const size_t lds_sc = scatter_lds_bytes(p.T, p.chunk);
-    if (lds_sc > 64 * 1024)
-        (void)hipFuncSetAttribute((const void *)kf_scatter<HAS_MAP, EV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc);
+    if (lds_sc > 64 * 1024) {
+        (void)hipFuncSetAttribute((const void *)kf_scatter<HAS_MAP, EV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc);
+        if (!EV) (void)hipFuncSetAttribute((const void *)kf_scatter<HAS_MAP, EV, !EV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc);
+    }
     const int hist_grid = p.chunks < 512 ? p.chunks : 512; // persistent: two workgroups per CU
     hipLaunchKernelGGL((kf_hist<HAS_MAP, EV>), dim3(hist_grid), dim3(kFT), (size_t)p.T * 4, st, G, S, counts, errs, tlut, leaky, p.chunks);
     const bool inline_slabs = (long long)p.slabs * p.T <= kInlineSlabScan;
@@ -1733,7 +1770,10 @@ void launch_fast(const FastGeom &G, const SeqTab &S, const FastPlan &p, char *w8
         hipLaunchKernelGGL(kf_slabscan, dim3((p.T + kWave - 1) / kWave, p.slabs), dim3(kWave), 0, st, S, counts, p.T, slabtot);
     hipLaunchKernelGGL(kf_tilescan, dim3(1), dim3(kFT), 0, st, S, slabtot, p.T, base, (uint32_t *)(w8 + p.off_seg0), hdr, errs,
                        p.chunks, inline_slabs ? counts : (uint32_t *)nullptr, p.slabs);
-    hipLaunchKernelGGL((kf_scatter<HAS_MAP, EV>), dim3(p.chunks), dim3(kFT), lds_sc, st, G, S, counts, slabtot, base, records, hdr);
+    if (!EV && G.order_check)
+        hipLaunchKernelGGL((kf_scatter<HAS_MAP, EV, !EV>), dim3(p.chunks), dim3(kFT), lds_sc, st, G, S, counts, slabtot, base, records, hdr);
+    else
+        hipLaunchKernelGGL((kf_scatter<HAS_MAP, EV, false>), dim3(p.chunks), dim3(kFT), lds_sc, st, G, S, counts, slabtot, base, records, hdr);
 }
 
 // ---- one-time check of the hardware property this file rests on ------------------------------------------------------
