@@ -108,6 +108,22 @@ def roofline(alg_bytes, dev_ms, kernel, copy_gbs, units):
             "units_per_launch": units, "device_ms": round(dev_ms, 4), "traffic": None}
 
 
+def attach_traffic(roof, tag):
+    """roofline.traffic = HBM bytes per encode from the separate rocprofv3 --pmc passes kept under profiles/ (tools/refresh_r03.sh),
+    reported only while the kernel sources are the ones those passes measured."""
+    path = os.path.join(ROOT, "profiles", f"traffic_{tag}.json")
+    if not os.path.exists(path):
+        return roof
+    with open(path) as f:
+        tr = json.load(f)
+    if tr.get("kernel_source_sha") == kernel_source_sha():
+        roof["traffic"] = tr.get("hbm_bytes_per_encode")
+        roof["traffic_source"] = f"{os.path.relpath(path, ROOT)} (separate rocprofv3 --pmc passes, {tr.get('source')})"
+    else:
+        roof["traffic_note"] = "kernel sources changed since the PMC pass in profiles/: not reported"
+    return roof
+
+
 def copy_bandwidth(torch):
     """float32 copy of 1 GiB (read + write = 2 GiB of traffic) with torch's vectorised copy kernel."""
     a = torch.empty(256 << 20, dtype=torch.float32, device="cuda")
@@ -296,15 +312,7 @@ def main():
         },
         "roofline": roofline(alg_bytes, dev_ms, kernels, copy_gbs, f"{n} events"),
     }
-    traffic_file = os.path.join(ROOT, "profiles", f"traffic_{args.workload}{'_hotspot' if args.hotspot else ''}.json")
-    if os.path.exists(traffic_file):  # PMC passes are separate runs (tools/pmc_cmd.sh): per-encode HBM bytes
-        with open(traffic_file) as f:
-            tr = json.load(f)
-        if tr.get("kernel_source_sha") == kernel_source_sha():
-            result["roofline"]["traffic"] = tr.get("hbm_bytes_per_encode")
-            result["roofline"]["traffic_source"] = f"{os.path.relpath(traffic_file, ROOT)} (separate rocprofv3 --pmc passes, {tr.get('source')})"
-        else:
-            result["roofline"]["traffic_note"] = "kernel sources changed since the PMC pass in profiles/: not reported"
+    attach_traffic(result["roofline"], f"{args.workload}{'_hotspot' if args.hotspot else ''}")
     if use_fast:  # the general path on the same workload, for comparison
         st2 = state.clone()
         per2, dev2 = timer.run(lambda: er.encode_taf_dat(dat, (H, W), st2, 0, win_us, n_win, K, check=False, fast=False),
@@ -315,6 +323,8 @@ def main():
         result["also"] = bench_also(args, torch, synth, er, timer, rank, n_gpus, copy_gbs)
         # the shape BASELINE.json's metric names (GEN1 304x240), promoted: a block of its own and a compact copy inside
         # `roofline` (the keys the driver keeps when it parses the line)
+        for row, tag in zip(result["also"], ("taf_gen1", "taf_gen1_x64", "ev_gen1", "ev_gen1_x64", "taf_mpx_hotspot")):
+            attach_traffic(row["roofline"], tag)
         names = ("taf_single", "taf_x64", "ev_single", "ev_x64")
         result["gen1"] = {k: row for k, row in zip(names, result["also"][:4])}
         result["roofline"]["gen1"] = {k: {"Mevents_per_s": row["value"], "ms": row["ms_per_step"], "GBps": row["roofline"]["achieved"],

@@ -52,7 +52,10 @@ constexpr int kMaxPairs = 8192;           // (sequence, tile) pairs per call (LD
 constexpr int kFastSlab = 32;             // chunks per slab of the two-level column scan
 constexpr int ST_MULBAD = 8;              // per-chunk flag next to the ST_* error bits (not an error)
 constexpr int kSplitSeg = 8192;           // records one workgroup of the sub-tile split handles
-constexpr int kSplitWhole = 8 * kSplitSeg; // tiles up to this many records are split by ONE workgroup (kf_split_whole) ...
+#ifndef FRLW_WHOLE_SEGS
+#define FRLW_WHOLE_SEGS 4 /* measured: 8 -> 4 takes 7 % (TAF hot spot at 10 M events) to 15 % (Event Volume batch with hot spots) off skewed calls, uniform calls unchanged; 3 sends ordinary 25 000-record GEN1 tiles through the segments (+9 %) */
+#endif
+constexpr int kSplitWhole = FRLW_WHOLE_SEGS * kSplitSeg; // tiles up to this many records are split by ONE workgroup (kf_split_whole) ...
 #ifndef FRLW_FEW_PAIRS
 #define FRLW_FEW_PAIRS 256
 #endif
@@ -635,6 +638,7 @@ struct TileP {
     int skip_whole;        // 1: tiles up to the whole-tile limit are NOT re-sorted (a tile-walk kernel splits them in LDS) ...
     int tile_walk;         // ... TAF: unless their sequence is not window-sorted (hdr->unsorted)
     int first_block;       // kf_split_whole: block b does the work of block b + first_block
+    int seg_grid;          // segment workgroups launched (they stride over the segments: most calls have none)
     uint32_t tile_max;     // tiles with more records than this go through the segment split
     const float *tlut;
     const uint32_t *leaky_thr;
@@ -744,7 +748,11 @@ __global__ __launch_bounds__(kFT) void kf_split_whole(TileP q)
     const int blk = (int)blockIdx.x + q.first_block;
     if (blk >= q.pairs) { // the blocks behind the tiles: one segment of a skewed tile each (4b, counting)
         if (q.first_block && blk == q.pairs && tid == 0) q.sub[(long long)q.pairs * kFW] = q.base[q.pairs]; // (the last tile's block is not there to do it)
-        split_count_segment(q, (uint32_t)(blk - q.pairs), wtot);
+        const uint32_t nseg = q.seg0[q.pairs];
+        for (uint32_t seg = (uint32_t)(blk - q.pairs); seg < nseg; seg += (uint32_t)q.seg_grid) {
+            split_count_segment(q, seg, wtot);
+            __syncthreads(); // wtot is reused
+        }
         return;
     }
     const int g = blk;
@@ -823,13 +831,10 @@ __global__ __launch_bounds__(kFT) void kf_split_whole(TileP q)
 //                     counters: lanes of one instruction are served in lane order, (round, wavefront) is the stream
 //                     order of the 64-record batches.
 constexpr int kSplitRpt = kSplitSeg / kFT;
-__global__ __launch_bounds__(kFT) void kf_split_place(TileP q)
+__device__ __forceinline__ void split_place_segment(const TileP &q, uint32_t seg, uint32_t (*scnt)[kFW][kFW], uint32_t *vtot)
 {
     constexpr int RPT = kSplitRpt, NE = RPT * kFW;
-    __shared__ uint32_t scnt[RPT][kFW][kFW]; // [round][wavefront][sub-tile]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const uint32_t seg = blockIdx.x;
-    if (q.hdr->status != 0 || seg >= q.seg0[q.pairs]) return;
     const int g = pair_of_segment(q.seg0, q.pairs, seg);
     const uint32_t beg = q.base[g] + (seg - q.seg0[g]) * (uint32_t)kSplitSeg;
     const uint32_t end = q.base[g + 1] - beg < (uint32_t)kSplitSeg ? q.base[g + 1] : beg + kSplitSeg;
@@ -838,7 +843,6 @@ __global__ __launch_bounds__(kFT) void kf_split_place(TileP q)
     // where this segment's records of sub-tile v (= this wavefront) go: v's list starts behind the lists of the
     // sub-tiles before it, and the earlier segments of the tile come first inside it.  Every workgroup adds up the
     // tile's segment counts for itself (<= a few hundred segments x 16 values, L2-resident).
-    __shared__ uint32_t vtot[kFW];
     uint32_t before = 0, total = 0;
     for (uint32_t sg = q.seg0[g] + lane; sg < q.seg0[g + 1]; sg += kWave) {
         const uint32_t c = q.segcnt[(long long)sg * kFW + wv];
@@ -882,6 +886,18 @@ __global__ __launch_bounds__(kFT) void kf_split_place(TileP q)
     for (int u = 0; u < RPT; ++u) {
         const uint32_t i = (uint32_t)(u * kFT + tid);
         if (i < nrec) q.rec2[scnt[u][wv][(m[u] & (kCells - 1)) >> 8] + rk[u]] = m[u];
+    }
+}
+
+__global__ __launch_bounds__(kFT) void kf_split_place(TileP q)
+{
+    __shared__ uint32_t scnt[kSplitRpt][kFW][kFW]; // [round][wavefront][sub-tile]
+    __shared__ uint32_t vtot[kFW];
+    if (q.hdr->status != 0) return;
+    const uint32_t nseg = q.seg0[q.pairs];
+    for (uint32_t seg = blockIdx.x; seg < nseg; seg += gridDim.x) { // (workgroup-uniform: most calls have no segment at all)
+        split_place_segment(q, seg, scnt, vtot);
+        __syncthreads(); // scnt / vtot are reused
     }
 }
 
@@ -1911,14 +1927,15 @@ int frlw_taf_encode_batch(const frlw_events_t *ev, const int64_t *seq_offsets, c
     q.pairs = p.pairs;
     q.skip_whole = 0;
     q.first_block = 0;
+    q.seg_grid = p.max_segs < 2048 ? p.max_segs : 2048;
     q.tile_walk = G.order_check;
     q.tile_max = whole_max_of(p.pairs);
     q.tlut = (const float *)(w8 + p.off_tlut);
     q.leaky_thr = (const uint32_t *)(w8 + p.off_leaky);
     q.hdr = (FastHeader *)w8;
     q.state = state; q.view_f32 = view_f32; q.out_u8 = out_u8;
-    hipLaunchKernelGGL(kf_split_whole, dim3(p.pairs + p.max_segs), dim3(kFT), 0, st, q); // tiles, then segment counts
-    hipLaunchKernelGGL(kf_split_place, dim3(p.max_segs), dim3(kFT), 0, st, q);
+    hipLaunchKernelGGL(kf_split_whole, dim3(p.pairs + q.seg_grid), dim3(kFT), 0, st, q); // tiles, then segment counts
+    hipLaunchKernelGGL(kf_split_place, dim3(q.seg_grid), dim3(kFT), 0, st, q);
     if (q.tile_walk) { // tiles of window-sorted sequences below the skew limit: split in LDS by the kernel that consumes them
         const int grid = (p.pairs + 7) / 8 * 8;
         if (K == 8) hipLaunchKernelGGL((kf_taf_tile<kFW, true>), dim3(grid), dim3(kFT), 0, st, q);
@@ -1986,8 +2003,9 @@ int frlw_ev_encode_batch(const frlw_events_t *ev, const int64_t *seq_offsets, co
     q.segcnt = (uint32_t *)(w8 + p.off_segcnt);
     q.hdr = (FastHeader *)w8;
     q.first_block = tile_walk ? p.pairs : 0; // with the tile walk only the segment-counting blocks have work
-    hipLaunchKernelGGL(kf_split_whole, dim3(p.pairs + p.max_segs - q.first_block), dim3(kFT), 0, st, q); // tiles, then segment counts
-    hipLaunchKernelGGL(kf_split_place, dim3(p.max_segs), dim3(kFT), 0, st, q);
+    q.seg_grid = p.max_segs < 2048 ? p.max_segs : 2048;
+    hipLaunchKernelGGL(kf_split_whole, dim3(p.pairs + q.seg_grid - q.first_block), dim3(kFT), 0, st, q); // tiles, then segment counts
+    hipLaunchKernelGGL(kf_split_place, dim3(q.seg_grid), dim3(kFT), 0, st, q);
     EvTileP e;
     e.H = H; e.W = W; e.twl = p.twl; e.thl = p.thl; e.tiles_x = p.tiles_x; e.T = p.T; e.bins = bins; e.win = (uint32_t)window_us;
     e.rec = q.rec; e.rec2 = q.rec2; e.base = q.base; e.sub = q.sub; e.pairs = p.pairs; e.tile_max = whole_max_of(p.pairs);

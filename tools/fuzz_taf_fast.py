@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from frlw_evd_amd import event_representation as er, synth  # noqa: E402
+from frlw_evd_amd import _lib, event_representation as er, synth  # noqa: E402
 
 
 def dev(rec):
@@ -34,6 +34,11 @@ def main():
         W = int(rng.integers(8, 700)) if rng.random() < 0.7 else int(rng.integers(600, 1300))
         if B >= 16:
             H, W = min(H, 120), min(W, 160)
+        # every third case through the tile walk (kf_taf_tile; takes effect from 256 (sequence, tile) pairs on: make some)
+        tile_walk = case % 3 == 2
+        if tile_walk and rng.random() < 0.7:
+            B, H, W = int(rng.choice([8, 16, 33])), int(rng.integers(150, 260)), int(rng.integers(250, 420))
+        er.TUNING = _lib.FrlwTuning(taf_tile_walk=1) if tile_walk else None
         K = int(rng.choice([8, 8, 8, 5, 4, 1, 7]))
         n_win = int(rng.choice([1, 2, 3, 8, 8, 13, 64]))
         win = int(rng.choice([1_000, 10_000, 10_000, 7_777, 50_000]))
@@ -72,12 +77,13 @@ def main():
         except NotImplementedError:
             skipped += 1
             continue
+        er.TUNING = None
         for s in range(B):
             sj = torch.from_numpy(state0[s]).cuda()
             uj, vj = er.encode_taf_dat(dev(recs[s]), (H, W), sj, starts[s], win, n_win, K, want_view=True, flip_k=flip, fast=False)
             if not (torch.equal(sj, st[s]) and torch.equal(vj, view[s]) and torch.equal(uj, u8[s])):
                 bad += 1
-                print(f"MISMATCH case {case} seq {s}: B={B} H={H} W={W} K={K} n_win={n_win} win={win} n={len(recs[s])} "
+                print(f"MISMATCH case {case} seq {s}: tile_walk={tile_walk} B={B} H={H} W={W} K={K} n_win={n_win} win={win} n={len(recs[s])} "
                       f"state={bool(torch.equal(sj, st[s]))} view={bool(torch.equal(vj, view[s]))} u8={bool(torch.equal(uj, u8[s]))}")
                 break
     print(f"{cases} cases ({skipped} outside the fast path's shapes), {bad} mismatches")
