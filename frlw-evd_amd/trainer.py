@@ -71,8 +71,12 @@ class Trainer:
             self.model = DistributedDataParallel(model, device_ids=ids, broadcast_buffers=False,  # core/exp.py:391
                                                  **ddp_kwargs())
             self.comm_hook = install_comm_hook(self.model, comm_hook)
-        params = filter(lambda p: p.requires_grad, self.model.parameters())
-        self.optimizer = torch.optim.Adam(params, lr=0.0 if warmup_epochs > 0 else self.lr0)  # core/exp.py:126-128
+        params = [p for p in self.model.parameters() if p.requires_grad]
+        # core/exp.py:126-128: torch.optim.Adam with its defaults.  On the GPU the update of all ~300 tensors runs as ONE
+        # multi-tensor kernel per chunk (fused=True: the same arithmetic per element as the default implementation, which
+        # issues eight launches per chunk -- 0.6 ms of a 33 ms step)
+        fused = bool(params) and all(p.is_cuda for p in params)
+        self.optimizer = torch.optim.Adam(params, lr=0.0 if warmup_epochs > 0 else self.lr0, **({"fused": True} if fused else {}))
         self.scheduler = LRScheduler("yoloxwarmcos", self.lr0, iters_per_epoch, max_epoch, warmup_epochs=warmup_epochs,
                                      warmup_lr_start=0.0, no_aug_epochs=0, min_lr_ratio=0.05)
         dev = "cuda" if next(model.parameters()).is_cuda else "cpu"

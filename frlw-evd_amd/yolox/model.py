@@ -37,7 +37,10 @@ class model(nn.Module):
     def _weights_signature(self):
         """Identity + in-place version of every parameter and buffer: changes on optimizer steps, load_state_dict(),
         BatchNorm running-statistics updates and .to() / .cuda()."""
-        return tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
+        ts = self.__dict__.get("_sig_tensors")
+        if ts is None:  # the module tree is walked once per engine lifetime, not on every eval forward
+            ts = self.__dict__["_sig_tensors"] = list(self.parameters()) + list(self.buffers())
+        return tuple((t.data_ptr(), t._version) for t in ts)
 
     def engine(self):
         """The gfx950 engine for the CURRENT weights.  The engine folds BatchNorm into the convolutions and keeps its
@@ -53,6 +56,15 @@ class model(nn.Module):
     def drop_engine(self):
         self._engine = None
         self._engine_sig = None
+        self.__dict__.pop("_sig_tensors", None)  # (.to() / .cuda() / load_state_dict(assign=True) may replace the tensors)
+
+    def _apply(self, fn, *a, **k):  # .to() / .cuda() / .float(): new tensors
+        self.drop_engine()
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self.drop_engine()
+        return super().load_state_dict(*a, **k)
 
     def train(self, mode=True):
         if mode:
@@ -63,6 +75,7 @@ class model(nn.Module):
         d = self.__dict__.copy()
         d["_engine"] = None
         d["_engine_sig"] = None
+        d.pop("_sig_tensors", None)
         return d
 
     def detect(self, x):

@@ -18,6 +18,7 @@ from .. import _lib
 
 _SCRATCH = {}
 _WCACHE = {}  # id(weight parameter) -> (weakref, operand cache): forward + data-gradient layouts, rebuilt every forward
+_WCACHE_GEOM = {}  # id(weight parameter) -> what the data-gradient layout in the cache was laid out for: (version, parity)
 
 
 def _weight_cache(lib, weight, Cin, Cout, k):
@@ -30,6 +31,12 @@ def _weight_cache(lib, weight, Cin, Cout, k):
         _WCACHE[key] = (weakref.ref(weight, lambda _r, key=key: _WCACHE.pop(key, None)), buf)
         return buf
     return hit[1]
+
+
+def _bump_versions(*tensors):
+    """Advance the in-place version counters of buffers a kernel has written through raw pointers (no launch)."""
+    for t in tensors:
+        torch.autograd.graph.increment_version(t)
 
 
 def _scratch(dev, key, numel, dtype):
@@ -85,6 +92,10 @@ class _BaseConvTrain(torch.autograd.Function):
                                                tracked.data_ptr() if tracked is not None else None,
                                                wc.data_ptr(), sc.data_ptr(), sc.numel(), _stream(dev)), "baseconv_train_fwd")
         ctx.wcache = wc
+        # the data-gradient half of the cache depends on the parity class of (k, stride, H, W): a second forward of the same
+        # layer on an input of another parity (shared layer, multi-scale graph) re-lays it -- remember what THIS forward wrote
+        ctx.wparity = int(lib.frlw_conv2d_dgrad_parity(k, stride, H, W))
+        _WCACHE_GEOM[id(weight)] = (weight._version, ctx.wparity)
         ctx.wversion = weight._version
         ctx.weight_ref = weight
         ctx.save_for_backward(x, z, w, g, b, stats)
@@ -107,7 +118,8 @@ class _BaseConvTrain(torch.autograd.Function):
         # the operand cache belongs to the forward of THIS graph only while the weight (and the cache) are untouched
         # since: a second forward of the same layer before this backward would have overwritten it with the same
         # weights' layout (fine), an in-place weight update in between would not (then lay out again)
-        fresh = ctx.weight_ref._version == ctx.wversion and _WCACHE.get(id(ctx.weight_ref), (None, None))[1] is ctx.wcache
+        fresh = (ctx.weight_ref._version == ctx.wversion and _WCACHE.get(id(ctx.weight_ref), (None, None))[1] is ctx.wcache
+                 and _WCACHE_GEOM.get(id(ctx.weight_ref)) == (ctx.wversion, ctx.wparity))
         _lib.check(lib.frlw_baseconv_train_bwd(dy.data_ptr(), x.data_ptr(), z.data_ptr(), w.data_ptr(), g.data_ptr(),
                                                b.data_ptr(), stats[0].data_ptr(), stats[2].data_ptr(), B, H, W, Cin, Cout, k,
                                                stride, dz.data_ptr(), dx.data_ptr() if dx is not None else None,
@@ -132,8 +144,13 @@ def base_conv_train(x, conv, bn):
             tracked = bn.num_batches_tracked if bn.num_batches_tracked.is_cuda else None
             if tracked is None:
                 bn.num_batches_tracked += 1
-    return _BaseConvTrain.apply(x, conv.weight, bn.weight, bn.bias, conv.stride[0], bn.eps,
-                                bn.running_mean if track else None, bn.running_var if track else None, float(momentum), tracked)
+    y = _BaseConvTrain.apply(x, conv.weight, bn.weight, bn.bias, conv.stride[0], bn.eps,
+                             bn.running_mean if track else None, bn.running_var if track else None, float(momentum), tracked)
+    if track:
+        # the kernels wrote the running statistics through raw pointers: tell autograd's version counters, which is what the
+        # eval engine's weight signature (yolox/model.py) watches -- also when only a submodule is in training mode
+        _bump_versions(bn.running_mean, bn.running_var)
+    return y
 
 
 class _PredLevel(torch.autograd.Function):

@@ -48,6 +48,7 @@ for f in os.listdir(O):
 taf = lambda n, H, W, K=8: 8 * n + 2 * 4 * 2 * K * H * W + 2 * K * H * W
 ev = lambda n, H, W, b=5: 8 * n + 4 * 2 * b * H * W
 traffic("mpx", "taf_mpx", taf(10_000_000, 720, 1280), ("kf_",))
+traffic("mpx_tilewalk", "taf_mpx_tilewalk", taf(10_000_000, 720, 1280), ("kf_",))
 traffic("mpx_hot", "taf_mpx_hotspot", taf(10_000_000, 720, 1280), ("kf_",))
 traffic("gen1", "taf_gen1", taf(1_000_000, 240, 304), ("kf_",))
 traffic("gen1x64", "taf_gen1_x64", 64 * taf(1_000_000, 240, 304), ("kf_",))   # (the lab's sequences are ragged: a few % fewer events)

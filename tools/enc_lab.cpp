@@ -4,7 +4,7 @@
 // also compares the outputs byte for byte (the first one is the reference build, e.g. the last parity-green commit).
 //
 //   hipcc -O2 -std=c++17 -I include tools/enc_lab.cpp -o build/enc_lab -ldl
-//   build/enc_lab frlw-evd_amd/csrc/libfrlw_evd.so [build/libfrlw_base.so] [--cfg mpx,mpx_hot,gen1,gen1x64,e2e64,ev1,ev64] [--reps 20]
+//   build/enc_lab frlw-evd_amd/csrc/libfrlw_evd.so [build/libfrlw_base.so] [--cfg mpx,mpx_hot,gen1,gen1x64,e2e64,ev1,evb64] [--reps 20] [--tile-walk]
 //   rocprofv3 --kernel-trace --stats -- build/enc_lab <lib> --cfg mpx          (per-kernel breakdown of exactly that encode)
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
@@ -126,6 +126,9 @@ struct Outputs {
     bool ran = false;
 };
 
+static frlw_tuning_t g_tuning = {-1, -1, -1, -1, -1, -1, -1};
+static bool g_use_tuning = false;
+
 static Outputs run_cfg(const Lib &L, const Cfg &c, const uint64_t *dat_d, const std::vector<int64_t> &offs, int reps)
 {
     Outputs o;
@@ -137,6 +140,7 @@ static Outputs run_cfg(const Lib &L, const Cfg &c, const uint64_t *dat_d, const 
     frlw_events_t ev;
     memset(&ev, 0, sizeof(ev));
     ev.data = dat_d; ev.n = n; ev.layout = FRLW_LAYOUT_DAT8;
+    if (g_use_tuning) ev.tuning = &g_tuning;
     const size_t plane = (size_t)c.H * c.W;
     if (c.kind == 0) {
         if (!L.taf || !L.taf_ws) return o;
@@ -227,6 +231,7 @@ int main(int argc, char **argv)
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--cfg") && i + 1 < argc) only = argv[++i];
         else if (!strcmp(argv[i], "--reps") && i + 1 < argc) reps = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--tile-walk")) { g_tuning.taf_tile_walk = 1; g_use_tuning = true; } // TAF through kf_taf_tile
         else libs.push_back(load(argv[i]));
     }
     if (libs.empty()) { fprintf(stderr, "usage: enc_lab <lib.so> [<reference lib.so>] [--cfg a,b] [--reps N]\n"); return 2; }

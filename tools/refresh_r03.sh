@@ -21,6 +21,13 @@ pmc() { # cfg tag counters...
   local cfg=$1 tag=$2; shift 2; local O=/tmp/frlw_r03_pmcsum_$cfg/$tag; rm -rf $O; mkdir -p $O
   rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $O -o p -- $R/build/enc_lab $LIB --cfg $cfg --reps 3 > $O/run.log 2>&1; echo "pmc $cfg $tag rc=$?"
 }
+# the opt-in tile walk (kf_taf_tile) on the headline shape: time and traffic, for DESIGN.md section 3.4
+stats lab_mpx_tilewalk $R/build/enc_lab $LIB --cfg mpx --reps 20 --tile-walk
+EXTRA=--tile-walk
+pmcx() { local cfg=$1 tag=$2; shift 2; local O=/tmp/frlw_r03_pmcsum_tw/$tag; rm -rf $O; mkdir -p $O
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $O -o p -- $R/build/enc_lab $LIB --cfg $cfg --reps 3 --tile-walk > $O/run.log 2>&1; echo "pmc tw $tag rc=$?"; }
+rm -rf /tmp/frlw_r03_pmcsum_tw; pmcx mpx fetch FETCH_SIZE; pmcx mpx write WRITE_SIZE
+python3 $R/tools/pmc_summary.py /tmp/frlw_r03_pmcsum_tw > $K/mpx_tilewalk_pmc_summary.txt
 for W in mpx mpx_hot gen1 gen1x64 ev1 evb64; do
   rm -rf /tmp/frlw_r03_pmcsum_$W
   if [ $W = mpx ] || [ $W = mpx_hot ]; then
