@@ -1188,7 +1188,7 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_waves_per_eu(8,
 struct WavePass {
     uint32_t *cnt;  // [128]: two 16-bit tickets per word, all zero between passes
     uint16_t *off;  // [256]
-    float *sorted;  // [256]
+    float *sorted;  // [256] (Event Volume: [2 * 256 + 2], pairs of weights + one all-zero pair)
 };
 
 // m[u], u < 4: the lane's records of this pass (0xffffffff = none), record u * 64 + lane of the pass in stream order;
@@ -1225,6 +1225,63 @@ __device__ __forceinline__ void wave_sort(const WavePass &P, const uint32_t (&m)
     for (int u = 0; u < 4; ++u)
         if (rk[u] != 0xffffffffu) P.sorted[(uint32_t)P.off[m[u] & 255u] + rk[u]] = val(m[u]);
     LDS_FENCE();
+}
+
+// The same with a PAIR of f32 per record (val2(m, a, b)): sorted[2 * slot], sorted[2 * slot + 1]; slot 256 is kept all zero.
+template <class Val2>
+__device__ __forceinline__ void wave_sort2(const WavePass &P, const uint32_t (&m)[4], int lane, Val2 val2, uint32_t (&n)[4], uint32_t (&o)[4])
+{
+    uint32_t rk[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        rk[u] = 0xffffffffu;
+        if (m[u] != 0xffffffffu) {
+            const uint32_t lc = m[u] & 255u, sh = 16u * (lc & 1u);
+            rk[u] = (atomicAdd(&P.cnt[lc >> 1], 1u << sh) >> sh) & 0xffffu;
+        }
+    }
+    LDS_FENCE();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) n[j] = (P.cnt[32 * j + (lane >> 1)] >> (16 * (lane & 1))) & 0xffffu;
+    LDS_FENCE();
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (!(lane & 1)) P.cnt[32 * j + (lane >> 1)] = 0u;
+    {
+        const uint32_t tl = n[0] + n[1] + n[2] + n[3];
+        const uint32_t inc = wave_incl_scan(tl);
+        o[0] = inc - tl; o[1] = o[0] + n[0]; o[2] = o[1] + n[1]; o[3] = o[2] + n[2];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) P.off[64 * j + lane] = (uint16_t)o[j];
+    LDS_FENCE();
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (rk[u] != 0xffffffffu) {
+            float a, b;
+            val2(m[u], u, a, b);
+            *(float2 *)&P.sorted[2u * ((uint32_t)P.off[m[u] & 255u] + rk[u])] = make_float2(a, b);
+        }
+    LDS_FENCE();
+}
+
+// add2(j, a, b): cell j of this lane receives the pair next; slots behind a segment's end read the all-zero pair, and
+// adding +0 to these non-negative sums changes nothing -- no select around the accumulators at all.
+template <class Add2>
+__device__ __forceinline__ void wave_segments2(const WavePass &P, const uint32_t (&n)[4], const uint32_t (&o)[4], Add2 add2)
+{
+    uint32_t nmax = n[0] > n[1] ? n[0] : n[1];
+    nmax = n[2] > nmax ? n[2] : nmax;
+    nmax = n[3] > nmax ? n[3] : nmax;
+    const uint32_t nm = wave_max_u32(nmax);
+#pragma nounroll
+    for (uint32_t a = 0; a < nm; ++a) {
+        float2 e[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e[j] = *(const float2 *)&P.sorted[2u * (a < n[j] ? o[j] + a : 256u)];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) add2(j, e[j].x, e[j].y);
+    }
 }
 
 // add(j, v, live): "cell j of this lane receives v next" when live -- a select, not a branch (divergent control flow
@@ -1539,47 +1596,51 @@ __device__ __forceinline__ void ev_add(float (&acc)[BINS], float binsf, float tn
     }
 }
 
-// The same when floor(t*) = K0 is known for every record of the pass (the usual case: a pass is 256 consecutive records of
-// one sub-tile of a time-sorted stream): two bins instead of BINS.
-template <int BINS, int K0>
-__device__ __forceinline__ void ev_add_at(float (&acc)[BINS], float binsf, float tn, bool live)
-{
-    const float ts = binsf * tn;
-#pragma unroll
-    for (int k = K0 - 1; k <= K0; ++k) { // 0-based bins K0 - 1 (weight 1 - (t* - K0)) and K0 (weight 1 - (K0 + 1 - t*))
-        if (k >= 0 && k < BINS) {
-            const float d = (float)(k + 1) - ts;
-            const float w = 1.0f - fabsf(d);
-            const float na = acc[k] + w;
-            acc[k] = (live && w > 0.0f) ? na : acc[k];
-        }
-    }
-}
-
-// One pass of up to 256 records of one sub-tile through the wave's accumulators.
+// One pass of up to 256 records of one sub-tile through the wave's accumulators.  Usual case (a pass is 256 consecutive
+// records of one sub-tile of a time-sorted stream): floor(t*) = K0 is the same for every record -- then each record works
+// out its own two weights (bins K0 and K0 + 1) once, and the owner lanes only ADD them in stream order.
 template <int BINS>
 __device__ __forceinline__ void ev_pass(const WavePass &P, const uint32_t (&pm)[4], int lane, const EvTileP &q, bool use_mul, double rcp,
                                         float binsf, float (&acc)[4][BINS])
 {
     uint32_t n[4], o[4];
-    // floor(t*) of the pass: the same for all its records?  Compared against the pass's first record (lane 0, u = 0: a
-    // pass is never empty) -- one ballot instead of a reduction.
+    float tn[4];
+    bool differs = false;
+    // (lane 0, u = 0 holds the pass's first record: a pass is never empty)
     const uint32_t r0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)pm[0]) >> kCellBits;
     const int kfirst = (int)(binsf * (use_mul ? (float)((double)r0 * rcp) : q.tlut[r0]));
-    bool differs = false;
-    wave_sort(P, pm, lane,
-              [&](uint32_t w) {
-                  const uint32_t r = w >> kCellBits;
-                  const float tn = use_mul ? (float)((double)r * rcp) : q.tlut[r]; // float((t - t0) / window), :141, :23
-                  differs |= (int)(binsf * tn) != kfirst;
-                  return tn;
-              }, n, o);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        tn[u] = 0.0f;
+        if (pm[u] != 0xffffffffu) {
+            const uint32_t r = pm[u] >> kCellBits;
+            tn[u] = use_mul ? (float)((double)r * rcp) : q.tlut[r]; // float((t - t0) / window), generate_eventvolume.py:141, :23
+            differs |= (int)(binsf * tn[u]) != kfirst;
+        }
+    }
     const int k0 = __ballot(differs) ? -1 : kfirst;
-    switch (k0) {
-#define EV_CASE(K) case K: wave_segments(P, n, o, [&](int j, float tn, bool live) { ev_add_at<BINS, K>(acc[j], binsf, tn, live); }); break;
-        EV_CASE(0) EV_CASE(1) EV_CASE(2) EV_CASE(3) EV_CASE(4) EV_CASE(5) EV_CASE(6) EV_CASE(7) EV_CASE(8)
+    if (k0 >= 0 && k0 <= BINS) {
+        // weights of the 1-based bins k0 (if >= 1) and k0 + 1 (if <= BINS), exactly as ev_add computes them; they are >= 0
+        const bool lo_ok = k0 >= 1, hi_ok = k0 + 1 <= BINS;
+        const float klo = (float)k0, khi = (float)(k0 + 1);
+        wave_sort2(P, pm, lane,
+                   [&](uint32_t, int u, float &a, float &b) {
+                       const float ts = binsf * tn[u]; // t* = bins * float(t), :23
+                       const float wl = 1.0f - fabsf(klo - ts), wh = 1.0f - fabsf(khi - ts); // :28
+                       a = (lo_ok && wl > 0.0f) ? wl : 0.0f; // :29
+                       b = (hi_ok && wh > 0.0f) ? wh : 0.0f;
+                   }, n, o);
+        switch (k0) {
+#define EV_CASE(K) case K: wave_segments2(P, n, o, [&](int j, float a, float b) { \
+            if (K >= 1 && K - 1 < BINS) acc[j][K >= 1 ? K - 1 : 0] += a; \
+            if (K < BINS) acc[j][K < BINS ? K : 0] += b; }); break;
+            EV_CASE(0) EV_CASE(1) EV_CASE(2) EV_CASE(3) EV_CASE(4) EV_CASE(5) EV_CASE(6) EV_CASE(7) EV_CASE(8)
 #undef EV_CASE
-    default: wave_segments(P, n, o, [&](int j, float tn, bool live) { ev_add<BINS>(acc[j], binsf, tn, live); }); break;
+        default: break;
+        }
+    } else {
+        wave_sort(P, pm, lane, [&](uint32_t w) { const uint32_t r = w >> kCellBits; return use_mul ? (float)((double)r * rcp) : q.tlut[r]; }, n, o);
+        wave_segments(P, n, o, [&](int j, float t, bool live) { ev_add<BINS>(acc[j], binsf, t, live); });
     }
     LDS_FENCE();
 }
@@ -1616,13 +1677,14 @@ __global__ __launch_bounds__(NW *kWave) void kf_ev_tile(EvTileP q)
     __shared__ TileSplit<NW, RPT> L;
     __shared__ uint32_t s_cnt[NW][kSubCells / 2];
     __shared__ uint16_t s_off[NW][kSubCells];
-    __shared__ float s_sorted[NW][kSubCells];
+    __shared__ __attribute__((aligned(8))) float s_sorted[NW][2 * kSubCells + 2];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int g, part;
     if (!pair_part_of_block<PARTS>(q.pairs, g, part)) return;
     if (q.hdr->status != 0) return;
     const uint32_t beg = q.base[g], end = q.base[g + 1];
     if (end - beg > q.tile_max) return; // skewed tile: segment split + kf_ev_sub
+    if (lane < 2) s_sorted[wv][2 * kSubCells + lane] = 0.0f; // the all-zero pair behind the segments
     const int s = g / q.T, tile = g - s * q.T;
     for (int i = lane; i < kSubCells / 2; i += kWave) s_cnt[wv][i] = 0u;
     for (int i = tid; i < RPT * NW * NW; i += NT) (&L.scnt[0][0][0])[i] = 0u;
@@ -1678,8 +1740,9 @@ __global__ __launch_bounds__(4 * kWave) void kf_ev_sub(EvTileP q, int all_tiles)
 {
     __shared__ uint32_t s_cnt[4][kSubCells / 2];
     __shared__ uint16_t s_off[4][kSubCells];
-    __shared__ float s_sorted[4][kSubCells];
+    __shared__ __attribute__((aligned(8))) float s_sorted[4][2 * kSubCells + 2];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (lane < 2) s_sorted[wv][2 * kSubCells + lane] = 0.0f; // the all-zero pair behind the segments
     const int sg = blockIdx.x * 4 + wv;
     if (sg >= q.pairs * kFW || q.hdr->status != 0) return;
     const int g = sg / kFW, sub = sg - g * kFW;
