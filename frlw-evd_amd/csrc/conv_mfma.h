@@ -408,6 +408,196 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
     }
 }
 
+#ifdef FRLW_DEV_BUILD // lab-only (tools/conv_lab.hip, FRLW_CONV_THIN16=1): measured in round 3, no net gain -- DESIGN.md section 4
+// ---- the thin-layer variant: 64 x 32 output tile, four wavefronts of 32 x 16 on v_mfma_f32_16x16x4_f32 -------------------
+// A layer of M x N outputs is M * N / 1024 wavefronts with the 32 x 32 MFMA (one accumulator tile per wavefront at least):
+// the detector's 16 x 20 and 8 x 10 levels give 1.25-2.5 wavefronts per SIMD, so the matrix pipes idle on quantisation and
+// there is nobody to hide a workgroup's prologue, barriers and epilogue.  The 16 x 16 x 4 instruction (same FLOP per cycle,
+// 40-cycle dependent latency) lets a wavefront own 32 x 16: twice the wavefronts for the same layer, 8 workgroups per CU.
+// Staging, ring, counted waits: as k_conv_mfma.  Fragments: lane l = (m = l & 15, kk = l >> 4) supplies A[row m][k] and
+// B[k][col m] with k = 4 kk + t in k-step t (the instruction sums over the four lane groups, so a k-step covers
+// k = t, 4 + t, 8 + t, 12 + t: any partition of the tile's 16 k works as long as both operands use it) -- the lane's four A
+// values are ONE 16-byte read.  LDS images (both arrive by DMA, lane-linear, so the layout is chosen on the SOURCE side):
+// row r of the gathered tile holds quad q in slot q ^ h((r >> 2) & 3), h = {0, 2, 3, 1}: the four 16-lane groups of a
+// ds_read_b128 then touch 16 distinct bank quads; row k of the weight tile has its two 16-column halves swapped when
+// (k >> 2) is odd, so the 32 lanes of a ds_read_b32 pass (kk = 0, 1 or 2, 3) hit 32 distinct banks.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+template <bool UT>
+__global__ __launch_bounds__(256) void k_conv_mfma16(ConvArgs a)
+{
+    constexpr int BM = 64, BN = 32, BK = 16, D = 2;
+    constexpr int KQ = BK / 4, RPP = 256 / KQ, LDB = BN;
+    constexpr int A_F4 = BM * BK / 4 / 256; // 1
+    constexpr int NA = D + 1, NB = D;
+    constexpr int kTileFloats = BK * (NA * BM + NB * LDB);
+    __shared__ __attribute__((aligned(16))) float smem[kTileFloats];
+    float (*As)[BM][BK] = (float (*)[BM][BK])smem;
+    float (*Bs)[BK][LDB] = (float (*)[BK][LDB])(smem + NA * BK * BM);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wr = wv >> 1, wc = wv & 1;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const __amdgpu_buffer_rsrc_t rx = conv_rsrc(a.x, a.x_bytes), rw = conv_rsrc(a.w, a.w_bytes);
+    const auto h4 = [](int g) { return g == 0 ? 0 : (g == 1 ? 2 : (g == 2 ? 3 : 1)); }; // h = {0, 2, 3, 1}
+
+    // ---- A staging: thread -> one row m, one float4 of 4 consecutive k (the quad that lands in slot tid & 3 of its row)
+    const int a_k4 = ((tid & 3) ^ h4((tid >> 4) & 3)) * 4;
+    int a_iy0, a_ix0;
+    uint32_t a_base;
+    {
+        const int m = m0 + tid / KQ;
+        const int mm = m < a.M ? m : 0;
+        const int b = mm / (a.Ho * a.Wo), pix = mm - b * (a.Ho * a.Wo);
+        const int oy = pix / a.Wo, ox = pix - oy * a.Wo;
+        a_iy0 = oy * a.stride - a.pad;
+        a_ix0 = ox * a.stride - a.pad;
+        a_base = m < a.M ? (uint32_t)(((long long)b * a.x_bs + a.x_co + (a.group_n ? (n0 / a.group_n) * a.Cin : 0)) * 4) : kOob;
+    }
+    const int kw = a.kw ? a.kw : a.k;
+    const int x_cs4 = a.x_cs * 4;
+    auto gather_off = [&](int ky, int kx) -> uint32_t {
+        int iy = a_iy0 + ky, ix = a_ix0 + kx;
+        bool ok = a_base != kOob;
+        if (a.tstride == 2) { ok = ok && !((iy | ix) & 1); iy >>= 1; ix >>= 1; }
+        ok = ok && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        return ok ? a_base + (uint32_t)((iy * a.W + ix) * x_cs4) : kOob;
+    };
+    // ---- B staging: the first two wavefronts, one float4 each: LDS position (row kr, columns n4 .. n4 + 3) receives the
+    // weights of columns n4 ^ 16 when (kr >> 2) is odd
+    const int nk_all = (a.K + BK - 1) / BK;
+    const int kt0 = (int)((long long)nk_all * blockIdx.z / a.splits), kt1 = (int)((long long)nk_all * (blockIdx.z + 1) / a.splits);
+    const int nk = kt1 - kt0;
+    uint32_t b_off;
+    {
+        const int kr = tid / (BN / 4), n4 = ((tid % (BN / 4)) * 4) ^ (((kr >> 2) & 1) * 16);
+        b_off = (tid < BN * BK / 4 && n0 + n4 < a.Npad) ? (uint32_t)((((long long)kt0 * BK + kr) * a.Npad + n0 + n4) * 4) : kOob;
+    }
+    int s_ci, s_ky, s_kx;
+    uint32_t a_pix = kOob;
+    {
+        const int k = kt0 * BK + (UT ? 0 : a_k4);
+        const int tap = k / a.Cin;
+        s_ci = k - tap * a.Cin;
+        s_ky = tap / kw;
+        s_kx = tap - s_ky * kw;
+    }
+    if (UT) a_pix = gather_off(s_ky, s_kx);
+    auto load_a = [&](int kt, int nbuf) {
+        if (UT) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void *)(&As[nbuf][0][0] + wv * 64 * 4), 16,
+                                                     (int)(a_pix + (uint32_t)(s_ci + a_k4) * 4), 0, 0, 0);
+            s_ci += BK;
+            if (s_ci == a.Cin) {
+                s_ci = 0;
+                if (++s_kx == kw) { s_kx = 0; ++s_ky; }
+                a_pix = gather_off(s_ky, s_kx);
+            }
+        } else {
+            const bool in_k = kt * BK + a_k4 < a.K;
+            const uint32_t o = gather_off(s_ky, s_kx);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void *)(&As[nbuf][0][0] + wv * 64 * 4), 16,
+                                                     (int)(in_k ? o + (uint32_t)s_ci * 4 : kOob), 0, 0, 0);
+            s_ci += BK;
+            while (s_ci >= a.Cin) { s_ci -= a.Cin; if (++s_kx == kw) { s_kx = 0; ++s_ky; } }
+        }
+    };
+    auto load_b = [&](int nbuf) {
+        if (wv < 2) // wave-uniform: 128 float4 = two wave-instructions
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void *)(&Bs[nbuf][0][0] + wv * 64 * 4), 16, (int)b_off, 0, 0, 0);
+        b_off += (uint32_t)(BK * 4) * (uint32_t)a.Npad;
+    };
+
+    f32x4v acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][r] = 0.0f;
+
+    // issue order per iteration: weights of tile t + 1, then rows of tile t + 2 (as k_conv_mfma with D = 2): "all but my
+    // newest one DMA instruction has landed" = "tile t + 1 is complete" for wavefronts 0 and 1 as well as 2 and 3 (which
+    // issue no weight DMA: their newest instruction is the same row load)
+    auto wait_next_tile = [&](bool steady) {
+        if (steady) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    load_a(kt0, 0);
+    if (0 < nk) load_b(0);
+    if (1 < nk) load_a(kt0 + 1, 1);
+    wait_next_tile(nk >= D);
+    __builtin_amdgcn_s_barrier();
+    const int fm = lane & 15, fkk = lane >> 4;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float *)smem;
+    // byte addresses in ring slot 0: A row (32 wr + 16 i + fm), slot fkk ^ h(fm >> 2); B row 4 fkk (+ t), column half wc ^ (fkk & 1)
+    const uint32_t a_lds = lds0 + (uint32_t)((32 * wr + fm) * BK + ((fkk ^ h4((fm >> 2) & 3)) * 4)) * 4;
+    const uint32_t b_lds = lds0 + (uint32_t)(NA * BK * BM + 4 * fkk * LDB + 16 * (wc ^ (fkk & 1)) + fm) * 4;
+    int buf = 0, bufb = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + D - 1 < nk) load_b(bufb == 0 ? NB - 1 : bufb - 1);
+        if (kt + D < nk) load_a(kt0 + kt + D, buf == 0 ? NA - 1 : buf - 1);
+        f32x4 fa0, fa1;
+        float fb0, fb1, fb2, fb3;
+        const uint32_t a_addr = a_lds + (uint32_t)buf * (BM * BK * 4), b_addr = b_lds + (uint32_t)bufb * (BK * LDB * 4);
+        // (asm reads with a hand-counted wait: the compiler would put s_waitcnt vmcnt(0) in front of LDS reads it can see
+        // while an LDS-DMA is in flight and drain the prefetch)
+        asm volatile("ds_read_b128 %0, %1" : "=v"(fa0) : "v"(a_addr));
+        asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(fa1) : "v"(a_addr)); // + 16 rows
+        asm volatile("ds_read_b32 %0, %1" : "=v"(fb0) : "v"(b_addr));
+        asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(fb1) : "v"(b_addr), "n"(1 * LDB * 4));
+        asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(fb2) : "v"(b_addr), "n"(2 * LDB * 4));
+        asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(fb3) : "v"(b_addr), "n"(3 * LDB * 4));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("" : "+v"(fa0), "+v"(fa1), "+v"(fb0), "+v"(fb1), "+v"(fb2), "+v"(fb3));
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa0[0], fb0, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa1[0], fb0, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa0[1], fb1, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa1[1], fb1, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa0[2], fb2, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa1[2], fb2, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa0[3], fb3, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa1[3], fb3, acc[1], 0, 0, 0);
+        wait_next_tile(kt + D < nk);
+        __builtin_amdgcn_s_barrier();
+        buf = buf == NA - 1 ? 0 : buf + 1;
+        bufb = bufb == NB - 1 ? 0 : bufb + 1;
+    }
+
+    // ---- epilogue: C/D layout of the 16 x 16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + r
+    const int n = n0 + 16 * wc + fm;
+    const int howo = a.Ho * a.Wo;
+    if (a.splits > 1) {
+        float *dst = a.partial + (long long)blockIdx.z * a.M * a.Npad;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + 32 * wr + 16 * i + 4 * fkk + r;
+                if (m < a.M && n < a.Npad) dst[(long long)m * a.Npad + n] = acc[i][r];
+            }
+        return;
+    }
+    if (n >= a.Cout) return;
+    const float bias = a.bias ? a.bias[n] : 0.0f;
+    const int act = (a.act == ACT_SIGMOID && n < a.sig_from) ? ACT_NONE : a.act;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int mrow0 = m0 + 32 * wr + 16 * i + 4 * fkk;
+        const int b0 = mrow0 / howo, pix0 = mrow0 - b0 * howo;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (mrow0 + r < a.M) {
+                int b = b0, pix = pix0 + r;
+                while (pix >= howo) { pix -= howo; ++b; }
+                float v = act_apply(acc[i][r] + bias, act);
+                if (a.res) v = v + a.res[(long long)b * a.r_bs + (long long)pix * a.r_cs + a.r_co + n];
+                long long yo = (long long)pix * a.y_cs;
+                if (a.y_rp) { const int oy = pix / a.Wo; yo = (long long)oy * a.y_rp + (long long)(pix - oy * a.Wo) * a.y_cs; }
+                a.y[(long long)b * a.y_bs + yo + a.y_co + n] = v;
+            }
+        }
+    }
+}
+
+#endif // FRLW_DEV_BUILD
+
 // y = act(sum over splits of partial + bias) [+ res].  VEC: four consecutive channels per thread (16-byte loads of every
 // split's partial row, one 16-byte store); the partial sums are added in split order, as the scalar form does.
 template <bool VEC>
@@ -514,6 +704,15 @@ inline bool launch_conv(ConvArgs &c, float *scratch, long long scratch_floats, h
         }
         // (a deeper ring, D = 4, for launches that leave a workgroup alone on its CU was measured: no gain -- such
         // workgroups are bound by the issue cost of their own DMA and fragment instructions, not by prefetch distance)
+#ifdef FRLW_DEV_BUILD
+        static const long long thin16 = dev_knob("FRLW_CONV_THIN16", 0ll); // lab: 1 = the 64 x 32 / 16x16x4 variant, no split-K
+        if (thin16 && c.group_n == 0) {
+            c.splits = 1; c.partial = nullptr;
+            if (c.Cin % 16 == 0) hipLaunchKernelGGL((k_conv_mfma16<true>), dim3((c.M + 63) / 64, (c.Npad + 31) / 32, 1), dim3(256), 0, s, c);
+            else hipLaunchKernelGGL((k_conv_mfma16<false>), dim3((c.M + 63) / 64, (c.Npad + 31) / 32, 1), dim3(256), 0, s, c);
+            return true;
+        }
+#endif
         launch_conv_tile<64, 64, 2, 2, CONV_BK_SMALL>(c, dim3((c.M + 63) / 64, (c.Npad + 63) / 64, c.splits), s);
         if (c.splits > 1) {
             const bool vec = ((c.Cout | c.Npad | c.y_cs | c.y_co | c.r_cs | c.r_co | c.y_rp) & 3) == 0 && (c.y_bs & 3) == 0 && (c.r_bs & 3) == 0;
