@@ -652,10 +652,11 @@ constexpr int kMaxK = 8;
 
 // One FIFO step of one cell, generate_taf.py:27,35-49.  Cell without events: every slot - 1; otherwise shift down
 // (slot k + 1, - 1) and the mean enters at K - 1.  `has` false (window empty in the whole sequence, :40-41): unchanged.
-__device__ __forceinline__ void fifo_step(float (&st)[kMaxK], int K, bool has, uint32_t n, float sum)
+__device__ __forceinline__ float fifo_mean(uint32_t n, float sum) { return sum / ((float)n + 1e-8f); } // generate_taf.py:27
+
+__device__ __forceinline__ void fifo_step(float (&st)[kMaxK], int K, bool has, uint32_t n, float mean)
 {
     const bool hit = n != 0u;
-    const float mean = sum / ((float)n + 1e-8f);
 #pragma unroll
     for (int k = 0; k < kMaxK; ++k) {
         const float nxt = k + 1 < kMaxK ? st[k + 1] : 0.0f;
@@ -668,10 +669,9 @@ __device__ __forceinline__ void fifo_step(float (&st)[kMaxK], int K, bool has, u
 // The same step for K = 8 with TWO lanes per cell: the even lane holds slots 0..3, the odd lane slots 4..7 of the row
 // (the whole workgroup works in phase 2, and a lane moves 16 bytes of the row).  Slot 3 takes over slot 4 from the
 // partner lane through a DPP row shift; the float operations per slot are those of fifo_step.
-__device__ __forceinline__ void fifo_step_half(float (&st)[4], bool upper, bool has, uint32_t n, float sum)
+__device__ __forceinline__ void fifo_step_half(float (&st)[4], bool upper, bool has, uint32_t n, float mean)
 {
     const bool hit = n != 0u;
-    const float mean = sum / ((float)n + 1e-8f);
     const float up = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, st[0]), 0x101, 0xf, 0xf, false)); // row_shl:1: lane l reads lane l + 1
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -1095,7 +1095,10 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_waves_per_eu(8,
             }
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { res_sum[wv][64 * j + lane] = sum[j]; res_cnt[wv][64 * j + lane] = num[j]; }
+        for (int j = 0; j < 4; ++j) { // the mean is taken HERE, once per (cell, window): 2048 correctly rounded divisions per workgroup
+            res_sum[wv][64 * j + lane] = fifo_mean(num[j], sum[j]); // and round of windows instead of 4096 in phase 2 (both lanes of a cell)
+            res_cnt[wv][64 * j + lane] = num[j];
+        }
         __syncthreads();
         // ---- phase 2: one cell per lane, the FIFO steps of this round's windows in order
         if (K8) {
@@ -1447,7 +1450,7 @@ __global__ __launch_bounds__(NW *kWave) void kf_taf_tile(TileP q)
             const bool has = (wmask >> cur_w) & 1ull;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                fifo_step(st[j], K, has, num[j], sum[j]);
+                fifo_step(st[j], K, has, num[j], fifo_mean(num[j], sum[j]));
                 sum[j] = 0.0f;
                 num[j] = 0u;
             }
