@@ -319,6 +319,23 @@ def main():
                                max(5, args.steps // 5), 2)
         result["general_path"] = {"value": round(n_gpus * n / per2 / 1e6, 2), "unit": "Mevents/s", "device_ms": round(dev2, 4)}
 
+    if world > 1 and args.workload == "taf_mpx":
+        # SURVEY.md 8(e), second form: ONE stream sharded spatially -- every rank holds the same 10 M-event stream and encodes its
+        # stripe of rows (events routed by y on the device, own stripe of state / output); the only exchange is the OR of the
+        # 64-bit window masks (generate_taf.py:40-41 is a per-frame rule) between the two halves of the encode.  Strong scaling
+        # of one encode: the partition still reads the whole stream on every rank.
+        ev_s = synth.synth_events(seed, n, W, H, t_span)  # the SAME stream on every rank
+        dat_s = torch.from_numpy(synth.to_dat8(ev_s).view(np.uint8).reshape(-1, 8)).cuda()
+        lo, hi = fd.shard_range(H, rank, world)
+        st_s = torch.full((1, hi - lo, W, 2, K), -6000.0, device="cuda")
+        er.encode_taf_stripe(dat_s, [0, n], (H, W), (lo, hi), st_s, 0, win_us, n_win, K, check=True)
+        per_s, dev_s = timer.run(lambda: er.encode_taf_stripe(dat_s, [0, n], (H, W), (lo, hi), st_s, 0, win_us, n_win, K, check=False),
+                                 max(5, args.steps // 2), 2)
+        result["stripe_sharding"] = {"workload": f"ONE {n}-event {W}x{H} stream, rows sharded over {world} GPUs (encode_taf_stripe: window "
+                                                 "masks OR-reduced over RCCL between partition and walk)", "scaling": "strong",
+                                     "value": round(n / per_s / 1e6, 2), "unit": "Mevents/s", "ms_per_step": round(per_s * 1e3, 4),
+                                     "rows_of_rank0": [lo, hi]}
+        del dat_s, st_s
     if args.workload == "taf_mpx" and not args.no_also:
         result["also"] = bench_also(args, torch, synth, er, timer, rank, n_gpus, copy_gbs)
         # the shape BASELINE.json's metric names (GEN1 304x240), promoted: a block of its own and a compact copy inside

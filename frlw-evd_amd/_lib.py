@@ -72,6 +72,10 @@ SYMBOLS = {
     "frlw_taf_batch_workspace_bytes": (_SZ, [_I64, _I, _I, _I, _I64]),
     "frlw_taf_encode_batch": (_I, [_EV, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _I, _I, _I, _I, _I64, _I, _P, _P, _P, _I,
                                   _P, _SZ, _P]),
+    "frlw_taf_stripe_partition": (_I, [_EV, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _I, _I, _I, _I, _I, _I, _I64, _I, _P, _SZ, _P]),
+    "frlw_taf_stripe_window_masks": (_P, [_P]),
+    "frlw_taf_stripe_finish": (_I, [_EV, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _I, _I, _I, _I, _I, _I, _I64, _I, _P, _P, _P, _I,
+                                   _P, _SZ, _P]),
     "frlw_ev_batch_workspace_bytes": (_SZ, [_I64, _I, _I, _I, _I64]),
     "frlw_ev_encode_batch": (_I, [_EV, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _I, _I, _I, _I, _I64, _P, _P, _P, _SZ, _P]),
     "frlw_leaky_transform": (_I, [_P, _I64, _P, _P, _P]),

@@ -83,6 +83,8 @@ struct FastGeom {
     int run;      // events per wavefront of the scatter workgroup = chunk_ev / 16
     long long n_total; // records in the array (loads never go past it)
     int order_check;   // TAF: flag sequences whose window index ever decreases (only the tile walk needs to know)
+    int y_lo, H_full;  // row-stripe sharding of one frame: this call encodes rows [y_lo, y_lo + H) of an H_full-row frame; events
+                       // of other rows are skipped (not an error); H_full == H, y_lo == 0: the whole frame
     int n_windows, wb;
     uint32_t win, win_magic;
 };
@@ -204,12 +206,14 @@ __device__ __forceinline__ FastEv fast_decode(const FastGeom &G, uint2 r, long l
         x = G.xmap[x];
         y = G.ymap[y];
     }
-    if (x >= G.W || y >= G.H) {
+    if (x >= G.W || y >= G.H_full) {
         const long long flat = (long long)x + (long long)G.W * y;
-        if (flat >= (long long)G.H * G.W) { o.err = ST_INDEX; return o; }
+        if (flat >= (long long)G.H_full * G.W) { o.err = ST_INDEX; return o; }
         y = (int)(flat / G.W);
         x = (int)(flat - (long long)y * G.W);
     }
+    y -= G.y_lo; // row-stripe sharding: another rank owns the rows outside [y_lo, y_lo + H)
+    if ((unsigned)y >= (unsigned)G.H) return o;
     const long long rel = (long long)r.x - t0;
     if (EV) {
         if (rel <= 0) return o; // generate_eventvolume.py:139: not an error, not encoded
@@ -1934,11 +1938,20 @@ size_t frlw_taf_batch_workspace_bytes(int64_t n_events, int n_seq, int H, int W,
     return off;
 }
 
-int frlw_taf_encode_batch(const frlw_events_t *ev, const int64_t *seq_offsets, const int64_t *t_start, int n_seq, int H,
-                          int W, int K, int64_t window_us, int n_windows, float *state, float *view_f32, uint8_t *out_u8,
-                          int flags, void *workspace, size_t workspace_bytes, frlw_stream_t stream)
+} // extern "C"
+
+namespace {
+enum : int { PHASE_PARTITION = 1, PHASE_FINISH = 2 };
+
+// The batch encode in two halves: PARTITION = kf_hist, scans, kf_scatter (leaves the per-sequence window masks in the
+// workspace header), FINISH = split + walk (reads them).  A row stripe [y_lo, y_lo + H) of an H_full-row frame runs the two
+// halves as separate calls with an OR-reduce of the masks over the stripes in between (frlw_taf_stripe_*).
+int taf_batch_run(int phases, const frlw_events_t *ev, const int64_t *seq_offsets, const int64_t *t_start, int n_seq, int H, int W,
+                  int y_lo, int H_full, int K, int64_t window_us, int n_windows, float *state, float *view_f32, uint8_t *out_u8,
+                  int flags, void *workspace, size_t workspace_bytes, frlw_stream_t stream)
 {
-    if (!ev || !seq_offsets || !t_start || !state || !workspace) return FRLW_ERR_ARG;
+    if (!ev || !seq_offsets || !t_start || !workspace || (!state && (phases & PHASE_FINISH))) return FRLW_ERR_ARG;
+    if (y_lo < 0 || H < 1 || y_lo + H > H_full) return FRLW_ERR_ARG;
     if (K < 1 || K > FRLW_MAX_BINS || n_windows < 1 || n_windows > FRLW_MAX_WINDOWS || window_us < 1) return FRLW_ERR_ARG;
     if (n_seq < 1 || n_seq > kMaxSeq) return FRLW_ERR_ARG;
     if (ev->layout != FRLW_LAYOUT_DAT8) return FRLW_ERR_UNSUPPORTED;
@@ -1964,6 +1977,7 @@ int frlw_taf_encode_batch(const frlw_events_t *ev, const int64_t *seq_offsets, c
     G.H = H; G.W = W; G.twl = p.twl; G.thl = p.thl; G.tiles_x = p.tiles_x; G.T = p.T; G.bpw = p.bpw;
     G.chunk_ev = p.chunk; G.run = p.chunk / kFW; G.n_total = ev->n;
     G.n_windows = n_windows; G.wb = wb; G.win = (uint32_t)window_us;
+    G.y_lo = y_lo; G.H_full = H_full;
     {
         const frlw_tuning_t *tu = ev->tuning;
         const bool want = (tu && tu->taf_tile_walk >= 0) ? tu->taf_tile_walk != 0 : kTafTileWalk;
@@ -1979,8 +1993,11 @@ int frlw_taf_encode_batch(const frlw_events_t *ev, const int64_t *seq_offsets, c
         const int ok = lds_order_ok(w8, st); // cached per device after the first call
         if (ok != FRLW_OK) return ok;
     }
-    if (ev->xmap) launch_fast<true>(G, S, p, w8, st);
-    else launch_fast<false>(G, S, p, w8, st);
+    if (phases & PHASE_PARTITION) {
+        if (ev->xmap) launch_fast<true>(G, S, p, w8, st);
+        else launch_fast<false>(G, S, p, w8, st);
+    }
+    if (!(phases & PHASE_FINISH)) { HIP_TRY(hipGetLastError()); return FRLW_OK; }
     TileP q;
     q.H = H; q.W = W; q.twl = p.twl; q.thl = p.thl; q.tiles_x = p.tiles_x; q.T = p.T; q.K = K; q.n_windows = n_windows;
     q.wb = wb; q.flip = (flags & FRLW_TAF_U8_FLIP_K) ? 1 : 0; q.win = (uint32_t)window_us;
@@ -2011,6 +2028,38 @@ int frlw_taf_encode_batch(const frlw_events_t *ev, const int64_t *seq_offsets, c
     else hipLaunchKernelGGL(kf_taf_walk<false>, dim3(p.pairs * kFW), dim3(kWalkThreads), 0, st, q);
     HIP_TRY(hipGetLastError());
     return FRLW_OK;
+}
+} // namespace
+
+extern "C" {
+
+int frlw_taf_encode_batch(const frlw_events_t *ev, const int64_t *seq_offsets, const int64_t *t_start, int n_seq, int H,
+                          int W, int K, int64_t window_us, int n_windows, float *state, float *view_f32, uint8_t *out_u8,
+                          int flags, void *workspace, size_t workspace_bytes, frlw_stream_t stream)
+{
+    return taf_batch_run(PHASE_PARTITION | PHASE_FINISH, ev, seq_offsets, t_start, n_seq, H, W, 0, H, K, window_us, n_windows, state,
+                         view_f32, out_u8, flags, workspace, workspace_bytes, stream);
+}
+
+int frlw_taf_stripe_partition(const frlw_events_t *ev, const int64_t *seq_offsets, const int64_t *t_start, int n_seq, int H_full,
+                              int W, int y_lo, int rows, int K, int64_t window_us, int n_windows, void *workspace,
+                              size_t workspace_bytes, frlw_stream_t stream)
+{
+    return taf_batch_run(PHASE_PARTITION, ev, seq_offsets, t_start, n_seq, rows, W, y_lo, H_full, K, window_us, n_windows, nullptr,
+                         nullptr, nullptr, 0, workspace, workspace_bytes, stream);
+}
+
+unsigned long long *frlw_taf_stripe_window_masks(void *workspace)
+{
+    return workspace ? ((FastHeader *)workspace)->wmask : nullptr;
+}
+
+int frlw_taf_stripe_finish(const frlw_events_t *ev, const int64_t *seq_offsets, const int64_t *t_start, int n_seq, int H_full, int W,
+                           int y_lo, int rows, int K, int64_t window_us, int n_windows, float *state, float *view_f32,
+                           uint8_t *out_u8, int flags, void *workspace, size_t workspace_bytes, frlw_stream_t stream)
+{
+    return taf_batch_run(PHASE_FINISH, ev, seq_offsets, t_start, n_seq, rows, W, y_lo, H_full, K, window_us, n_windows, state, view_f32,
+                         out_u8, flags, workspace, workspace_bytes, stream);
 }
 
 size_t frlw_ev_batch_workspace_bytes(int64_t n_events, int n_seq, int H, int W, int64_t window_us)
@@ -2046,7 +2095,7 @@ int frlw_ev_encode_batch(const frlw_events_t *ev, const int64_t *seq_offsets, co
     G.xmap = ev->xmap; G.ymap = ev->ymap; G.map_w = ev->map_w; G.map_h = ev->map_h;
     G.H = H; G.W = W; G.twl = p.twl; G.thl = p.thl; G.tiles_x = p.tiles_x; G.T = p.T; G.bpw = p.bpw;
     G.chunk_ev = p.chunk; G.run = p.chunk / kFW; G.n_total = ev->n;
-    G.n_windows = 1; G.wb = 0; G.win = (uint32_t)window_us; G.win_magic = 0u; G.order_check = 0;
+    G.n_windows = 1; G.wb = 0; G.win = (uint32_t)window_us; G.win_magic = 0u; G.order_check = 0; G.y_lo = 0; G.H_full = H;
 
     hipStream_t st = (hipStream_t)stream;
     char *w8 = (char *)workspace;

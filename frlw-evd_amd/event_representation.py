@@ -235,11 +235,11 @@ def quantize_u8(volume, clip255=False):
 # ------------------------------------------------------------------------------------------------
 # fused DAT-record fast path (harness glue on device)
 # ------------------------------------------------------------------------------------------------
-def _batch_workspace(n, n_seq, H, W, window_us, device):
+def _batch_workspace(n, n_seq, H, W, window_us, device, slot="batch"):
     need = _lib.load().frlw_taf_batch_workspace_bytes(int(n), int(n_seq), int(H), int(W), int(window_us))
     if need == 0:
         return None
-    key = ("batch", device.index, torch.cuda.current_stream().cuda_stream)
+    key = (slot, device.index, torch.cuda.current_stream().cuda_stream)
     ws = _WORKSPACES.get(key)
     if ws is None or ws.numel() < need:
         ws = _new_workspace(ws, need, device)
@@ -286,6 +286,69 @@ def encode_taf_batch(dat, seq_offsets, shape, state, t_start, window_us=10000, n
     _lib.check(rc, "encode_taf_batch")
     if check:
         _finish(ws, "encode_taf_batch")
+    return u8, view
+
+
+def _or_reduce_window_masks(masks, group):
+    """OR of the 64-bit window masks over the ranks of ``group``, in place.  RCCL / NCCL have no bitwise reductions: the bits
+    travel as a (B, 64) int32 tensor under MAX (256 bytes per sequence instead of 8 -- still nothing)."""
+    import torch.distributed as dist
+    shifts = torch.arange(64, device=masks.device, dtype=torch.int64)
+    bits = ((masks[:, None] >> shifts) & 1).to(torch.int32)
+    dist.all_reduce(bits, op=dist.ReduceOp.MAX, group=group)
+    masks.copy_((bits.to(torch.int64) << shifts).sum(dim=1))
+
+
+def encode_taf_stripe(dat, seq_offsets, shape, stripe, state, t_start, window_us=10000, n_windows=8, volume_bins=8,
+                      want_view=False, want_u8=True, flip_k=True, xmap=None, ymap=None, check=True, group=None,
+                      exchange=None):
+    """Row-stripe sharding of ONE frame over several GPUs: this rank encodes rows ``stripe = (y_lo, y_hi)`` of
+    the ``shape = (H, W)`` frame from the WHOLE stream ``dat`` (events of other rows are skipped) into its stripe of the FIFO
+    state ``(B, y_hi - y_lo, W, 2, K)`` (in place) and of the outputs.  No halo, no event exchange; the one global quantity --
+    "a window without any event in the whole frame leaves the state untouched", generate_taf.py:40-41 -- is OR-reduced
+    between the two halves of the encode: 8 bytes per sequence over ``torch.distributed`` (``group``; RCCL on the GPU box).
+    The stripes of all ranks put together equal ``encode_taf_batch`` on the whole frame, bit for bit.
+
+    ``exchange(masks)``: replaces the collective (tests emulate the other stripes in one process: it receives the
+    ``(B,)`` int64 device tensor of this stripe's masks and ORs the others' into it in place)."""
+    import torch.distributed as dist
+    H, W = int(shape[0]), int(shape[1])
+    y_lo, y_hi = int(stripe[0]), int(stripe[1])
+    rows = y_hi - y_lo
+    if not (0 <= y_lo < y_hi <= H):
+        raise ValueError("stripe must be (y_lo, y_hi) with 0 <= y_lo < y_hi <= H")
+    K = int(volume_bins)
+    offs = [int(o) for o in seq_offsets]
+    B = len(offs) - 1
+    if B < 1 or B > _lib.MAX_SEQUENCES:
+        raise ValueError(f"1..{_lib.MAX_SEQUENCES} sequences per call")
+    t0 = [int(t_start)] * B if not hasattr(t_start, "__len__") else [int(t) for t in t_start]
+    assert state.dtype == torch.float32 and state.is_contiguous() and tuple(state.shape) == (B, rows, W, 2, K)
+    d, desc = _events_dat(dat, xmap, ymap)
+    ws = _batch_workspace(offs[-1] - offs[0], B, rows, W, window_us, d.device, slot=("stripe", y_lo, y_hi))
+    if ws is None:
+        raise NotImplementedError("shape outside the fast TAF path")
+    lib = _lib.load()
+    c_offs, c_t0 = (C.c_int64 * (B + 1))(*offs), (C.c_int64 * B)(*t0)
+    rc = lib.frlw_taf_stripe_partition(C.byref(desc), c_offs, c_t0, B, H, W, y_lo, rows, K, int(window_us), int(n_windows),
+                                       _ptr(ws), ws.numel(), _stream())
+    if rc == _lib.FRLW_ERR_UNSUPPORTED:
+        raise NotImplementedError("window / shape outside the fast TAF path")
+    _lib.check(rc, "encode_taf_stripe (partition)")
+    off = int(lib.frlw_taf_stripe_window_masks(_ptr(ws))) - ws.data_ptr()
+    masks = ws[off:off + 8 * B].view(torch.int64)  # the kernels' own words: reduced in place, read by the second half
+    if exchange is not None:
+        exchange(masks)
+    elif dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        _or_reduce_window_masks(masks, group)
+    u8 = torch.empty((B, K, 2, rows, W), dtype=torch.uint8, device=d.device) if want_u8 else None
+    view = torch.empty((B, 2 * K, rows, W), dtype=torch.float32, device=d.device) if want_view else None
+    flags = _lib.TAF_U8_FLIP_K if flip_k else 0
+    _lib.check(lib.frlw_taf_stripe_finish(C.byref(desc), c_offs, c_t0, B, H, W, y_lo, rows, K, int(window_us), int(n_windows),
+                                          _ptr(state), _ptr(view), _ptr(u8), flags, _ptr(ws), ws.numel(), _stream()),
+               "encode_taf_stripe (finish)")
+    if check:
+        _finish(ws, "encode_taf_stripe")
     return u8, view
 
 

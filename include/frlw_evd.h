@@ -185,6 +185,27 @@ int frlw_taf_encode_batch(const frlw_events_t *ev, const int64_t *seq_offsets, c
                           uint8_t *out_u8, int flags, void *workspace, size_t workspace_bytes, frlw_stream_t stream);
 
 /*
+ * Row-stripe sharding of ONE frame over several GPUs ("route events by y; each GPU owns its stripe of state /
+ * output -- no halo, no exchange"): every rank holds the stream, encodes rows [y_lo, y_lo + rows) of the H_full x W frame
+ * (events of other rows are skipped) into ITS stripe of the state / outputs -- (n_seq, rows, W, 2, K) and so on.  One quantity
+ * is global: "a window without any event in the whole frame leaves the state untouched" (generate_taf.py:40-41).  So the
+ * encode runs in two halves around one 8-byte-per-sequence exchange:
+ *   frlw_taf_stripe_partition(...)            hist, scans, scatter of this stripe; leaves the stripe's window masks in the workspace
+ *   frlw_taf_stripe_window_masks(workspace)   device pointer to the n_seq 64-bit masks: OR-reduce them IN PLACE over the ranks
+ *                                             (RCCL all-reduce with BOR through torch.distributed in the shim), same stream order
+ *   frlw_taf_stripe_finish(...)               split + walk with the reduced masks; same arguments, same workspace
+ * The stripes put together are bit-identical to frlw_taf_encode_batch on the whole frame.  Workspace:
+ * frlw_taf_batch_workspace_bytes(total events, n_seq, rows, W, window_us).
+ */
+int frlw_taf_stripe_partition(const frlw_events_t *ev, const int64_t *seq_offsets, const int64_t *t_start, int n_seq, int H_full,
+                              int W, int y_lo, int rows, int K, int64_t window_us, int n_windows, void *workspace,
+                              size_t workspace_bytes, frlw_stream_t stream);
+unsigned long long *frlw_taf_stripe_window_masks(void *workspace);
+int frlw_taf_stripe_finish(const frlw_events_t *ev, const int64_t *seq_offsets, const int64_t *t_start, int n_seq, int H_full, int W,
+                           int y_lo, int rows, int K, int64_t window_us, int n_windows, float *state, float *view_f32,
+                           uint8_t *out_u8, int flags, void *workspace, size_t workspace_bytes, frlw_stream_t stream);
+
+/*
  * Event Volume for a batch of independent streams -- the harness lines generate_eventvolume.py:139-157 (window cut,
  * f64 normalisation) around generate_agile_event_volume_cuda (:15-42) for n_seq <= FRLW_MAX_SEQUENCES label windows in one
  * launch sequence.  Sequence s owns the DAT8 records [seq_offsets[s], seq_offsets[s + 1]) and ends at t_end[s] (HOST

@@ -89,3 +89,55 @@ def test_two_ddp_ranks_native_train_ops(tmp_path, hook):
         m.load_state_dict(_build().state_dict())  # undo the running-statistics update of this pass
     want = want / world
     assert np.abs(g0 - want).max() <= 1e-3 * np.abs(want).max()
+
+
+def _stripe_worker(rank, world, port, out_dir):
+    two_gpus = torch.cuda.device_count() >= world
+    dev = rank if two_gpus else 0
+    backend = "nccl" if two_gpus else "gloo"
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(dev), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), FRLW_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    from frlw_evd_amd import dist as fd, event_representation as er, synth
+    fd.init_from_env(backend)
+    torch.cuda.set_device(dev)
+    H, W, K, win, n_win = 240, 304, 8, 10_000, 8
+    ev = synth.synth_events(77, 400_000, W, H, n_win * win)
+    w_idx = np.minimum(ev["t"] // win, n_win - 1)
+    keep = ~((w_idx == 3) & (ev["y"] < H // 2)) & (w_idx != 6)   # window 3 only in the lower half, window 6 nowhere
+    rec = synth.to_dat8({k: v[keep] for k, v in ev.items()})
+    dat = torch.from_numpy(np.ascontiguousarray(rec).view(np.uint8).reshape(-1, 8).copy()).cuda()
+    lo, hi = fd.shard_range(H, rank, world)                     # this rank's rows
+    st = torch.full((1, hi - lo, W, 2, K), -6000.0, device="cuda")
+    if backend == "gloo":  # gloo reduces host tensors: the 8-byte masks make the round trip (RCCL: on the device)
+        def exchange(m):
+            h = m.cpu()
+            parts = [torch.zeros_like(h) for _ in range(world)]
+            torch.distributed.all_gather(parts, h)
+            for p in parts:
+                h |= p
+            m.copy_(h)
+        er.encode_taf_stripe(dat, [0, len(rec)], (H, W), (lo, hi), st, 0, win, n_win, K, exchange=exchange)
+    else:
+        er.encode_taf_stripe(dat, [0, len(rec)], (H, W), (lo, hi), st, 0, win, n_win, K)
+    np.save(os.path.join(out_dir, f"s{rank}.npy"), st.cpu().numpy())
+    torch.distributed.destroy_process_group()
+
+
+def test_row_stripe_sharding_two_ranks(tmp_path):
+    """One stream, two ranks, each encodes its half of the rows; the window masks are OR-reduced between the two halves of
+    the encode (RCCL when the box has two GPUs, else both ranks on GPU 0 over gloo): halves together == whole frame."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from frlw_evd_amd import event_representation as er, synth
+    world = 2
+    mp.spawn(_stripe_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    H, W, K, win, n_win = 240, 304, 8, 10_000, 8
+    ev = synth.synth_events(77, 400_000, W, H, n_win * win)
+    w_idx = np.minimum(ev["t"] // win, n_win - 1)
+    keep = ~((w_idx == 3) & (ev["y"] < H // 2)) & (w_idx != 6)
+    rec = synth.to_dat8({k: v[keep] for k, v in ev.items()})
+    dat = torch.from_numpy(np.ascontiguousarray(rec).view(np.uint8).reshape(-1, 8).copy()).cuda()
+    full = torch.full((1, H, W, 2, K), -6000.0, device="cuda")
+    er.encode_taf_batch(dat, [0, len(rec)], (H, W), full, 0, win, n_win, K)
+    got = np.concatenate([np.load(tmp_path / f"s{r}.npy") for r in range(world)], axis=1)
+    assert got.shape == (1, H, W, 2, K) and got.tobytes() == full.cpu().numpy().tobytes()

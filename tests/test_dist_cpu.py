@@ -149,3 +149,23 @@ def test_bench_under_an_external_launcher():
     assert '"n_gpus": 2' in p.stdout and '"launched_by": "external launcher"' in p.stdout
     rc, _, err = _run_bench(["--gpus", "2", "--launch-only"], {"WORLD_SIZE": "3", "RANK": "0"})
     assert rc != 0
+
+
+def _mask_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    fd.init_from_env(backend="gloo")
+    from frlw_evd_amd.event_representation import _or_reduce_window_masks
+    masks = torch.from_numpy(np.array([[0b1011, 1 << 40, 0], [0b0100, 1 << 63, 0]][rank], dtype=np.uint64).view(np.int64))  # bit 63: the sign bit travels too
+    _or_reduce_window_masks(masks, None)
+    np.save(os.path.join(out_dir, f"m{rank}.npy"), masks.numpy())
+    torch.distributed.destroy_process_group()
+
+
+def test_window_masks_or_reduce_two_ranks(tmp_path):
+    """The one exchange of the row-stripe sharding (event_representation.encode_taf_stripe): 64-bit window masks OR-ed over the
+    ranks through a MAX all-reduce of their bits (RCCL has no bitwise reductions)."""
+    world = 2
+    mp.spawn(_mask_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    want = np.array([0b1111, (1 << 40) | (1 << 63), 0], dtype=np.uint64).view(np.int64)
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f"m{r}.npy"), want)

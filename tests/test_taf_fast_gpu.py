@@ -300,3 +300,53 @@ def test_tile_walk_mpx_golden(er, monkeypatch, golden_dir):
     monkeypatch.setattr(er, "TUNING", _lib.FrlwTuning(taf_tile_walk=1))
     er.encode_taf_batch(to_dev(rec), [0, len(rec)], (H, W), st, 0, 10_000, 8, K)
     assert hashlib.sha256(host(st[0]).tobytes()).hexdigest() == str(g["state_sha"])
+
+
+# ---- row-stripe sharding of one frame: stripes of several "ranks" == the whole-frame encode --------------
+def _stripe_case(seed, H, W, n, n_win, win, hotspot):
+    ev = synth.synth_events(seed, n, W, H, n_win * win, hotspot=hotspot)
+    # window 2: events ONLY in the upper stripe rows; window 5: no event anywhere (the per-frame rule, generate_taf.py:40-41)
+    w_idx = np.minimum(ev["t"] // win, n_win - 1)
+    keep = ~((w_idx == 2) & (ev["y"] >= H // 3)) & (w_idx != 5)
+    ev = {k: v[keep] for k, v in ev.items()}
+    ev["x"][:7] = W + 3   # x >= W aliases into the next row of the WHOLE frame (flat index, generate_taf.py:23): may change stripe
+    ev["y"][:7] = np.minimum(ev["y"][:7], H - 2)
+    return synth.to_dat8(ev)
+
+
+@pytest.mark.parametrize("cuts", [(0, 100, 240), (0, 33, 170, 240)])
+def test_row_stripes_equal_whole_frame(er, cuts):
+    """Two / three stripes encoded one after the other in this process -- each from the whole stream, each with its own
+    workspace, the window masks OR-ed between the two halves of the encodes -- equal one encode of the whole frame."""
+    H, W, K, win, n_win = 240, 304, 8, 10_000, 8
+    recs = [_stripe_case(610, H, W, 700_000, n_win, win, False), _stripe_case(611, H, W, 90_000, n_win, win, True)]
+    offs = np.concatenate([[0], np.cumsum([len(r) for r in recs])])
+    dat = to_dev(np.concatenate(recs))
+    B = len(recs)
+    init = torch.from_numpy(np.random.default_rng(8).uniform(-40, 0, (B, H, W, 2, K)).astype(np.float32)).cuda()
+    full = init.clone()
+    u_full, v_full = er.encode_taf_batch(dat, offs, (H, W), full, 0, win, n_win, K, want_view=True)
+    stripes = list(zip(cuts[:-1], cuts[1:]))
+    # pass 1: every stripe's own masks (what each rank has before the exchange); pass 2: the real encodes with the OR of all
+    own = []
+    for (lo, hi) in stripes:
+        st = init[:, lo:hi].contiguous()
+        er.encode_taf_stripe(dat, offs, (H, W), (lo, hi), st, 0, win, n_win, K, exchange=lambda m: own.append(m.clone()))
+    assert len({tuple(m.tolist()) for m in own}) > 1, "the stripes should differ in their window masks (window 2)"
+    total = own[0].clone()
+    for m in own[1:]:
+        total |= m
+    assert all(((int(v) >> 5) & 1) == 0 for v in total.tolist()), "window 5 is empty in the whole frame"
+    state = init.clone()
+    for (lo, hi) in stripes:
+        st = init[:, lo:hi].contiguous()
+        u8, view = er.encode_taf_stripe(dat, offs, (H, W), (lo, hi), st, 0, win, n_win, K, want_view=True,
+                                        exchange=lambda m: m.copy_(total))
+        state[:, lo:hi] = st
+        assert torch.equal(u8, u_full[:, :, :, lo:hi]), f"uint8 of stripe {lo}:{hi}"
+        assert torch.equal(view, v_full[:, :, lo:hi]), f"view of stripe {lo}:{hi}"
+    assert torch.equal(state, full), "stripes put together == whole frame"
+    # without the exchange the upper stripe would age window 2 alone: the rule really is global
+    st = init[:, stripes[-1][0]:stripes[-1][1]].contiguous()
+    er.encode_taf_stripe(dat, offs, (H, W), stripes[-1], st, 0, win, n_win, K)
+    assert not torch.equal(st, full[:, stripes[-1][0]:stripes[-1][1]])
