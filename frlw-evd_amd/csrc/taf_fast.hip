@@ -737,16 +737,22 @@ __device__ __forceinline__ void split_count_segment(const TileP &q, uint32_t seg
 }
 
 // 4a. Tiles of ordinary size (at most kSplitWhole records): ONE workgroup per (sequence, tile) reorders the tile's
-// records sub-tile-major, STABLY.  Pass 1 counts the 16 sub-tiles; pass 2 ranks chunk by chunk with one returning LDS atomic per record on
-// (round, wavefront, sub-tile) counters: lanes of one instruction are served in lane order, (round, wavefront) is the
-// stream order of the 64-record batches.
+// records sub-tile-major, STABLY, in ONE pass over the list: every thread loads its (up to) 32 records at once -- all
+// loads of the tile in flight together, the list is read once and stays in registers -- and takes one returning LDS
+// atomic per record on a (sub-tile, batch) counter, batch = the 64 records of one wave-instruction: lanes of one
+// instruction are served in lane order and the batches are numbered in stream order, so the ticket plus the prefix of the
+// sub-tile's earlier batches is the record's stable slot.  (Until round 3 this kernel counted the sub-tiles in a first
+// pass and then re-read the list in chunks of 8192: six dependent trips to memory per workgroup where this has one.)
+constexpr int kWholeChunks = FRLW_WHOLE_SEGS;
+constexpr int kWholeBatches = kWholeChunks * kSplitSeg / kWave; // 512 batches of 64 records
+constexpr int kWholeRow = kWholeBatches + 1;                    // row stride of scnt: the 16 counters of one batch in 16 banks
 __global__ __launch_bounds__(kFT) void kf_split_whole(TileP q)
 {
-    constexpr int RPT = kSplitSeg / kFT, CH = RPT * kFT, NE = RPT * kFW;
-    __shared__ uint32_t scnt[RPT][kFW][kFW]; // [round][wavefront][sub-tile]
-    __shared__ uint32_t wtot[kFW][kFW];      // pass 1: [wavefront][sub-tile]
-    __shared__ uint32_t run[kFW];            // next free slot of every sub-tile's list
-    __shared__ uint32_t btot[kFW];
+    constexpr int RPT = kSplitSeg / kFT; // 8 records per thread and chunk of 8192
+    __shared__ uint32_t scnt[kFW * kWholeRow]; // [sub-tile][batch] tickets, then exclusive prefixes
+    __shared__ uint32_t wtot[kFW][kFW];        // segment counting (4b): [wavefront][sub-tile]
+    __shared__ uint32_t vtot[kFW];             // records of every sub-tile
+    __shared__ uint32_t vbeg[kFW][kFW];        // [wavefront]: every wavefront's own copy of the sub-tile starts
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (q.hdr->status != 0) return;
     const int blk = (int)blockIdx.x + q.first_block;
@@ -764,64 +770,82 @@ __global__ __launch_bounds__(kFT) void kf_split_whole(TileP q)
     if (g == q.pairs - 1 && tid == 0) q.sub[(long long)q.pairs * kFW] = end; // end of the last sub-tile's list
     if (end - beg > whole_max_of(q.pairs) || q.skip_whole) return; // a skewed tile (or a call with few tiles): left to the segment kernels below
     if (q.tile_walk && q.hdr->unsorted[g / q.T] == 0u) return;     // split in LDS by kf_taf_tile
-    if (tid < kFW * kFW) (&wtot[0][0])[tid] = 0u;
-    __syncthreads();
-    count_subtiles(q.rec, beg, end, wtot);
-    __syncthreads();
-    if (tid < kFW) {
-        uint32_t t = 0;
+    const uint32_t n = end - beg;
+    if (n == 0u) {
+        if (tid < kFW) q.sub[(long long)g * kFW + tid] = beg;
+        return;
+    }
+    // 1. the whole list into registers (indices clamped: no load sits under a lane condition)
+    uint32_t m[kWholeChunks][RPT];
 #pragma unroll
-        for (int w = 0; w < kFW; ++w) t += wtot[w][tid];
+    for (int c = 0; c < kWholeChunks; ++c)
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) {
+            const uint32_t i = (uint32_t)(c * kSplitSeg + u * kFT + tid);
+            m[c][u] = q.rec[beg + (i < n ? i : n - 1u)];
+        }
+    for (int i = tid; i < kFW * kWholeRow; i += kFT) scnt[i] = 0u;
+    __syncthreads();
+    // 2. tickets: batch (c, u, wv) of the stream, counter [sub-tile][batch]; packed four to a register (a ticket is < 64)
+    uint32_t rk[kWholeChunks][RPT / 4];
+#pragma unroll
+    for (int c = 0; c < kWholeChunks; ++c) {
+#pragma unroll
+        for (int u4 = 0; u4 < RPT / 4; ++u4) rk[c][u4] = 0u;
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) {
+            const uint32_t i0 = (uint32_t)(c * kSplitSeg + u * kFT + wv * kWave); // first record of the batch: wave-uniform
+            if (i0 < n) {
+                const bool valid = i0 + (uint32_t)lane < n;
+                const uint32_t b = valid ? (m[c][u] & (kCells - 1)) >> 8 : (uint32_t)(lane & 15); // (lanes behind the end add 0, spread over the counters)
+                const uint32_t t = atomicAdd(&scnt[b * kWholeRow + (c * RPT + u) * kFW + wv], valid ? 1u : 0u);
+                rk[c][u >> 2] |= t << (8 * (u & 3));
+            }
+        }
+    }
+    __syncthreads();
+    // 3. wavefront b: exclusive prefix of sub-tile b's batch counts in stream order (eight scans of 64 batches)
+    {
+        uint32_t carry = 0;
+#pragma unroll
+        for (int k = 0; k < kWholeBatches / kWave; ++k) {
+            if ((uint32_t)(k * kWave * kWave) < n) { // (batches behind the end of the list hold zeros)
+                const uint32_t v = scnt[wv * kWholeRow + k * kWave + lane];
+                const uint32_t inc = wave_incl_scan(v);
+                scnt[wv * kWholeRow + k * kWave + lane] = carry + inc - v;
+                carry += __shfl(inc, kWave - 1);
+            }
+        }
+        if (lane == 0) vtot[wv] = carry;
+    }
+    __syncthreads();
+    {
+        // every wavefront: where the 16 lists start (its own copy: no further barrier)
+        const uint32_t t = vtot[lane & 15];
         uint32_t inc = t;
 #pragma unroll
         for (int o2 = 1; o2 < kFW; o2 <<= 1) {
             const uint32_t u = __shfl_up(inc, o2);
-            if (lane >= o2) inc += u;
+            if ((lane & 15) >= o2) inc += u;
         }
-        run[tid] = beg + inc - t;
-        q.sub[(long long)g * kFW + tid] = beg + inc - t;
+        if (lane < kFW) {
+            vbeg[wv][lane] = beg + inc - t;
+            if (wv == 0) q.sub[(long long)g * kFW + lane] = beg + inc - t;
+        }
+        LDS_FENCE();
     }
-    for (uint32_t c0 = beg; c0 < end; c0 += CH) {
-        const uint32_t nrec = end - c0 < (uint32_t)CH ? end - c0 : (uint32_t)CH;
-        for (int i = tid; i < RPT * kFW * kFW; i += kFT) (&scnt[0][0][0])[i] = 0u;
-        __syncthreads();
-        uint32_t m[RPT], rk[RPT];
+    // 4. records to their slots
+#pragma unroll
+    for (int c = 0; c < kWholeChunks; ++c)
 #pragma unroll
         for (int u = 0; u < RPT; ++u) {
-            const uint32_t i = (uint32_t)(u * kFT + tid);
-            m[u] = i < nrec ? q.rec[c0 + i] : 0u;
-        }
-#pragma unroll
-        for (int u = 0; u < RPT; ++u) {
-            const uint32_t i = (uint32_t)(u * kFT + tid);
-            rk[u] = 0u;
-            if (i < nrec) rk[u] = atomicAdd(&scnt[u][wv][(m[u] & (kCells - 1)) >> 8], 1u);
-        }
-        __syncthreads();
-        {
-            // wavefront b: exclusive prefix of sub-tile b's counts over (round, wavefront) = stream order
-            uint32_t v0 = 0, v1 = 0;
-            const int e0 = 2 * lane, e1 = 2 * lane + 1;
-            if (e0 < NE) v0 = scnt[e0 / kFW][e0 % kFW][wv];
-            if (e1 < NE) v1 = scnt[e1 / kFW][e1 % kFW][wv];
-            const uint32_t inc = wave_incl_scan(v0 + v1);
-            const uint32_t ex = inc - (v0 + v1);
-            if (e0 < NE) scnt[e0 / kFW][e0 % kFW][wv] = ex;
-            if (e1 < NE) scnt[e1 / kFW][e1 % kFW][wv] = ex + v0;
-            if (lane == kWave - 1) btot[wv] = inc;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < RPT; ++u) {
-            const uint32_t i = (uint32_t)(u * kFT + tid);
-            if (i < nrec) {
-                const uint32_t b = (m[u] & (kCells - 1)) >> 8;
-                q.rec2[run[b] + scnt[u][wv][b] + rk[u]] = m[u];
+            const uint32_t i = (uint32_t)(c * kSplitSeg + u * kFT + tid);
+            if (i < n) {
+                const uint32_t b = (m[c][u] & (kCells - 1)) >> 8;
+                const uint32_t t = (rk[c][u >> 2] >> (8 * (u & 3))) & 255u;
+                q.rec2[vbeg[wv][b] + scnt[b * kWholeRow + (c * RPT + u) * kFW + wv] + t] = m[c][u];
             }
         }
-        __syncthreads();
-        if (tid < kFW) run[tid] += btot[tid];
-    }
 }
 
 // 4b. Skewed tiles (more than kSplitWhole records).  Reorders every tile's records sub-tile-major (sub-tile = the 256 cells [256 v, 256 v + 256) one workgroup of
