@@ -536,13 +536,14 @@ def _train_inputs(torch, B, rank):
     return x, lab.cuda()
 
 
-def _train_variant(torch, timer, world, rank, local_rank, per_gpu_batch, ddp, hook, steps=5, warmup=3):
-    """One configuration of the train step on a fresh model: (seconds per step, device ms per step, Trainer, last loss)."""
+def _train_variant(torch, timer, world, rank, local_rank, per_gpu_batch, ddp, hook, steps=5, warmup=3, graph=False):
+    """One configuration of the train step on a fresh model: (seconds per step, device ms per step, Trainer, last loss).
+    graph: the whole step replayed as one HIP graph (one rank without DDP; captured during the warm-up calls)."""
     from frlw_evd_amd import e2e
     from frlw_evd_amd.trainer import Trainer
     m = e2e.build_model(in_channels=16, num_classes=2)
     tr = Trainer(m, global_batch=per_gpu_batch * world, nodes=world, iters_per_epoch=100, local_rank=local_rank,
-                 ddp=ddp, comm_hook=hook)
+                 ddp=ddp, comm_hook=hook, graph=graph)
     x, lab = _train_inputs(torch, per_gpu_batch, rank)
     state = {"i": 0, "loss": None}
 
@@ -590,7 +591,9 @@ def bench_train(args, torch, world, rank, local_rank, timer):
     from frlw_evd_amd import e2e
     B = args.train_batch
     steps = 5
-    per, dev_ms, tr, state, one, (x, lab) = _train_variant(torch, timer, world, rank, local_rank, B, world > 1, None, steps)
+    use_graph = world == 1  # one rank: forward + SimOTA + losses + backward + Adam replayed as ONE HIP graph; DDP ranks: eager
+    per, dev_ms, tr, state, one, (x, lab) = _train_variant(torch, timer, world, rank, local_rank, B, world > 1, None, steps,
+                                                           graph=use_graph)
     loss = state["loss"]
     from frlw_evd_amd.detector import DetectorEngine
     probe = DetectorEngine(e2e.build_model(16, 2, device="cpu").eval(), device="cpu")
@@ -601,6 +604,8 @@ def bench_train(args, torch, world, rank, local_rank, timer):
     out = {"metric": "YOLOX train step (frames/s)", "value": round(world * B / per, 1), "unit": "frames/s",
            "ms_per_step": round(per * 1e3, 3), "per_gpu_batch": B, "global_batch": B * world, "steps": steps,
            "loss": round(loss, 4), "parallelism": f"ddp{world}" if world > 1 else "single", "scaling": "weak",
+           "launch": "one HIP graph per step (Trainer(graph=True): ~1 200 kernel nodes, the loss read back after every replay "
+                     "like core/exp.py:303)" if use_graph else "eager launches (DDP ranks)",
            "convolutions": "csrc/train_ops.hip (fp32 MFMA fwd / dgrad / wgrad, BatchNorm + SiLU fwd / bwd), SimOTA csrc/simota.hip",
            "roofline": {"bound": "mfma", "kernel": "k_conv_mfma (fwd + dgrad) + k_wgrad_mfma", "achieved": round(tflops, 2),
                         "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / FP32_MFMA_PEAK_TFLOPS, 4),
@@ -624,17 +629,23 @@ def bench_train(args, torch, world, rank, local_rank, timer):
                                      "ms_per_step": round(per_e2e * 1e3, 3), "encode_ms_per_batch": round(per_enc * 1e3, 3)}
     del src
     if world == 1:
+        # the same step launched eagerly (what the DDP ranks do), and eagerly with torch autograd / MIOpen convolutions
+        per_e, dev_e, tr_e, _st, one_e, _xy = _train_variant(torch, timer, world, rank, local_rank, B, False, None, steps)
+        out["eager"] = {"value": round(B / per_e, 1), "ms_per_step": round(per_e * 1e3, 3), "device_ms_per_step": round(dev_e, 3),
+                        "graph_speedup": round(per_e / per, 3)}
         prev = os.environ.get("FRLW_NATIVE_TRAIN")
-        os.environ["FRLW_NATIVE_TRAIN"] = "0"  # the same step with torch autograd / MIOpen convolutions, for comparison
+        os.environ["FRLW_NATIVE_TRAIN"] = "0"
         try:
-            per_t, _ = timer.run(one, steps, 3)
+            per_t, _ = timer.run(one_e, steps, 3)
         finally:
             if prev is None:
                 os.environ.pop("FRLW_NATIVE_TRAIN", None)
             else:
                 os.environ["FRLW_NATIVE_TRAIN"] = prev
         out["same_step_with_miopen_convs"] = {"value": round(world * B / per_t, 1), "ms_per_step": round(per_t * 1e3, 3),
-                                              "native_speedup": round(per_t / per, 3)}
+                                              "launch": "eager", "native_speedup": round(per_t / per_e, 3),
+                                              "native_graph_speedup": round(per_t / per, 3)}
+        del tr_e, one_e, _xy
     del tr, one, x, lab
     torch.cuda.empty_cache()
     # ---- the reference's semantics: GLOBAL batch 64 (settings.py:41: 64 / nodes per GPU) -> strong scaling over N

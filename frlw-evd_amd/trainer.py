@@ -12,6 +12,11 @@ Every training-mode ``BaseConv`` on a ROCm tensor runs forward and backward in t
 csrc/train_ops.hip (``yolox/train_ops.py``: fp32 MFMA convolution, data and weight gradient, BatchNorm + SiLU), SimOTA
 in csrc/simota.hip; torch autograd only strings the blocks together.  The gradient all-reduce is DDP's bucketed RCCL
 all-reduce, or the direct reduce-scatter + all-gather hook of ``dist.py``.
+
+One rank without DDP can replay the whole step -- forward, SimOTA + losses, backward, Adam: ~1 200 launches, none of them
+data-dependent on the host -- as ONE HIP graph (``Trainer(..., graph=True)`` or ``capture()``): the step is launch-bound
+in its loss and gradient-accumulation stretches and ends in the reference's ``loss.cpu()``, which drains the queue
+(15-20 % of the step idle in an eager trace, tools/train_gaps.sh); the replay leaves no gaps.
 """
 from __future__ import annotations
 
@@ -60,8 +65,10 @@ class Trainer:
     """One rank of the reference's training loop around an already built ``model``."""
 
     def __init__(self, model, global_batch=64, nodes=1, iters_per_epoch=100, max_epoch=50, warmup_epochs=5,
-                 local_rank=None, ddp=False, comm_hook=None):
+                 local_rank=None, ddp=False, comm_hook=None, graph=False):
         self.lr0, self.per_gpu_batch = init_lr(global_batch, nodes)
+        self._graph = None          # (HIP graph, static images, static labels, static loss) once captured
+        self._want_graph = bool(graph) and not ddp  # (DDP: eager -- capture of RCCL collectives is not validated here)
         self.model = model
         self.comm_hook = None
         if ddp:
@@ -76,7 +83,13 @@ class Trainer:
         # multi-tensor kernel per chunk (fused=True: the same arithmetic per element as the default implementation, which
         # issues eight launches per chunk -- 0.6 ms of a 33 ms step)
         fused = bool(params) and all(p.is_cuda for p in params)
-        self.optimizer = torch.optim.Adam(params, lr=0.0 if warmup_epochs > 0 else self.lr0, **({"fused": True} if fused else {}))
+        self._want_graph = self._want_graph and fused
+        lr_start = 0.0 if warmup_epochs > 0 else self.lr0
+        if self._want_graph:  # a graph replays device work only: the step counter and the learning rate live on the device
+            self.optimizer = torch.optim.Adam(params, lr=torch.tensor(lr_start, dtype=torch.float32, device=params[0].device),
+                                              fused=True, capturable=True)
+        else:
+            self.optimizer = torch.optim.Adam(params, lr=lr_start, **({"fused": True} if fused else {}))
         self.scheduler = LRScheduler("yoloxwarmcos", self.lr0, iters_per_epoch, max_epoch, warmup_epochs=warmup_epochs,
                                      warmup_lr_start=0.0, no_aug_epochs=0, min_lr_ratio=0.05)
         dev = "cuda" if next(model.parameters()).is_cuda else "cpu"
@@ -84,14 +97,66 @@ class Trainer:
         self.iters_per_epoch = iters_per_epoch
         self.epoch_step = 0
 
-    def train_step(self, imgs, targets, i_batch=0):
-        """core/exp.py:292-303 for one batch; returns (loss as a Python float, lr)."""
-        self.model.train()
+    def _set_lr(self, lr):
+        for g in self.optimizer.param_groups:
+            if torch.is_tensor(g["lr"]):
+                g["lr"].fill_(lr)
+            else:
+                g["lr"] = lr
+
+    def _eager_step(self, imgs, targets):
         self.optimizer.zero_grad()
         loss = self.model(imgs, targets, None, None)
         self.scaler.scale(loss).backward()
         self.optimizer.step()  # NOT scaler.step: the 65536x scale reaches Adam (reference behaviour)
+        return loss
+
+    def capture(self, imgs, targets, warmup=3):
+        """Capture one whole step for batches shaped like (imgs, targets) into a HIP graph.  Runs ``warmup`` REAL steps on
+        the given batch first (they train: count them), on a side stream as torch's capture rules ask; the gradients are
+        allocated inside the graph's memory pool, so ``zero_grad`` is part of the replay (set_to_none before capture)."""
+        if not self._want_graph:
+            raise RuntimeError("graph capture needs Trainer(graph=True), one rank without DDP, parameters on the GPU")
+        self.model.train()
+        x, lab = imgs.clone(), targets.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self.optimizer.zero_grad(set_to_none=True)
+                loss = self.model(x, lab, None, None)
+                self.scaler.scale(loss).backward()
+                self.optimizer.step()
+                del loss  # (nothing of this iteration's autograd graph may live into the capture)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        self.optimizer.zero_grad(set_to_none=True)
+        with torch.cuda.graph(graph):
+            loss = self.model(x, lab, None, None)
+            self.scaler.scale(loss).backward()
+            self.optimizer.step()
+        self._graph = (graph, x, lab, loss)
+        return warmup
+
+    def train_step(self, imgs, targets, i_batch=0, sync=True):
+        """core/exp.py:292-303 for one batch; returns (loss as a Python float, lr).  ``sync=False`` returns the loss as a
+        device tensor instead (the caller reads it when it logs: no queue drain per step)."""
+        self.model.train()
+        if self._want_graph and self._graph is None:
+            self.capture(imgs, targets, warmup=3)
+        if self._graph is not None and imgs.shape == self._graph[1].shape and targets.shape == self._graph[2].shape:
+            graph, x, lab, loss = self._graph
+            x.copy_(imgs, non_blocking=True)
+            lab.copy_(targets, non_blocking=True)
+            graph.replay()
+            # the replay moved the parameters without telling autograd: bump their version counters so that every cache
+            # keyed on them (weight layouts, the folded inference engine) sees the change
+            torch.autograd.graph.increment_version([p for g in self.optimizer.param_groups for p in g["params"]])
+        else:
+            loss = self._eager_step(imgs, targets)
         lr = self.scheduler.update_lr(self.epoch_step * self.iters_per_epoch + i_batch + 1)
-        for g in self.optimizer.param_groups:
-            g["lr"] = lr
+        self._set_lr(lr)
+        if not sync:
+            return loss.detach().clone() if self._graph is not None else loss.detach(), lr
         return float(loss.detach().cpu()), lr

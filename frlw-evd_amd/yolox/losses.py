@@ -36,12 +36,27 @@ def iou_loss(pred, target):
     return 1 - iou ** 2
 
 
+_GRIDS = {}
+
+
+def _level_grid(h, w, stride, device, dtype):
+    """((1, h*w, 2) cell grid, (1, h*w) stride row) of one level, built once per (shape, device) and kept: the reference
+    rebuilds both on the host and uploads them every step (yolo_head.py:242-246) -- two host-to-device copies per level
+    that also keep the step from being captured into a HIP graph.  Constants: never written."""
+    key = (h, w, float(stride), str(device), dtype)
+    hit = _GRIDS.get(key)
+    if hit is None:
+        yv, xv = torch.meshgrid([torch.arange(h), torch.arange(w)], indexing="ij")
+        grid = torch.stack((xv, yv), 2).view(1, h * w, 2).to(device=device, dtype=dtype)
+        hit = _GRIDS[key] = (grid, torch.zeros(1, h * w).fill_(stride).to(device=device, dtype=dtype))
+    return hit
+
+
 def output_and_grid(output, stride):
     """(B, 5 + nc, h, w) raw level output -> decoded (B, h*w, 5 + nc) and its (1, h*w, 2) grid
     (yolo_head.py:237-256): xy = (xy + grid) * stride, wh = square(wh) * stride."""
     B, n_ch, h, w = output.shape
-    yv, xv = torch.meshgrid([torch.arange(h), torch.arange(w)], indexing="ij")
-    grid = torch.stack((xv, yv), 2).view(1, h * w, 2).to(device=output.device, dtype=output.dtype)
+    grid = _level_grid(h, w, stride, output.device, output.dtype)[0]
     out = output.view(B, 1, n_ch, h, w).permute(0, 1, 3, 4, 2).reshape(B, h * w, n_ch)
     xy = (out[..., :2] + grid) * stride
     wh = torch.square(out[..., 2:4]) * stride
@@ -188,7 +203,7 @@ def yolox_losses(level_outputs, strides, labels, num_classes, radius):
         outs.append(dec)
         xs.append(grid[:, :, 0])
         ys.append(grid[:, :, 1])
-        ss.append(torch.zeros(1, grid.shape[1]).fill_(stride).type_as(o))
+        ss.append(_level_grid(o.shape[2], o.shape[3], stride, o.device, o.dtype)[1])
     outputs = torch.cat(outs, 1)
     x_shifts, y_shifts, strides_all = torch.cat(xs, 1), torch.cat(ys, 1), torch.cat(ss, 1)
     if outputs.is_cuda and not _FORCE_LOOP:

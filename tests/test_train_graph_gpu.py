@@ -1,0 +1,70 @@
+"""The train step replayed as one HIP graph (Trainer(graph=True)) against the eager step: same kernels in the same order,
+so losses and parameters must agree bit for bit; caches keyed on parameter versions must notice the replayed updates."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(B, seed):
+    rng = np.random.default_rng(seed)
+    x = torch.from_numpy(rng.integers(0, 256, size=(B, 16, 128, 160, 1, 1)).astype(np.float32) / np.float32(255))
+    lab = torch.zeros(B, 80, 5, dtype=torch.float64)
+    lab[:, 0] = torch.tensor([0, 60.0 + seed, 50.0, 40.0, 30.0])
+    lab[:, 1] = torch.tensor([1, 100.0, 90.0 - seed, 30.0, 50.0])
+    return x.cuda(), lab.cuda()
+
+
+def _trainer(graph):
+    from frlw_evd_amd.trainer import Trainer
+    from frlw_evd_amd.yolox import build_yolox
+    from frlw_evd_amd.yolox.model import recipe_state_dict
+    m = build_yolox(16, 2)
+    m.load_state_dict(recipe_state_dict(m, seed=31))
+    return Trainer(m.cuda(), global_batch=4, nodes=1, iters_per_epoch=4, max_epoch=10, warmup_epochs=1, graph=graph)
+
+
+def test_graph_replay_equals_eager_steps():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    batches = [_inputs(4, s) for s in range(5)]
+    eager, graphed = _trainer(False), _trainer(True)
+    assert graphed.capture(*batches[0], warmup=3) == 3
+    eager.model.train()
+    for _ in range(3):  # the capture's warm-up steps are real steps (at the schedule's starting rate)
+        eager._eager_step(*batches[0])
+    le, lg = [], []
+    for i, (x, lab) in enumerate(batches):
+        le.append(eager.train_step(x, lab, i)[0])
+        lg.append(graphed.train_step(x, lab, i)[0])
+    assert graphed._graph is not None
+    assert le == lg, (le, lg)
+    for (n, a), b in zip(eager.model.named_parameters(), graphed.model.parameters()):
+        assert torch.equal(a, b), n
+    for (n, a), b in zip(eager.model.named_buffers(), graphed.model.buffers()):
+        assert torch.equal(a, b), n
+    # deferred read-back: a device tensor that survives the next replay
+    l0, _ = graphed.train_step(*batches[0], 5, sync=False)
+    l1, _ = graphed.train_step(*batches[1], 6, sync=False)
+    assert l0.is_cuda and float(l0) != float(l1)
+
+
+def test_replayed_updates_reach_the_inference_engine():
+    """The folded inference weights are cached per parameter version: a replay must invalidate them."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    tr = _trainer(True)
+    x, lab = _inputs(4, 9)
+    for i in range(6):  # capture + replays past the zero-rate first step of the warm-up schedule
+        tr.train_step(x, lab, i)
+    m = tr.model
+    m.eval()
+    with torch.no_grad():
+        got = m.engine().raw_outputs(x[..., 0])
+        m2 = _trainer(False).model
+        m2.load_state_dict(m.state_dict())
+        m2.eval()
+        want = m2.engine().raw_outputs(x[..., 0])
+    assert torch.allclose(got, want, rtol=1e-5, atol=1e-6)
