@@ -106,6 +106,7 @@ SYMBOLS = {
                                    _P, _P, _P]),
     "frlw_conv2d_dgrad_parity": (_I, [_I, _I, _I, _I]),
     "frlw_conv_weight_layouts": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
+    "frlw_conv_weight_layouts_batch": (_I, [_P, _I, C.c_int64, _P]),
     "frlw_conv2d_fwd": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _P, _P, _I64, _P]),
     "frlw_conv2d_dgrad": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _P, _P, _I64, _P]),
     "frlw_conv2d_wgrad_scratch_floats": (_I64, [_I, _I, _I, _I, _I, _I]),

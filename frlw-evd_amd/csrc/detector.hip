@@ -35,24 +35,50 @@ namespace {
 
 // ---- glue kernels ------------------------------------------------------------------------------
 // Focus: (B, C, H, W) NCHW -> (B, H/2, W/2, 4C) NHWC, channel blocks TL, BL, TR, BR (network_blocks.py:205-217).
-// One workgroup per output row (b, oy): the 2C input rows are read along x (coalesced), transposed through LDS and
-// the output row (Wo x 4C floats, contiguous) is written along its memory order.
-__global__ __launch_bounds__(256) void k_focus(const float *x, int B, int C, int H, int W, float *y)
+// One workgroup per `Wp` pixels of an output row (b, oy): the 2C input rows are read along x as float2 = the two column
+// parities of one output pixel (coalesced; eight loads in flight per thread), transposed through LDS and the piece of the
+// output row (Wp x 4C floats, contiguous) is written along its memory order.  (Until round 3: scalar loads, one exposed
+// round trip each, and whole rows = three workgroups per CU -- 0.7 TB/s.)
+__global__ __launch_bounds__(256) void k_focus(const float *x, int B, int C, int H, int W, float *y, int Wp)
 {
-    extern __shared__ float frow[]; // [Wo][4C + 1]
-    const int Ho = H / 2, Wo = W / 2, C4 = 4 * C, LD = C4 + 1;
-    const int b = blockIdx.x / Ho, oy = blockIdx.x - b * Ho;
-    // source rows: (c, q & 1) -> x[b][c][2 oy + (q & 1)][:], column parity q >> 1
-    for (int i = threadIdx.x; i < 2 * C * W; i += 256) {
-        const int ix = i % W, r = i / W;      // r = c * 2 + row parity
-        const int c = r >> 1, py = r & 1;
-        const float v = x[(((long long)b * C + c) * H + 2 * oy + py) * W + ix];
-        const int q = py + 2 * (ix & 1);      // 0 TL, 1 BL, 2 TR, 3 BR
-        frow[(ix >> 1) * LD + q * C + c] = v;
+    extern __shared__ float frow[]; // [Wp][4C + 1]
+    const int Ho = H / 2, Wo = W / 2, C4 = 4 * C, LD = C4 + 1, parts = Wo / Wp;
+    const int part = blockIdx.x % parts, row = blockIdx.x / parts;
+    const int b = row / Ho, oy = row - b * Ho, j0 = part * Wp;
+    // source rows: r = c * 2 + row parity -> x[b][c][2 oy + (r & 1)][:]; pair j of a row = output pixel j, parities 0 / 1
+    const int n2 = 2 * C * Wp;
+    for (int i0 = threadIdx.x; i0 < n2; i0 += 8 * 256) {
+        float2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + 256 * u, ic = i < n2 ? i : n2 - 1;
+            const int j = ic % Wp, r = ic / Wp;
+            v[u] = *(const float2 *)(x + (((long long)b * C + (r >> 1)) * H + 2 * oy + (r & 1)) * W + 2 * (j0 + j));
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + 256 * u;
+            if (i < n2) {
+                const int j = i % Wp, r = i / Wp, c = r >> 1, py = r & 1;
+                frow[j * LD + py * C + c] = v[u].x;           // q = py: TL / BL
+                frow[j * LD + (py + 2) * C + c] = v[u].y;     // q = py + 2: TR / BR
+            }
+        }
     }
     __syncthreads();
-    float *dst = y + ((long long)b * Ho + oy) * Wo * C4;
-    for (int i = threadIdx.x; i < Wo * C4; i += 256) dst[i] = frow[(i / C4) * LD + (i % C4)];
+    float *dst = y + (((long long)b * Ho + oy) * Wo + j0) * C4;
+    for (int i = threadIdx.x; i < Wp * C4; i += 256) dst[i] = frow[(i / C4) * LD + (i % C4)];
+}
+
+inline bool launch_focus(const float *x, int B, int C, int H, int W, float *y, hipStream_t s)
+{
+    int Wp = W / 2; // pixels per workgroup: pieces of at most 20 KB (eight workgroups per CU) where the row divides
+    while (Wp % 2 == 0 && (size_t)Wp * (4 * C + 1) * sizeof(float) > 20 * 1024) Wp /= 2;
+    const size_t lds = (size_t)Wp * (4 * C + 1) * sizeof(float);
+    if (lds > 150 * 1024) return false;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_focus, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_focus, dim3(B * (H / 2) * ((W / 2) / Wp)), dim3(256), lds, s, x, B, C, H, W, y, Wp);
+    return true;
 }
 
 // Focus + stem convolution in one kernel (network_blocks.py:205-217 followed by the 3x3 BaseConv of darknet.py:292):
@@ -668,10 +694,7 @@ int frlw_focus_nhwc(const float *x, int B, int C, int H, int W, float *y, frlw_s
 {
     (void)hipGetLastError();
     if (!x || !y || B < 1 || C < 1 || (H & 1) || (W & 1)) return FRLW_ERR_ARG;
-    const size_t lds = (size_t)(W / 2) * (4 * C + 1) * sizeof(float);
-    if (lds > 150 * 1024) return FRLW_ERR_UNSUPPORTED;
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_focus, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_focus, dim3(B * (H / 2)), dim3(256), lds, (hipStream_t)stream, x, B, C, H, W, y);
+    if (!launch_focus(x, B, C, H, W, y, (hipStream_t)stream)) return FRLW_ERR_UNSUPPORTED;
     return hipGetLastError() == hipSuccess ? FRLW_OK : FRLW_ERR_HIP;
 }
 
@@ -824,9 +847,7 @@ int frlw_det_run(const frlw_detector_t *d, int B, void *const *bufs, int n_bufs,
         auto buf = [&](int i) -> float * { return (i >= 0 && i < n_bufs) ? (float *)bufs[i] : nullptr; };
         switch (op.type) {
         case OP_FOCUS: {
-            const size_t lds = (size_t)(op.W / 2) * (4 * op.C + 1) * sizeof(float);
-            if (lds > 150 * 1024) return FRLW_ERR_UNSUPPORTED;
-            hipLaunchKernelGGL(k_focus, dim3(B * (op.H / 2)), dim3(256), lds, s, buf(op.src), B, op.C, op.H, op.W, buf(op.dst));
+            if (!launch_focus(buf(op.src), B, op.C, op.H, op.W, buf(op.dst), s)) return FRLW_ERR_UNSUPPORTED;
             break;
         }
         case OP_FOCUS_STEM: {

@@ -347,12 +347,18 @@ int frlw_pred_bwd(const float *reg_feat, const float *cls_feat, const float *dou
 // pixel looks at the outputs whose window holds it, k = 5, 9, 13, row-major) -- a fixed summation order, no float atomics.
 namespace {
 
-// channels per workgroup: the widest of 64 / 32 / 16 whose maps (backward: 3 x (float + uint16) per element) fit the LDS
-inline int spp_train_ch(int HW, int per_elem_bytes)
+// channels per workgroup: the widest of 64 / 32 / 16 whose maps (backward: 3 x (float + uint16) per element) fit the LDS AND
+// that still gives the chip 1024 workgroups; otherwise the narrowest that fits.  (The window scans are chains of dependent
+// LDS reads: with 64 channels the 8 x 10 x 256 maps of a batch of 64 were 256 workgroups = one wavefront per SIMD, 290 us.)
+inline int spp_train_ch(int HW, int per_elem_bytes, int C, int B)
 {
-    for (int ch = 64; ch >= 16; ch >>= 1)
-        if ((size_t)HW * ch * per_elem_bytes <= 144 * 1024) return ch;
-    return 0;
+    int fit = 0;
+    for (int ch = 64; ch >= 16; ch >>= 1) {
+        if ((size_t)HW * ch * per_elem_bytes > 144 * 1024) continue;
+        fit = ch;
+        if ((long long)((C + ch - 1) / ch) * B >= 1024) return ch;
+    }
+    return fit;
 }
 
 __global__ __launch_bounds__(256) void k_spp_train_fwd(const float *x, int H, int W, int C, int ch, float *out, uint16_t *arg)
@@ -424,7 +430,7 @@ int frlw_spp_train_fwd(const float *x, int B, int H, int W, int C, float *out, u
 {
     (void)hipGetLastError();
     if (!x || !out || !argmax || B < 1 || H < 1 || W < 1 || C < 1) return FRLW_ERR_ARG;
-    const int ch = spp_train_ch(H * W, 3 * 6); // the same chunking as the backward, which needs the most LDS
+    const int ch = spp_train_ch(H * W, 3 * 6, C, B); // the same chunking as the backward, which needs the most LDS
     if (H * W > 65535 || ch == 0) return FRLW_ERR_UNSUPPORTED;
     const size_t lds = (size_t)H * W * ch * sizeof(float);
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_spp_train_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -436,7 +442,7 @@ int frlw_spp_train_bwd(const float *dout, const uint16_t *argmax, int B, int H, 
 {
     (void)hipGetLastError();
     if (!dout || !argmax || !dx || B < 1 || H < 1 || W < 1 || C < 1) return FRLW_ERR_ARG;
-    const int ch = spp_train_ch(H * W, 3 * 6);
+    const int ch = spp_train_ch(H * W, 3 * 6, C, B);
     if (H * W > 65535 || ch == 0) return FRLW_ERR_UNSUPPORTED;
     const size_t lds = (size_t)3 * H * W * ch * (sizeof(float) + sizeof(uint16_t));
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_spp_train_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -40,31 +40,69 @@ namespace {
 // `parity` != 0 (stride-2, k = 3): the data-gradient operand is grouped by output parity class (py, px) in the order
 // (0,0) (0,1) (1,0) (1,1) with 1, 2, 2, 4 taps -- row blocks starting at 0, 1, 3, 5 times Cout; inside a class the rows
 // are (t_ky, t_kx, co) where tap t reads dz[o' + t] and stands for kernel index 1 (parity 0) or 2, 0 (parity 1, t = 0, 1).
+__device__ __forceinline__ void weight_layout_elem(const float *w, int Cout, int Cin, int k, float *fwd, int np_f, float *dgr, int np_d,
+                                                   int parity, long long nf, long long i)
+{
+    const int kk = k * k;
+    if (i < nf) {
+        const int co = (int)(i % np_f);
+        const long long row = i / np_f;
+        const int ci = (int)(row % Cin), tap = (int)(row / Cin);
+        fwd[i] = co < Cout ? w[((long long)co * Cin + ci) * kk + tap] : 0.0f;
+    } else {
+        const long long e = i - nf;
+        const int ci = (int)(e % np_d);
+        const long long row = e / np_d;
+        const int co = (int)(row % Cout), tapf = (int)(row / Cout); // tapf = flipped tap index
+        int tap = kk - 1 - tapf;
+        if (parity) {
+            const int cls = tapf < 1 ? 0 : (tapf < 3 ? 1 : (tapf < 5 ? 2 : 3));
+            const int tl = tapf - (cls == 0 ? 0 : (cls == 1 ? 1 : (cls == 2 ? 3 : 5)));
+            const int py = cls >> 1, px = cls & 1, kwc = px ? 2 : 1;
+            const int t_ky = tl / kwc, t_kx = tl - t_ky * kwc;
+            const int ky = py ? (t_ky == 0 ? 2 : 0) : 1, kx = px ? (t_kx == 0 ? 2 : 0) : 1;
+            tap = ky * 3 + kx;
+        }
+        dgr[e] = ci < Cin ? w[((long long)co * Cin + ci) * kk + tap] : 0.0f;
+    }
+}
+
 __global__ void k_weight_layouts(const float *w, int Cout, int Cin, int k, float *fwd, int np_f, float *dgr, int np_d, int parity)
 {
     const int kk = k * k;
     const long long nf = fwd ? (long long)kk * Cin * np_f : 0, nd = dgr ? (long long)kk * Cout * np_d : 0;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nf + nd; i += (long long)gridDim.x * blockDim.x) {
-        if (i < nf) {
-            const int co = (int)(i % np_f);
-            const long long row = i / np_f;
-            const int ci = (int)(row % Cin), tap = (int)(row / Cin);
-            fwd[i] = co < Cout ? w[((long long)co * Cin + ci) * kk + tap] : 0.0f;
-        } else {
-            const long long e = i - nf;
-            const int ci = (int)(e % np_d);
-            const long long row = e / np_d;
-            const int co = (int)(row % Cout), tapf = (int)(row / Cout); // tapf = flipped tap index
-            int tap = kk - 1 - tapf;
-            if (parity) {
-                const int cls = tapf < 1 ? 0 : (tapf < 3 ? 1 : (tapf < 5 ? 2 : 3));
-                const int tl = tapf - (cls == 0 ? 0 : (cls == 1 ? 1 : (cls == 2 ? 3 : 5)));
-                const int py = cls >> 1, px = cls & 1, kwc = px ? 2 : 1;
-                const int t_ky = tl / kwc, t_kx = tl - t_ky * kwc;
-                const int ky = py ? (t_ky == 0 ? 2 : 0) : 1, kx = px ? (t_kx == 0 ? 2 : 0) : 1;
-                tap = ky * 3 + kx;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nf + nd; i += (long long)gridDim.x * blockDim.x)
+        weight_layout_elem(w, Cout, Cin, k, fwd, np_f, dgr, np_d, parity, nf, i);
+}
+
+// every weight of a model in one launch: element i belongs to the entry with the largest `first` <= i.  A workgroup walks
+// tiles of 2048 consecutive elements and looks the entry of a tile's first element up ONCE (wave-uniform: scalar loads);
+// only the elements of a tile that straddles two entries search again.
+__global__ __launch_bounds__(256) void k_weight_layouts_batch(const frlw_weight_layout_item_t *items, int n, long long total)
+{
+    constexpr int kTile = 2048;
+    for (long long base = (long long)blockIdx.x * kTile; base < total; base += (long long)gridDim.x * kTile) {
+        int lo = 0, hi = n;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (items[mid].first <= base) lo = mid; else hi = mid;
+        }
+        const frlw_weight_layout_item_t cur = items[lo];
+        const long long next = lo + 1 < n ? items[lo + 1].first : total;
+#pragma unroll
+        for (int u = 0; u < kTile / 256; ++u) {
+            const long long i = base + u * 256 + threadIdx.x;
+            if (i >= total) break;
+            frlw_weight_layout_item_t it = cur;
+            if (i >= next) {
+                int j = lo + 1;
+                while (j + 1 < n && items[j + 1].first <= i) ++j;
+                it = items[j];
             }
-            dgr[e] = ci < Cin ? w[((long long)co * Cin + ci) * kk + tap] : 0.0f;
+            const int np_f = (it.Cout + 31) / 32 * 32, np_d = (it.Cin + 31) / 32 * 32;
+            const long long nf = it.w_fwd ? (long long)it.k * it.k * it.Cin * np_f : 0;
+            weight_layout_elem(it.w, it.Cout, it.Cin, it.k, it.w_fwd, np_f, it.w_dgrad, np_d, (it.dgrad_parity && it.k == 3) ? 1 : 0, nf,
+                               i - it.first);
         }
     }
 }
@@ -365,6 +403,16 @@ int frlw_conv_weight_layouts(const float *w, int Cout, int Cin, int k, int dgrad
     return FRLW_OK;
 }
 
+int frlw_conv_weight_layouts_batch(const frlw_weight_layout_item_t *items, int n, int64_t total, frlw_stream_t stream)
+{
+    (void)hipGetLastError();
+    if (!items || n < 1 || total < 1) return FRLW_ERR_ARG;
+    const long long tiles = (total + 2047) / 2048;
+    hipLaunchKernelGGL(k_weight_layouts_batch, dim3((unsigned)(tiles < 8192 ? tiles : 8192)), dim3(256), 0, (hipStream_t)stream, items, n, (long long)total);
+    TRY_HIP(hipGetLastError());
+    return FRLW_OK;
+}
+
 static int conv_common(const float *x, int B, int H, int W, int Cin, const float *w_gemm, int Cout, int k, int stride,
                        int tstride, int Ho, int Wo, float *y, float *scratch, int64_t scratch_floats, hipStream_t s)
 {
@@ -588,7 +636,7 @@ int frlw_baseconv_train_fwd(const float *x, const float *w, const float *gamma, 
                             int64_t *num_batches_tracked, float *w_cache, void *scratch, int64_t scratch_bytes,
                             frlw_stream_t stream)
 {
-    if (!x || !w || !gamma || !beta || !z || !y || !mean || !var || !invstd || !scratch) return FRLW_ERR_ARG;
+    if (!x || (!w && !w_cache) || !gamma || !beta || !z || !y || !mean || !var || !invstd || !scratch) return FRLW_ERR_ARG;
     if (scratch_bytes < frlw_baseconv_train_scratch_bytes(B, H, W, Cin, Cout, k, stride)) return FRLW_ERR_WORKSPACE;
     const int pad = (k - 1) / 2;
     const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
@@ -596,7 +644,9 @@ int frlw_baseconv_train_fwd(const float *x, const float *w, const float *gamma, 
     TrainScratch t = carve(scratch, B, Ho, Wo, Cin, Cout, k);
     int rc;
     const float *w_fwd = t.w_fwd;
-    if (w_cache) { // both operands in ONE launch, kept by the caller: the backward of this step finds its operand ready
+    if (w_cache && !w) { // the caller has laid both operands out already (frlw_conv_weight_layouts_batch)
+        w_fwd = w_cache;
+    } else if (w_cache) { // both operands in ONE launch, kept by the caller: the backward of this step finds its operand ready
         float *w_dg = w_cache + (int64_t)k * k * Cin * npad32(Cout);
         if ((rc = frlw_conv_weight_layouts(w, Cout, Cin, k, frlw_conv2d_dgrad_parity(k, stride, H, W), w_cache, w_dg, stream)) != FRLW_OK) return rc;
         w_fwd = w_cache;

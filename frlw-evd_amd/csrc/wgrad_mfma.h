@@ -15,24 +15,27 @@ struct WgradArgs {
     uint32_t x_bytes, dz_bytes; // extents for the buffer descriptors (set by launch_wgrad_tiles)
 };
 
-// BM = 64 or 128 rows (r) x BN = 64 or 128 columns (co) per workgroup; the 4 wavefronts are 2 x 2, each
-// TM x TN = (BM / 64) x (BN / 64) MFMA tiles of 32 x 32; k-tiles of 16 pixels; blockIdx.z owns a slice of the pixels and
-// writes a partial tile (always: the reduction kernel also converts to torch's layout).
+// BM = 64 or 128 rows (r) x BN = 32, 64 or 128 columns (co) per workgroup; the 4 wavefronts are WR x WC (2 x 2, or 4 x 1 for
+// the 32-column tile of the stem's 32 output channels: with 2 x 2 half the wavefronts multiplied zero columns, 872 us
+// at 35 % of peak), each TM x TN = (BM / 32 WR) x (BN / 32 WC) MFMA tiles of 32 x 32; k-tiles of 16 pixels; blockIdx.z owns a
+// slice of the pixels and writes a partial tile (always: the reduction kernel also converts to torch's layout).
 // Same machinery as k_conv_mfma: both operands arrive by LDS-DMA through buffer descriptors (padding, rows past R,
 // columns past Cout and pixels past M carry the offset kOob and land as zeros), a ring of NBUF stages with counted vmcnt
 // waits and raw barriers, fragment reads as asm statements with hand-counted lgkmcnt (see conv_mfma.h for why).
 // LDS image of a stage: one [16 pixels][64 channels] block per 64-wide channel group (lane-linear for the DMA: a
 // wave-instruction brings 4 pixels x 64 channels = 1 KB).
-template <int BM, int BN, int NBUF>
+template <int BM, int BN, int NBUF, int WR = 2, int WC = 2>
 __global__ __launch_bounds__(256) void k_wgrad_mfma(WgradArgs a)
 {
-    constexpr int BK = 16, TM = BM / 64, TN = BN / 64, GA = BM / 64, GB = BN / 64;
-    constexpr int kStage = BK * (BM + BN);            // floats per ring stage: A groups first, then B groups
+    static_assert(WR * WC == 4 && BM % (32 * WR) == 0 && BN % (32 * WC) == 0, "four wavefronts");
+    constexpr int BK = 16, TM = BM / (32 * WR), TN = BN / (32 * WC), GA = (BM + 63) / 64, GB = (BN + 63) / 64;
+    static_assert(TM <= 2 && TN <= 2 && (TM == 1 || (32 * TM) % 64 == 0) && (TN == 1 || (32 * TN) % 64 == 0), "a wavefront's tiles lie in one group");
+    constexpr int kStage = BK * 64 * (GA + GB);       // floats per ring stage: A groups first, then B groups
     constexpr int EPLD = 36;
     constexpr int kEpiFloats = 4 * 32 * EPLD;
     __shared__ __attribute__((aligned(16))) float smem[NBUF * kStage > kEpiFloats ? NBUF * kStage : kEpiFloats];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int wr = wv >> 1, wc = wv & 1;
+    const int wr = wv / WC, wc = wv % WC;
     const int r0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const __amdgpu_buffer_rsrc_t rx = conv_rsrc(a.x, a.x_bytes), rz = conv_rsrc(a.dz, a.dz_bytes);
     // staging: thread -> pixel (tid / 16) of the k-tile, float4 #(tid % 16) of each 64-wide group of r / co columns
@@ -101,11 +104,12 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(WgradArgs a)
     if (NBUF >= 3 && nk > 1) load_tiles(1);
     wait_next_tile(nk > 1 ? 1 : 0);
     __builtin_amdgcn_s_barrier();
-    // fragment addresses (bytes) inside a stage: A column wr * 32 TM + 32 i + l lies in group wr (TM = 2) or 0 (TM = 1)
+    // fragment addresses (bytes) inside a stage
     const int fh = lane >> 5, fl = lane & 31;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float *)smem;
-    const uint32_t a_lds = lds0 + (uint32_t)((TM == 2 ? wr : 0) * (BK * 64) + fh * 64 + (TM == 2 ? 0 : wr * 32) + fl) * 4;
-    const uint32_t b_lds = lds0 + (uint32_t)((GA + (TN == 2 ? wc : 0)) * (BK * 64) + fh * 64 + (TN == 2 ? 0 : wc * 32) + fl) * 4;
+    const int ac = wr * 32 * TM, bc = wc * 32 * TN; // first column of this wavefront's tiles: group c / 64, column c % 64 of it
+    const uint32_t a_lds = lds0 + (uint32_t)((ac / 64) * (BK * 64) + fh * 64 + (ac % 64) + fl) * 4;
+    const uint32_t b_lds = lds0 + (uint32_t)((GA + bc / 64) * (BK * 64) + fh * 64 + (bc % 64) + fl) * 4;
     int stage = 0;
     for (int kt = 0; kt < nk; ++kt) {
         if (kt + NBUF - 1 < nk) load_tiles(stage == 0 ? NBUF - 1 : stage - 1); // the stage read last in iteration kt - 1
@@ -186,6 +190,8 @@ inline bool launch_wgrad_tiles(WgradArgs &a, hipStream_t s) // a.splits and a.pa
     a.dz_bytes = (uint32_t)zb;
     if (wgrad_wide(a.R, a.Cout))
         hipLaunchKernelGGL((k_wgrad_mfma<128, 128, WGRAD_NBUF>), dim3((a.R + 127) / 128, (a.Cout + 127) / 128, a.splits), dim3(256), 0, s, a);
+    else if (a.R > 64 && a.Cout <= 32)
+        hipLaunchKernelGGL((k_wgrad_mfma<128, 32, WGRAD_NBUF, 4, 1>), dim3((a.R + 127) / 128, 1, a.splits), dim3(256), 0, s, a);
     else if (a.R > 64)
         hipLaunchKernelGGL((k_wgrad_mfma<128, 64, WGRAD_NBUF>), dim3((a.R + 127) / 128, (a.Cout + 63) / 64, a.splits), dim3(256), 0, s, a);
     else
@@ -195,7 +201,7 @@ inline bool launch_wgrad_tiles(WgradArgs &a, hipStream_t s) // a.splits and a.pa
 
 inline long long wgrad_want_splits(long long R, int Cout, long long M, long long target)
 {
-    const long long bm = R > 64 ? 128 : 64, bn = wgrad_wide(R, Cout) ? 128 : 64;
+    const long long bm = R > 64 ? 128 : 64, bn = wgrad_wide(R, Cout) ? 128 : (R > 64 && Cout <= 32 ? 32 : 64);
     const long long tiles = ((R + bm - 1) / bm) * ((Cout + bn - 1) / bn);
     const long long nk = (M + 15) / 16;
     long long sp = (target + tiles - 1) / tiles;

@@ -104,9 +104,15 @@ class Trainer:
             else:
                 g["lr"] = lr
 
+    def _forward(self, imgs, targets):
+        if imgs.is_cuda:  # the GEMM operands of all BaseConv weights in ONE launch (the layers skip their own layout kernels)
+            from .yolox import train_ops
+            train_ops.layout_all_weights(self.model.module if hasattr(self.model, "module") else self.model)
+        return self.model(imgs, targets, None, None)
+
     def _eager_step(self, imgs, targets):
         self.optimizer.zero_grad()
-        loss = self.model(imgs, targets, None, None)
+        loss = self._forward(imgs, targets)
         self.scaler.scale(loss).backward()
         self.optimizer.step()  # NOT scaler.step: the 65536x scale reaches Adam (reference behaviour)
         return loss
@@ -124,7 +130,7 @@ class Trainer:
         with torch.cuda.stream(side):
             for _ in range(warmup):
                 self.optimizer.zero_grad(set_to_none=True)
-                loss = self.model(x, lab, None, None)
+                loss = self._forward(x, lab)
                 self.scaler.scale(loss).backward()
                 self.optimizer.step()
                 del loss  # (nothing of this iteration's autograd graph may live into the capture)
@@ -133,7 +139,7 @@ class Trainer:
         graph = torch.cuda.CUDAGraph()
         self.optimizer.zero_grad(set_to_none=True)
         with torch.cuda.graph(graph):
-            loss = self.model(x, lab, None, None)
+            loss = self._forward(x, lab)
             self.scaler.scale(loss).backward()
             self.optimizer.step()
         self._graph = (graph, x, lab, loss)
@@ -142,7 +148,8 @@ class Trainer:
     def train_step(self, imgs, targets, i_batch=0, sync=True):
         """core/exp.py:292-303 for one batch; returns (loss as a Python float, lr).  ``sync=False`` returns the loss as a
         device tensor instead (the caller reads it when it logs: no queue drain per step)."""
-        self.model.train()
+        if not self.model.training:
+            self.model.train()
         if self._want_graph and self._graph is None:
             self.capture(imgs, targets, warmup=3)
         if self._graph is not None and imgs.shape == self._graph[1].shape and targets.shape == self._graph[2].shape:

@@ -33,6 +33,66 @@ def _weight_cache(lib, weight, Cin, Cout, k):
     return hit[1]
 
 
+_WREADY = {}  # id(weight parameter) -> (version, parity, cache data_ptr) the batched layout below has laid the cache out for
+_PLANS = {}  # id(model) -> (weakref, item table on the device, total elements, [(weight, parity, cache, weight pointer)])
+
+
+def _layout_plan(model):
+    """One table entry per natively trained BaseConv weight of `model` whose operand cache exists (= that has run one
+    forward): frlw_weight_layout_item_t {w, w_fwd, w_dgrad, Cout, Cin, k, parity, first}."""
+    import struct
+    import weakref
+    rows, blob, first = [], b"", 0
+    for mod in model.modules():
+        conv, bn = getattr(mod, "conv", None), getattr(mod, "bn", None)
+        if not isinstance(conv, torch.nn.Conv2d) or not isinstance(bn, torch.nn.BatchNorm2d):
+            continue
+        w = conv.weight
+        hit, geom = _WCACHE.get(id(w)), _WCACHE_GEOM.get(id(w))
+        if hit is None or geom is None or hit[0]() is not w or not w.is_cuda or not w.is_contiguous() or w.dtype != torch.float32:
+            continue
+        Cout, Cin, k, _ = w.shape
+        cache = hit[1]
+        n_f, n_d = k * k * Cin * pad32(Cout), k * k * Cout * pad32(Cin)
+        blob += struct.pack("<QQQiiiiq", w.data_ptr(), cache.data_ptr(), cache.data_ptr() + 4 * n_f, Cout, Cin, k, geom[1], first)
+        first += n_f + n_d
+        rows.append((w, geom[1], cache, w.data_ptr()))
+    if not rows:
+        return None
+    import numpy as np
+    table = torch.from_numpy(np.frombuffer(blob, dtype=np.uint8).copy()).to(rows[0][0].device)
+    return (weakref.ref(model), table, first, rows)
+
+
+def layout_all_weights(model):
+    """Lay out the GEMM operands of EVERY BaseConv weight of `model` in one launch (call it once per step, before the
+    forward: the per-layer forwards then find their cache ready and skip their own layout kernel -- 74 launches of ~5 us).
+    Does nothing until the layers have run once (their caches are created by the first forward), or off the GPU."""
+    if not native_enabled():
+        return False
+    plan = _PLANS.get(id(model))
+    stale = plan is None or plan[0]() is not model
+    if not stale:
+        for w, parity, cache, ptr in plan[3]:
+            hit, geom = _WCACHE.get(id(w)), _WCACHE_GEOM.get(id(w))
+            if hit is None or hit[1] is not cache or geom is None or geom[1] != parity or w.data_ptr() != ptr:
+                stale = True
+                break
+    if stale:
+        plan = _layout_plan(model)
+        if plan is None:
+            _PLANS.pop(id(model), None)
+            return False
+        _PLANS[id(model)] = plan
+    _, table, total, rows = plan
+    lib = _lib.load()
+    _lib.check(lib.frlw_conv_weight_layouts_batch(table.data_ptr(), len(rows), total, _stream(table.device)), "weight_layouts_batch")
+    for w, parity, cache, _ptr in rows:
+        _WREADY[id(w)] = (w._version, parity, cache.data_ptr())
+        _WCACHE_GEOM[id(w)] = (w._version, parity)
+    return True
+
+
 def _bump_versions(*tensors):
     """Advance the in-place version counters of buffers a kernel has written through raw pointers (no launch)."""
     for t in tensors:
@@ -84,7 +144,10 @@ class _BaseConvTrain(torch.autograd.Function):
         stats = torch.empty((3, Cout), dtype=torch.float32, device=dev)  # mean, biased variance, invstd
         sc = _scratch(dev, "block", lib.frlw_baseconv_train_scratch_bytes(B, H, W, Cin, Cout, k, stride), torch.uint8)
         wc = _weight_cache(lib, weight, Cin, Cout, k)  # both GEMM operands of this weight, laid out once per step
-        _lib.check(lib.frlw_baseconv_train_fwd(x.data_ptr(), w.data_ptr(), g.data_ptr(), b.data_ptr(), C.c_float(eps), B, H, W,
+        parity = int(lib.frlw_conv2d_dgrad_parity(k, stride, H, W))
+        # laid out already by layout_all_weights() for exactly this weight version, parity class and buffer?
+        ready = _WREADY.get(id(weight)) == (weight._version, parity, wc.data_ptr()) and w.data_ptr() == weight.data_ptr()
+        _lib.check(lib.frlw_baseconv_train_fwd(x.data_ptr(), None if ready else w.data_ptr(), g.data_ptr(), b.data_ptr(), C.c_float(eps), B, H, W,
                                                Cin, Cout, k, stride, z.data_ptr(), y.data_ptr(), stats[0].data_ptr(),
                                                stats[1].data_ptr(), stats[2].data_ptr(),
                                                run_mean.data_ptr() if run_mean is not None else None,
@@ -94,7 +157,7 @@ class _BaseConvTrain(torch.autograd.Function):
         ctx.wcache = wc
         # the data-gradient half of the cache depends on the parity class of (k, stride, H, W): a second forward of the same
         # layer on an input of another parity (shared layer, multi-scale graph) re-lays it -- remember what THIS forward wrote
-        ctx.wparity = int(lib.frlw_conv2d_dgrad_parity(k, stride, H, W))
+        ctx.wparity = parity
         _WCACHE_GEOM[id(weight)] = (weight._version, ctx.wparity)
         ctx.wversion = weight._version
         ctx.weight_ref = weight

@@ -415,6 +415,16 @@ int frlw_eval_transform_dt(const float *dets, const int32_t *img_of_row, const i
 int frlw_conv2d_dgrad_parity(int k, int stride, int H, int W);
 int frlw_conv_weight_layouts(const float *w, int Cout, int Cin, int k, int dgrad_parity, float *w_fwd, float *w_dgrad,
                              frlw_stream_t stream);
+/* The same for MANY weights in one launch (the ~74 BaseConv weights of the detector after an optimizer step: 74 launches
+ * of ~5 us each otherwise).  `items`: DEVICE array of n entries, `first` = running sum of the entries' element counts
+ * (k*k*Cin*pad32(Cout) + k*k*Cout*pad32(Cin) each; either operand pointer may be NULL and then counts 0), `total` = the sum. */
+typedef struct frlw_weight_layout_item {
+    const float *w;
+    float *w_fwd, *w_dgrad;
+    int32_t Cout, Cin, k, dgrad_parity;
+    int64_t first;
+} frlw_weight_layout_item_t;
+int frlw_conv_weight_layouts_batch(const frlw_weight_layout_item_t *items, int n, int64_t total, frlw_stream_t stream);
 /* z (B, Ho, Wo, Cout) = conv2d(x (B, H, W, Cin), w), padding (k - 1) / 2, stride 1 or 2.  scratch: optional split-K
  * partial sums (scratch_floats floats; NULL = never split). */
 int frlw_conv2d_fwd(const float *x, int B, int H, int W, int Cin, const float *w_fwd, int Cout, int k, int stride, float *z,
@@ -451,7 +461,9 @@ int frlw_bn_silu_bwd(const float *dy, const float *z, int64_t M, int C, const fl
  * scratch: frlw_baseconv_train_scratch_bytes(...) bytes, reusable between calls.
  * w_cache (may be NULL): frlw_baseconv_weight_cache_floats(Cin, Cout, k) floats owned by the caller, one per layer: the
  * forward then lays the weight out for itself AND for the data gradient in one launch, and the backward of the same
- * step (weights unchanged in between) reuses it instead of laying the weight out again. */
+ * step (weights unchanged in between) reuses it instead of laying the weight out again.  w == NULL with a w_cache in
+ * the forward: the cache holds both operands of the current weights already (frlw_conv_weight_layouts_batch: forward
+ * operand first, the data-gradient operand k*k*Cin*pad32(Cout) floats behind it) and no layout kernel is launched. */
 int64_t frlw_baseconv_weight_cache_floats(int Cin, int Cout, int k);
 int64_t frlw_baseconv_train_scratch_bytes(int B, int H, int W, int Cin, int Cout, int k, int stride);
 int frlw_baseconv_train_fwd(const float *x, const float *w, const float *gamma, const float *beta, float eps, int B, int H,

@@ -68,3 +68,25 @@ def test_replayed_updates_reach_the_inference_engine():
         m2.eval()
         want = m2.engine().raw_outputs(x[..., 0])
     assert torch.allclose(got, want, rtol=1e-5, atol=1e-6)
+
+
+def test_batched_weight_layouts_equal_per_layer(monkeypatch):
+    """layout_all_weights (one launch for all BaseConv weights, from the second step on) against the per-layer layout
+    kernels: same operands, so the same parameters bit for bit after a few steps."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from frlw_evd_amd.yolox import train_ops
+    batches = [_inputs(4, s) for s in range(4)]
+    a = _trainer(False)
+    calls = []
+    real = train_ops.layout_all_weights
+    monkeypatch.setattr(train_ops, "layout_all_weights", lambda m: calls.append(real(m)) or calls[-1])
+    for i, (x, lab) in enumerate(batches):
+        a.train_step(x, lab, i)
+    assert calls[0] is False and all(calls[1:])  # no caches before the first forward, one batched launch per step after it
+    monkeypatch.setattr(train_ops, "layout_all_weights", lambda m: False)
+    b = _trainer(False)
+    for i, (x, lab) in enumerate(batches):
+        b.train_step(x, lab, i)
+    for (n, p), q in zip(a.model.named_parameters(), b.model.parameters()):
+        assert torch.equal(p, q), n

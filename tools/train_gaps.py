@@ -68,8 +68,24 @@ def report(path):
             print(f"    {g[0] / 1e3:8.1f} us at +{g[3]:6.2f} ms  after {g[1]:40s} before {g[2]}")
 
 
+def sequence(path, out):
+    """The dispatch sequence of the last complete step: start (us from the step's first kernel), duration, grid, name."""
+    rows = list(csv.DictReader(open(path)))
+    ks = sorted(rows, key=lambda r: int(r["Start_Timestamp"]))
+    starts = [i for i, r in enumerate(ks) if "k_focus" in r["Kernel_Name"]]
+    seg = ks[starts[-2]:starts[-1]]
+    t0 = int(seg[0]["Start_Timestamp"])
+    with open(out, "w") as f:
+        for r in seg:
+            n = re.sub(r"\(anonymous namespace\)::|void |at::native::", "", r["Kernel_Name"])[:110]
+            f.write(f"{(int(r['Start_Timestamp']) - t0) / 1e3:10.1f} {(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:8.1f} "
+                    f"g={r['Grid_Size_X']}x{r['Grid_Size_Y']}x{r['Grid_Size_Z']} {n}\n")
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "run":
         run()
+    elif sys.argv[1] == "sequence":
+        sequence(sys.argv[2], sys.argv[3])
     else:
         report(sys.argv[2])

@@ -7,3 +7,4 @@ rocprofv3 --kernel-trace --output-format csv -d $OUT -o t -- python3 $R/tools/tr
 tail -3 $OUT/run.log
 F=$(find $OUT -name "*kernel_trace.csv" | head -1)
 python3 $R/tools/train_gaps.py report "$F" | tee $KEEP/gaps.txt
+python3 $R/tools/train_gaps.py sequence "$F" $KEEP/sequence.txt
