@@ -623,10 +623,23 @@ def bench_train(args, torch, world, rank, local_rank, timer):
         state["i"] += 1
     per_e2e, _ = timer.run(e2e_step, steps, 2)
     per_enc, _ = timer.run(lambda: src.encode_batch(idx), steps, 1)
+    # the same with the encode of batch i + 1 on its own stream while step i runs (e2e.EncodeAhead): every step still
+    # consumes a batch that was encoded for it inside the timed region
+    ahead = e2e.EncodeAhead(src)
+    ahead.start(idx)
+
+    def e2e_overlapped():
+        state["loss"], _ = tr.train_step(ahead.take(), lab, state["i"], after_launch=lambda: ahead.start(idx))
+        state["i"] += 1
+    per_ovl, _ = timer.run(e2e_overlapped, steps, 2)
+    del ahead
     out["encode_plus_train_step"] = {"workload": "BASELINE.json configs[4]: TAF encode of the batch (8 x 125 000 events per "
                                                  "304x240 sample, one frlw_taf_encode_batch call) + train step",
                                      "value": round(world * B / per_e2e, 1), "unit": "frames/s",
-                                     "ms_per_step": round(per_e2e * 1e3, 3), "encode_ms_per_batch": round(per_enc * 1e3, 3)}
+                                     "ms_per_step": round(per_e2e * 1e3, 3), "encode_ms_per_batch": round(per_enc * 1e3, 3),
+                                     "encode_ahead": {"value": round(world * B / per_ovl, 1), "ms_per_step": round(per_ovl * 1e3, 3),
+                                                      "what": "batch i + 1 encoded on a second HIP stream while step i runs "
+                                                              "(frlw_evd_amd.e2e.EncodeAhead)"}}
     del src
     if world == 1:
         # the same step launched eagerly (what the DDP ranks do), and eagerly with torch autograd / MIOpen convolutions

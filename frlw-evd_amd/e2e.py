@@ -86,6 +86,31 @@ class SyntheticTafSource:
         return (u8.float() / 255.0)[..., None, None]
 
 
+class EncodeAhead:
+    """The encode of batch i + 1 on its own HIP stream while the train step of batch i runs on the current one: the encoders
+    are VALU / HBM work, the step's convolutions sit on the matrix cores, and the step leaves the host idle until its loss
+    is read back.  ``start(idx)`` right after a step has been queued (``Trainer.train_step(after_launch=...)``), ``take()``
+    before the next one.  Every batch is encoded exactly once into its own buffer; the consumer's stream is recorded on it."""
+
+    def __init__(self, source, batched=True):
+        self.src, self.batched = source, batched
+        self.side = torch.cuda.Stream(device=source.device)
+        self.ready = None
+
+    def start(self, idx):
+        with torch.cuda.stream(self.side):
+            self.ready = self.src.encode_batch(idx, self.batched)  # ends with the deferred-status check of ITS stream only
+
+    def take(self):
+        if self.ready is None:
+            raise RuntimeError("EncodeAhead.take() without start()")
+        main = torch.cuda.current_stream(self.src.device)
+        main.wait_stream(self.side)
+        t, self.ready = self.ready, None
+        t.record_stream(main)
+        return t
+
+
 def build_model(in_channels=16, num_classes=2, device="cuda", seed=1004):
     net = build_yolox(in_channels, num_classes)
     net.load_state_dict(recipe_state_dict(net, seed=seed))

@@ -145,9 +145,11 @@ class Trainer:
         self._graph = (graph, x, lab, loss)
         return warmup
 
-    def train_step(self, imgs, targets, i_batch=0, sync=True):
+    def train_step(self, imgs, targets, i_batch=0, sync=True, after_launch=None):
         """core/exp.py:292-303 for one batch; returns (loss as a Python float, lr).  ``sync=False`` returns the loss as a
-        device tensor instead (the caller reads it when it logs: no queue drain per step)."""
+        device tensor instead (the caller reads it when it logs: no queue drain per step).  ``after_launch``: called once
+        the step's device work is queued and before the loss is read back (the place to start the next batch's encode on
+        another stream, ``e2e.EncodeAhead``)."""
         if not self.model.training:
             self.model.train()
         if self._want_graph and self._graph is None:
@@ -164,6 +166,8 @@ class Trainer:
             loss = self._eager_step(imgs, targets)
         lr = self.scheduler.update_lr(self.epoch_step * self.iters_per_epoch + i_batch + 1)
         self._set_lr(lr)
+        if after_launch is not None:
+            after_launch()
         if not sync:
             return loss.detach().clone() if self._graph is not None else loss.detach(), lr
         return float(loss.detach().cpu()), lr

@@ -102,3 +102,42 @@ def test_entry_points_train_then_test(tmp_path):
                         "--log_path", log], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "'images':" in r.stdout and os.path.exists(os.path.join(log, "E", "summarise.npz"))
+
+
+def test_encode_ahead_feeds_the_same_batches():
+    """e2e.EncodeAhead (the next batch encoded on a second stream while a step runs): the steps see exactly the batches
+    the serial loop would have encoded, so the losses agree bit for bit -- eager and graph-replayed trainer alike."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from frlw_evd_amd import e2e
+    from frlw_evd_amd.trainer import Trainer
+    src = e2e.SyntheticTafSource(6, seed=77, events_per_window=8_000)
+    lab = src.labels(2)
+    order = [[0, 1], [2, 3], [4, 5], [0, 1]]
+    serial = Trainer(e2e.build_model(16, 2), global_batch=2, nodes=1, iters_per_epoch=10)
+    want = [serial.train_step(src.encode_batch(idx), lab, i)[0] for i, idx in enumerate(order)]
+    for graph in (False, True):
+        tr = Trainer(e2e.build_model(16, 2), global_batch=2, nodes=1, iters_per_epoch=10, graph=graph)
+        if graph:  # the capture's warm-up steps would be extra updates: capture on a throw-away batch at rate 0, then reset
+            state = {k: v.clone() for k, v in tr.model.state_dict().items()}
+            tr.capture(src.encode_batch(order[0]), lab, warmup=3)
+            tr.model.load_state_dict(state)
+            for st in tr.optimizer.state.values():
+                for v in st.values():
+                    if torch.is_tensor(v):
+                        v.zero_()
+        ahead = e2e.EncodeAhead(src)
+        ahead.start(order[0])
+        got, started = [], []
+        for i in range(len(order)):
+            nxt = order[i + 1] if i + 1 < len(order) else None
+
+            def after(nxt=nxt):
+                started.append(nxt)
+                if nxt is not None:
+                    ahead.start(nxt)
+            got.append(tr.train_step(ahead.take(), lab, i, after_launch=after)[0])
+        assert started == order[1:] + [None]
+        assert got == want, (graph, got, want)
+    with pytest.raises(RuntimeError):
+        ahead.take()

@@ -14,7 +14,7 @@ stats bench python3 $R/bench.py --steps 20 --warmup 3 --no-also --no-detector --
 stats hot python3 $R/bench.py --steps 10 --warmup 2 --hotspot --no-also --no-detector --no-train --no-cpu-baseline
 for c in gen1 gen1x64 ev1 evb64; do stats lab_$c $R/build/enc_lab $LIB --cfg $c --reps 20; done
 stats det python3 $R/tools/time_detector.py
-B=64 stats train python3 $R/tools/train_breakdown.py
+GRAPH=1 B=64 stats train python3 $R/tools/train_gaps.py run   # Trainer(graph=True): 3 eager warm-up steps, the capture, 8 replays
 # PMC passes (separate runs, kernel-trace only) of the encoder workloads through build/enc_lab (same kernels, same shapes,
 # no Python in the profiled process)
 pmc() { # cfg tag counters...
