@@ -426,7 +426,7 @@ __global__ __launch_bounds__(NT) void k_ev_tile(const uint2 *rec, const uint32_t
 struct TafParams {
     int H, W, twl, tiles_x, K, n_windows, flip;
     WsHeader *hdr;
-    const uint32_t *leaky_thr; // level thresholds of uint8(leaky_transform(.)), built by k_hist
+    const uint32_t *leaky_thr; // level thresholds of uint8(leaky_transform(.)): the per-device table of partition.hip
     float *state;    // (H, W, 2, K)
     float *view_f32; // (2K, H, W) or NULL
     uint8_t *out_u8; // (K, 2, H, W) or NULL

@@ -282,6 +282,13 @@ __device__ __forceinline__ uint8_t leaky_u8_lookup(float v, const uint32_t *thr)
     return (uint8_t)k;
 }
 
+// The 256 thresholds are a constant of the device's f32 pipeline: built ONCE per device and process (partition.hip) into a
+// device-resident table, on the stream of the first encoder call; calls on other streams wait for that fill through an
+// event until it has completed (no host synchronisation; inside a stream capture the fill becomes a node of the graph).
+// Until round 3 every TAF encode rebuilt the table in the last workgroup of its histogram kernel: 31 bisection steps of
+// log1pf on one wavefront, ~8 us on the critical path of every small call.  nullptr: a HIP call failed.
+const uint32_t *leaky_table(hipStream_t s);
+
 // Out-of-line on purpose: it is the rare path of the batched look-up below, which would otherwise inline
 // N copies of log1pf per cell.
 __device__ __noinline__ uint8_t leaky_u8_exact(float v, const uint32_t *thr) { return leaky_u8_lookup(v, thr); }
@@ -322,7 +329,7 @@ struct Plan {
     int staged;       // < 0: by size
     int quarter_below;
     int no_lut;
-    size_t off_counts, off_slabtot, off_base, off_errs, off_tlut, off_leaky, off_records, bytes;
+    size_t off_counts, off_slabtot, off_base, off_errs, off_tlut, off_records, bytes;
 };
 
 struct Partitioned {

@@ -19,6 +19,8 @@
 
 #include "frlw_common.h"
 
+#include <mutex>
+
 namespace frlw {
 
 int hip_fail(hipError_t e, const char *what, int line)
@@ -36,7 +38,7 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 template <int LAYOUT, int KIND, bool HAS_MAP>
 __global__ __launch_bounds__(kPartThreads) void k_hist(Decode P, int bpw, uint32_t *counts,
-                                                        int32_t *errs, float *tlut_w, uint32_t *leaky_w)
+                                                        int32_t *errs, float *tlut_w)
 {
     extern __shared__ uint32_t lds[];
     uint32_t *hist = lds; // [n_tiles]
@@ -48,10 +50,6 @@ __global__ __launch_bounds__(kPartThreads) void k_hist(Decode P, int bpw, uint32
     __syncthreads();
     const long long begin = wg * (long long)kPartThreads * bpw;
     int err = 0;
-    if (KIND == KIND_TAF && leaky_w && wg == gridDim.x - 1 && tid < kLeakyLevels) {
-        // level thresholds of uint8(leaky_transform(.)) for the tile kernel's epilogue (generate_taf.py:69-76)
-        leaky_w[tid] = tid == 0 ? 0x7f800000u : leaky_threshold_bits(tid);
-    }
     if (KIND == KIND_TAF && tlut_w) {
         // value table for k_scatter: tlut[r] = float(r / (win + 1e-8)) - 1 (generate_taf.py:215, :26);
         // one correctly rounded f64 division per distinct in-window time instead of one per event
@@ -385,7 +383,7 @@ __global__ __launch_bounds__(kPartThreads, 8) void k_scatter(Decode P, int bpw, 
 
 template <int LAYOUT, int KIND, bool HAS_MAP>
 void launch_partition_m(const Decode &d, const Plan &p, uint32_t *counts, uint32_t *slabtot,
-                      uint32_t *base, uint2 *records, WsHeader *hdr, int32_t *errs, float *tlut_w, uint32_t *leaky_w, hipStream_t s)
+                      uint32_t *base, uint2 *records, WsHeader *hdr, int32_t *errs, float *tlut_w, hipStream_t s)
 {
     const size_t lds_hist = (size_t)p.n_tiles * 4;
     const int nt2 = (p.n_tiles + 1) & ~1;
@@ -396,7 +394,7 @@ void launch_partition_m(const Decode &d, const Plan &p, uint32_t *counts, uint32
     // barriers cost more than the write traffic saves (GEN1-shaped 1 M events: 66 -> 74 us).
     // frlw_tuning_t::staged_scatter forces it.
     const bool staged = (p.staged >= 0 ? p.staged != 0 : (p.bpw >= 4 && d.n >= 3000000)) && lds_staged <= 150 * 1024;
-    hipLaunchKernelGGL((k_hist<LAYOUT, KIND, HAS_MAP>), dim3(p.units), dim3(kPartThreads), lds_hist, s, d, p.bpw, counts, errs, tlut_w, leaky_w);
+    hipLaunchKernelGGL((k_hist<LAYOUT, KIND, HAS_MAP>), dim3(p.units), dim3(kPartThreads), lds_hist, s, d, p.bpw, counts, errs, tlut_w);
     hipLaunchKernelGGL(k_slabscan, dim3((p.n_tiles + kWave - 1) / kWave, p.slabs), dim3(kWave), 0, s, counts,
                        p.units, p.n_tiles, slabtot);
     hipLaunchKernelGGL(k_tilescan, dim3(1), dim3(1024), 0, s, slabtot, p.slabs, p.n_tiles, base, hdr, p.hot_thr, errs, p.units);
@@ -414,23 +412,23 @@ void launch_partition_m(const Decode &d, const Plan &p, uint32_t *counts, uint32
 
 template <int LAYOUT, int KIND>
 void launch_partition(const Decode &d, const Plan &p, uint32_t *counts, uint32_t *slabtot, uint32_t *base,
-                      uint2 *records, WsHeader *hdr, int32_t *errs, float *tlut_w, uint32_t *leaky_w, hipStream_t s)
+                      uint2 *records, WsHeader *hdr, int32_t *errs, float *tlut_w, hipStream_t s)
 {
     if (LAYOUT == FRLW_LAYOUT_DAT8 && d.xmap)
-        launch_partition_m<LAYOUT, KIND, true>(d, p, counts, slabtot, base, records, hdr, errs, tlut_w, leaky_w, s);
+        launch_partition_m<LAYOUT, KIND, true>(d, p, counts, slabtot, base, records, hdr, errs, tlut_w, s);
     else
-        launch_partition_m<LAYOUT, KIND, false>(d, p, counts, slabtot, base, records, hdr, errs, tlut_w, leaky_w, s);
+        launch_partition_m<LAYOUT, KIND, false>(d, p, counts, slabtot, base, records, hdr, errs, tlut_w, s);
 }
 
 template <int LAYOUT>
 void launch_partition_kind(int kind, const Decode &d, const Plan &p, uint32_t *counts, uint32_t *slabtot,
-                           uint32_t *base, uint2 *records, WsHeader *hdr, int32_t *errs, float *tlut_w, uint32_t *leaky_w, hipStream_t s)
+                           uint32_t *base, uint2 *records, WsHeader *hdr, int32_t *errs, float *tlut_w, hipStream_t s)
 {
     switch (kind) {
-    case KIND_ECI: launch_partition<LAYOUT, KIND_ECI>(d, p, counts, slabtot, base, records, hdr, errs, tlut_w, leaky_w, s); break;
-    case KIND_EV: launch_partition<LAYOUT, KIND_EV>(d, p, counts, slabtot, base, records, hdr, errs, tlut_w, leaky_w, s); break;
-    case KIND_SAE: launch_partition<LAYOUT, KIND_SAE>(d, p, counts, slabtot, base, records, hdr, errs, tlut_w, leaky_w, s); break;
-    default: launch_partition<LAYOUT, KIND_TAF>(d, p, counts, slabtot, base, records, hdr, errs, tlut_w, leaky_w, s); break;
+    case KIND_ECI: launch_partition<LAYOUT, KIND_ECI>(d, p, counts, slabtot, base, records, hdr, errs, tlut_w, s); break;
+    case KIND_EV: launch_partition<LAYOUT, KIND_EV>(d, p, counts, slabtot, base, records, hdr, errs, tlut_w, s); break;
+    case KIND_SAE: launch_partition<LAYOUT, KIND_SAE>(d, p, counts, slabtot, base, records, hdr, errs, tlut_w, s); break;
+    default: launch_partition<LAYOUT, KIND_TAF>(d, p, counts, slabtot, base, records, hdr, errs, tlut_w, s); break;
     }
 }
 
@@ -473,7 +471,6 @@ bool make_plan(long long n, int H, int W, const frlw_tuning_t *tuning, Plan &p)
     p.off_base = off;    off = align_up(off + (size_t)(p.n_tiles + 1) * 4, 256);
     p.off_errs = off;    off = align_up(off + (size_t)p.units * 4, 256);
     p.off_tlut = off;    off = align_up(off + (size_t)(kMaxTlut + 1) * 4, 256);
-    p.off_leaky = off;   off = align_up(off + (size_t)kLeakyLevels * 4, 256);
     p.off_records = off; off = align_up(off + (size_t)(n > 0 ? n : 1) * 8, 256);
     p.bytes = off;
     // more than two slices and more than 4x the mean: worth sharing (frlw_tuning_t::hot_tile_records: tests force it)
@@ -522,16 +519,58 @@ int partition_events(const frlw_events_t *ev, int H, int W, int kind, long long 
     float *tlut_w = nullptr;
     if (kind == KIND_TAF && ev->layout == FRLW_LAYOUT_DAT8 && win <= kMaxTlut && !p.no_lut) tlut_w = (float *)(w8 + p.off_tlut);
     d.tlut = tlut_w;
-    uint32_t *leaky_w = kind == KIND_TAF ? (uint32_t *)(w8 + p.off_leaky) : nullptr;
+    const uint32_t *leaky = nullptr; // level thresholds of uint8(leaky_transform(.)) for the tile kernel's epilogue (generate_taf.py:69-76)
+    if (kind == KIND_TAF && !(leaky = leaky_table(s))) return FRLW_ERR_HIP;
 
     (void)hipGetLastError(); // stale errors of other libraries in the process
     if (ev->layout == FRLW_LAYOUT_DAT8)
-        launch_partition_kind<FRLW_LAYOUT_DAT8>(kind, d, p, counts, slabtot, base, records, hdr, errs, tlut_w, leaky_w, s);
+        launch_partition_kind<FRLW_LAYOUT_DAT8>(kind, d, p, counts, slabtot, base, records, hdr, errs, tlut_w, s);
     else
-        launch_partition_kind<FRLW_LAYOUT_XYTP_F64>(kind, d, p, counts, slabtot, base, records, hdr, errs, tlut_w, leaky_w, s);
+        launch_partition_kind<FRLW_LAYOUT_XYTP_F64>(kind, d, p, counts, slabtot, base, records, hdr, errs, tlut_w, s);
     HIP_TRY(hipGetLastError());
-    out.records = records; out.base = base; out.hdr = hdr; out.plan = p; out.leaky_thr = leaky_w;
+    out.records = records; out.base = base; out.hdr = hdr; out.plan = p; out.leaky_thr = leaky;
     return FRLW_OK;
+}
+
+// ---- the uint8(leaky_transform(.)) threshold table: one per device, built on first use (see frlw_common.h) -----------
+namespace {
+__device__ uint32_t g_leaky_thr[kLeakyLevels];
+__global__ __launch_bounds__(kLeakyLevels) void k_leaky_fill()
+{
+    const int t = threadIdx.x;
+    g_leaky_thr[t] = t == 0 ? 0x7f800000u : leaky_threshold_bits(t); // generate_taf.py:69-76 as a 256-level step function
+}
+struct LeakyDev { int state = 0; hipEvent_t ev = nullptr; const uint32_t *ptr = nullptr; }; // 0 never filled, 1 fill queued, 2 done
+std::mutex g_leaky_mu;
+LeakyDev g_leaky_dev[64];
+} // namespace
+
+const uint32_t *leaky_table(hipStream_t s)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(g_leaky_mu);
+    LeakyDev &d = g_leaky_dev[dev];
+    if (!d.ptr) {
+        void *p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_leaky_thr)) != hipSuccess) return nullptr;
+        d.ptr = (const uint32_t *)p;
+    }
+    if (d.state == 2) return d.ptr;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s, &cap);
+    if (cap != hipStreamCaptureStatusNone) { // the fill becomes a node of that graph (idempotent); nothing is remembered
+        hipLaunchKernelGGL(k_leaky_fill, dim3(1), dim3(kLeakyLevels), 0, s);
+        return d.ptr;
+    }
+    if (d.state == 0) { // in front of the caller's kernels on its own stream
+        hipLaunchKernelGGL(k_leaky_fill, dim3(1), dim3(kLeakyLevels), 0, s);
+        if (hipEventCreateWithFlags(&d.ev, hipEventDisableTiming) == hipSuccess && hipEventRecord(d.ev, s) == hipSuccess) d.state = 1;
+        return d.ptr; // (no event: the next call fills again)
+    }
+    if (hipEventQuery(d.ev) == hipSuccess) d.state = 2;
+    else if (hipStreamWaitEvent(s, d.ev, 0) != hipSuccess) return nullptr;
+    return d.ptr;
 }
 
 } // namespace frlw

@@ -103,7 +103,7 @@ struct FastPlan {
     int twl, thl, tiles_x, tiles_y, T;
     int bpw, chunk;
     int chunks, slabs, pairs;
-    size_t off_counts, off_slabtot, off_base, off_sub, off_seg0, off_segcnt, off_errs, off_tlut, off_leaky, off_records, off_records2, bytes;
+    size_t off_counts, off_slabtot, off_base, off_sub, off_seg0, off_segcnt, off_errs, off_tlut, off_records, off_records2, bytes;
     int max_segs;
 };
 
@@ -174,7 +174,6 @@ bool fast_layout(const int64_t *seq_offsets, const int64_t *t_start, int n_seq, 
     p.off_segcnt = off;  off = align_up(off + (size_t)p.max_segs * kFW * 4, 256);
     p.off_errs = off;    off = align_up(off + (size_t)(c > 0 ? c : 1) * 4, 256);
     p.off_tlut = off;    off = align_up(off + (size_t)(win + 1) * 4, 256);
-    p.off_leaky = off;   off = align_up(off + (size_t)kLeakyLevels * 4, 256);
     p.off_records = off; off = align_up(off + (size_t)(n > 0 ? n : 1) * 4, 256);
     p.off_records2 = off; off = align_up(off + (size_t)(n > 0 ? n : 1) * 4, 256);
     p.bytes = off;
@@ -298,8 +297,7 @@ __device__ __forceinline__ void hist_issue(const FastGeom &G, const HistSpan &L,
 
 template <bool HAS_MAP, bool EV = false>
 __global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(8, 8))) void kf_hist(FastGeom G, SeqTab S, uint32_t *counts,
-                                                                                         int32_t *errs, float *tlut_w,
-                                                                                         uint32_t *leaky_w, int n_chunks)
+                                                                                         int32_t *errs, float *tlut_w, int n_chunks)
 {
     extern __shared__ uint32_t lds[];
     uint32_t *hist = lds; // [T]
@@ -308,8 +306,6 @@ __global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     for (int b = tid; b < G.T; b += kFT) hist[b] = 0;
     if (tid == 0) serr = 0;
     int mul_err = 0;
-    if (!EV && blockIdx.x == gridDim.x - 1 && tid < kLeakyLevels) // generate_taf.py:69-76 as a 256-level threshold table
-        leaky_w[tid] = tid == 0 ? 0x7f800000u : leaky_threshold_bits(tid);
     if (EV) {
         // Event Volume: tlut[r] = float(r / window) (generate_eventvolume.py:141, :23: t.float()), r = t - (t_end - window);
         // the same exhaustive check decides whether the tile kernels may multiply by 1 / window instead
@@ -1866,7 +1862,6 @@ void launch_fast(const FastGeom &G, const SeqTab &S, const FastPlan &p, char *w8
     uint32_t *base = (uint32_t *)(w8 + p.off_base);
     int32_t *errs = (int32_t *)(w8 + p.off_errs);
     float *tlut = (float *)(w8 + p.off_tlut);
-    uint32_t *leaky = (uint32_t *)(w8 + p.off_leaky);
     uint32_t *records = (uint32_t *)(w8 + p.off_records);
     const size_t lds_sc = scatter_lds_bytes(p.T, p.chunk);
     if (lds_sc > 64 * 1024) {
@@ -1874,7 +1869,7 @@ void launch_fast(const FastGeom &G, const SeqTab &S, const FastPlan &p, char *w8
         if (!EV) (void)hipFuncSetAttribute((const void *)kf_scatter<HAS_MAP, EV, !EV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc);
     }
     const int hist_grid = p.chunks < 512 ? p.chunks : 512; // persistent: two workgroups per CU
-    hipLaunchKernelGGL((kf_hist<HAS_MAP, EV>), dim3(hist_grid), dim3(kFT), (size_t)p.T * 4, st, G, S, counts, errs, tlut, leaky, p.chunks);
+    hipLaunchKernelGGL((kf_hist<HAS_MAP, EV>), dim3(hist_grid), dim3(kFT), (size_t)p.T * 4, st, G, S, counts, errs, tlut, p.chunks);
     const bool inline_slabs = (long long)p.slabs * p.T <= kInlineSlabScan;
     if (!inline_slabs)
         hipLaunchKernelGGL(kf_slabscan, dim3((p.T + kWave - 1) / kWave, p.slabs), dim3(kWave), 0, st, S, counts, p.T, slabtot);
@@ -2038,7 +2033,7 @@ int taf_batch_run(int phases, const frlw_events_t *ev, const int64_t *seq_offset
     q.tile_walk = G.order_check;
     q.tile_max = whole_max_of(p.pairs);
     q.tlut = (const float *)(w8 + p.off_tlut);
-    q.leaky_thr = (const uint32_t *)(w8 + p.off_leaky);
+    if (!(q.leaky_thr = leaky_table(st))) return FRLW_ERR_HIP; // device-resident constant, built once per device (partition.hip)
     q.hdr = (FastHeader *)w8;
     q.state = state; q.view_f32 = view_f32; q.out_u8 = out_u8;
     hipLaunchKernelGGL(kf_split_whole, dim3(p.pairs + q.seg_grid), dim3(kFT), 0, st, q); // tiles, then segment counts
