@@ -87,6 +87,8 @@ struct FastGeom {
                        // of other rows are skipped (not an error); H_full == H, y_lo == 0: the whole frame
     int n_windows, wb;
     uint32_t win, win_magic;
+    double rcp; // 1 / (win + 1e-8) (TAF) or 1 / win (Event Volume), IEEE f64, computed ONCE on the host: kf_hist checks that
+                // multiplying by it gives every r of the window the float the division gives; the tile kernels multiply
 };
 
 struct FastHeader {
@@ -309,7 +311,7 @@ __global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     if (EV) {
         // Event Volume: tlut[r] = float(r / window) (generate_eventvolume.py:141, :23: t.float()), r = t - (t_end - window);
         // the same exhaustive check decides whether the tile kernels may multiply by 1 / window instead
-        const double den = (double)G.win, rcp = 1.0 / den;
+        const double den = (double)G.win, rcp = G.rcp;
         for (long long r = (long long)blockIdx.x * kFT + tid; r <= (long long)G.win; r += (long long)gridDim.x * kFT) {
             const float exact = (float)((double)r / den);
             if ((float)((double)r * rcp) != exact) mul_err = ST_MULBAD;
@@ -320,7 +322,7 @@ __global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         // distinct in-window time instead of one per event
         // The walk kernel would rather multiply by 1 / den than gather from the table: allowed only if that gives the
         // same float for EVERY r of the domain, which is checked right here, exhaustively, per call.
-        const double den = (double)G.win + 1e-8, rcp = 1.0 / den;
+        const double den = (double)G.win + 1e-8, rcp = G.rcp;
         for (long long r = (long long)blockIdx.x * kFT + tid; r <= (long long)G.win; r += (long long)gridDim.x * kFT) {
             const float exact = (float)((double)r / den);
             if ((float)((double)r * rcp) != exact) mul_err = ST_MULBAD;
@@ -643,6 +645,7 @@ struct TileP {
     const float *tlut;
     const uint32_t *leaky_thr;
     FastHeader *hdr;
+    double rcp;      // FastGeom::rcp
     float *state;    // (B, H, W, 2, K)
     float *view_f32; // (B, 2K, H, W) or NULL
     uint8_t *out_u8; // (B, K, 2, H, W) or NULL
@@ -977,7 +980,7 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_waves_per_eu(8,
     if (tid == 0) s_unsorted = 0;
     const unsigned long long wmask = q.hdr->wmask[s];
     const bool use_mul = q.hdr->mul_bad == 0u; // checked for every r of the domain by kf_hist
-    const double rcp = 1.0 / ((double)q.win + 1e-8);
+    const double rcp = q.rcp;
     const uint32_t wfield = (1u << q.wb) - 1u;
     const int rshift = kCellBits + q.wb;
     __syncthreads();
@@ -1101,9 +1104,9 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_waves_per_eu(8,
                     float e0[4], e1[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const uint32_t at = o[j] + a;
-                        e0[j] = sorted[at < (uint32_t)kWalkChunk ? at : (uint32_t)kWalkChunk - 1u];
-                        e1[j] = sorted[at + 1 < (uint32_t)kWalkChunk ? at + 1 : (uint32_t)kWalkChunk - 1u];
+                        const uint32_t at = o[j] + a; // (a slot behind the segment's end is read and not used: any in-range address does)
+                        e0[j] = sorted[at & (uint32_t)(kWalkChunk - 1)];
+                        e1[j] = sorted[(at + 1u) & (uint32_t)(kWalkChunk - 1)];
                     }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -1431,7 +1434,7 @@ __global__ __launch_bounds__(NW *kWave) void kf_taf_tile(TileP q)
     const WavePass P = {wl[wv].cnt, wl[wv].off, wl[wv].sorted};
     const unsigned long long wmask = q.hdr->wmask[s];
     const bool use_mul = q.hdr->mul_bad == 0u; // checked for every r of the domain by kf_hist
-    const double rcp = 1.0 / ((double)q.win + 1e-8);
+    const double rcp = q.rcp;
     const uint32_t wfield = (1u << q.wb) - 1u;
     const int rshift = kCellBits + q.wb;
     // the lane's four cells: cell 64 j + lane of sub-tile `sub` = pixel 128 sub + 32 j + lane / 2 of the tile, polarity lane & 1
@@ -1595,6 +1598,7 @@ __global__ __launch_bounds__(NW *kWave) void kf_taf_tile(TileP q)
 struct EvTileP {
     int H, W, twl, thl, tiles_x, T, bins;
     uint32_t win;
+    double rcp;           // FastGeom::rcp
     const uint32_t *rec;  // tile-major records (scatter output)
     const uint32_t *rec2; // sub-tile-major (segment split), for the tiles the tile walk leaves alone
     const uint32_t *base; // [pairs + 1]
@@ -1717,7 +1721,7 @@ __global__ __launch_bounds__(NW *kWave) void kf_ev_tile(EvTileP q)
     for (int i = tid; i < RPT * NW * NW; i += NT) (&L.scnt[0][0][0])[i] = 0u;
     const WavePass P = {s_cnt[wv], s_off[wv], s_sorted[wv]};
     const bool use_mul = q.hdr->mul_bad == 0u;
-    const double rcp = 1.0 / (double)q.win;
+    const double rcp = q.rcp;
     const float binsf = (float)q.bins;
     float acc[4][BINS];
 #pragma unroll
@@ -1778,7 +1782,7 @@ __global__ __launch_bounds__(4 * kWave) void kf_ev_sub(EvTileP q, int all_tiles)
     for (int i = lane; i < kSubCells / 2; i += kWave) s_cnt[wv][i] = 0u;
     const WavePass P = {s_cnt[wv], s_off[wv], s_sorted[wv]};
     const bool use_mul = q.hdr->mul_bad == 0u;
-    const double rcp = 1.0 / (double)q.win;
+    const double rcp = q.rcp;
     const float binsf = (float)q.bins;
     float acc[4][BINS];
 #pragma unroll
@@ -1996,6 +2000,7 @@ int taf_batch_run(int phases, const frlw_events_t *ev, const int64_t *seq_offset
     G.H = H; G.W = W; G.twl = p.twl; G.thl = p.thl; G.tiles_x = p.tiles_x; G.T = p.T; G.bpw = p.bpw;
     G.chunk_ev = p.chunk; G.run = p.chunk / kFW; G.n_total = ev->n;
     G.n_windows = n_windows; G.wb = wb; G.win = (uint32_t)window_us;
+    G.rcp = 1.0 / ((double)(uint32_t)window_us + 1e-8); // generate_taf.py:215: t / (w + 1e-8)
     G.y_lo = y_lo; G.H_full = H_full;
     {
         const frlw_tuning_t *tu = ev->tuning;
@@ -2019,7 +2024,7 @@ int taf_batch_run(int phases, const frlw_events_t *ev, const int64_t *seq_offset
     if (!(phases & PHASE_FINISH)) { HIP_TRY(hipGetLastError()); return FRLW_OK; }
     TileP q;
     q.H = H; q.W = W; q.twl = p.twl; q.thl = p.thl; q.tiles_x = p.tiles_x; q.T = p.T; q.K = K; q.n_windows = n_windows;
-    q.wb = wb; q.flip = (flags & FRLW_TAF_U8_FLIP_K) ? 1 : 0; q.win = (uint32_t)window_us;
+    q.wb = wb; q.flip = (flags & FRLW_TAF_U8_FLIP_K) ? 1 : 0; q.win = (uint32_t)window_us; q.rcp = G.rcp;
     q.rec = (const uint32_t *)(w8 + p.off_records);
     q.rec2 = (uint32_t *)(w8 + p.off_records2);
     q.base = (const uint32_t *)(w8 + p.off_base);
@@ -2115,6 +2120,7 @@ int frlw_ev_encode_batch(const frlw_events_t *ev, const int64_t *seq_offsets, co
     G.H = H; G.W = W; G.twl = p.twl; G.thl = p.thl; G.tiles_x = p.tiles_x; G.T = p.T; G.bpw = p.bpw;
     G.chunk_ev = p.chunk; G.run = p.chunk / kFW; G.n_total = ev->n;
     G.n_windows = 1; G.wb = 0; G.win = (uint32_t)window_us; G.win_magic = 0u; G.order_check = 0; G.y_lo = 0; G.H_full = H;
+    G.rcp = 1.0 / (double)(uint32_t)window_us; // generate_eventvolume.py:141
 
     hipStream_t st = (hipStream_t)stream;
     char *w8 = (char *)workspace;
@@ -2141,7 +2147,7 @@ int frlw_ev_encode_batch(const frlw_events_t *ev, const int64_t *seq_offsets, co
     hipLaunchKernelGGL(kf_split_whole, dim3(p.pairs + q.seg_grid - q.first_block), dim3(kFT), 0, st, q); // tiles, then segment counts
     hipLaunchKernelGGL(kf_split_place, dim3(q.seg_grid), dim3(kFT), 0, st, q);
     EvTileP e;
-    e.H = H; e.W = W; e.twl = p.twl; e.thl = p.thl; e.tiles_x = p.tiles_x; e.T = p.T; e.bins = bins; e.win = (uint32_t)window_us;
+    e.H = H; e.W = W; e.twl = p.twl; e.thl = p.thl; e.tiles_x = p.tiles_x; e.T = p.T; e.bins = bins; e.win = (uint32_t)window_us; e.rcp = G.rcp;
     e.rec = q.rec; e.rec2 = q.rec2; e.base = q.base; e.sub = q.sub; e.pairs = p.pairs; e.tile_max = whole_max_of(p.pairs);
     e.tlut = (const float *)(w8 + p.off_tlut); e.hdr = (FastHeader *)w8; e.out_f32 = out_f32; e.out_u8 = out_u8;
     const int sub_grid = (p.pairs * kFW + 3) / 4;
