@@ -558,6 +558,12 @@ def _train_variant(torch, timer, world, rank, local_rank, per_gpu_batch, ddp, ho
         state["loss"], _ = tr.train_step(x, lab, state["i"])
         state["i"] += 1
 
+    if graph:  # capture, then feed the step from the graph's own input buffers like the eager step reads its batch in place
+        one()
+        bx, bl = tr.input_buffers()
+        bx.copy_(x)
+        bl.copy_(lab)
+        x, lab = bx, bl
     per, dev_ms = timer.run(one, steps, warmup)
     return per, dev_ms, tr, state, one, (x, lab)
 

@@ -145,6 +145,11 @@ class Trainer:
         self._graph = (graph, x, lab, loss)
         return warmup
 
+    def input_buffers(self):
+        """(images, labels) the captured graph reads: a data pipeline that writes its batch into these (and passes them to
+        ``train_step``) saves the device-to-device copy of the batch (84 MB at batch 64).  None before the capture."""
+        return None if self._graph is None else (self._graph[1], self._graph[2])
+
     def train_step(self, imgs, targets, i_batch=0, sync=True, after_launch=None):
         """core/exp.py:292-303 for one batch; returns (loss as a Python float, lr).  ``sync=False`` returns the loss as a
         device tensor instead (the caller reads it when it logs: no queue drain per step).  ``after_launch``: called once
@@ -156,8 +161,10 @@ class Trainer:
             self.capture(imgs, targets, warmup=3)
         if self._graph is not None and imgs.shape == self._graph[1].shape and targets.shape == self._graph[2].shape:
             graph, x, lab, loss = self._graph
-            x.copy_(imgs, non_blocking=True)
-            lab.copy_(targets, non_blocking=True)
+            if imgs.data_ptr() != x.data_ptr():  # (a producer that writes straight into input_buffers() skips this copy)
+                x.copy_(imgs, non_blocking=True)
+            if targets.data_ptr() != lab.data_ptr():
+                lab.copy_(targets, non_blocking=True)
             graph.replay()
             # the replay moved the parameters without telling autograd: bump their version counters so that every cache
             # keyed on them (weight layouts, the folded inference engine) sees the change
