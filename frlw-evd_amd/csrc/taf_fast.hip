@@ -2131,7 +2131,15 @@ int frlw_ev_encode_batch(const frlw_events_t *ev, const int64_t *seq_offsets, co
     }
     if (ev->xmap) launch_fast<true, true>(G, S, p, w8, st);
     else launch_fast<false, true>(G, S, p, w8, st);
-    const bool tile_walk = p.pairs >= kFewPairs;
+    // Second-level split: kf_split_whole + kf_ev_sub by default; the tile walk (kf_ev_tile, 3.4: the split in LDS, 2.44x instead
+    // of 2.8x HBM traffic) on request -- it was the default until kf_split_whole became a one-pass kernel, which made the two-kernel
+    // form the faster one (64 x 1 M events: 985 against 1 041 us)
+    bool tile_walk = false;
+    {
+        const frlw_tuning_t *tu = ev->tuning;
+        const bool want = (tu && tu->taf_tile_walk >= 0) ? tu->taf_tile_walk != 0 : kTafTileWalk;
+        tile_walk = want && p.pairs >= kFewPairs;
+    }
     TileP q;
     memset(&q, 0, sizeof(q));
     q.T = p.T; q.pairs = p.pairs; q.skip_whole = tile_walk ? 1 : 0;

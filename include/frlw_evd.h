@@ -66,8 +66,9 @@ typedef struct frlw_tuning {
     int32_t staged_scatter;   /* 0 / 1: records leave the partition through an LDS staging area */
     int32_t quarter_below;    /* frames with at most this many wavefronts run every tile as four quarter workgroups */
     int32_t no_value_table;   /* 1: TAF DAT8 computes the f64 division per event instead of the per-call table */
-    int32_t taf_tile_walk;    /* frlw_taf_encode_batch: 1 = tiles are split in LDS by the kernel that walks them (kf_taf_tile:
-                               * less HBM traffic, measured slower), 0 = split pass + sub-tile kernel (the default) */
+    int32_t taf_tile_walk;    /* frlw_taf_encode_batch / frlw_ev_encode_batch: 1 = tiles are split in LDS by the kernel that walks
+                               * them (kf_taf_tile / kf_ev_tile: less HBM traffic, measured slower), 0 = split pass + sub-tile
+                               * kernel (the default) */
 } frlw_tuning_t;
 
 typedef struct frlw_events {

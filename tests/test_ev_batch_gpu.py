@@ -48,11 +48,15 @@ def test_gen1_golden_single_sequence(er, golden_dir, tag, hot):
     assert hashlib.sha256(host(out[0]).tobytes()).hexdigest() == str(g[tag + "native_sha"])
 
 
+@pytest.mark.parametrize("tile_walk", [0, 1])
 @pytest.mark.parametrize("bins", [1, 2, 5, 8])
-def test_batch_vs_oracle_and_general_path(er, orc, bins):
-    """Eight label windows in one call (320 (sequence, tile) pairs -> the tile walk): own t_end each, a sparse one, an empty
-    one, one with a hot spot, one unsorted, one with events in front of its window (dropped like the harness' time filter)
-    and events exactly on t_end."""
+def test_batch_vs_oracle_and_general_path(er, orc, bins, tile_walk, monkeypatch):
+    """Eight label windows in one call (320 (sequence, tile) pairs): own t_end each, a sparse one, an empty one, one with a
+    hot spot, one unsorted, one with events in front of its window (dropped like the harness' time filter) and events exactly
+    on t_end.  Both second-level forms: the split pass + kf_ev_sub (default) and the opt-in tile walk (kf_ev_tile)."""
+    from frlw_evd_amd import _lib
+    if tile_walk:
+        monkeypatch.setattr(er, "TUNING", _lib.FrlwTuning(taf_tile_walk=1))
     H, W, B, win = 240, 304, 8, 50_000
     t_end = [50_000, 50_000, 1_050_000, 50_000, 50_000, 80_000, 50_000, 50_000]
     recs = []
@@ -74,7 +78,7 @@ def test_batch_vs_oracle_and_general_path(er, orc, bins):
     for j in range(B):
         want = orc.ev_stream_dat8(recs[j], (H, W), (H, W), bins, t_end[j], win)
         assert_bitexact(host(out[j]), want, f"sequence {j}")
-        if len(recs[j]):
+        if len(recs[j]) and not tile_walk:
             oj, uj = er.encode_ev_dat(to_dev(recs[j]), (H, W), t_end[j], win, bins, want_u8=True)
             assert torch.equal(oj, out[j]) and torch.equal(uj, u8[j]), f"general path, sequence {j}"
     assert float(out[2].abs().sum()) == 0.0          # the empty sequence: an all-zero volume

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from frlw_evd_amd import event_representation as er, synth  # noqa: E402
+from frlw_evd_amd import _lib, event_representation as er, synth  # noqa: E402
 
 
 def dev(rec):
@@ -55,11 +55,14 @@ def main():
             recs.append(synth.to_dat8(ev))
             ends.append(t_end)
         offs = np.concatenate([[0], np.cumsum([len(r) for r in recs])])
+        er.TUNING = _lib.FrlwTuning(taf_tile_walk=1) if case % 3 == 2 else None  # every third case: the opt-in tile walk (kf_ev_tile)
         try:
             out, u8 = er.encode_ev_batch(dev(np.concatenate(recs)), offs, (H, W), ends, win, bins, want_u8=True)
         except NotImplementedError:
             skipped += 1
             continue
+        finally:
+            er.TUNING = None
         for s in range(B):
             if len(recs[s]) == 0:
                 ok = float(out[s].abs().sum()) == 0.0
