@@ -745,13 +745,15 @@ __device__ __forceinline__ void split_count_segment(const TileP &q, uint32_t seg
 constexpr int kWholeChunks = FRLW_WHOLE_SEGS;
 constexpr int kWholeBatches = kWholeChunks * kSplitSeg / kWave; // 512 batches of 64 records
 constexpr int kWholeRow = kWholeBatches + 1;                    // row stride of scnt: the 16 counters of one batch in 16 banks
-__global__ __launch_bounds__(kFT) void kf_split_whole(TileP q)
+__global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(8, 8))) void kf_split_whole(TileP q) // (64 VGPRs: two workgroups per CU)
 {
     constexpr int RPT = kSplitSeg / kFT; // 8 records per thread and chunk of 8192
     __shared__ uint32_t scnt[kFW * kWholeRow]; // [sub-tile][batch] tickets, then exclusive prefixes
     __shared__ uint32_t wtot[kFW][kFW];        // segment counting (4b): [wavefront][sub-tile]
     __shared__ uint32_t vtot[kFW];             // records of every sub-tile
     __shared__ uint32_t vbeg[kFW][kFW];        // [wavefront]: every wavefront's own copy of the sub-tile starts
+    __shared__ uint32_t cE[kFW][kFW], cD[kFW][kFW]; // [wavefront]: per chunk, see step 4
+    __shared__ uint32_t stage[kSplitSeg];      // one chunk of records, sub-tile-major
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (q.hdr->status != 0) return;
     const int blk = (int)blockIdx.x + q.first_block;
@@ -833,18 +835,54 @@ __global__ __launch_bounds__(kFT) void kf_split_whole(TileP q)
         }
         LDS_FENCE();
     }
-    // 4. records to their slots
+    // 4. records to their slots, chunk by chunk THROUGH LDS: the 8192 records of a chunk are laid out sub-tile-major in the
+    // staging area (slot = the chunk's records of lower sub-tiles + the record's rank inside the chunk), then leave in one
+    // linear sweep -- consecutive threads write consecutive records of a sub-tile's run (whole lines; the direct form wrote
+    // 64 records of one instruction to 16 lists, ~16 bytes per line touched: 61 MB of write traffic for 40 MB of records).
+    // Per chunk and sub-tile b (every wavefront keeps its own copy, no barrier for the tables):
+    //   cE[b] = (records of sub-tiles < b in the chunk) - (prefix of b at the chunk's first batch)   -> slot = cE[b] + prefix + ticket
+    //   cD[b] = (start of b's list) + (prefix of b at the chunk's first batch) - (records of sub-tiles < b)  -> address = cD[b] + slot
 #pragma unroll
-    for (int c = 0; c < kWholeChunks; ++c)
+    for (int c = 0; c < kWholeChunks; ++c) {
+        if ((uint32_t)(c * kSplitSeg) >= n) break; // workgroup-uniform
+        const uint32_t nch = n - (uint32_t)(c * kSplitSeg) < (uint32_t)kSplitSeg ? n - (uint32_t)(c * kSplitSeg) : (uint32_t)kSplitSeg;
+        {
+            const int b = lane & 15;
+            const uint32_t p0 = scnt[b * kWholeRow + c * (kSplitSeg / kWave)];
+            const uint32_t p1 = (uint32_t)((c + 1) * kSplitSeg) < n ? scnt[b * kWholeRow + (c + 1) * (kSplitSeg / kWave)] : vtot[b];
+            const uint32_t cnt = p1 - p0;
+            uint32_t inc = cnt;
+#pragma unroll
+            for (int o2 = 1; o2 < kFW; o2 <<= 1) {
+                const uint32_t u = __shfl_up(inc, o2);
+                if (b >= o2) inc += u;
+            }
+            if (lane < kFW) {
+                cE[wv][lane] = (inc - cnt) - p0;
+                cD[wv][lane] = vbeg[wv][lane] + p0 - (inc - cnt);
+            }
+            LDS_FENCE();
+        }
 #pragma unroll
         for (int u = 0; u < RPT; ++u) {
-            const uint32_t i = (uint32_t)(c * kSplitSeg + u * kFT + tid);
-            if (i < n) {
+            const uint32_t i = (uint32_t)(u * kFT + tid);
+            if (i < nch) {
                 const uint32_t b = (m[c][u] & (kCells - 1)) >> 8;
                 const uint32_t t = (rk[c][u >> 2] >> (8 * (u & 3))) & 255u;
-                q.rec2[vbeg[wv][b] + scnt[b * kWholeRow + (c * RPT + u) * kFW + wv] + t] = m[c][u];
+                stage[cE[wv][b] + scnt[b * kWholeRow + (c * RPT + u) * kFW + wv] + t] = m[c][u];
             }
         }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) {
+            const uint32_t i = (uint32_t)(u * kFT + tid);
+            if (i < nch) {
+                const uint32_t r = stage[i];
+                q.rec2[cD[wv][(r & (kCells - 1)) >> 8] + i] = r;
+            }
+        }
+        __syncthreads(); // the staging area is reused by the next chunk
+    }
 }
 
 // 4b. Skewed tiles (more than kSplitWhole records).  Reorders every tile's records sub-tile-major (sub-tile = the 256 cells [256 v, 256 v + 256) one workgroup of
@@ -858,7 +896,15 @@ __global__ __launch_bounds__(kFT) void kf_split_whole(TileP q)
 //                     counters: lanes of one instruction are served in lane order, (round, wavefront) is the stream
 //                     order of the 64-record batches.
 constexpr int kSplitRpt = kSplitSeg / kFT;
-__device__ __forceinline__ void split_place_segment(const TileP &q, uint32_t seg, uint32_t (*scnt)[kFW][kFW], uint32_t *vtot)
+struct PlaceLds {
+    uint32_t scnt[kSplitRpt][kFW][kFW]; // [round][wavefront][sub-tile] tickets, then prefixes inside the segment
+    uint32_t vtot[kFW];                 // records of every sub-tile in the whole tile
+    uint32_t stot[kFW], sdst[kFW];      // this segment: records of sub-tile b / where they go in b's list
+    uint32_t cE[kFW][kFW], cD[kFW][kFW]; // [wavefront]: slot = cE[b] + prefix + ticket, address = cD[b] + slot (as in kf_split_whole)
+    uint32_t stage[kSplitSeg];          // the segment's records, sub-tile-major
+};
+
+__device__ __forceinline__ void split_place_segment(const TileP &q, uint32_t seg, PlaceLds &L)
 {
     constexpr int RPT = kSplitRpt, NE = RPT * kFW;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -866,7 +912,7 @@ __device__ __forceinline__ void split_place_segment(const TileP &q, uint32_t seg
     const uint32_t beg = q.base[g] + (seg - q.seg0[g]) * (uint32_t)kSplitSeg;
     const uint32_t end = q.base[g + 1] - beg < (uint32_t)kSplitSeg ? q.base[g + 1] : beg + kSplitSeg;
     const uint32_t nrec = end - beg;
-    for (int i = tid; i < RPT * kFW * kFW; i += kFT) (&scnt[0][0][0])[i] = 0u;
+    for (int i = tid; i < RPT * kFW * kFW; i += kFT) (&L.scnt[0][0][0])[i] = 0u;
     // where this segment's records of sub-tile v (= this wavefront) go: v's list starts behind the lists of the
     // sub-tiles before it, and the earlier segments of the tile come first inside it.  Every workgroup adds up the
     // tile's segment counts for itself (<= a few hundred segments x 16 values, L2-resident).
@@ -878,10 +924,10 @@ __device__ __forceinline__ void split_place_segment(const TileP &q, uint32_t seg
     }
 #pragma unroll
     for (int o2 = 32; o2 >= 1; o2 >>= 1) { before += __shfl_xor(before, o2); total += __shfl_xor(total, o2); }
-    if (lane == 0) vtot[wv] = total;
+    if (lane == 0) L.vtot[wv] = total;
     __syncthreads();
     uint32_t vstart = q.base[g];
-    for (int k = 0; k < wv; ++k) vstart += vtot[k];
+    for (int k = 0; k < wv; ++k) vstart += L.vtot[k];
     if (seg == q.seg0[g] && lane == 0) q.sub[(long long)g * kFW + wv] = vstart; // the tile's first segment publishes sub[]
     uint32_t m[RPT], rk[RPT];
 #pragma unroll
@@ -893,38 +939,62 @@ __device__ __forceinline__ void split_place_segment(const TileP &q, uint32_t seg
     for (int u = 0; u < RPT; ++u) {
         const uint32_t i = (uint32_t)(u * kFT + tid);
         rk[u] = 0u;
-        if (i < nrec) rk[u] = atomicAdd(&scnt[u][wv][(m[u] & (kCells - 1)) >> 8], 1u);
+        if (i < nrec) rk[u] = atomicAdd(&L.scnt[u][wv][(m[u] & (kCells - 1)) >> 8], 1u);
     }
     __syncthreads();
     {
-        // wavefront b: exclusive prefix of sub-tile b's counts over (round, wavefront) = stream order, on top of where
-        // this segment's records of b go in b's list
+        // wavefront b: exclusive prefix of sub-tile b's counts over (round, wavefront) = stream order inside the segment
         uint32_t v0 = 0, v1 = 0;
         const int e0 = 2 * lane, e1 = 2 * lane + 1;
-        if (e0 < NE) v0 = scnt[e0 / kFW][e0 % kFW][wv];
-        if (e1 < NE) v1 = scnt[e1 / kFW][e1 % kFW][wv];
+        if (e0 < NE) v0 = L.scnt[e0 / kFW][e0 % kFW][wv];
+        if (e1 < NE) v1 = L.scnt[e1 / kFW][e1 % kFW][wv];
         const uint32_t inc = wave_incl_scan(v0 + v1);
-        const uint32_t ex = inc - (v0 + v1) + vstart + before;
-        if (e0 < NE) scnt[e0 / kFW][e0 % kFW][wv] = ex;
-        if (e1 < NE) scnt[e1 / kFW][e1 % kFW][wv] = ex + v0;
+        const uint32_t ex = inc - (v0 + v1);
+        if (e0 < NE) L.scnt[e0 / kFW][e0 % kFW][wv] = ex;
+        if (e1 < NE) L.scnt[e1 / kFW][e1 % kFW][wv] = ex + v0;
+        if (lane == kWave - 1) { L.stot[wv] = inc; L.sdst[wv] = vstart + before; }
     }
     __syncthreads();
+    {
+        // every wavefront for itself: the segment's records sub-tile-major in the staging area (see kf_split_whole, step 4)
+        const int b = lane & 15;
+        const uint32_t cnt = L.stot[b];
+        uint32_t inc = cnt;
+#pragma unroll
+        for (int o2 = 1; o2 < kFW; o2 <<= 1) {
+            const uint32_t u = __shfl_up(inc, o2);
+            if (b >= o2) inc += u;
+        }
+        if (lane < kFW) { L.cE[wv][lane] = inc - cnt; L.cD[wv][lane] = L.sdst[lane] - (inc - cnt); }
+        LDS_FENCE();
+    }
 #pragma unroll
     for (int u = 0; u < RPT; ++u) {
         const uint32_t i = (uint32_t)(u * kFT + tid);
-        if (i < nrec) q.rec2[scnt[u][wv][(m[u] & (kCells - 1)) >> 8] + rk[u]] = m[u];
+        if (i < nrec) {
+            const uint32_t b = (m[u] & (kCells - 1)) >> 8;
+            L.stage[L.cE[wv][b] + L.scnt[u][wv][b] + rk[u]] = m[u];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) { // linear sweep: consecutive threads write consecutive records of a sub-tile's run
+        const uint32_t i = (uint32_t)(u * kFT + tid);
+        if (i < nrec) {
+            const uint32_t r = L.stage[i];
+            q.rec2[L.cD[wv][(r & (kCells - 1)) >> 8] + i] = r;
+        }
     }
 }
 
-__global__ __launch_bounds__(kFT) void kf_split_place(TileP q)
+__global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(8, 8))) void kf_split_place(TileP q)
 {
-    __shared__ uint32_t scnt[kSplitRpt][kFW][kFW]; // [round][wavefront][sub-tile]
-    __shared__ uint32_t vtot[kFW];
+    __shared__ PlaceLds L;
     if (q.hdr->status != 0) return;
     const uint32_t nseg = q.seg0[q.pairs];
     for (uint32_t seg = blockIdx.x; seg < nseg; seg += gridDim.x) { // (workgroup-uniform: most calls have no segment at all)
-        split_place_segment(q, seg, scnt, vtot);
-        __syncthreads(); // scnt / vtot are reused
+        split_place_segment(q, seg, L);
+        __syncthreads(); // the LDS image is reused
     }
 }
 
