@@ -239,12 +239,19 @@ __device__ __forceinline__ FastEv fast_decode(const FastGeom &G, uint2 r, long l
     return o;
 }
 
-__device__ __forceinline__ int seq_of_chunk(const SeqTab &S, int chunk)
+// largest s with first[s] <= v (first[0] = 0; empty sequences repeat a value: the last of them wins, like a linear walk).
+// Bisection: the table sits in the kernel arguments, every probe is a DEPENDENT scalar load -- the linear walk this replaces
+// cost a 64-sequence call up to 64 of them per chunk and wavefront (66 M scalar instructions in kf_hist for 64 M events).
+__device__ __forceinline__ int seq_of(const int *first, int n_seq, int v)
 {
-    int s = 0;
-    while (s + 1 < S.n_seq && chunk >= S.chunk0[s + 1]) ++s;
-    return s;
+    int lo = 0, hi = n_seq;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (v >= first[mid]) lo = mid; else hi = mid;
+    }
+    return lo;
 }
+__device__ __forceinline__ int seq_of_chunk(const SeqTab &S, int chunk) { return seq_of(S.chunk0, S.n_seq, chunk); }
 
 // ---- 1. histogram ------------------------------------------------------------------------------------
 // Persistent workgroups (two per CU) walk the chunks grid-stride; a thread takes eight records of a chunk as four 16-byte
@@ -377,8 +384,7 @@ __global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 // counts[c][b], c in one slab of 32 chunks of ONE sequence -> exclusive prefix over c (in place), slabtot[slab][b]
 __device__ __forceinline__ void slabscan_one(const SeqTab &S, uint32_t *counts, int T, uint32_t *slabtot, int slab, int b)
 {
-    int s = 0;
-    while (s + 1 < S.n_seq && slab >= S.slab0[s + 1]) ++s;
+    const int s = seq_of(S.slab0, S.n_seq, slab);
     const int c0 = S.chunk0[s] + (slab - S.slab0[s]) * kFastSlab, cend = S.chunk0[s + 1];
     uint32_t v[kFastSlab];
 #pragma unroll
