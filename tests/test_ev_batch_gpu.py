@@ -107,3 +107,15 @@ def test_event_behind_the_window_is_outside_the_contract(er):
         er.raise_deferred()
     with pytest.raises(NotImplementedError):  # window beyond the 20 bits of the 4-byte record
         er.encode_ev_batch(dat, [0, len(ev["t"])], (H, W), 2_000_000, 2_000_000, 5)
+
+
+def test_label_inside_the_first_window_of_a_file(er, orc):
+    """t_end < window: the window starts before time 0 (t0 negative), which the 32-bit SIMPLE decode of kf_hist / kf_scatter does
+    not cover -- the call takes the general instantiation.  Mixed with an ordinary sequence in one batch."""
+    H, W, win = 120, 160, 50_000
+    t_end = [20_000, 60_000]
+    recs = [synth.to_dat8(synth.synth_events(40 + j, 80_000, W, H, t_end[j] - 1, t_offset=1)) for j in range(2)]
+    offs = np.concatenate([[0], np.cumsum([len(r) for r in recs])])
+    out, _ = er.encode_ev_batch(to_dev(np.concatenate(recs)), offs, (H, W), t_end, win, 5)
+    for j in range(2):
+        assert_bitexact(host(out[j]), orc.ev_stream_dat8(recs[j], (H, W), (H, W), 5, t_end[j], win), f"sequence {j}")

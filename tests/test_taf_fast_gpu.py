@@ -350,3 +350,24 @@ def test_row_stripes_equal_whole_frame(er, cuts):
     st = init[:, stripes[-1][0]:stripes[-1][1]].contiguous()
     er.encode_taf_stripe(dat, offs, (H, W), stripes[-1], st, 0, win, n_win, K)
     assert not torch.equal(st, full[:, stripes[-1][0]:stripes[-1][1]])
+
+
+def test_negative_start_time_takes_the_general_decode():
+    """A sequence whose t_start is negative (or beyond 32 bits) is outside the SIMPLE decode of kf_hist / kf_scatter (32-bit time
+    arithmetic, csrc/taf_fast.hip): the call falls back to the general instantiation -- same bits as the general path."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from frlw_evd_amd import event_representation as er, synth
+    H, W, K, win, n_win = 120, 160, 8, 10_000, 8
+    recs = [synth.to_dat8(synth.synth_events(900 + j, 150_000, W, H, n_win * win - 5_000)) for j in range(3)]
+    starts = [-5_000, 0, -1]  # events at t in [0, 75 000): inside [t_start, t_start + 80 000] for every sequence
+    offs = np.concatenate([[0], np.cumsum([len(r) for r in recs])])
+
+    def dev(r):
+        return torch.from_numpy(np.ascontiguousarray(r).view(np.uint8).reshape(-1, 8).copy()).cuda()
+    st = torch.full((3, H, W, 2, K), -6000.0, device="cuda")
+    u8, view = er.encode_taf_batch(dev(np.concatenate(recs)), offs, (H, W), st, starts, win, n_win, K, want_view=True)
+    for j in range(3):
+        sj = torch.full((H, W, 2, K), -6000.0, device="cuda")
+        uj, vj = er.encode_taf_dat(dev(recs[j]), (H, W), sj, starts[j], win, n_win, K, want_view=True, fast=False)
+        assert torch.equal(sj, st[j]) and torch.equal(vj, view[j]) and torch.equal(uj, u8[j]), j
