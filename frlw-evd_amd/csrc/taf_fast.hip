@@ -48,7 +48,8 @@ constexpr int kSubCells = kCells / kFW;   // 256 cells owned by one wavefront of
 constexpr int kPixLog = 11;               // log2 pixels per tile
 constexpr int kMaxSeq = FRLW_MAX_SEQUENCES;
 constexpr int kMaxFastTiles = 1024;       // tiles per sequence (LDS of the scatter workgroup: 72 B per tile)
-constexpr int kMaxPairs = 8192;           // (sequence, tile) pairs per call (LDS of the tile scan)
+constexpr int kMaxPairs = 8192;           // (sequence, tile) pairs per call (LDS of the tile scan: one round)
+constexpr int kMaxBinPairs = 65536;       // (sequence, bin) pairs per call in the direct mode (the tile scan runs in rounds)
 constexpr int kFastSlab = 32;             // chunks per slab of the two-level column scan
 constexpr int ST_MULBAD = 8;              // per-chunk flag next to the ST_* error bits (not an error)
 constexpr int kSplitSeg = 8192;           // records one workgroup of the sub-tile split handles
@@ -87,6 +88,7 @@ struct FastGeom {
                        // of other rows are skipped (not an error); H_full == H, y_lo == 0: the whole frame
     int n_windows, wb;
     uint32_t win, win_magic;
+    int bin_shift, bin_mask; // direct mode (FastPlan): bin = tile << 4 | sub-tile of the cell; otherwise 0, 0: bin = tile
     int simple;   // the call meets the conditions of the SIMPLE decode (below): decided on the host
     uint32_t span; // n_windows * win when that fits 32 bits (SIMPLE)
     double rcp; // 1 / (win + 1e-8) (TAF) or 1 / win (Event Volume), IEEE f64, computed ONCE on the host: kf_hist checks that
@@ -105,6 +107,11 @@ static_assert(sizeof(FastHeader) <= kSelftestOffset, "header");
 
 struct FastPlan {
     int twl, thl, tiles_x, tiles_y, T;
+    // Direct mode (small calls on small frames): the partition's bins are the 256-cell SUB-TILES (16 per tile) instead of the tiles, so kf_scatter's output
+    // already is sub-tile-major and the second-level split (kf_split_whole / kf_split_place: a read + write of every record)
+    // is not run at all.  Possible while a sequence has at most kMaxFastTiles bins (the scatter workgroup keeps 16 counters
+    // per bin in LDS): the GEN1 / 304x240 class of frames (36 tiles = 576 bins), not 1280x720 (450 tiles = 7200 bins).
+    int direct, TB, bin_shift, pairs_b; // bins per sequence (T or 16 T), log2 of bins per tile, (sequence, bin) pairs
     int bpw, chunk;
     int chunks, slabs, pairs;
     size_t off_counts, off_slabtot, off_base, off_sub, off_seg0, off_segcnt, off_errs, off_tlut, off_records, off_records2, bytes;
@@ -115,7 +122,8 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // Tile shape: 2^twl x 2^(11 - twl) pixels, the one that covers the frame with the fewest tiles (ties: the widest,
 // longest contiguous rows).
-bool fast_plan(long long n, int n_seq, int H, int W, FastPlan &p)
+enum : int { DIRECT_OFF = 0, DIRECT_AUTO = 1, DIRECT_FORCE = 2 };
+bool fast_plan(long long n, int n_seq, int H, int W, FastPlan &p, int direct_mode = DIRECT_AUTO)
 {
     if (H <= 0 || W <= 0 || n < 0 || n_seq < 1 || n_seq > kMaxSeq || n >= (1ll << 31)) return false;
     long long best = -1;
@@ -130,10 +138,22 @@ bool fast_plan(long long n, int n_seq, int H, int W, FastPlan &p)
     p.T = p.tiles_x * p.tiles_y;
     if (p.T > kMaxFastTiles || (long long)p.T * n_seq > kMaxPairs) return false;
     p.pairs = p.T * n_seq;
+    // AUTO: calls with few (sequence, tile) pairs -- the launch-bound ones, which would otherwise run the segment kernels (one
+    // GEN1 stream: 52 -> 42 us).  With many pairs kf_split_whole is the cheaper second level (64 GEN1 streams: 842 us against
+    // 875 direct): there only when forced (frlw_tuning_t::direct_bins = 1).
+    p.direct = (direct_mode != DIRECT_OFF && kFW * p.T <= kMaxFastTiles && (long long)kFW * p.T * n_seq <= kMaxBinPairs &&
+                (direct_mode == DIRECT_FORCE || p.pairs < kFewPairs)) ? 1 : 0;
+    p.TB = p.direct ? kFW * p.T : p.T;
+    p.bin_shift = p.direct ? 4 : 0;
+    p.pairs_b = p.TB * n_seq;
     // Chunk size: the partition kernels run two workgroups per CU (512 at a time), and a grid that is not a whole number
     // of such rounds ends on a part-filled one (10 M events in chunks of 8192 = 2.4 rounds: the last one 38 % full).  So
     // the stream is cut into 512 * k chunks with the smallest k whose chunks fit the 8192-event staging area.
-    const long long cap = (long long)kFT * kMaxBpw;
+    long long cap = (long long)kFT * kMaxBpw;
+    if (p.direct) { // 16 counters per bin: shorter chunks keep the scatter workgroup at two per CU (78 KB of LDS)
+        const long long lds_cap = ((79ll * 1024 - 16 - (long long)kFW * p.TB * 4 - (p.TB + 2) * 4) / 6) / 16 * 16;
+        if (lds_cap >= 2048 && lds_cap < cap) cap = lds_cap;
+    }
     long long k = (n + 512 * cap - 1) / (512 * cap);
     if (k < 1) k = 1;
     long long ce = (n + 512 * k - 1) / (512 * k);
@@ -169,12 +189,12 @@ bool fast_layout(const int64_t *seq_offsets, const int64_t *t_start, int n_seq, 
     p.slabs = sl;
     const long long n = seq_offsets[n_seq] - seq_offsets[0];
     size_t off = kHeaderBytes;
-    p.off_counts = off;  off = align_up(off + (size_t)(c > 0 ? c : 1) * p.T * 4, 256);
-    p.off_slabtot = off; off = align_up(off + (size_t)(sl > 0 ? sl : 1) * p.T * 4, 256);
-    p.off_base = off;    off = align_up(off + (size_t)(p.pairs + 1) * 4, 256);
+    p.off_counts = off;  off = align_up(off + (size_t)(c > 0 ? c : 1) * p.TB * 4, 256);
+    p.off_slabtot = off; off = align_up(off + (size_t)(sl > 0 ? sl : 1) * p.TB * 4, 256);
+    p.off_base = off;    off = align_up(off + (size_t)(p.pairs_b + 1) * 4, 256);
     p.off_sub = off;     off = align_up(off + ((size_t)p.pairs * kFW + 1) * 4, 256);
     p.max_segs = 2 * (int)(n / kSplitSeg) + 1; // tiles above the whole-tile limit (>= one segment): full segments + one partial each
-    p.off_seg0 = off;    off = align_up(off + (size_t)(p.pairs + 1) * 4, 256);
+    p.off_seg0 = off;    off = align_up(off + (size_t)(p.pairs_b + 1) * 4, 256);
     p.off_segcnt = off;  off = align_up(off + (size_t)p.max_segs * kFW * 4, 256);
     p.off_errs = off;    off = align_up(off + (size_t)(c > 0 ? c : 1) * 4, 256);
     p.off_tlut = off;    off = align_up(off + (size_t)(win + 1) * 4, 256);
@@ -225,8 +245,9 @@ __device__ __forceinline__ FastEv fast_decode(const FastGeom &G, uint2 r, long l
             if (r.x <= t0lo) return o; // generate_eventvolume.py:139: not an error, not encoded
             if (relu > G.win) { o.err = ST_SPAN; return o; }
             const int tw1e = (1 << G.twl) - 1, th1e = (1 << G.thl) - 1;
-            o.tile = (y >> G.thl) * G.tiles_x + (x >> G.twl);
-            o.word = (relu << kCellBits) | (uint32_t)((((y & th1e) << G.twl) | (x & tw1e)) << 1) | p;
+            const uint32_t celle = (uint32_t)((((y & th1e) << G.twl) | (x & tw1e)) << 1) | p;
+            o.tile = (((y >> G.thl) * G.tiles_x + (x >> G.twl)) << G.bin_shift) | (int)((celle >> 8) & (uint32_t)G.bin_mask);
+            o.word = (relu << kCellBits) | celle;
             return o;
         }
         if (r.x < t0lo || relu > G.span) { o.err = ST_SPAN; return o; }
@@ -235,8 +256,8 @@ __device__ __forceinline__ FastEv fast_decode(const FastGeom &G, uint2 r, long l
         if (rem >= G.win) { ++z; rem -= G.win; }
         if (z >= (uint32_t)G.n_windows) { z = (uint32_t)G.n_windows - 1u; rem = G.win; } // t == end of the last window
         const int tw1 = (1 << G.twl) - 1, th1 = (1 << G.thl) - 1;
-        o.tile = (y >> G.thl) * G.tiles_x + (x >> G.twl);
         const uint32_t cell = (uint32_t)((((y & th1) << G.twl) | (x & tw1)) << 1) | p;
+        o.tile = (((y >> G.thl) * G.tiles_x + (x >> G.twl)) << G.bin_shift) | (int)((cell >> 8) & (uint32_t)G.bin_mask);
         o.window = z;
         o.word = (rem << (kCellBits + G.wb)) | (z << kCellBits) | cell;
         return o;
@@ -248,8 +269,9 @@ __device__ __forceinline__ FastEv fast_decode(const FastGeom &G, uint2 r, long l
         if (rel <= 0) return o; // generate_eventvolume.py:139: not an error, not encoded
         if (rel > (long long)G.win) { o.err = ST_SPAN; return o; }
         const int tw1e = (1 << G.twl) - 1, th1e = (1 << G.thl) - 1;
-        o.tile = (y >> G.thl) * G.tiles_x + (x >> G.twl);
-        o.word = ((uint32_t)rel << kCellBits) | (uint32_t)((((y & th1e) << G.twl) | (x & tw1e)) << 1) | p;
+        const uint32_t celle = (uint32_t)((((y & th1e) << G.twl) | (x & tw1e)) << 1) | p;
+        o.tile = (((y >> G.thl) * G.tiles_x + (x >> G.twl)) << G.bin_shift) | (int)((celle >> 8) & (uint32_t)G.bin_mask);
+        o.word = ((uint32_t)rel << kCellBits) | celle;
         return o;
     }
     if (rel < 0 || rel > (long long)G.n_windows * G.win) { o.err = ST_SPAN; return o; }
@@ -260,8 +282,8 @@ __device__ __forceinline__ FastEv fast_decode(const FastGeom &G, uint2 r, long l
     if (rem >= G.win) { ++z; rem -= G.win; }
     if (z >= (uint32_t)G.n_windows) { z = (uint32_t)G.n_windows - 1u; rem = G.win; } // t == end of the last window
     const int tw1 = (1 << G.twl) - 1, th1 = (1 << G.thl) - 1;
-    o.tile = (y >> G.thl) * G.tiles_x + (x >> G.twl);
     const uint32_t cell = (uint32_t)((((y & th1) << G.twl) | (x & tw1)) << 1) | p;
+    o.tile = (((y >> G.thl) * G.tiles_x + (x >> G.twl)) << G.bin_shift) | (int)((cell >> 8) & (uint32_t)G.bin_mask);
     o.window = z;
     o.word = (rem << (kCellBits + G.wb)) | (z << kCellBits) | cell;
     return o;
@@ -441,7 +463,7 @@ __global__ __launch_bounds__(kWave) void kf_slabscan(SeqTab S, uint32_t *counts,
 constexpr int kInlineSlabScan = 8192;
 __global__ __launch_bounds__(kFT) void kf_tilescan(SeqTab S, uint32_t *slabtot, int T, uint32_t *base, uint32_t *seg0,
                                                    FastHeader *hdr, const int32_t *errs, int chunks, uint32_t *counts_inline,
-                                                   int slabs_inline)
+                                                   int slabs_inline, int no_segments)
 {
     if (counts_inline) {
         for (int i = threadIdx.x; i < slabs_inline * T; i += kFT) slabscan_one(S, counts_inline, T, slabtot, i / T, i % T);
@@ -450,7 +472,7 @@ __global__ __launch_bounds__(kFT) void kf_tilescan(SeqTab S, uint32_t *slabtot, 
     __shared__ uint32_t tot[kMaxPairs];
     __shared__ uint32_t wsum[kFW], wsum2[kFW];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int pairs = S.n_seq * T;
+    const int pairs = S.n_seq * T; // (T = bins per sequence: tiles, or sub-tiles in the direct mode)
     if (tid == 0) { hdr->status = 0; hdr->filtered_tiles = 0u; hdr->mul_bad = 0u; }
     if (tid < kMaxSeq) { hdr->wmask[tid] = 0ull; hdr->unsorted[tid] = 0u; }
     __syncthreads();
@@ -460,50 +482,60 @@ __global__ __launch_bounds__(kFT) void kf_tilescan(SeqTab S, uint32_t *slabtot, 
         if (e & ~ST_MULBAD) atomicOr(&hdr->status, e & ~ST_MULBAD);
         if (e & ST_MULBAD) hdr->mul_bad = 1u;
     }
-    for (int idx = tid; idx < pairs; idx += kFT) {
-        const int s = idx / T, b = idx - s * T;
-        uint32_t run = 0;
-        const int sl1 = S.slab0[s + 1];
-        for (int sl = S.slab0[s]; sl < sl1; sl += 8) { // 8 independent loads in flight, then the 8 prefix stores
-            uint32_t v[8];
+    // two exclusive scans over the (sequence, bin) pairs: records -> base[], split segments (kSplitSeg records each, at least
+    // one per pair; none in the direct mode) -> seg0[]; rounds of kMaxPairs pairs (the direct mode has up to 65 536)
+    const uint32_t whole_max = no_segments ? 0xffffffffu : whole_max_of(pairs);
+    uint32_t carry = 0, scarry = 0;
+    for (int p0 = 0; p0 < pairs; p0 += kMaxPairs) {
+        const int np = pairs - p0 < kMaxPairs ? pairs - p0 : kMaxPairs;
+        for (int idx = tid; idx < np; idx += kFT) {
+            const int gi = p0 + idx, s = gi / T, b = gi - s * T;
+            uint32_t run = 0;
+            const int sl1 = S.slab0[s + 1];
+            for (int sl = S.slab0[s]; sl < sl1; sl += 8) { // 8 independent loads in flight, then the 8 prefix stores
+                uint32_t v[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = sl + k < sl1 ? slabtot[(long long)(sl + k) * T + b] : 0u;
+                for (int k = 0; k < 8; ++k) v[k] = sl + k < sl1 ? slabtot[(long long)(sl + k) * T + b] : 0u;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                if (sl + k < sl1) slabtot[(long long)(sl + k) * T + b] = run;
-                run += v[k];
+                for (int k = 0; k < 8; ++k) {
+                    if (sl + k < sl1) slabtot[(long long)(sl + k) * T + b] = run;
+                    run += v[k];
+                }
             }
+            tot[idx] = run;
         }
-        tot[idx] = run;
-    }
-    __syncthreads();
-    const int per = (pairs + kFT - 1) / kFT;
-    const int b0 = tid * per;
-    int b1 = b0 + per;
-    if (b1 > pairs) b1 = pairs;
-    // two exclusive scans over the (sequence, tile) pairs: records -> base[], split segments (kSplitSeg records each,
-    // at least one per pair) -> seg0[]
-    uint32_t sum = 0, ssum = 0;
-    const uint32_t whole_max = whole_max_of(pairs);
-    for (int b = b0; b < b1; ++b) { sum += tot[b]; ssum += split_segments(tot[b], whole_max); }
-    uint32_t inc = sum, sinc = ssum;
+        __syncthreads();
+        const int per = (np + kFT - 1) / kFT;
+        const int b0 = tid * per;
+        int b1 = b0 + per;
+        if (b1 > np) b1 = np;
+        uint32_t sum = 0, ssum = 0;
+        for (int b = b0; b < b1; ++b) { sum += tot[b]; ssum += split_segments(tot[b], whole_max); }
+        uint32_t inc = sum, sinc = ssum;
 #pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-        const uint32_t v = __shfl_up(inc, off), v2 = __shfl_up(sinc, off);
-        if (lane >= off) { inc += v; sinc += v2; }
+        for (int off = 1; off < kWave; off <<= 1) {
+            const uint32_t v = __shfl_up(inc, off), v2 = __shfl_up(sinc, off);
+            if (lane >= off) { inc += v; sinc += v2; }
+        }
+        if (lane == kWave - 1) { wsum[wv] = inc; wsum2[wv] = sinc; }
+        __syncthreads();
+        uint32_t pre = 0, spre = 0, all = 0, sall = 0;
+        for (int k = 0; k < kFW; ++k) {
+            if (k < wv) { pre += wsum[k]; spre += wsum2[k]; }
+            all += wsum[k]; sall += wsum2[k];
+        }
+        uint32_t run = carry + pre + inc - sum, srun = scarry + spre + sinc - ssum;
+        for (int b = b0; b < b1; ++b) {
+            base[p0 + b] = run;
+            seg0[p0 + b] = srun;
+            run += tot[b];
+            srun += split_segments(tot[b], whole_max);
+        }
+        carry += all;
+        scarry += sall;
+        __syncthreads(); // tot / wsum are reused by the next round
     }
-    if (lane == kWave - 1) { wsum[wv] = inc; wsum2[wv] = sinc; }
-    __syncthreads();
-    uint32_t pre = 0, spre = 0;
-    for (int k = 0; k < wv; ++k) { pre += wsum[k]; spre += wsum2[k]; }
-    uint32_t run = pre + inc - sum, srun = spre + sinc - ssum;
-    for (int b = b0; b < b1; ++b) {
-        base[b] = run;
-        seg0[b] = srun;
-        run += tot[b];
-        srun += split_segments(tot[b], whole_max);
-    }
-    if (tid == kFT - 1) { base[pairs] = pre + inc; seg0[pairs] = spre + sinc; }
+    if (tid == 0) { base[pairs] = carry; seg0[pairs] = scarry; }
     if (tid == 0) fold_sticky_status(hdr, hdr->status); // all error flags are in since the barrier behind the fold above
 }
 
@@ -671,6 +703,7 @@ struct TileP {
     const uint32_t *seg0;  // [pairs + 1] first split segment of every (sequence, tile) pair
     uint32_t *segcnt;      // [segments][16] records of every sub-tile in a segment, then their offsets inside the sub-tile
     int pairs;
+    int direct;            // 1: rec2 / sub are the scatter's own output (sub-tile bins): no split kernel has run
     int skip_whole;        // 1: tiles up to the whole-tile limit are NOT re-sorted (a tile-walk kernel splits them in LDS) ...
     int tile_walk;         // ... TAF: unless their sequence is not window-sorted (hdr->unsorted)
     int first_block;       // kf_split_whole: block b does the work of block b + first_block
@@ -1079,7 +1112,7 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_waves_per_eu(8,
     for (int i = tid; i < kLeakyLevels; i += kWalkThreads) thr[i] = q.leaky_thr[i];
     for (int i = lane; i < kSubCells / 2; i += kWave) s_cnt[wv][i] = 0u;
     // (sub[] of the NEXT pair is only written if that pair went through a split kernel: take the tile's own end)
-    const uint32_t beg = q.sub[sg], end = sub == kFW - 1 ? q.base[g + 1] : q.sub[sg + 1];
+    const uint32_t beg = q.sub[sg], end = (sub == kFW - 1 && !q.direct) ? q.base[g + 1] : q.sub[sg + 1];
     for (int i = tid; i <= NW; i += kWalkThreads) wstart[i] = end;
     if (tid == 0) s_unsorted = 0;
     const unsigned long long wmask = q.hdr->wmask[s];
@@ -1708,6 +1741,7 @@ struct EvTileP {
     const uint32_t *base; // [pairs + 1]
     const uint32_t *sub;  // [pairs * 16 + 1]
     int pairs;
+    int direct;           // TileP::direct
     uint32_t tile_max;    // tiles with more records go through the segment split + kf_ev_sub
     const float *tlut;    // tlut[r] = float(r / window)
     FastHeader *hdr;
@@ -1894,7 +1928,7 @@ __global__ __launch_bounds__(4 * kWave) void kf_ev_sub(EvTileP q, int all_tiles)
 #pragma unroll
         for (int k = 0; k < BINS; ++k) acc[j][k] = 0.0f;
     // (sub[] of the NEXT pair is only written if that pair went through a split kernel: take the tile's own end)
-    const uint32_t beg = q.sub[sg], end = sub == kFW - 1 ? q.base[g + 1] : q.sub[sg + 1];
+    const uint32_t beg = q.sub[sg], end = (sub == kFW - 1 && !q.direct) ? q.base[g + 1] : q.sub[sg + 1];
     uint32_t nx[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -1971,7 +2005,7 @@ void launch_fast(const FastGeom &G, const SeqTab &S, const FastPlan &p, char *w8
     int32_t *errs = (int32_t *)(w8 + p.off_errs);
     float *tlut = (float *)(w8 + p.off_tlut);
     uint32_t *records = (uint32_t *)(w8 + p.off_records);
-    const size_t lds_sc = scatter_lds_bytes(p.T, p.chunk);
+    const size_t lds_sc = scatter_lds_bytes(p.TB, p.chunk);
     if (lds_sc > 64 * 1024) {
         (void)hipFuncSetAttribute((const void *)kf_scatter<HAS_MAP, EV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc);
         if (!EV) (void)hipFuncSetAttribute((const void *)kf_scatter<HAS_MAP, EV, !EV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc);
@@ -1981,15 +2015,15 @@ void launch_fast(const FastGeom &G, const SeqTab &S, const FastPlan &p, char *w8
     if (simple) {
         if (lds_sc > 64 * 1024)
             (void)hipFuncSetAttribute((const void *)kf_scatter<false, EV, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc);
-        hipLaunchKernelGGL((kf_hist<false, EV, true>), dim3(hist_grid), dim3(kFT), (size_t)p.T * 4, st, G, S, counts, errs, tlut, p.chunks);
+        hipLaunchKernelGGL((kf_hist<false, EV, true>), dim3(hist_grid), dim3(kFT), (size_t)p.TB * 4, st, G, S, counts, errs, tlut, p.chunks);
     } else {
-        hipLaunchKernelGGL((kf_hist<HAS_MAP, EV>), dim3(hist_grid), dim3(kFT), (size_t)p.T * 4, st, G, S, counts, errs, tlut, p.chunks);
+        hipLaunchKernelGGL((kf_hist<HAS_MAP, EV>), dim3(hist_grid), dim3(kFT), (size_t)p.TB * 4, st, G, S, counts, errs, tlut, p.chunks);
     }
-    const bool inline_slabs = (long long)p.slabs * p.T <= kInlineSlabScan;
+    const bool inline_slabs = (long long)p.slabs * p.TB <= kInlineSlabScan;
     if (!inline_slabs)
-        hipLaunchKernelGGL(kf_slabscan, dim3((p.T + kWave - 1) / kWave, p.slabs), dim3(kWave), 0, st, S, counts, p.T, slabtot);
-    hipLaunchKernelGGL(kf_tilescan, dim3(1), dim3(kFT), 0, st, S, slabtot, p.T, base, (uint32_t *)(w8 + p.off_seg0), hdr, errs,
-                       p.chunks, inline_slabs ? counts : (uint32_t *)nullptr, p.slabs);
+        hipLaunchKernelGGL(kf_slabscan, dim3((p.TB + kWave - 1) / kWave, p.slabs), dim3(kWave), 0, st, S, counts, p.TB, slabtot);
+    hipLaunchKernelGGL(kf_tilescan, dim3(1), dim3(kFT), 0, st, S, slabtot, p.TB, base, (uint32_t *)(w8 + p.off_seg0), hdr, errs,
+                       p.chunks, inline_slabs ? counts : (uint32_t *)nullptr, p.slabs, p.direct);
     if (simple)
         hipLaunchKernelGGL((kf_scatter<false, EV, false, true>), dim3(p.chunks), dim3(kFT), lds_sc, st, G, S, counts, slabtot, base, records, hdr);
     else if (!EV && G.order_check)
@@ -2053,31 +2087,45 @@ int frlw_selftest_lds_atomic_order(int n_addr, int iters, unsigned long long *ou
 
 size_t frlw_taf_batch_workspace_bytes(int64_t n_events, int n_seq, int H, int W, int64_t window_us)
 {
-    FastPlan p;
-    if (window_us < 1 || window_us >= (1ll << 20) || !fast_plan(n_events, n_seq, H, W, p)) return 0;
-    // the layout depends on how the events are spread over the sequences only through the chunk count: every sequence
-    // can add one partly filled chunk and one partly filled slab
-    const size_t chunks = (size_t)(n_events + p.chunk - 1) / p.chunk + n_seq;
-    const size_t slabs = chunks / kFastSlab + n_seq + 1;
-    size_t off = kHeaderBytes;
-    off = align_up(off + chunks * p.T * 4, 256);
-    off = align_up(off + slabs * p.T * 4, 256);
-    off = align_up(off + (size_t)(p.pairs + 1) * 4, 256);
-    off = align_up(off + ((size_t)p.pairs * kFW + 1) * 4, 256);
-    off = align_up(off + (size_t)(p.pairs + 1) * 4, 256);
-    off = align_up(off + (2 * (size_t)(n_events / kSplitSeg) + 1) * kFW * 4, 256);
-    off = align_up(off + chunks * 4, 256);
-    off = align_up(off + (size_t)(window_us + 1) * 4, 256);
-    off = align_up(off + (size_t)kLeakyLevels * 4, 256);
-    off = align_up(off + (size_t)(n_events > 0 ? n_events : 1) * 4, 256);
-    off = align_up(off + (size_t)(n_events > 0 ? n_events : 1) * 4, 256);
-    return off;
+    if (window_us < 1 || window_us >= (1ll << 20)) return 0;
+    size_t need = 0;
+    for (int direct = 0; direct < 2; ++direct) { // the larger of the two partition modes (the call's tuning picks one)
+        FastPlan p;
+        if (!fast_plan(n_events, n_seq, H, W, p, direct ? DIRECT_FORCE : DIRECT_OFF)) return 0;
+        if (direct && !p.direct) break;
+        // the layout depends on how the events are spread over the sequences only through the chunk count: every sequence
+        // can add one partly filled chunk and one partly filled slab
+        const size_t chunks = (size_t)(n_events + p.chunk - 1) / p.chunk + n_seq;
+        const size_t slabs = chunks / kFastSlab + n_seq + 1;
+        size_t off = kHeaderBytes;
+        off = align_up(off + chunks * p.TB * 4, 256);
+        off = align_up(off + slabs * p.TB * 4, 256);
+        off = align_up(off + (size_t)(p.pairs_b + 1) * 4, 256);
+        off = align_up(off + ((size_t)p.pairs * kFW + 1) * 4, 256);
+        off = align_up(off + (size_t)(p.pairs_b + 1) * 4, 256);
+        off = align_up(off + (2 * (size_t)(n_events / kSplitSeg) + 1) * kFW * 4, 256);
+        off = align_up(off + chunks * 4, 256);
+        off = align_up(off + (size_t)(window_us + 1) * 4, 256);
+        off = align_up(off + (size_t)(n_events > 0 ? n_events : 1) * 4, 256);
+        off = align_up(off + (size_t)(n_events > 0 ? n_events : 1) * 4, 256);
+        if (off > need) need = off;
+    }
+    return need;
 }
 
 } // extern "C"
 
 namespace {
 enum : int { PHASE_PARTITION = 1, PHASE_FINISH = 2 };
+
+// frlw_tuning_t: direct_bins 0 / 1 forces the partition mode (FastPlan::direct); taf_tile_walk = 1 asks for the in-LDS split,
+// which needs tile bins; default: direct where the frame allows it
+inline int direct_allowed(const frlw_tuning_t *tu)
+{
+    if (tu && tu->direct_bins >= 0) return tu->direct_bins != 0 ? DIRECT_FORCE : DIRECT_OFF;
+    const bool walk = (tu && tu->taf_tile_walk >= 0) ? tu->taf_tile_walk != 0 : kTafTileWalk;
+    return walk ? DIRECT_OFF : DIRECT_AUTO;
+}
 
 // The batch encode in two halves: PARTITION = kf_hist, scans, kf_scatter (leaves the per-sequence window masks in the
 // workspace header), FINISH = split + walk (reads them).  A row stripe [y_lo, y_lo + H) of an H_full-row frame runs the two
@@ -2101,16 +2149,16 @@ int taf_batch_run(int phases, const frlw_events_t *ev, const int64_t *seq_offset
     if (kCellBits + wb + rb > 32 || (long long)n_windows * window_us >= (1ll << 32)) return FRLW_ERR_UNSUPPORTED;
     const long long n = seq_offsets[n_seq] - seq_offsets[0];
     FastPlan p;
-    if (!fast_plan(n, n_seq, H, W, p)) return FRLW_ERR_UNSUPPORTED;
+    if (!fast_plan(n, n_seq, H, W, p, direct_allowed(ev->tuning))) return FRLW_ERR_UNSUPPORTED;
     SeqTab S;
     if (!fast_layout(seq_offsets, t_start, n_seq, p, S, (uint32_t)window_us)) return FRLW_ERR_ARG;
     if (workspace_bytes < p.bytes) return FRLW_ERR_WORKSPACE;
-    if (scatter_lds_bytes(p.T, p.chunk) > 160 * 1024) return FRLW_ERR_UNSUPPORTED;
+    if (scatter_lds_bytes(p.TB, p.chunk) > 160 * 1024) return FRLW_ERR_UNSUPPORTED;
 
     FastGeom G;
     G.data = (const uint2 *)ev->data;
     G.xmap = ev->xmap; G.ymap = ev->ymap; G.map_w = ev->map_w; G.map_h = ev->map_h;
-    G.H = H; G.W = W; G.twl = p.twl; G.thl = p.thl; G.tiles_x = p.tiles_x; G.T = p.T; G.bpw = p.bpw;
+    G.H = H; G.W = W; G.twl = p.twl; G.thl = p.thl; G.tiles_x = p.tiles_x; G.T = p.TB; G.bin_shift = p.bin_shift; G.bin_mask = p.direct ? 15 : 0; G.bpw = p.bpw;
     G.chunk_ev = p.chunk; G.run = p.chunk / kFW; G.n_total = ev->n;
     G.n_windows = n_windows; G.wb = wb; G.win = (uint32_t)window_us;
     G.rcp = 1.0 / ((double)(uint32_t)window_us + 1e-8); // generate_taf.py:215: t / (w + 1e-8)
@@ -2118,7 +2166,7 @@ int taf_batch_run(int phases, const frlw_events_t *ev, const int64_t *seq_offset
     {
         const frlw_tuning_t *tu = ev->tuning;
         const bool want = (tu && tu->taf_tile_walk >= 0) ? tu->taf_tile_walk != 0 : kTafTileWalk;
-        G.order_check = (want && p.pairs >= kFewPairs) ? 1 : 0;
+        G.order_check = (want && !p.direct && p.pairs >= kFewPairs) ? 1 : 0;
     }
     const unsigned long long magic = (1ull << 32) / (unsigned long long)window_us;
     G.win_magic = magic > 0xffffffffull ? 0xffffffffu : (uint32_t)magic;
@@ -2161,8 +2209,14 @@ int taf_batch_run(int phases, const frlw_events_t *ev, const int64_t *seq_offset
     if (!(q.leaky_thr = leaky_table(st))) return FRLW_ERR_HIP; // device-resident constant, built once per device (partition.hip)
     q.hdr = (FastHeader *)w8;
     q.state = state; q.view_f32 = view_f32; q.out_u8 = out_u8;
-    hipLaunchKernelGGL(kf_split_whole, dim3(p.pairs + q.seg_grid), dim3(kFT), 0, st, q); // tiles, then segment counts
-    hipLaunchKernelGGL(kf_split_place, dim3(q.seg_grid), dim3(kFT), 0, st, q);
+    q.direct = p.direct;
+    if (p.direct) { // kf_scatter's bins were the sub-tiles: its output IS the sub-tile-major list, base[] its sub[]
+        q.rec2 = (uint32_t *)(w8 + p.off_records);
+        q.sub = (uint32_t *)(w8 + p.off_base);
+    } else {
+        hipLaunchKernelGGL(kf_split_whole, dim3(p.pairs + q.seg_grid), dim3(kFT), 0, st, q); // tiles, then segment counts
+        hipLaunchKernelGGL(kf_split_place, dim3(q.seg_grid), dim3(kFT), 0, st, q);
+    }
     if (q.tile_walk) { // tiles of window-sorted sequences below the skew limit: split in LDS by the kernel that consumes them
         const int grid = (p.pairs + 7) / 8 * 8;
         if (K == 8) hipLaunchKernelGGL((kf_taf_tile<kFW, true>), dim3(grid), dim3(kFT), 0, st, q);
@@ -2226,18 +2280,18 @@ int frlw_ev_encode_batch(const frlw_events_t *ev, const int64_t *seq_offsets, co
     if (kCellBits + rb > 32) return FRLW_ERR_UNSUPPORTED;
     const long long n = seq_offsets[n_seq] - seq_offsets[0];
     FastPlan p;
-    if (!fast_plan(n, n_seq, H, W, p)) return FRLW_ERR_UNSUPPORTED;
+    if (!fast_plan(n, n_seq, H, W, p, direct_allowed(ev->tuning))) return FRLW_ERR_UNSUPPORTED;
     SeqTab S;
     int64_t t_begin[kMaxSeq];
     for (int s = 0; s < n_seq; ++s) t_begin[s] = t_end[s] - window_us; // generate_eventvolume.py:139-141
     if (!fast_layout(seq_offsets, t_begin, n_seq, p, S, (uint32_t)window_us)) return FRLW_ERR_ARG;
     if (workspace_bytes < p.bytes) return FRLW_ERR_WORKSPACE;
-    if (scatter_lds_bytes(p.T, p.chunk) > 160 * 1024) return FRLW_ERR_UNSUPPORTED;
+    if (scatter_lds_bytes(p.TB, p.chunk) > 160 * 1024) return FRLW_ERR_UNSUPPORTED;
 
     FastGeom G;
     G.data = (const uint2 *)ev->data;
     G.xmap = ev->xmap; G.ymap = ev->ymap; G.map_w = ev->map_w; G.map_h = ev->map_h;
-    G.H = H; G.W = W; G.twl = p.twl; G.thl = p.thl; G.tiles_x = p.tiles_x; G.T = p.T; G.bpw = p.bpw;
+    G.H = H; G.W = W; G.twl = p.twl; G.thl = p.thl; G.tiles_x = p.tiles_x; G.T = p.TB; G.bin_shift = p.bin_shift; G.bin_mask = p.direct ? 15 : 0; G.bpw = p.bpw;
     G.chunk_ev = p.chunk; G.run = p.chunk / kFW; G.n_total = ev->n;
     G.n_windows = 1; G.wb = 0; G.win = (uint32_t)window_us; G.win_magic = 0u; G.order_check = 0; G.y_lo = 0; G.H_full = H;
     G.rcp = 1.0 / (double)(uint32_t)window_us; // generate_eventvolume.py:141
@@ -2264,7 +2318,7 @@ int frlw_ev_encode_batch(const frlw_events_t *ev, const int64_t *seq_offsets, co
     {
         const frlw_tuning_t *tu = ev->tuning;
         const bool want = (tu && tu->taf_tile_walk >= 0) ? tu->taf_tile_walk != 0 : kTafTileWalk;
-        tile_walk = want && p.pairs >= kFewPairs;
+        tile_walk = want && !p.direct && p.pairs >= kFewPairs;
     }
     TileP q;
     memset(&q, 0, sizeof(q));
@@ -2278,11 +2332,16 @@ int frlw_ev_encode_batch(const frlw_events_t *ev, const int64_t *seq_offsets, co
     q.hdr = (FastHeader *)w8;
     q.first_block = tile_walk ? p.pairs : 0; // with the tile walk only the segment-counting blocks have work
     q.seg_grid = p.max_segs < 2048 ? p.max_segs : 2048;
-    hipLaunchKernelGGL(kf_split_whole, dim3(p.pairs + q.seg_grid - q.first_block), dim3(kFT), 0, st, q); // tiles, then segment counts
-    hipLaunchKernelGGL(kf_split_place, dim3(q.seg_grid), dim3(kFT), 0, st, q);
+    if (p.direct) { // kf_scatter's bins were the sub-tiles: its output IS the sub-tile-major list, base[] its sub[]
+        q.rec2 = (uint32_t *)(w8 + p.off_records);
+        q.sub = (uint32_t *)(w8 + p.off_base);
+    } else {
+        hipLaunchKernelGGL(kf_split_whole, dim3(p.pairs + q.seg_grid - q.first_block), dim3(kFT), 0, st, q); // tiles, then segment counts
+        hipLaunchKernelGGL(kf_split_place, dim3(q.seg_grid), dim3(kFT), 0, st, q);
+    }
     EvTileP e;
     e.H = H; e.W = W; e.twl = p.twl; e.thl = p.thl; e.tiles_x = p.tiles_x; e.T = p.T; e.bins = bins; e.win = (uint32_t)window_us; e.rcp = G.rcp;
-    e.rec = q.rec; e.rec2 = q.rec2; e.base = q.base; e.sub = q.sub; e.pairs = p.pairs; e.tile_max = whole_max_of(p.pairs);
+    e.rec = q.rec; e.rec2 = q.rec2; e.base = q.base; e.sub = q.sub; e.pairs = p.pairs; e.tile_max = whole_max_of(p.pairs); e.direct = p.direct;
     e.tlut = (const float *)(w8 + p.off_tlut); e.hdr = (FastHeader *)w8; e.out_f32 = out_f32; e.out_u8 = out_u8;
     const int sub_grid = (p.pairs * kFW + 3) / 4;
     if (tile_walk) {

@@ -69,6 +69,10 @@ typedef struct frlw_tuning {
     int32_t taf_tile_walk;    /* frlw_taf_encode_batch / frlw_ev_encode_batch: 1 = tiles are split in LDS by the kernel that walks
                                * them (kf_taf_tile / kf_ev_tile: less HBM traffic, measured slower), 0 = split pass + sub-tile
                                * kernel (the default) */
+    int32_t direct_bins;      /* frlw_taf_encode_batch / frlw_ev_encode_batch: 1 = the partition's bins are the 256-cell sub-tiles
+                               * wherever the frame allows it (at most 64 tiles: the 304x240 class) -- no second-level split pass
+                               * at all; 0 = always tile bins + split pass; default: sub-tile bins for calls with fewer than 256
+                               * (sequence, tile) pairs */
 } frlw_tuning_t;
 
 typedef struct frlw_events {

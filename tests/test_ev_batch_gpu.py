@@ -119,3 +119,19 @@ def test_label_inside_the_first_window_of_a_file(er, orc):
     out, _ = er.encode_ev_batch(to_dev(np.concatenate(recs)), offs, (H, W), t_end, win, 5)
     for j in range(2):
         assert_bitexact(host(out[j]), orc.ev_stream_dat8(recs[j], (H, W), (H, W), 5, t_end[j], win), f"sequence {j}")
+
+
+@pytest.mark.parametrize("n_seq", [1, 40])
+def test_direct_bins_equal_tile_bins(er, n_seq, monkeypatch):
+    """frlw_tuning_t::direct_bins 1 against 0 for the Event Volume batch (see tests/test_taf_fast_gpu.py)."""
+    from frlw_evd_amd import _lib
+    H, W, win = 240, 304, 50_000
+    recs = [synth.to_dat8(synth.synth_events(1300 + j, 0 if j == 3 else 40_000 + 500 * j, W, H, win - 1, hotspot=(j % 5 == 1), t_offset=1))
+            for j in range(n_seq)]
+    offs = np.concatenate([[0], np.cumsum([len(r) for r in recs])])
+    dat = to_dev(np.concatenate(recs))
+    outs = []
+    for direct in (1, 0):
+        monkeypatch.setattr(er, "TUNING", _lib.FrlwTuning(direct_bins=direct))
+        outs.append(er.encode_ev_batch(dat, offs, (H, W), win, win, 5, want_u8=True))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])

@@ -371,3 +371,28 @@ def test_negative_start_time_takes_the_general_decode():
         sj = torch.full((H, W, 2, K), -6000.0, device="cuda")
         uj, vj = er.encode_taf_dat(dev(recs[j]), (H, W), sj, starts[j], win, n_win, K, want_view=True, fast=False)
         assert torch.equal(sj, st[j]) and torch.equal(vj, view[j]) and torch.equal(uj, u8[j]), j
+
+
+@pytest.mark.parametrize("n_seq", [1, 40])
+def test_direct_bins_equal_tile_bins(n_seq, monkeypatch):
+    """The direct partition mode (bins = 256-cell sub-tiles, no split pass; the default for calls with few (sequence, tile)
+    pairs) against tile bins + split pass, both forced through frlw_tuning_t: same bits.  40 sequences x 576 bins = 23 040
+    (sequence, bin) pairs: the tile scan runs in three rounds."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from frlw_evd_amd import _lib, event_representation as er, synth
+    H, W, K, win, n_win = 240, 304, 8, 10_000, 8
+    recs = []
+    for j in range(n_seq):
+        n = 0 if j == 5 else (400_000 if n_seq == 1 else 30_000 + 1_000 * j)
+        recs.append(synth.to_dat8(synth.synth_events(1200 + j, n, W, H, n_win * win, hotspot=(j % 7 == 3))))
+    offs = np.concatenate([[0], np.cumsum([len(r) for r in recs])])
+    dat = torch.from_numpy(np.ascontiguousarray(np.concatenate(recs)).view(np.uint8).reshape(-1, 8).copy()).cuda()
+    outs = []
+    for direct in (1, 0):
+        monkeypatch.setattr(er, "TUNING", _lib.FrlwTuning(direct_bins=direct))
+        st = torch.full((n_seq, H, W, 2, K), -6000.0, device="cuda")
+        u8, view = er.encode_taf_batch(dat, offs, (H, W), st, 0, win, n_win, K, want_view=True)
+        outs.append((st, u8, view))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)

@@ -126,7 +126,7 @@ struct Outputs {
     bool ran = false;
 };
 
-static frlw_tuning_t g_tuning = {-1, -1, -1, -1, -1, -1, -1};
+static frlw_tuning_t g_tuning = {-1, -1, -1, -1, -1, -1, -1, -1};
 static bool g_use_tuning = false;
 
 static Outputs run_cfg(const Lib &L, const Cfg &c, const uint64_t *dat_d, const std::vector<int64_t> &offs, int reps)
@@ -232,6 +232,7 @@ int main(int argc, char **argv)
         if (!strcmp(argv[i], "--cfg") && i + 1 < argc) only = argv[++i];
         else if (!strcmp(argv[i], "--reps") && i + 1 < argc) reps = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--tile-walk")) { g_tuning.taf_tile_walk = 1; g_use_tuning = true; } // TAF through kf_taf_tile
+        else if (!strcmp(argv[i], "--no-direct")) { g_tuning.direct_bins = 0; g_use_tuning = true; } // tile bins + split pass also on small frames
         else libs.push_back(load(argv[i]));
     }
     if (libs.empty()) { fprintf(stderr, "usage: enc_lab <lib.so> [<reference lib.so>] [--cfg a,b] [--reps N]\n"); return 2; }

@@ -55,7 +55,9 @@ def main():
             recs.append(synth.to_dat8(ev))
             ends.append(t_end)
         offs = np.concatenate([[0], np.cumsum([len(r) for r in recs])])
-        er.TUNING = _lib.FrlwTuning(taf_tile_walk=1) if case % 3 == 2 else None  # every third case: the opt-in tile walk (kf_ev_tile)
+        # every third case: the opt-in tile walk (kf_ev_tile); the others: the partition mode at random
+        er.TUNING = (_lib.FrlwTuning(taf_tile_walk=1) if case % 3 == 2 else
+                     [None, _lib.FrlwTuning(direct_bins=1), _lib.FrlwTuning(direct_bins=0)][int(rng.integers(0, 3))])
         try:
             out, u8 = er.encode_ev_batch(dev(np.concatenate(recs)), offs, (H, W), ends, win, bins, want_u8=True)
         except NotImplementedError:
