@@ -338,17 +338,17 @@ struct EvParams {
     uint8_t *out_u8;
 };
 
-template <int NT, int C>
+template <int NT, int C, int BINS>
 __device__ __forceinline__ void ev_tile_body(const uint2 *rec, const uint32_t *base, const EvParams &q, int tile, int j0,
                                              uint32_t *cnt, uint2 *slot, uint32_t *red)
 {
     constexpr int SLICE = TileLds<NT>::SLICE;
     const uint32_t beg = base[tile], end = base[tile + 1];
-    float acc[C][kMaxK]; // cell (pixel, polarity) x time bin
+    float acc[C][BINS]; // cell (pixel, polarity) x time bin (BINS = 5 for the recipe's five bins, else kMaxK)
 #pragma unroll
     for (int j = 0; j < C; ++j)
 #pragma unroll
-        for (int k = 0; k < kMaxK; ++k) acc[j][k] = 0.0f;
+        for (int k = 0; k < BINS; ++k) acc[j][k] = 0.0f;
     const float binsf = (float)q.bins;
     for (uint32_t s0 = beg; s0 < end; s0 += SLICE) {
         const uint32_t span = end - s0 < (uint32_t)SLICE ? end - s0 : (uint32_t)SLICE;
@@ -370,7 +370,7 @@ __device__ __forceinline__ void ev_tile_body(const uint2 *rec, const uint32_t *b
                 const bool live = a < c[j];
                 const float ts = binsf * __uint_as_float(tv[j]); // t* = bins * float(t), generate_eventvolume.py:23
 #pragma unroll
-                for (int k = 0; k < kMaxK; ++k) { // bins beyond q.bins are accumulated but never stored
+                for (int k = 0; k < BINS; ++k) { // bins beyond q.bins are accumulated but never stored
                     const float d = (float)(k + 1) - ts;
                     const float w = 1.0f - fabsf(d); // :28; negative weights -> 0 (:29) = skipped
                     const float na = acc[j][k] + w;
@@ -388,7 +388,7 @@ __device__ __forceinline__ void ev_tile_body(const uint2 *rec, const uint32_t *b
     for (int j = 0; j < C; ++j) {
         if (ow.ok[j]) {
 #pragma unroll
-            for (int k = 0; k < kMaxK; ++k) {
+            for (int k = 0; k < BINS; ++k) {
                 if (k < q.bins) {
                     const float v = acc[j][k] / 5.0f * 255.0f; // generate_eventvolume.py:37
                     const long long idx = (long long)(2 * k + ch) * plane + ow.pix[j];
@@ -401,25 +401,37 @@ __device__ __forceinline__ void ev_tile_body(const uint2 *rec, const uint32_t *b
 }
 
 // grid = 4 * kMaxHot + n_tiles: the four quarters of every listed hot tile, then one workgroup per tile
-template <int NT>
-__global__ __launch_bounds__(NT) void k_ev_tile(const uint2 *rec, const uint32_t *base, EvParams q, int n_tiles)
+template <int NT, int BINS>
+__device__ __forceinline__ void ev_tile_kernel(const uint2 *rec, const uint32_t *base, const EvParams &q, int n_tiles)
 {
     __shared__ uint32_t cnt[NT * CPT];
     __shared__ uint2 slot[TileLds<NT>::SLICE];
     __shared__ uint32_t red[32];
     if (n_tiles < 0) { // small frame (-n_tiles tiles): every tile as four quarters, grid = 4 * tiles
-        ev_tile_body<NT, 1>(rec, base, q, (int)blockIdx.x >> 2, (int)blockIdx.x & 3, cnt, slot, red);
+        ev_tile_body<NT, 1, BINS>(rec, base, q, (int)blockIdx.x >> 2, (int)blockIdx.x & 3, cnt, slot, red);
         return;
     }
     if ((int)blockIdx.x >= 4 * kMaxHot) {
         const int tile = (int)blockIdx.x - 4 * kMaxHot;
         if (tile_is_listed(q.hdr, base, tile)) return; // hot: left to its quarters
-        ev_tile_body<NT, CPT>(rec, base, q, tile, 0, cnt, slot, red);
+        ev_tile_body<NT, CPT, BINS>(rec, base, q, tile, 0, cnt, slot, red);
     } else { // the long-running workgroups come first in the grid
         int tile, quarter;
         if (!pick_quarter(q.hdr, (int)blockIdx.x, tile, quarter)) return;
-        ev_tile_body<NT, 1>(rec, base, q, tile, quarter, cnt, slot, red);
+        ev_tile_body<NT, 1, BINS>(rec, base, q, tile, quarter, cnt, slot, red);
     }
+}
+// (two instantiations: the recipe's five bins keep five accumulators per cell instead of eight -- the loop over the bins is the
+// kernel's VALU work)
+template <int NT>
+__global__ __launch_bounds__(NT) void k_ev_tile(const uint2 *rec, const uint32_t *base, EvParams q, int n_tiles)
+{
+    ev_tile_kernel<NT, kMaxK>(rec, base, q, n_tiles);
+}
+template <int NT>
+__global__ __launch_bounds__(NT) void k_ev_tile5(const uint2 *rec, const uint32_t *base, EvParams q, int n_tiles)
+{
+    ev_tile_kernel<NT, 5>(rec, base, q, n_tiles);
 }
 
 // ---- TAF -------------------------------------------------------------------------------------
@@ -744,7 +756,8 @@ int frlw_ev_encode(const frlw_events_t *ev, int H, int W, int bins, int64_t t_en
     EvParams q;
     q.H = H; q.W = W; q.twl = pt.plan.twl; q.tiles_x = pt.plan.tiles_x; q.bins = bins;
     q.hdr = pt.hdr; q.out_f32 = out_f32; q.out_u8 = out_u8;
-    LAUNCH_TILE_Q(k_ev_tile, pt.plan, s, pt.records, pt.base, q);
+    if (bins <= 5) LAUNCH_TILE_Q(k_ev_tile5, pt.plan, s, pt.records, pt.base, q);
+    else LAUNCH_TILE_Q(k_ev_tile, pt.plan, s, pt.records, pt.base, q);
     HIP_TRY(hipGetLastError());
     return FRLW_OK;
 }
