@@ -138,11 +138,13 @@ bool fast_plan(long long n, int n_seq, int H, int W, FastPlan &p, int direct_mod
     p.T = p.tiles_x * p.tiles_y;
     if (p.T > kMaxFastTiles || (long long)p.T * n_seq > kMaxPairs) return false;
     p.pairs = p.T * n_seq;
-    // AUTO: calls with few (sequence, tile) pairs -- the launch-bound ones, which would otherwise run the segment kernels (one
-    // GEN1 stream: 52 -> 42 us).  With many pairs kf_split_whole is the cheaper second level (64 GEN1 streams: 842 us against
-    // 875 direct): there only when forced (frlw_tuning_t::direct_bins = 1).
+    // AUTO: calls with few (sequence, tile) pairs whose tiles hold more than one split segment on average -- the launch-bound
+    // ones (one GEN1 stream of 1 M events: 52 -> 42 us; eight: 150 -> 136 us; tools/time_direct.py).  With many pairs
+    // kf_split_whole is the cheaper second level (64 GEN1 streams: 820 us against 876 direct), with few events per tile the
+    // 576-bin scatter costs more than the whole-tile split it replaces (one stream of 250 k events: 40 us against 46):
+    // there only when forced (frlw_tuning_t::direct_bins = 1).
     p.direct = (direct_mode != DIRECT_OFF && kFW * p.T <= kMaxFastTiles && (long long)kFW * p.T * n_seq <= kMaxBinPairs &&
-                (direct_mode == DIRECT_FORCE || p.pairs < kFewPairs)) ? 1 : 0;
+                (direct_mode == DIRECT_FORCE || (p.pairs < 2 * kFewPairs && n >= (long long)kSplitSeg * p.pairs))) ? 1 : 0;
     p.TB = p.direct ? kFW * p.T : p.T;
     p.bin_shift = p.direct ? 4 : 0;
     p.pairs_b = p.TB * n_seq;

@@ -71,8 +71,8 @@ typedef struct frlw_tuning {
                                * kernel (the default) */
     int32_t direct_bins;      /* frlw_taf_encode_batch / frlw_ev_encode_batch: 1 = the partition's bins are the 256-cell sub-tiles
                                * wherever the frame allows it (at most 64 tiles: the 304x240 class) -- no second-level split pass
-                               * at all; 0 = always tile bins + split pass; default: sub-tile bins for calls with fewer than 256
-                               * (sequence, tile) pairs */
+                               * at all; 0 = always tile bins + split pass; default: sub-tile bins for calls with fewer than 512
+                               * (sequence, tile) pairs and more than 8192 events per pair on average */
 } frlw_tuning_t;
 
 typedef struct frlw_events {
