@@ -31,6 +31,25 @@ def test_workspace_query_is_host_only():
     assert lib.frlw_encoder_workspace_bytes(10, 0, 12) == 0
 
 
+def test_batch_workspace_queries_are_host_only():
+    """frlw_taf_batch_workspace_bytes / frlw_ev_batch_workspace_bytes: host arithmetic only; the answer covers BOTH partition
+    modes (tile bins, and sub-tile bins where the frame allows them: 16 x the counters per chunk), grows with the events and
+    is 0 for shapes the fast path refuses."""
+    lib = _lib.load()
+    mpx = lib.frlw_taf_batch_workspace_bytes(10_000_000, 1, 720, 1280, 10_000)
+    assert mpx > 2 * 4 * 10_000_000                      # two 4-byte record arrays at least
+    gen1 = lib.frlw_taf_batch_workspace_bytes(1_000_000, 1, 240, 304, 10_000)
+    gen1x8 = lib.frlw_taf_batch_workspace_bytes(8_000_000, 8, 240, 304, 10_000)
+    assert 8_000_000 < gen1 < gen1x8
+    # 304x240 = 36 tiles = 576 sub-tile bins per sequence: the counters of the direct mode (576 per chunk) are budgeted
+    chunks = 1_000_000 // 8192
+    assert gen1 > 2 * 4 * 1_000_000 + chunks * 576 * 4
+    assert lib.frlw_ev_batch_workspace_bytes(1_000_000, 1, 240, 304, 250_000) == lib.frlw_taf_batch_workspace_bytes(1_000_000, 1, 240, 304, 250_000)
+    assert lib.frlw_taf_batch_workspace_bytes(1_000, 65, 240, 304, 10_000) == 0        # more than 64 sequences
+    assert lib.frlw_taf_batch_workspace_bytes(1_000, 1, 240, 304, 1 << 21) == 0        # window beyond 2^20 us
+    assert lib.frlw_taf_batch_workspace_bytes(1_000, 1, 4000, 4000, 10_000) == 0       # more tiles than the scatter's LDS holds
+
+
 def test_product_path_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "frlw-evd_amd")
     for dirpath, _, files in os.walk(pkg):
