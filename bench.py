@@ -75,11 +75,30 @@ def cpu_model():
     return "unknown"
 
 
-def best_of(timer, fn, steps, warmup, regions=2):
-    """Auxiliary rows with few, long steps (train): the faster of `regions` timed regions -- one stall of tens of ms (a clock
-    transition, an allocator trim) would otherwise own a 5-step average.  The headline metric is ONE region of exactly K steps."""
-    runs = [timer.run(fn, steps, warmup if i == 0 else 1) for i in range(regions)]
-    return min(runs)
+def one_region(timer, fn, steps, warmup, extra=0):
+    """Every reported row is ONE timed region of `steps` steps (the first one after the warm-up) -- never a best-of.  `extra`
+    further regions are measured for information only and returned third (a reader sees the spread, the value ignores it)."""
+    first = timer.run(fn, steps, warmup)
+    more = [timer.run(fn, steps, 1) for _ in range(extra)]
+    return first[0], first[1], [first] + more
+
+
+def physical_cores():
+    """(physical cores this process may run on, hardware threads per core): the CPU baselines use one thread per PHYSICAL
+    core (n = 1 and n = all cores), not one per logical CPU and not an arbitrary cap."""
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        cpus = list(range(os.cpu_count() or 1))
+    cores = set()
+    for c in cpus:
+        try:
+            with open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list") as f:
+                cores.add(f.read().strip())
+        except OSError:
+            cores.add(str(c))
+    n = max(1, len(cores))
+    return n, max(1, len(cpus) // n)
 
 
 class Timer:
@@ -351,23 +370,51 @@ def main():
             attach_traffic(row["roofline"], tag)
         names = ("taf_single", "taf_x64", "ev_single", "ev_x64")
         result["gen1"] = {k: row for k, row in zip(names, result["also"][:4])}
-        result["roofline"]["gen1"] = {k: {"Mevents_per_s": row["value"], "ms": row["ms_per_step"], "GBps": row["roofline"]["achieved"],
-                                          "frac": row["roofline"]["frac"]} for k, row in result["gen1"].items()}
+        # the driver's parser keeps SCALAR keys of `roofline` only: one flat key per number
+        flat = result["roofline"]
+        for k, row in result["gen1"].items():
+            flat[f"gen1_{k}_mev_s"] = row["value"]
+            flat[f"gen1_{k}_ms"] = row["ms_per_step"]
+            flat[f"gen1_{k}_GBs"] = row["roofline"]["achieved"]
+            flat[f"gen1_{k}_frac"] = row["roofline"]["frac"]
+            flat[f"gen1_{k}_traffic"] = row["roofline"].get("traffic")
+        for row in result["also"][4:]:
+            tag = row.get("tag")
+            if tag:
+                flat[f"{tag}_mev_s"] = row["value"]
+                flat[f"{tag}_ms"] = row["ms_per_step"]
+                flat[f"{tag}_frac"] = row["roofline"]["frac"]
     if not args.no_detector:
         result["detector"] = bench_detector(args, torch, world, rank, timer)
-        d = result["detector"]  # the second half of BASELINE.json's metric, in the keys the driver keeps
-        result["roofline"]["detector_gen1"] = {"frames_per_s": d["value"], "ms_per_batch": d["ms_per_batch"], "batch_per_gpu": d["batch_per_gpu"],
-                                               "TFLOPs": d["roofline"]["achieved"], "frac_of_fp32_mfma_peak": d["roofline"]["frac"]}
+        d = result["detector"]  # the second half of BASELINE.json's metric, in the keys the driver keeps (scalars)
+        flat = result["roofline"]
+        flat["detector_frames_per_s"] = d["value"]
+        flat["detector_ms_per_batch"] = d["ms_per_batch"]
+        flat["detector_batch_per_gpu"] = d["batch_per_gpu"]
+        flat["detector_TFLOPs"] = d["roofline"]["achieved"]
+        flat["detector_frac"] = d["roofline"]["frac"]
+        if "shape_1mpx" in d:
+            flat["detector_1mpx_frames_per_s"] = d["shape_1mpx"]["value"]
+            flat["detector_1mpx_frac"] = d["shape_1mpx"]["roofline"]["frac"]
     if not args.no_train:
         try:
             result["train"] = bench_train(args, torch, world, rank, local_rank, timer)
+            t = result["train"]
+            flat = result["roofline"]
+            flat["train_frames_per_s"] = t["value"]
+            flat["train_ms"] = t["ms_per_step"]
+            flat["train_TFLOPs"] = t["roofline"]["achieved"]
+            flat["train_frac"] = t["roofline"]["frac"]
+            if "encode_plus_train_step" in t:
+                flat["encode_plus_train_ms"] = t["encode_plus_train_step"]["ms_per_step"]
+                flat["encode_plus_train_frames_per_s"] = t["encode_plus_train_step"]["value"]
         except Exception as e:  # never lose the headline line to the extra leg
             result["train"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline_taf(dat_h, n, H, W, K, n_win, win_us)
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
@@ -441,7 +488,7 @@ def bench_also(args, torch, synth, er, timer, rank, n_gpus, copy_gbs):
         dat3 = torch.from_numpy(synth.to_dat8(ev3).view(np.uint8).reshape(-1, 8)).cuda()
         st3 = torch.full((H, W, 2, K), -6000.0, device="cuda")
         per, dev = timer.run(lambda: er.encode_taf_dat(dat3, (H, W), st3, 0, win_us, n_win, K, check=False, fast=True), steps, 2)
-        out.append({"workload": "taf_mpx, hotspot variant (25 % of the events in a sigma = 8 px blob)",
+        out.append({"tag": "taf_mpx_hotspot", "workload": "taf_mpx, hotspot variant (25 % of the events in a sigma = 8 px blob)",
                     "value": round(n_gpus * n / per / 1e6, 2), "unit": "Mevents/s", "ms_per_step": round(per * 1e3, 4),
                     "roofline": roofline(taf_algorithmic_bytes(n, H, W, K), dev, "frlw_taf_encode_batch", copy_gbs, f"{n} events")})
     return out
@@ -483,15 +530,14 @@ def bench_detector(args, torch, world, rank, timer):
         x = x_h.cuda()
         eng = net.engine()
         steps = max(5, min(args.steps, 30))
-        # three timed regions of `steps` forwards each, the fastest reported (all three listed): a fresh box now and then
-        # spends tens of ms of ONE region on a clock / power transition (seen: 6.3 ms per batch next to 3.8 in the same process)
-        runs = [timer.run(lambda: eng.raw_outputs(x), steps, 10 if i == 0 else 2) for i in range(3)]
-        per, dev_ms = min(runs)
+        # ONE timed region of `steps` forwards is the value (after a 20-forward warm-up: a fresh box now and then spends tens
+        # of ms on a clock / power transition); two more regions are listed for the spread, never selected
+        per, dev_ms, runs = one_region(timer, lambda: eng.raw_outputs(x), steps, 20, extra=2)
         tflops = eng.flops_per_image * B / (dev_ms * 1e-3) / 1e12
         row = {
             "value": round(world * B / per, 1), "unit": "frames/s", "batch_per_gpu": B,
             "input": f"(B, 10, {Hd}, {Wd}) f32, recipe weights", "steps": steps, "ms_per_batch": round(per * 1e3, 3), "dtype": "f32",
-            "ms_per_batch_runs": [round(r[0] * 1e3, 3) for r in runs],
+            "ms_per_batch_runs": [round(r[0] * 1e3, 3) for r in runs], "value_is": "the first timed region (runs[0])",
             "roofline": {"bound": "mfma", "kernel": f"k_conv_mfma ({eng.n_conv} launches per forward)", "achieved": round(tflops, 2),
                          "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / FP32_MFMA_PEAK_TFLOPS, 4),
                          "flops_per_image": eng.flops_per_image, "device_ms_per_batch": round(dev_ms, 3),
@@ -512,7 +558,7 @@ def bench_detector(args, torch, world, rank, timer):
                 # PyTorch-CPU forward of the same module definition: all cores and 1
                 xb = x_h[:8, ..., None]
                 cpu = {}
-                for nthreads in (min(os.cpu_count() or 1, 64), 1):
+                for nthreads in (physical_cores()[0], 1):
                     torch.set_num_threads(nthreads)
                     xs = xb if nthreads > 1 else xb[:1]
                     with torch.no_grad():
@@ -571,7 +617,7 @@ def _train_variant(torch, timer, world, rank, local_rank, per_gpu_batch, ddp, ho
         bx.copy_(x)
         bl.copy_(lab)
         x, lab = bx, bl
-    per, dev_ms = best_of(timer, one, steps, warmup)
+    per, dev_ms, _runs = one_region(timer, one, steps, warmup)
     return per, dev_ms, tr, state, one, (x, lab)
 
 
@@ -610,7 +656,7 @@ def bench_train(args, torch, world, rank, local_rank, timer):
     the same step with torch autograd / MIOpen convolutions is timed beside it at N = 1."""
     from frlw_evd_amd import e2e
     B = args.train_batch
-    steps = 5
+    steps = 10
     use_graph = world == 1  # one rank: forward + SimOTA + losses + backward + Adam replayed as ONE HIP graph; DDP ranks: eager
     per, dev_ms, tr, state, one, (x, lab) = _train_variant(torch, timer, world, rank, local_rank, B, world > 1, None, steps,
                                                            graph=use_graph)
@@ -618,7 +664,10 @@ def bench_train(args, torch, world, rank, local_rank, timer):
     from frlw_evd_amd.detector import DetectorEngine
     probe = DetectorEngine(e2e.build_model(16, 2, device="cpu").eval(), device="cpu")
     probe.build((16, 256, 320))  # the plan builder counts the convolution MACs of the 16-channel network
-    flops_img = 3 * probe.flops_per_image
+    # forward + data gradient + weight gradient of every convolution, EXCEPT the data gradient of the stem: the network input
+    # needs no gradient (yolox/train_ops.py: needs_input_grad[0] is false there) and none is computed
+    stem_fl = next(m[4] for m in probe.ops_meta if m[0] in ("fstem", "conv"))
+    flops_img = 3 * probe.flops_per_image - stem_fl
     flops = flops_img * B
     tflops = flops / (dev_ms * 1e-3) / 1e12
     out = {"metric": "YOLOX train step (frames/s)", "value": round(world * B / per, 1), "unit": "frames/s",
@@ -629,8 +678,9 @@ def bench_train(args, torch, world, rank, local_rank, timer):
            "convolutions": "csrc/train_ops.hip (fp32 MFMA fwd / dgrad / wgrad, BatchNorm + SiLU fwd / bwd), SimOTA csrc/simota.hip",
            "roofline": {"bound": "mfma", "kernel": "k_conv_mfma (fwd + dgrad) + k_wgrad_mfma", "achieved": round(tflops, 2),
                         "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / FP32_MFMA_PEAK_TFLOPS, 4),
-                        "flops_per_step": flops, "flops_model": "3 x (conv MACs x 2 of the 16-channel forward) x batch: forward + data "
-                        "gradient + weight gradient", "device_ms_per_step": round(dev_ms, 3)}}
+                        "flops_per_step": flops, "flops_model": "(3 x conv MACs x 2 of the 16-channel forward - the stem's data gradient, which "
+                        "is never computed: the network input needs none) x batch = forward + data gradient + weight gradient",
+                        "stem_fraction_of_forward": round(stem_fl / probe.flops_per_image, 4), "device_ms_per_step": round(dev_ms, 3)}}
     if world > 1:
         out["allreduce"] = _allreduce_rows(torch, timer, world, rank, local_rank, B, per, steps)
     # BASELINE.json configs[4]: the same step fed by the TAF encode of its batch (B GEN1-shaped streams of 8 x 125 000
@@ -641,7 +691,7 @@ def bench_train(args, torch, world, rank, local_rank, timer):
     def e2e_step():
         state["loss"], _ = tr.train_step(src.encode_batch(idx), lab, state["i"])
         state["i"] += 1
-    per_e2e, _ = best_of(timer, e2e_step, steps, 2)
+    per_e2e, _, _r = one_region(timer, e2e_step, steps, 2)
     per_enc, _ = timer.run(lambda: src.encode_batch(idx), steps, 1)
     # the same with the encode of batch i + 1 on its own stream while step i runs (e2e.EncodeAhead): every step still
     # consumes a batch that was encoded for it inside the timed region
@@ -651,7 +701,7 @@ def bench_train(args, torch, world, rank, local_rank, timer):
     def e2e_overlapped():
         state["loss"], _ = tr.train_step(ahead.take(), lab, state["i"], after_launch=lambda: ahead.start(idx))
         state["i"] += 1
-    per_ovl, _ = best_of(timer, e2e_overlapped, steps, 2)
+    per_ovl, _, _r = one_region(timer, e2e_overlapped, steps, 2)
     del ahead
     out["encode_plus_train_step"] = {"workload": "BASELINE.json configs[4]: TAF encode of the batch (8 x 125 000 events per "
                                                  "304x240 sample, one frlw_taf_encode_batch call) + train step",
@@ -669,7 +719,7 @@ def bench_train(args, torch, world, rank, local_rank, timer):
         prev = os.environ.get("FRLW_NATIVE_TRAIN")
         os.environ["FRLW_NATIVE_TRAIN"] = "0"
         try:
-            per_t, _ = best_of(timer, one_e, steps, 3)
+            per_t, _, _r = one_region(timer, one_e, steps, 3)
         finally:
             if prev is None:
                 os.environ.pop("FRLW_NATIVE_TRAIN", None)
@@ -729,15 +779,18 @@ def cpu_baseline_taf(dat_h, n, H, W, K, n_win, win_us, all_cores=True, budget_s=
     best, runs = _best_of(one, budget_s)
     out = {"value": round(n / best / 1e6, 3), "unit": "Mevents/s", "cores": 1, "kind": "port",
            "sample": f"the full workload ({n} events, {n_win} windows), best of {runs} runs, {best:.3f} s each",
-           "host_cpus": os.cpu_count(), "cpu": cpu_model()}
+           "host_cpus": os.cpu_count(), "host_physical_cores": physical_cores()[0], "threads_per_core": physical_cores()[1],
+           "cpu": cpu_model()}
     if all_cores:
-        threads = min(os.cpu_count() or 1, 64)
+        threads = physical_cores()[0]  # one thread per physical core of this host
         with ThreadPoolExecutor(threads) as pool:
             t0 = time.perf_counter()
             list(pool.map(lambda _i: one(), range(threads)))
             dt = time.perf_counter() - t0
         out["all_cores"] = {"value": round(threads * n / dt / 1e6, 3), "unit": "Mevents/s", "cores": threads,
                             "sample": f"{threads} threads, each the full workload on its own copy of the state ({dt:.3f} s)"}
+        out["all_cores_value"] = out["all_cores"]["value"]  # (scalar copies: the driver's parser drops nested objects)
+        out["all_cores_threads"] = threads
     return out
 
 
@@ -753,7 +806,7 @@ def cpu_baseline_ev(rec, H, W, budget_s=6.0):
     best, runs = _best_of(one, budget_s, 5)
     out = {"value": round(len(rec) / best / 1e6, 3), "unit": "Mevents/s", "cores": 1, "kind": "port",
            "sample": f"the full workload ({len(rec)} events), best of {runs} runs, {best:.4f} s each", "cpu": cpu_model()}
-    threads = min(os.cpu_count() or 1, 64)
+    threads = physical_cores()[0]  # one thread per physical core of this host
     reps = 8  # ~10 ms per call: several calls per thread so that the pool's start-up does not dominate
     with ThreadPoolExecutor(threads) as pool:
         t0 = time.perf_counter()

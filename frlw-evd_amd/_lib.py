@@ -37,12 +37,14 @@ _ERR_TEXT = {
 
 class FrlwTuning(C.Structure):
     """frlw_tuning_t: per-call overrides of the launch heuristics, every field < 0 = the library's choice."""
-    _fields_ = [("tile_width_log2", C.c_int32), ("batches_per_wave", C.c_int32), ("hot_tile_records", C.c_int32),
+    _fields_ = [("struct_size", C.c_int32),
+                ("tile_width_log2", C.c_int32), ("batches_per_wave", C.c_int32), ("hot_tile_records", C.c_int32),
                 ("staged_scatter", C.c_int32), ("quarter_below", C.c_int32), ("no_value_table", C.c_int32),
                 ("taf_tile_walk", C.c_int32), ("direct_bins", C.c_int32)]
 
     def __init__(self, **kw):
         super().__init__(*[int(kw.pop(name, -1)) for name, _ in self._fields_])
+        self.struct_size = C.sizeof(type(self))  # the library reads only what lies inside (frlw_evd.h)
         if kw:
             raise TypeError(f"unknown tuning fields {sorted(kw)}")
 
@@ -62,7 +64,6 @@ SYMBOLS = {
     "frlw_encoder_status": (_I, [_P, _P, C.POINTER(C.c_int)]),
     "frlw_workspace_init": (_I, [_P, _SZ, _P]),
     "frlw_encoder_deferred_status": (_I, [_P, _P, C.POINTER(C.c_int)]),
-    "frlw_debug_force_lds_order": (_I, [_I]),
     "frlw_eci_encode": (_I, [_EV, _I, _I, _P, _P, _P, _SZ, _P]),
     "frlw_ev_encode": (_I, [_EV, _I, _I, _I, _I64, _I64, _P, _P, _P, _SZ, _P]),
     "frlw_sae_encode": (_I, [_EV, _I, _I, C.POINTER(C.c_double), _I, _P, _P, _I64, _I64, _P, _P, _P, _SZ, _P]),
@@ -133,6 +134,12 @@ SYMBOLS = {
 _lib = None
 
 
+# symbols of the developer build only (-DFRLW_DEV_BUILD, libfrlw_evd_dev.so): bound when present
+DEV_SYMBOLS = {
+    "frlw_debug_force_lds_order": (_I, [_I]),
+}
+
+
 def library_path() -> str:
     # FRLW_LIB_PATH: developer knob to A/B a differently-built libfrlw_evd (tools/variants.sh)
     return os.environ.get("FRLW_LIB_PATH") or _build.LIB
@@ -156,6 +163,11 @@ def load():
             fn = getattr(lib, name)  # AttributeError = header and library out of sync
             fn.restype = res
             fn.argtypes = args
+        for name, (res, args) in DEV_SYMBOLS.items():
+            fn = getattr(lib, name, None)
+            if fn is not None:
+                fn.restype = res
+                fn.argtypes = args
         _lib = lib
     return _lib
 

@@ -680,7 +680,7 @@ int frlw_debug_prof(unsigned long long *out, int reset)
 }
 #endif
 
-const char *frlw_version(void) { return "frlw_evd 0.4.0 gfx950"; }
+const char *frlw_version(void) { return "frlw_evd 0.5.0 gfx950"; }
 
 size_t frlw_encoder_workspace_bytes(int64_t n_events, int H, int W)
 {

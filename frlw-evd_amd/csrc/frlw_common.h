@@ -341,6 +341,18 @@ struct Partitioned {
 };
 
 bool make_plan(long long n, int H, int W, const frlw_tuning_t *tuning, Plan &p);
+
+// One knob of the caller's frlw_tuning_t: a field that lies outside the caller's `struct_size` (an older header) or is
+// negative takes the default.
+inline int tuning_knob(const frlw_tuning_t *tu, int32_t frlw_tuning_t::*f, int dflt)
+{
+    if (!tu) return dflt;
+    const size_t end = (size_t)((const char *)&(tu->*f) - (const char *)tu) + sizeof(int32_t);
+    if ((size_t)tu->struct_size < end) return dflt;
+    const int v = (int)(tu->*f);
+    return v >= 0 ? v : dflt;
+}
+inline bool tuning_valid(const frlw_tuning_t *tu) { return !tu || (tu->struct_size >= 8 && tu->struct_size <= 4096); }
 int hip_fail(hipError_t e, const char *what, int line);
 
 // hist -> scans -> stable scatter: tile-major 8-byte records {window << (twl + 4) | cell, f32 bits}.

@@ -439,7 +439,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 bool make_plan(long long n, int H, int W, const frlw_tuning_t *tuning, Plan &p)
 {
     if (H <= 0 || W <= 0 || n < 0) return false;
-    const auto knob = [&](int32_t frlw_tuning_t::*f, int dflt) { return tuning && tuning->*f >= 0 ? (int)(tuning->*f) : dflt; };
+    const auto knob = [&](int32_t frlw_tuning_t::*f, int dflt) { return tuning_knob(tuning, f, dflt); };
     p.twl = knob(&frlw_tuning_t::tile_width_log2, W > 512 ? 8 : 6);
     if (p.twl < 6 || p.twl > 8) return false;
     for (;; ++p.twl) { // tall frames (a batch of sequences stacked along y): widen the tiles to stay under kMaxTiles
@@ -491,6 +491,7 @@ int partition_events(const frlw_events_t *ev, int H, int W, int kind, long long 
     if (ev->layout != FRLW_LAYOUT_XYTP_F64 && ev->layout != FRLW_LAYOUT_DAT8) return FRLW_ERR_ARG;
     if (ev->layout == FRLW_LAYOUT_XYTP_F64 && ev->row_stride < 4) return FRLW_ERR_ARG;
     if ((ev->xmap == nullptr) != (ev->ymap == nullptr)) return FRLW_ERR_ARG;
+    if (!tuning_valid(ev->tuning)) return FRLW_ERR_ARG;
     if (ev->n >= (1ll << 32)) return FRLW_ERR_UNSUPPORTED;
     if (win < 1) win = 1;
     if (kind == KIND_TAF && ev->layout == FRLW_LAYOUT_DAT8 &&

@@ -2066,6 +2066,7 @@ int lds_order_ok(char *w8, hipStream_t st)
 
 extern "C" {
 
+#ifdef FRLW_DEV_BUILD // not in the product library: a process-wide switch has no place in its ABI
 int frlw_debug_force_lds_order(int value)
 {
     int dev = 0;
@@ -2074,6 +2075,7 @@ int frlw_debug_force_lds_order(int value)
     g_lds_order[dev].store(value < 0 ? 0 : (value == 1 ? 1 : 2), std::memory_order_release);
     return FRLW_OK;
 }
+#endif
 
 int frlw_selftest_lds_atomic_order(int n_addr, int iters, unsigned long long *out_dev, frlw_stream_t stream)
 {
@@ -2124,8 +2126,9 @@ enum : int { PHASE_PARTITION = 1, PHASE_FINISH = 2 };
 // which needs tile bins; default: direct where the frame allows it
 inline int direct_allowed(const frlw_tuning_t *tu)
 {
-    if (tu && tu->direct_bins >= 0) return tu->direct_bins != 0 ? DIRECT_FORCE : DIRECT_OFF;
-    const bool walk = (tu && tu->taf_tile_walk >= 0) ? tu->taf_tile_walk != 0 : kTafTileWalk;
+    const int direct = tuning_knob(tu, &frlw_tuning_t::direct_bins, -1);
+    if (direct >= 0) return direct != 0 ? DIRECT_FORCE : DIRECT_OFF;
+    const bool walk = tuning_knob(tu, &frlw_tuning_t::taf_tile_walk, kTafTileWalk ? 1 : 0) != 0;
     return walk ? DIRECT_OFF : DIRECT_AUTO;
 }
 
@@ -2142,6 +2145,7 @@ int taf_batch_run(int phases, const frlw_events_t *ev, const int64_t *seq_offset
     if (n_seq < 1 || n_seq > kMaxSeq) return FRLW_ERR_ARG;
     if (ev->layout != FRLW_LAYOUT_DAT8) return FRLW_ERR_UNSUPPORTED;
     if ((ev->xmap == nullptr) != (ev->ymap == nullptr)) return FRLW_ERR_ARG;
+    if (!tuning_valid(ev->tuning)) return FRLW_ERR_ARG;
     if (seq_offsets[0] < 0 || seq_offsets[n_seq] > ev->n) return FRLW_ERR_ARG;
     if (seq_offsets[n_seq] > seq_offsets[0] && !ev->data) return FRLW_ERR_ARG;
     // record = r | window | cell in 32 bits
@@ -2166,8 +2170,7 @@ int taf_batch_run(int phases, const frlw_events_t *ev, const int64_t *seq_offset
     G.rcp = 1.0 / ((double)(uint32_t)window_us + 1e-8); // generate_taf.py:215: t / (w + 1e-8)
     G.y_lo = y_lo; G.H_full = H_full;
     {
-        const frlw_tuning_t *tu = ev->tuning;
-        const bool want = (tu && tu->taf_tile_walk >= 0) ? tu->taf_tile_walk != 0 : kTafTileWalk;
+        const bool want = tuning_knob(ev->tuning, &frlw_tuning_t::taf_tile_walk, kTafTileWalk ? 1 : 0) != 0;
         G.order_check = (want && !p.direct && p.pairs >= kFewPairs) ? 1 : 0;
     }
     const unsigned long long magic = (1ull << 32) / (unsigned long long)window_us;
@@ -2275,6 +2278,7 @@ int frlw_ev_encode_batch(const frlw_events_t *ev, const int64_t *seq_offsets, co
     if (bins < 1 || bins > FRLW_MAX_BINS || window_us < 1 || n_seq < 1 || n_seq > kMaxSeq) return FRLW_ERR_ARG;
     if (ev->layout != FRLW_LAYOUT_DAT8) return FRLW_ERR_UNSUPPORTED;
     if ((ev->xmap == nullptr) != (ev->ymap == nullptr)) return FRLW_ERR_ARG;
+    if (!tuning_valid(ev->tuning)) return FRLW_ERR_ARG;
     if (seq_offsets[0] < 0 || seq_offsets[n_seq] > ev->n) return FRLW_ERR_ARG;
     if (seq_offsets[n_seq] > seq_offsets[0] && !ev->data) return FRLW_ERR_ARG;
     int rb = 0; // record = (t - t_begin) | cell in 32 bits
@@ -2318,8 +2322,7 @@ int frlw_ev_encode_batch(const frlw_events_t *ev, const int64_t *seq_offsets, co
     // form the faster one (64 x 1 M events: 985 against 1 041 us)
     bool tile_walk = false;
     {
-        const frlw_tuning_t *tu = ev->tuning;
-        const bool want = (tu && tu->taf_tile_walk >= 0) ? tu->taf_tile_walk != 0 : kTafTileWalk;
+        const bool want = tuning_knob(ev->tuning, &frlw_tuning_t::taf_tile_walk, kTafTileWalk ? 1 : 0) != 0;
         tile_walk = want && !p.direct && p.pairs >= kFewPairs;
     }
     TileP q;

@@ -13,13 +13,16 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None, local_rank_arg=None):
+def init_from_env(backend=None, local_rank_arg=None, force=False):
     """(rank, world, local_rank) from RANK / WORLD_SIZE / LOCAL_RANK; accepts the launcher's --local_rank too
-    (train.py:10; torch >= 2 passes --local-rank / LOCAL_RANK)."""
+    (train.py:10; torch >= 2 passes --local-rank / LOCAL_RANK).  A one-rank job joins no process
+    group unless ``force`` (or ``FRLW_DIST_FORCE=1``) asks for it -- the reference's train.py:31 always does, and a
+    one-rank ``nccl`` group is how the RCCL code paths are exercised on a one-GPU box (tests/test_rccl_gpu.py)."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", local_rank_arg if local_rank_arg is not None else 0))
-    if world > 1 and not dist.is_initialized():
+    force = force or os.environ.get("FRLW_DIST_FORCE") == "1"
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         backend = os.environ.get("FRLW_DIST_BACKEND", backend)  # e.g. gloo: several ranks on one GPU in tests

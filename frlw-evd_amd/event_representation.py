@@ -339,7 +339,7 @@ def encode_taf_stripe(dat, seq_offsets, shape, stripe, state, t_start, window_us
     masks = ws[off:off + 8 * B].view(torch.int64)  # the kernels' own words: reduced in place, read by the second half
     if exchange is not None:
         exchange(masks)
-    elif dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    elif dist.is_available() and dist.is_initialized():  # (also a one-rank group: the collective is the same code path)
         _or_reduce_window_masks(masks, group)
     u8 = torch.empty((B, K, 2, rows, W), dtype=torch.uint8, device=d.device) if want_u8 else None
     view = torch.empty((B, 2 * K, rows, W), dtype=torch.float32, device=d.device) if want_view else None
@@ -374,6 +374,14 @@ def encode_taf_dat(dat, shape, state, t_start, window_us=10000, n_windows=8, vol
     if fast == "auto":
         fast = bool(check) and n >= FAST_MIN_EVENTS
     if fast:
+        if check:
+            # The fall-back below takes a ValueError / IndexError of the fast call to mean "THIS call wrote nothing".  The status
+            # word it reads is sticky: an earlier unchecked call on the same workspace may have left its error there.  Drain
+            # that first and let it propagate -- it belongs to the earlier call, and swallowing it here would run the general
+            # path on a state the fast call has already stepped.
+            pending = _WORKSPACES.get(("batch", dat.device.index, torch.cuda.current_stream().cuda_stream))
+            if pending is not None:
+                _raise_deferred_of(pending, "an earlier unchecked encoder call on this stream")
         try:
             u8, view = encode_taf_batch(dat, [0, n], (H, W), state.view(1, H, W, 2, K), t_start, window_us, n_windows, K,
                                         want_view, want_u8, flip_k, xmap, ymap, check)

@@ -68,6 +68,7 @@ class Trainer:
                  local_rank=None, ddp=False, comm_hook=None, graph=False):
         self.lr0, self.per_gpu_batch = init_lr(global_batch, nodes)
         self._graph = None          # (HIP graph, static images, static labels, static loss) once captured
+        self._pinned = False
         self._want_graph = bool(graph) and not ddp  # (DDP: eager -- capture of RCCL collectives is not validated here)
         self.model = model
         self.comm_hook = None
@@ -118,13 +119,21 @@ class Trainer:
         return loss
 
     def capture(self, imgs, targets, warmup=3):
-        """Capture one whole step for batches shaped like (imgs, targets) into a HIP graph.  Runs ``warmup`` REAL steps on
-        the given batch first (they train: count them), on a side stream as torch's capture rules ask; the gradients are
-        allocated inside the graph's memory pool, so ``zero_grad`` is part of the replay (set_to_none before capture)."""
+        """Capture one whole step for batches shaped like (imgs, targets) into a HIP graph.  The ``warmup`` steps torch's capture
+        rules ask for (on a side stream) run on the given batch but DO NOT TRAIN: parameters, BatchNorm buffers (running
+        statistics, ``num_batches_tracked``) and the optimizer state (moments, step counters) are snapshotted before and
+        copied back IN PLACE after the capture (addresses stay fixed for the graph), so that a graphed trainer follows the
+        same trajectory as the eager one -- and as core/exp.py:292-303 -- on the same data stream.  Returns the number of
+        steps that trained: 0.  The gradients are allocated inside the graph's memory pool, so ``zero_grad`` is part of the
+        replay (set_to_none before capture)."""
         if not self._want_graph:
             raise RuntimeError("graph capture needs Trainer(graph=True), one rank without DDP, parameters on the GPU")
         self.model.train()
         x, lab = imgs.clone(), targets.clone()
+        snap_model = {k: v.detach().clone() for k, v in self.model.state_dict().items()}
+        snap_opt = {p: {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in st.items()}
+                    for p, st in self.optimizer.state.items()}
+        snap_lr = [g["lr"].clone() if torch.is_tensor(g["lr"]) else g["lr"] for g in self.optimizer.param_groups]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -143,7 +152,38 @@ class Trainer:
             self.scaler.scale(loss).backward()
             self.optimizer.step()
         self._graph = (graph, x, lab, loss)
-        return warmup
+        # undo the warm-up: everything the steps above moved goes back to its snapshot, in place
+        with torch.no_grad():
+            for k, v in self.model.state_dict().items():
+                v.copy_(snap_model[k])
+            for p, st in self.optimizer.state.items():
+                old = snap_opt.get(p)
+                for k, v in st.items():
+                    if torch.is_tensor(v):
+                        if old is not None and k in old:
+                            v.copy_(old[k])
+                        else:
+                            v.zero_()  # a fresh Adam starts from zero moments and step 0
+            for g, lr in zip(self.optimizer.param_groups, snap_lr):
+                if torch.is_tensor(g["lr"]):
+                    g["lr"].copy_(lr)
+                else:
+                    g["lr"] = lr
+        torch.cuda.synchronize()
+        from . import _pins
+        if not self._pinned:
+            _pins.pin()  # module-level scratch / operand caches the graph points into must outlive it
+            self._pinned = True
+        return 0
+
+    def __del__(self):
+        try:
+            if getattr(self, "_pinned", False):
+                from . import _pins
+                self._graph = None
+                _pins.unpin()
+        except Exception:
+            pass
 
     def input_buffers(self):
         """(images, labels) the captured graph reads: a data pipeline that writes its batch into these (and passes them to

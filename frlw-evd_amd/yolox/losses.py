@@ -153,6 +153,8 @@ def simota_assign(outputs, labels, x_shifts, y_shifts, strides_all, num_classes,
     key = (dev.index, stream)
     ws = _SIMOTA_WS.get(key)
     if ws is None or ws.numel() < need:
+        from .. import _pins
+        _pins.retire(ws)  # a live HIP graph may still launch kernels on the old workspace
         ws = torch.empty(need, dtype=torch.uint8, device=dev)
         _SIMOTA_WS[key] = ws
     _lib.check(lib.frlw_simota_assign(preds.data_ptr(), lab.data_ptr(), xs.data_ptr(), ys.data_ptr(), st.data_ptr(),

@@ -14,7 +14,7 @@ import os
 
 import torch
 
-from .. import _lib
+from .. import _lib, _pins
 
 _SCRATCH = {}
 _WCACHE = {}  # id(weight parameter) -> (weakref, operand cache): forward + data-gradient layouts, rebuilt every forward
@@ -28,6 +28,8 @@ def _weight_cache(lib, weight, Cin, Cout, k):
     n = lib.frlw_baseconv_weight_cache_floats(Cin, Cout, k)
     if hit is None or hit[0]() is not weight or hit[1].numel() < n or hit[1].device != weight.device:
         buf = torch.empty(int(n), dtype=torch.float32, device=weight.device)
+        if hit is not None:
+            _pins.retire(hit[1])  # a live HIP graph may still launch kernels on the old cache
         _WCACHE[key] = (weakref.ref(weight, lambda _r, key=key: _WCACHE.pop(key, None)), buf)
         return buf
     return hit[1]
@@ -79,6 +81,8 @@ def layout_all_weights(model):
                 stale = True
                 break
     if stale:
+        if plan is not None:
+            _pins.retire(plan[1])  # the item table a captured layout launch reads
         plan = _layout_plan(model)
         if plan is None:
             _PLANS.pop(id(model), None)
@@ -103,6 +107,7 @@ def _scratch(dev, key, numel, dtype):
     k = (dev.index, key, dtype)
     t = _SCRATCH.get(k)
     if t is None or t.numel() < numel:
+        _pins.retire(t)
         t = torch.empty(max(int(numel), 1), dtype=dtype, device=dev)
         _SCRATCH[k] = t
     return t

@@ -58,8 +58,12 @@ enum {
 };
 
 /* Optional per-call overrides of the launch heuristics (experiments, and tests that force a rarely taken path).
- * Every field: < 0 = the library's choice.  There is no process-wide state: the knobs travel with the call. */
+ * Every field: < 0 = the library's choice.  There is no process-wide state: the knobs travel with the call.
+ * `struct_size` = sizeof(frlw_tuning_t) as the CALLER compiled it: the struct has grown and will grow at its end, and the
+ * library reads only the fields that lie inside `struct_size` (the others take their defaults), so a caller built against
+ * an older header never has its stack read past the struct.  A struct_size below 8 or above 4096 is FRLW_ERR_ARG. */
 typedef struct frlw_tuning {
+    int32_t struct_size;     /* = sizeof(frlw_tuning_t) */
     int32_t tile_width_log2; /* 6..8 */
     int32_t batches_per_wave; /* 1..8: 64-event batches per wavefront of a partition workgroup */
     int32_t hot_tile_records; /* a tile with more records than this is shared by several workgroups (EV / TAF) */
@@ -233,8 +237,12 @@ int frlw_ev_encode_batch(const frlw_events_t *ev, const int64_t *seq_offsets, co
 int frlw_selftest_lds_atomic_order(int n_addr, int iters, unsigned long long *out_dev, frlw_stream_t stream);
 /* frlw_taf_encode_batch runs that self-test by itself on its first call per device (one host synchronisation for the
  * lifetime of the process, result cached) and returns FRLW_ERR_UNSUPPORTED from then on if the property does not hold, so
- * that callers take frlw_taf_encode.  Tests force the outcome: value 0 = "does not hold", 1 = "holds", -1 = forget. */
+ * that callers take frlw_taf_encode. */
+#ifdef FRLW_DEV_BUILD
+/* Developer builds only (-DFRLW_DEV_BUILD -> libfrlw_evd_dev.so; NOT a symbol of the product library): tests force the
+ * cached verdict of the self-test: value 0 = "does not hold", 1 = "holds", -1 = forget. */
 int frlw_debug_force_lds_order(int value);
+#endif
 
 /* leaky_transform(ecd), generate_taf.py:69-76, on n floats; either output may be NULL. */
 int frlw_leaky_transform(const float *in, int64_t n, float *out_f32, uint8_t *out_u8,

@@ -11,7 +11,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared_symbols():
     text = open(os.path.join(ROOT, "include", "frlw_evd.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"#ifdef FRLW_DEV_BUILD.*?#endif", "", text, flags=re.S)  # developer-build hooks: not product symbols
     return sorted(set(re.findall(r"\b(frlw_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_product_library_has_no_developer_hooks():
+    """frlw_debug_force_lds_order (a process-wide switch) exists only in the -DFRLW_DEV_BUILD library."""
+    lib = _lib.load()
+    for name in _lib.DEV_SYMBOLS:
+        assert not hasattr(lib, name), f"{name} is exported by the product library"
+
+
+def test_tuning_struct_carries_its_size():
+    t = _lib.FrlwTuning(direct_bins=1)
+    assert t.struct_size == 9 * 4 and t.direct_bins == 1 and t.tile_width_log2 == -1
 
 
 def test_library_exports_every_declared_symbol():

@@ -118,14 +118,8 @@ def test_encode_ahead_feeds_the_same_batches():
     want = [serial.train_step(src.encode_batch(idx), lab, i)[0] for i, idx in enumerate(order)]
     for graph in (False, True):
         tr = Trainer(e2e.build_model(16, 2), global_batch=2, nodes=1, iters_per_epoch=10, graph=graph)
-        if graph:  # the capture's warm-up steps would be extra updates: capture on a throw-away batch at rate 0, then reset
-            state = {k: v.clone() for k, v in tr.model.state_dict().items()}
-            tr.capture(src.encode_batch(order[0]), lab, warmup=3)
-            tr.model.load_state_dict(state)
-            for st in tr.optimizer.state.values():
-                for v in st.values():
-                    if torch.is_tensor(v):
-                        v.zero_()
+        # (graph: train_step captures on first use; the capture's warm-up steps do not train -- Trainer.capture restores
+        #  parameters, BatchNorm buffers and Adam's state in place)
         ahead = e2e.EncodeAhead(src)
         ahead.start(order[0])
         got, started = [], []

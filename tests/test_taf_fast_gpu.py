@@ -233,28 +233,75 @@ def test_unchecked_calls_leave_a_deferred_status(er, orc):
         er.raise_deferred()
 
 
-def test_failed_lane_order_selftest_disables_the_fast_path(er, orc):
-    """The library checks the LDS lane-order property on its first fast-path call per device and caches the verdict; if it
-    does not hold the fast path refuses and ``encode_taf_dat`` runs the general path -- same bits."""
-    from frlw_evd_amd import _lib
-    lib = _lib.load()
+def test_an_earlier_unchecked_error_is_not_mistaken_for_this_calls(er, orc):
+    """the status word is sticky.  An unchecked call leaves an error; a later CLEAN checked
+    ``encode_taf_dat(fast=True)`` must raise that earlier error BEFORE it touches the state -- not step the state with the fast
+    path, read the old error, take it for its own and step the state a second time through the general path."""
     H, W, K = 64, 96, 8
-    rec = synth.to_dat8(synth.synth_events(79, 30_000, W, H, 80_000))
+    rec = synth.to_dat8(synth.synth_events(81, 40_000, W, H, 80_000))
+    bad = rec.copy()
+    bad["t"][-5:] += 1_000_000
     st0 = np.full((H, W, 2, K), -6000, np.float32)
-    _, ost, _ = oracle_taf(orc, rec, (H, W), K, 0, 10_000, 8, st0)
-    try:
-        _lib.check(lib.frlw_debug_force_lds_order(0))  # "the property does not hold on this device"
-        st = torch.from_numpy(st0.copy()).cuda()
-        with pytest.raises(NotImplementedError):
-            er.encode_taf_batch(to_dev(rec), [0, len(rec)], (H, W), st.view(1, H, W, 2, K), 0, 10_000, 8, K)
-        assert_bitexact(host(st), st0, "refused before anything ran")
-        er.encode_taf_dat(to_dev(rec), (H, W), st, 0, 10_000, 8, K, fast=True)  # falls back to the general path
-        assert_bitexact(host(st), ost, "general path after the refusal")
-    finally:
-        _lib.check(lib.frlw_debug_force_lds_order(-1))  # forget: the next call runs the real self-test again
+    er.raise_deferred()
+    junk = torch.from_numpy(st0.copy()).cuda()
+    er.encode_taf_batch(to_dev(bad), [0, len(bad)], (H, W), junk.view(1, H, W, 2, K), 0, 10_000, 8, K, check=False)
     st = torch.from_numpy(st0.copy()).cuda()
-    er.encode_taf_batch(to_dev(rec), [0, len(rec)], (H, W), st.view(1, H, W, 2, K), 0, 10_000, 8, K)
-    assert_bitexact(host(st), ost, "fast path after the real self-test passed")
+    with pytest.raises(ValueError):
+        er.encode_taf_dat(to_dev(rec), (H, W), st, 0, 10_000, 8, K, fast=True)
+    assert_bitexact(host(st), st0, "the earlier call's error surfaced before this call ran")
+    er.encode_taf_dat(to_dev(rec), (H, W), st, 0, 10_000, 8, K, fast=True)  # the word is clean now: ONE step
+    _, ost, _ = oracle_taf(orc, rec, (H, W), K, 0, 10_000, 8, st0)
+    assert_bitexact(host(st), ost, "stepped exactly once")
+
+
+_FORCED_FAILURE_CHILD = r"""
+import sys
+import numpy as np, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from frlw_evd_amd import _lib, synth, event_representation as er
+from oracle import oracle as orc
+lib = _lib.load()
+assert hasattr(lib, "frlw_debug_force_lds_order"), "the developer library must carry the hook"
+H, W, K = 64, 96, 8
+rec = synth.to_dat8(synth.synth_events(79, 30_000, W, H, 80_000))
+st0 = np.full((H, W, 2, K), -6000, np.float32)
+_, ost = orc.taf_stream_dat8(rec, (H, W), (H, W), K, 0, 10_000, 8, st0)
+dev = lambda r: torch.from_numpy(np.ascontiguousarray(r).view(np.uint8).reshape(-1, 8).copy()).cuda()
+try:
+    _lib.check(lib.frlw_debug_force_lds_order(0))  # "the property does not hold on this device"
+    st = torch.from_numpy(st0.copy()).cuda()
+    try:
+        er.encode_taf_batch(dev(rec), [0, len(rec)], (H, W), st.view(1, H, W, 2, K), 0, 10_000, 8, K)
+        raise SystemExit("the fast path did not refuse")
+    except NotImplementedError:
+        pass
+    assert st.cpu().numpy().tobytes() == st0.tobytes(), "refused before anything ran"
+    er.encode_taf_dat(dev(rec), (H, W), st, 0, 10_000, 8, K, fast=True)  # falls back to the general path
+    assert st.cpu().numpy().tobytes() == ost.tobytes(), "general path after the refusal"
+finally:
+    _lib.check(lib.frlw_debug_force_lds_order(-1))  # forget: the next call runs the real self-test again
+st = torch.from_numpy(st0.copy()).cuda()
+er.encode_taf_batch(dev(rec), [0, len(rec)], (H, W), st.view(1, H, W, 2, K), 0, 10_000, 8, K)
+assert st.cpu().numpy().tobytes() == ost.tobytes(), "fast path after the real self-test passed"
+print("forced-failure ok")
+"""
+
+
+def test_failed_lane_order_selftest_disables_the_fast_path():
+    """The library checks the LDS lane-order property on its first fast-path call per device and caches the verdict; if it
+    does not hold the fast path refuses and ``encode_taf_dat`` runs the general path -- same bits.  The hook that forces the
+    verdict exists only in the developer build (libfrlw_evd_dev.so, -DFRLW_DEV_BUILD): a fresh child process loads that."""
+    import os
+    import subprocess
+    import sys
+    from frlw_evd_amd import _build
+    dev_lib = _build.DEV_LIB
+    if not os.path.exists(dev_lib):
+        dev_lib = _build.build_dev()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-c", _FORCED_FAILURE_CHILD, root], env=dict(os.environ, FRLW_LIB_PATH=dev_lib),
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "forced-failure ok" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
 
 
 # ---- the tile walk (kf_taf_tile, frlw_tuning_t::taf_tile_walk = 1): same bits as the default split + sub-tile kernels ----

@@ -126,7 +126,7 @@ struct Outputs {
     bool ran = false;
 };
 
-static frlw_tuning_t g_tuning = {-1, -1, -1, -1, -1, -1, -1, -1};
+static frlw_tuning_t g_tuning = {(int32_t)sizeof(frlw_tuning_t), -1, -1, -1, -1, -1, -1, -1, -1};
 static bool g_use_tuning = false;
 
 static Outputs run_cfg(const Lib &L, const Cfg &c, const uint64_t *dat_d, const std::vector<int64_t> &offs, int reps)
