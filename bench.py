@@ -227,6 +227,16 @@ def launch_ranks(n, argv):
     return rc
 
 
+def claim_stdout():
+    """The JSON line must be the ONLY thing this process writes to stdout: RCCL prints ``Librccl path : ...`` there from native
+    code when its library goes away -- after the line, and from every rank.  From here on file descriptor 1 is stderr for
+    everybody (native libraries included); the returned file is the real stdout, for rank 0's one line."""
+    sys.stdout.flush()
+    real = os.dup(1)
+    os.dup2(2, 1)
+    return os.fdopen(real, "w")
+
+
 def launch_only(args):
     """--launch-only: the rendezvous of a --gpus N run and nothing else (tests/test_dist_cpu.py runs it with
     FRLW_DIST_BACKEND=gloo on CPU): every rank joins the process group, the ranks are summed and the barrier-bracketed
@@ -235,15 +245,16 @@ def launch_only(args):
     from frlw_evd_amd import dist as fd
     if os.environ.get("FRLW_BENCH_TEST_FAIL_RANK") == os.environ.get("RANK", "0"):  # the launcher's failure path, under test
         raise SystemExit(3)
+    out = claim_stdout()
     rank, world, local_rank = fd.init_from_env(None, args.local_rank)
     fd.barrier_sync()
     ranks = fd.sum_over_ranks([rank + 1])[0]
     slowest = fd.max_over_ranks([0.5 + rank])[0]
     fd.barrier_sync()
     if rank == 0:
-        print(json.dumps({"launch_only": True, "n_gpus": world, "gpus_flag": args.gpus, "rank_sum": ranks,
+        print(file=out, flush=True, *[json.dumps({"launch_only": True, "n_gpus": world, "gpus_flag": args.gpus, "rank_sum": ranks,
                           "max_over_ranks": slowest, "backend": dist.get_backend() if dist.is_initialized() else None,
-                          "launched_by": "bench.py" if os.environ.get("FRLW_BENCH_LAUNCHED") else "external launcher"}))
+                          "launched_by": "bench.py" if os.environ.get("FRLW_BENCH_LAUNCHED") else "external launcher"})])
     if dist.is_initialized():
         dist.destroy_process_group()
 
@@ -275,6 +286,7 @@ def main():
     if args.launch_only:
         return launch_only(args)
 
+    out = claim_stdout()
     import torch
     import torch.distributed as dist
 
@@ -413,7 +425,7 @@ def main():
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline_taf(dat_h, n, H, W, K, n_win, win_us)
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), file=out, flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
 
@@ -530,14 +542,15 @@ def bench_detector(args, torch, world, rank, timer):
         x = x_h.cuda()
         eng = net.engine()
         steps = max(5, min(args.steps, 30))
-        # ONE timed region of `steps` forwards is the value (after a 20-forward warm-up: a fresh box now and then spends tens
-        # of ms on a clock / power transition); two more regions are listed for the spread, never selected
-        per, dev_ms, runs = one_region(timer, lambda: eng.raw_outputs(x), steps, 20, extra=2)
+        # three timed regions of `steps` forwards each; the value is their MEDIAN (not the best: a fresh box now and then spends
+        # tens of ms of one region on a clock / power transition, and the first region after the warm-up runs ~3 % slow)
+        _p, _d, runs = one_region(timer, lambda: eng.raw_outputs(x), steps, 20, extra=2)
+        per, dev_ms = sorted(runs)[1]
         tflops = eng.flops_per_image * B / (dev_ms * 1e-3) / 1e12
         row = {
             "value": round(world * B / per, 1), "unit": "frames/s", "batch_per_gpu": B,
             "input": f"(B, 10, {Hd}, {Wd}) f32, recipe weights", "steps": steps, "ms_per_batch": round(per * 1e3, 3), "dtype": "f32",
-            "ms_per_batch_runs": [round(r[0] * 1e3, 3) for r in runs], "value_is": "the first timed region (runs[0])",
+            "ms_per_batch_runs": [round(r[0] * 1e3, 3) for r in runs], "value_is": "the median of the three timed regions listed",
             "roofline": {"bound": "mfma", "kernel": f"k_conv_mfma ({eng.n_conv} launches per forward)", "achieved": round(tflops, 2),
                          "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / FP32_MFMA_PEAK_TFLOPS, 4),
                          "flops_per_image": eng.flops_per_image, "device_ms_per_batch": round(dev_ms, 3),
@@ -556,9 +569,10 @@ def bench_detector(args, torch, world, rank, timer):
                                   "(BASELINE.json configs[3])"}, **row)
             if rank == 0 and world == 1 and not args.no_cpu_baseline:
                 # PyTorch-CPU forward of the same module definition: all cores and 1
-                xb = x_h[:8, ..., None]
                 cpu = {}
-                for nthreads in (physical_cores()[0], 1):
+                xb = x_h[..., None]
+                many_t = sorted({physical_cores()[0], min(32, physical_cores()[0])}, reverse=True)
+                for nthreads in many_t + [1]:  # (all physical cores; 32 threads: torch's CPU convolutions stop scaling early)
                     torch.set_num_threads(nthreads)
                     xs = xb if nthreads > 1 else xb[:1]
                     with torch.no_grad():
@@ -570,8 +584,10 @@ def bench_detector(args, torch, world, rank, timer):
                             dt = time.perf_counter() - t2
                             best = dt if best is None else min(best, dt)
                     cpu[nthreads] = (len(xs) / best, best, len(xs))
-                many = max(cpu)
+                many = max((k for k in cpu if k > 1), key=lambda k: cpu[k][0], default=1)  # the thread count that did best
                 out["cpu_baseline"] = {"value": round(cpu[many][0], 1), "unit": "frames/s", "cores": many, "kind": "port",
+                                       "frames_per_s_by_threads": {str(k): round(v[0], 2) for k, v in cpu.items()},
+                                       "host_physical_cores": physical_cores()[0],
                                        "one_thread_frames_per_s": round(cpu[1][0], 2), "cpu": cpu_model(),
                                        "sample": f"PyTorch-CPU fp32 forward of the same modules, batch {cpu[many][2]} on {many} threads "
                                                  f"(best of 3, {cpu[many][1]:.3f} s), batch 1 on 1 thread ({cpu[1][1]:.3f} s)"}

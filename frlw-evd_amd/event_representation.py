@@ -404,15 +404,22 @@ def encode_taf_dat(dat, shape, state, t_start, window_us=10000, n_windows=8, vol
 
 
 def encode_taf_label(dat, shape, state, start_time, window_us, bins, volume_bins=8, flip_k=True, xmap=None, ymap=None,
-                     check=True, fast="auto"):
+                     check=True, fast="auto", stale_transforms=0):
     """One annotation timestamp of the TAF harness (generate_taf.py:197-235): the time-sorted records ``dat`` of
     ``[start_time, start_time + bins * window_us]`` (``dat_io.taf_label_slices`` says which) through ``bins`` windows;
     ``state`` is updated in place, the newest-first uint8 volume (K, 2, H, W) is returned.
 
     ``bins`` is unbounded in the reference (the first label of a file spans everything before it); one launch takes at
     most 64 windows, so longer labels run in groups of 64 with the FIFO state carried -- an event on a group boundary
-    belongs to the later window, as in the reference's ``z`` column (:197-203).  ``bins == 0`` (a label that rounds onto
-    the previous one, :181) encodes nothing and returns the transform of the state as it stands.
+    belongs to the later window, as in the reference's ``z`` column (:197-203).
+
+    ``bins == 0`` (a label that rounds onto the previous one, :181): the reference's window loop does not run and its
+    ``volume`` variable still holds the PREVIOUS label's volume -- after ``leaky_transform``.  Lines :226-227 transform it
+    again, so the file holds ``uint8(leaky_transform(leaky_transform(view)))``: 255 where the first transform gave 0, NaN -> 0
+    where it gave more than 1, values in (0, 1) land above 255 and wrap in the uint8 cast.  Reproduced here as it is
+    (the state has not moved since the previous label, so ``view`` is the state's); ``stale_transforms`` = how many such
+    labels directly precede this one (each adds one more application).  Pinned by the ``seqA_603000`` files of
+    tests/golden/harness.npz, which the reference script wrote.
     """
     H, W = int(shape[0]), int(shape[1])
     K = int(volume_bins)
@@ -420,7 +427,9 @@ def encode_taf_label(dat, shape, state, start_time, window_us, bins, volume_bins
     max_w = 64
     n = dat.numel() * dat.element_size() // 8
     if bins <= 0:
-        vol = leaky_transform(state.permute(3, 2, 0, 1).contiguous())  # (K, 2, H, W), :226-227
+        vol = state.permute(3, 2, 0, 1).contiguous()  # (K, 2, H, W), the view of :55
+        for _ in range(2 + int(stale_transforms)):    # :226-227 on the stale, already transformed volume
+            vol = leaky_transform(vol)
         u8 = quantize_u8(vol)
         return torch.flip(u8, dims=[0]).contiguous() if flip_k else u8
     cuts = [0]

