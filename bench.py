@@ -55,6 +55,16 @@ def ev_algorithmic_bytes(n, H, W, bins):
     return 8 * n + 4 * 2 * bins * H * W
 
 
+def sae_algorithmic_bytes(n, H, W, n_lam):
+    """8 B per event + the (2, H, W) f32 memory read and written + the f32 (2 * n_lam, H, W) output."""
+    return 8 * n + 2 * (4 * 2 * H * W) + 4 * 2 * n_lam * H * W
+
+
+def eci_algorithmic_bytes(n, H, W):
+    """8 B per event + the f32 (2, H, W) output."""
+    return 8 * n + 4 * 2 * H * W
+
+
 def kernel_source_sha():
     """Identity of the encoder kernels a PMC traffic figure belongs to."""
     h = hashlib.sha256()
@@ -378,7 +388,8 @@ def main():
         result["also"] = bench_also(args, torch, synth, er, timer, rank, n_gpus, copy_gbs)
         # the shape BASELINE.json's metric names (GEN1 304x240), promoted: a block of its own and a compact copy inside
         # `roofline` (the keys the driver keeps when it parses the line)
-        for row, tag in zip(result["also"], ("taf_gen1", "taf_gen1_x64", "ev_gen1", "ev_gen1_x64", "taf_mpx_hotspot")):
+        for row, tag in zip(result["also"], ("taf_gen1", "taf_gen1_x64", "ev_gen1", "ev_gen1_x64", "sae_gen1", "eci_gen1",
+                                             "taf_mpx_hotspot")):
             attach_traffic(row["roofline"], tag)
         names = ("taf_single", "taf_x64", "ev_single", "ev_x64")
         result["gen1"] = {k: row for k, row in zip(names, result["also"][:4])}
@@ -396,6 +407,7 @@ def main():
                 flat[f"{tag}_mev_s"] = row["value"]
                 flat[f"{tag}_ms"] = row["ms_per_step"]
                 flat[f"{tag}_frac"] = row["roofline"]["frac"]
+                flat[f"{tag}_traffic"] = row["roofline"].get("traffic")
     if not args.no_detector:
         result["detector"] = bench_detector(args, torch, world, rank, timer)
         d = result["detector"]  # the second half of BASELINE.json's metric, in the keys the driver keeps (scalars)
@@ -492,6 +504,43 @@ def bench_also(args, torch, synth, er, timer, rank, n_gpus, copy_gbs):
                 "roofline": roofline(B * ev_algorithmic_bytes(1_000_000, H2, W2, 5), dev, "frlw_ev_encode_batch (kf_ev_tile dominant)",
                                      copy_gbs, f"{B} x 1000000 events")})
     del dat5
+    # ---- Surface of Active Events (generate_surfaceofactiveevents.py:44-80): 1 M events over 5 s, 304x240, three lambdas, the
+    #      per-pixel memory carried from call to call like consecutive labels (:176-190)
+    LAM = [0.00001, 0.0000025, 0.000001]
+    ev6 = synth.synth_events(1006 + 7919 * rank, 1_000_000, W2, H2, 5_000_000, t_offset=30_000_000)
+    rec6 = synth.to_dat8(ev6)
+    dat6 = torch.from_numpy(rec6.view(np.uint8).reshape(-1, 8)).cuda()
+    now6, win6 = 35_000_000, 5_541_263
+    mem = {"m": er.encode_sae_dat(dat6, (H2, W2), LAM, None, now6, win6, check=True)[2]}
+
+    def sae_step():
+        mem["m"] = er.encode_sae_dat(dat6, (H2, W2), LAM, mem["m"], now6, win6, check=False)[2]
+    per, dev = timer.run(sae_step, steps, 3)
+    row = {"tag": "sae_gen1", "workload": "sae_gen1: Surface of Active Events, 3 lambdas, 1000000 events over 5 s, 304x240, memory carried "
+                                        "(frlw_sae_encode)",
+           "value": round(n_gpus * 1_000_000 / per / 1e6, 2), "unit": "Mevents/s", "ms_per_step": round(per * 1e3, 4),
+           "roofline": roofline(sae_algorithmic_bytes(1_000_000, H2, W2, len(LAM)), dev, "frlw_sae_encode (k_sae_tile dominant)", copy_gbs,
+                                "1000000 events")}
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+        row["cpu_baseline"] = cpu_baseline_generic(
+            lambda orc: orc.sae_stream_dat8(rec6, (H2, W2), (H2, W2), LAM, None, now6, win6), len(rec6), "sae_stream_dat8")
+    out.append(row)
+    del dat6
+    # ---- Event Count Image (BASELINE.json configs[0]; generate_eventcountimage.py:19-41): 100 k events, 304x240
+    ev7 = synth.synth_events(1001 + 7919 * rank, 100_000, W2, H2, 50_000)
+    rec7 = synth.to_dat8(ev7)
+    dat7 = torch.from_numpy(rec7.view(np.uint8).reshape(-1, 8)).cuda()
+    er.encode_eci_dat(dat7, (H2, W2), check=True)
+    per, dev = timer.run(lambda: er.encode_eci_dat(dat7, (H2, W2), check=False), steps, 3)
+    row = {"tag": "eci_gen1", "workload": "eci_gen1 (BASELINE.json configs[0]): Event Count Image, 100000 events, 304x240 (frlw_eci_encode)",
+           "value": round(n_gpus * 100_000 / per / 1e6, 2), "unit": "Mevents/s", "ms_per_step": round(per * 1e3, 4),
+           "roofline": roofline(eci_algorithmic_bytes(100_000, H2, W2), dev, "frlw_eci_encode (launch-bound at this size)", copy_gbs,
+                                "100000 events")}
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+        row["cpu_baseline"] = cpu_baseline_generic(lambda orc: orc.eci_stream_dat8(rec7, (H2, W2), (H2, W2)), len(rec7),
+                                                   "eci_stream_dat8", reps=40)
+    out.append(row)
+    del dat7
     if not args.hotspot:
         # SURVEY.md 8(d) "report both": the contention variant of the headline workload (25 % of the events in a
         # sigma = 8 px blob -> a few tiles hold most of them; skewed tiles are split by segments)
@@ -830,6 +879,27 @@ def cpu_baseline_ev(rec, H, W, budget_s=6.0):
         dt = time.perf_counter() - t0
     out["all_cores"] = {"value": round(threads * reps * len(rec) / dt / 1e6, 3), "unit": "Mevents/s", "cores": threads,
                         "sample": f"{threads} threads x {reps} encodes of the full workload each ({dt:.3f} s)"}
+    return out
+
+
+def cpu_baseline_generic(call, n_events, what, reps=8, budget_s=4.0):
+    """One of the smaller oracle encoders (oracle/frlw_oracle.c) on the same stream: one thread (best of a few runs), and one
+    independent copy per physical core (`reps` encodes per thread so that the pool's start-up does not dominate)."""
+    from oracle import oracle as orc
+    orc.build()
+    best, runs = _best_of(lambda: call(orc), budget_s, 5)
+    out = {"value": round(n_events / best / 1e6, 3), "unit": "Mevents/s", "cores": 1, "kind": "port",
+           "sample": f"the full workload ({n_events} events) through oracle.{what}, best of {runs} runs, {best:.4f} s each",
+           "cpu": cpu_model()}
+    threads = physical_cores()[0]
+    with ThreadPoolExecutor(threads) as pool:
+        t0 = time.perf_counter()
+        list(pool.map(lambda _i: [call(orc) for _ in range(reps)], range(threads)))
+        dt = time.perf_counter() - t0
+    out["all_cores"] = {"value": round(threads * reps * n_events / dt / 1e6, 3), "unit": "Mevents/s", "cores": threads,
+                        "sample": f"{threads} threads x {reps} encodes of the full workload each ({dt:.3f} s)"}
+    out["all_cores_value"] = out["all_cores"]["value"]
+    out["all_cores_threads"] = threads
     return out
 
 

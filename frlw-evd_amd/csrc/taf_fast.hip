@@ -27,7 +27,9 @@
 #include "frlw_common.h"
 
 #include <atomic>
+#include <stddef.h>
 #include <string.h>
+#include <type_traits>
 
 using namespace frlw;
 
@@ -102,6 +104,13 @@ struct FastHeader {
     uint32_t mul_bad; // != 0: float(r * (1 / den)) differs from float(r / den) for some r in [0, win]: use the table
     uint32_t unsorted[kMaxSeq]; // != 0: somewhere in the sequence an event's window is lower than its predecessor's (the
                                 // tile walk needs window-sorted lists; such a sequence takes the split + sub-tile kernels)
+    // chunk-major partition: where the next (sequence, tile) list goes in rec2[] / the next split segment id (the header is
+    // zeroed by a memset node in front of kf_scatter_cm; placement order is whatever order the workgroups arrive in -- the
+    // lists themselves, and everything computed from them, do not depend on it)
+    uint32_t rec_cursor, seg_cursor;
+    // kf_scatter_cm's first workgroup resets everything above and then publishes the call's epoch here; the other workgroups
+    // touch the header only at their very end and only once they see that epoch (no memset node: 4.8 us of every call)
+    uint32_t epoch;
 };
 static_assert(sizeof(FastHeader) <= kSelftestOffset, "header");
 
@@ -115,6 +124,8 @@ struct FastPlan {
     int bpw, chunk;
     int chunks, slabs, pairs;
     size_t off_counts, off_slabtot, off_base, off_sub, off_seg0, off_segcnt, off_errs, off_tlut, off_records, off_records2, bytes;
+    size_t off_sub_end, off_segdesc; // chunk-major partition: list ends, pair of every split segment
+    int max_seq_chunks;              // chunks of the longest sequence (the column a chunk-major consumer keeps in LDS)
     int max_segs;
 };
 
@@ -123,7 +134,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // Tile shape: 2^twl x 2^(11 - twl) pixels, the one that covers the frame with the fewest tiles (ties: the widest,
 // longest contiguous rows).
 enum : int { DIRECT_OFF = 0, DIRECT_AUTO = 1, DIRECT_FORCE = 2 };
-bool fast_plan(long long n, int n_seq, int H, int W, FastPlan &p, int direct_mode = DIRECT_AUTO)
+bool fast_plan(long long n, int n_seq, int H, int W, FastPlan &p, int direct_mode = DIRECT_AUTO, int min_bpw = 0, bool cm = false)
 {
     if (H <= 0 || W <= 0 || n < 0 || n_seq < 1 || n_seq > kMaxSeq || n >= (1ll << 31)) return false;
     long long best = -1;
@@ -143,8 +154,10 @@ bool fast_plan(long long n, int n_seq, int H, int W, FastPlan &p, int direct_mod
     // kf_split_whole is the cheaper second level (64 GEN1 streams: 820 us against 876 direct), with few events per tile the
     // 576-bin scatter costs more than the whole-tile split it replaces (one stream of 250 k events: 40 us against 46):
     // there only when forced (frlw_tuning_t::direct_bins = 1).
+    // Chunk-major partition (cm): the consumers of a direct-mode call gather their own lists -- two launches in all -- so every
+    // call with few pairs goes that way, however few events a pair holds (5 sequences of 70 k events on 97x131: 36 us against 55).
     p.direct = (direct_mode != DIRECT_OFF && kFW * p.T <= kMaxFastTiles && (long long)kFW * p.T * n_seq <= kMaxBinPairs &&
-                (direct_mode == DIRECT_FORCE || (p.pairs < 2 * kFewPairs && n >= (long long)kSplitSeg * p.pairs))) ? 1 : 0;
+                (direct_mode == DIRECT_FORCE || (p.pairs < 2 * kFewPairs && (cm || n >= (long long)kSplitSeg * p.pairs)))) ? 1 : 0;
     p.TB = p.direct ? kFW * p.T : p.T;
     p.bin_shift = p.direct ? 4 : 0;
     p.pairs_b = p.TB * n_seq;
@@ -160,7 +173,13 @@ bool fast_plan(long long n, int n_seq, int H, int W, FastPlan &p, int direct_mod
     if (k < 1) k = 1;
     long long ce = (n + 512 * k - 1) / (512 * k);
     ce = (ce + 15) / 16 * 16;
+    // cm: a consumer gathers one run per chunk, so a call that cannot fill 512 workgroups anyway takes the largest chunks there are
+    // (one GEN1 stream: 144 chunks of 6944 events instead of 509 of 1968: 32 us against 50)
+    if (cm && k == 1) ce = cap;
     if (ce < 1024) ce = 1024; // tiny calls: keep whole 64-event batches per wavefront
+    // frlw_tuning_t::batches_per_wave: at least this many 64-event batches per wavefront (only ever LARGER chunks than the
+    // default: the workspace query budgets the default's chunk count)
+    if (min_bpw > 0 && ce < (long long)min_bpw * kFT) ce = (long long)min_bpw * kFT;
     if (ce > cap) ce = cap;
     p.chunk = (int)ce;
     p.bpw = (p.chunk / kFW + kWave - 1) / kWave;
@@ -172,6 +191,7 @@ bool fast_layout(const int64_t *seq_offsets, const int64_t *t_start, int n_seq, 
 {
     S.n_seq = n_seq;
     int c = 0, sl = 0;
+    p.max_seq_chunks = 1;
     for (int s = 0; s < n_seq; ++s) {
         const long long n_s = seq_offsets[s + 1] - seq_offsets[s];
         if (n_s < 0) return false;
@@ -181,6 +201,7 @@ bool fast_layout(const int64_t *seq_offsets, const int64_t *t_start, int n_seq, 
         S.t0[s] = t_start[s];
         int cs = (int)((n_s + p.chunk - 1) / p.chunk);
         if (cs < 1) cs = 1; // an empty sequence keeps one (empty) chunk: no special cases downstream
+        if (cs > p.max_seq_chunks) p.max_seq_chunks = cs;
         c += cs;
         sl += (cs + kFastSlab - 1) / kFastSlab;
     }
@@ -202,6 +223,8 @@ bool fast_layout(const int64_t *seq_offsets, const int64_t *t_start, int n_seq, 
     p.off_tlut = off;    off = align_up(off + (size_t)(win + 1) * 4, 256);
     p.off_records = off; off = align_up(off + (size_t)(n > 0 ? n : 1) * 4, 256);
     p.off_records2 = off; off = align_up(off + (size_t)(n > 0 ? n : 1) * 4, 256);
+    p.off_sub_end = off; off = align_up(off + ((size_t)p.pairs * kFW + 1) * 4, 256);
+    p.off_segdesc = off; off = align_up(off + (size_t)p.max_segs * 4, 256);
     p.bytes = off;
     return true;
 }
@@ -694,6 +717,155 @@ __global__ __launch_bounds__(kFT) void kf_scatter(FastGeom G, SeqTab S, const ui
     }
 }
 
+// ---- 3'. chunk-major scatter: the partition WITHOUT a histogram pass (round 4) -----------------------------------------
+// kf_hist exists only so that kf_scatter knows, before it writes, where every (chunk, bin) run goes in a bin-major array --
+// a whole extra pass over the 8-byte events (80 MB and 19 us at 10 M events) plus two scan launches.  Here the scatter
+// workgroup sorts its chunk by bin in LDS exactly as before and writes it out AS IT IS, chunk-major: chunk c's records
+// occupy rec[first event of c - first event of the call ...) in one linear sweep (whole lines, no per-record address), and
+// the chunk leaves one directory row dir[c][bin] = count << 16 | offset of the bin's run inside the chunk.  A bin's list is
+// then the concatenation of its runs in chunk order -- still stream order -- and whoever consumes the bin reads its column
+// of the directory (a few hundred to a few thousand entries), prefix-sums it in LDS and gathers the runs (col_* below).
+// The kernel also does what kf_hist did on the side: the per-call value table + the check that multiplying by 1 / den gives
+// the same floats, the data-dependent status (straight into the header: no per-chunk flags to fold), the window masks.
+__host__ __device__ inline size_t scatter_cm_lds_bytes(int T, int chunk)
+{
+    return (size_t)kFW * T * 4 + (size_t)(T + 2) * 4 + (size_t)chunk * 4 + 16;
+}
+
+template <bool HAS_MAP, bool EV = false, bool SIMPLE = false>
+__global__ __launch_bounds__(kFT) void kf_scatter_cm(FastGeom G, SeqTab S, uint32_t *dir, uint32_t *records, FastHeader *hdr, float *tlut_w,
+                                                     uint32_t epoch)
+{
+    extern __shared__ uint32_t lds[];
+    const int T = G.T;
+    uint32_t *wcnt_all = lds;                    // [16][T]: per-wavefront running counts, then prefixes
+    uint32_t *loff = wcnt_all + (size_t)kFW * T; // [T + 1] slot of bin b's first record in the staged chunk
+    uint32_t *stage = loff + ((T + 2) & ~1);
+    __shared__ uint32_t wtot[kFW];
+    __shared__ unsigned long long wg_seen;
+    __shared__ int serr;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int chunk = (int)chunk_of_block(blockIdx.x, gridDim.x);
+    const int s = seq_of_chunk(S, chunk);
+    uint32_t *wcnt = wcnt_all + (size_t)wv * T;
+    for (int b = tid; b < kFW * T; b += kFT) wcnt_all[b] = 0;
+    if (tid == 0) { wg_seen = 0ull; serr = 0; }
+    if (blockIdx.x == 0) {
+        // The header's per-call words are reset HERE, by the workgroup the dispatcher starts first, instead of by a memset node
+        // in front of the kernel.  Every other workgroup writes to the header only at its very end and only after it has seen
+        // this call's epoch (published below, behind the reset): the first workgroup is resident before any other one starts,
+        // so that wait always ends.
+        uint32_t *h32 = (uint32_t *)hdr;
+        for (int i = tid; i < (int)(offsetof(FastHeader, epoch) / 4); i += kFT) h32[i] = 0u;
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(&hdr->epoch, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+
+    const long long chunk_begin = S.ev0[s] + (long long)(chunk - S.chunk0[s]) * G.chunk_ev;
+    const long long wave_begin = chunk_begin + (long long)wv * G.run; // wavefront w owns the w-th run of the chunk
+    const long long left = S.ev0[s + 1] - wave_begin;
+    const uint32_t nloc = left < (long long)G.run ? (uint32_t)(left < 0 ? 0 : left) : (uint32_t)G.run;
+    const long long t0 = S.t0[s];
+    uint2 q[kMaxBpw];
+    if (nloc > 0) { // wave-uniform; no load under a lane condition: lanes behind the run's end re-read its last event
+        const uint2 *src = G.data + wave_begin;
+#pragma unroll
+        for (int j = 0; j < kMaxBpw; ++j) {
+            const uint32_t i = (uint32_t)(j * kWave + lane);
+            q[j] = src[i < nloc ? i : nloc - 1u];
+        }
+    }
+    // the per-call value table, spread over the grid while the event loads fly (generate_taf.py:215,:26 /
+    // generate_eventvolume.py:141,:23): tlut[r] and the exhaustive check "float(r * (1 / den)) == float(r / den) for every r"
+    if (tlut_w) {
+        const double den = EV ? (double)G.win : (double)G.win + 1e-8, rcp = G.rcp;
+        bool bad = false;
+        for (long long r = (long long)blockIdx.x * kFT + tid; r <= (long long)G.win; r += (long long)gridDim.x * kFT) {
+            const float exact = (float)((double)r / den);
+            bad |= (float)((double)r * rcp) != exact;
+            tlut_w[r] = EV ? exact : exact - 1.0f;
+        }
+        if (bad) atomicOr(&serr, ST_MULBAD); // (reaches the header with the other flags, at the end)
+    }
+    __syncthreads();
+    // ---- phase A: stream rank of every event inside (wavefront, bin), one returning LDS atomic each (lane order = stream order)
+    uint32_t where[kMaxBpw], word[kMaxBpw];
+    unsigned long long wseen = 0ull;
+    int err = 0;
+#pragma unroll
+    for (int j = 0; j < kMaxBpw; ++j) {
+        where[j] = 0xffffffffu;
+        word[j] = 0u;
+        if (j < G.bpw) {
+            const uint32_t i = (uint32_t)(j * kWave + lane);
+            if (i < nloc) {
+                const FastEv o = fast_decode<HAS_MAP, EV, SIMPLE>(G, q[j], t0);
+                err |= o.err;
+                if (o.tile >= 0) {
+                    const uint32_t r = atomicAdd(&wcnt[o.tile], 1u);
+                    where[j] = ((uint32_t)o.tile << 16) | r;
+                    word[j] = o.word;
+                    wseen |= 1ull << o.window;
+                }
+            }
+        }
+    }
+    if (err) atomicOr(&serr, err);
+    __syncthreads();
+    // ---- phase B: per bin, exclusive prefix of the 16 wavefront counts; chunk-local offsets of the bins
+    uint32_t mine = 0; // records of bin `tid` in this chunk
+    for (int b = tid; b < T; b += kFT) {
+        uint32_t run = 0;
+#pragma unroll
+        for (int w = 0; w < kFW; ++w) {
+            const uint32_t v = wcnt_all[(size_t)w * T + b];
+            wcnt_all[(size_t)w * T + b] = run;
+            run += v;
+        }
+        mine = run;
+    }
+    const uint32_t inc = wave_incl_scan(mine);
+    if (lane == kWave - 1) wtot[wv] = inc;
+    __syncthreads();
+    uint32_t pre = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < kFW; ++k) { if (k < wv) pre += wtot[k]; total += wtot[k]; }
+    const uint32_t my_off = pre + inc - mine;
+    if (tid < T) {
+        loff[tid] = my_off;
+        dir[(long long)chunk * T + tid] = (mine << 16) | my_off; // the chunk's directory row (every chunk writes all of it)
+    }
+    __syncthreads();
+    // ---- phase C: stage the chunk bin-major in LDS
+#pragma unroll
+    for (int j = 0; j < kMaxBpw; ++j) {
+        if (j < G.bpw && where[j] != 0xffffffffu) {
+            const uint32_t b = where[j] >> 16;
+            stage[loff[b] + wcnt[b] + (where[j] & 0xffffu)] = word[j];
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const unsigned lo = __shfl_xor((unsigned)wseen, off), hi = __shfl_xor((unsigned)(wseen >> 32), off);
+        wseen |= ((unsigned long long)hi << 32) | lo;
+    }
+    if (lane == 0 && wseen) atomicOr(&wg_seen, wseen);
+    __syncthreads();
+    // ---- phase D: the staged chunk leaves as it is, one linear sweep into the chunk's own stretch of rec[]
+    uint32_t *dst = records + (chunk_begin - S.ev0[0]);
+    for (uint32_t qi = tid; qi < total; qi += kFT) dst[qi] = stage[qi];
+    if (tid == 0) {
+        while (__hip_atomic_load(&hdr->epoch, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(2);
+        const unsigned long long m = wg_seen;
+        const unsigned long long have = __hip_atomic_load(&hdr->wmask[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (m & ~have) atomicOr(&hdr->wmask[s], m);
+        const int e = serr;
+        if (e & ~ST_MULBAD) { atomicOr(&hdr->status, e & ~ST_MULBAD); fold_sticky_status(hdr, e & ~ST_MULBAD); }
+        if (e & ST_MULBAD) hdr->mul_bad = 1u; // (every writer stores the same value)
+    }
+}
+
 // ---- 4. per-tile split by sub-tile, 5. one wavefront per sub-tile -----------------------------------------
 struct TileP {
     int H, W, twl, thl, tiles_x, T, K, n_windows, wb, flip;
@@ -702,6 +874,8 @@ struct TileP {
     uint32_t *rec2;        // the same records, inside every tile sub-tile-major (split output)
     const uint32_t *base;  // [pairs + 1]
     uint32_t *sub;         // [pairs * 16 + 1] first record of every sub-tile in rec2
+    uint32_t *sub_end;     // chunk-major partition: [pairs * 16] end of every sub-tile's list (lists are placed through a cursor,
+                           // not back to back in pair order); NULL otherwise: a list ends where the next one starts
     const uint32_t *seg0;  // [pairs + 1] first split segment of every (sequence, tile) pair
     uint32_t *segcnt;      // [segments][16] records of every sub-tile in a segment, then their offsets inside the sub-tile
     int pairs;
@@ -719,6 +893,78 @@ struct TileP {
     float *view_f32; // (B, 2K, H, W) or NULL
     uint8_t *out_u8; // (B, K, 2, H, W) or NULL
 };
+
+// ---- the consumer side of the chunk-major partition: a bin's column of the directory ----------------------------------
+constexpr int kColMax = 4096; // chunks per sequence a consumer keeps in LDS (32 KB); longer sequences take the histogram path
+
+struct CmP { // kernel argument of the chunk-major consumers
+    const uint32_t *dir; // [chunks][TB]: count << 16 | offset of the bin's run inside the chunk's records
+    const uint32_t *rec; // chunk-major records (kf_scatter_cm)
+    int TB;              // bins per sequence
+    int chunk_ev;        // events per chunk = records a chunk's stretch of rec[] can hold
+    uint32_t *hot_start; // [pairs] skewed tiles: where the tile's 16 lists start in rec2[]
+    uint32_t *hot_seg0;  // [pairs] ... and the id of the tile's first split segment
+    uint32_t *segdesc;   // [max_segs] pair of every split segment
+    int max_segs;
+};
+
+// Column of bin `b` of sequence `s`: L[c] = records of the bin in the sequence's chunks before c (L[C] = all of them, the
+// return value), D[c] = index in rec[] of the bin's first record of chunk c MINUS L[c] -- list position i (stream order) is
+// rec[D[c] + i] for the chunk c with L[c] <= i < L[c + 1].  NT threads, workgroup barriers inside; wsum: NT / 64 + 1 words.
+template <int NT>
+__device__ __forceinline__ uint32_t col_load(const CmP &m, const SeqTab &S, int s, int b, uint32_t *L, uint32_t *D, uint32_t *wsum)
+{
+    constexpr int NWV = NT / kWave;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int c0 = S.chunk0[s], C = S.chunk0[s + 1] - c0; // >= 1: an empty sequence keeps one (empty) chunk
+    const uint32_t out0 = (uint32_t)(S.ev0[s] - S.ev0[0]);
+    uint32_t carry = 0;
+    for (int cb = 0; cb < C; cb += NT) { // passes of NT chunks, one per thread (workgroup-uniform trip count: usually one)
+        const int c = cb + tid;
+        // (clamped index, masked value: no load sits under a lane condition)
+        const uint32_t v = m.dir[(long long)(c0 + (c < C ? c : C - 1)) * m.TB + b];
+        const uint32_t e = c < C ? v : 0u, cnt = e >> 16;
+        const uint32_t inc = wave_incl_scan(cnt);
+        if (lane == kWave - 1) wsum[wv] = inc;
+        __syncthreads();
+        uint32_t run = carry + inc - cnt, total = 0;
+#pragma unroll
+        for (int k = 0; k < NWV; ++k) { if (k < wv) run += wsum[k]; total += wsum[k]; }
+        if (c < C) {
+            L[c] = run;
+            D[c] = out0 + (uint32_t)c * (uint32_t)m.chunk_ev + (e & 0xffffu) - run;
+        }
+        carry += total;
+        __syncthreads(); // wsum is reused by the next pass
+    }
+    if (tid == 0) L[C] = carry;
+    __syncthreads();
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)carry); // (uniform for the compiler too: scalar branches downstream)
+}
+
+// idx[(i - lo) >> 4] = the chunk that holds list position i, for every i = lo (mod 16) ... in [lo, hi) -- lo a multiple of 16:
+// a lane then finds its own position's chunk with the short walk of col_addr instead of a bisection.  Call after col_load.
+template <int NT>
+__device__ __forceinline__ void col_index(const uint32_t *L, int C, uint32_t lo, uint32_t hi, uint16_t *idx)
+{
+    for (int c = threadIdx.x; c < C; c += NT) {
+        const uint32_t a = L[c] > lo ? L[c] : lo, z = L[c + 1] < hi ? L[c + 1] : hi;
+        for (uint32_t i = (a + 15u) & ~15u; i < z; i += 16u) idx[(i - lo) >> 4] = (uint16_t)c;
+    }
+}
+
+__device__ __forceinline__ uint32_t col_addr(const uint32_t *L, const uint32_t *D, uint32_t c, uint32_t i) // c: a chunk at or in front of i's
+{
+    // (i < L[C]: ends inside the column; empty runs are stepped over).  Two steps without a branch -- 16 positions rarely span
+    // more runs -- then the loop for whoever is still short
+    c += L[c + 1] <= i ? 1u : 0u;
+    c += L[c + 1] <= i ? 1u : 0u;
+#ifndef COLX
+    if (__builtin_expect(__ballot(L[c + 1] <= i) != 0ull, 0))
+        while (L[c + 1] <= i) ++c;
+#endif
+    return D[c] + i;
+}
 
 constexpr int kMaxK = 8;
 
@@ -814,19 +1060,27 @@ __device__ __forceinline__ void split_count_segment(const TileP &q, uint32_t seg
 constexpr int kWholeChunks = FRLW_WHOLE_SEGS;
 constexpr int kWholeBatches = kWholeChunks * kSplitSeg / kWave; // 512 batches of 64 records
 constexpr int kWholeRow = kWholeBatches + 1;                    // row stride of scnt: the 16 counters of one batch in 16 banks
-__global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(8, 8))) void kf_split_whole(TileP q) // (64 VGPRs: two workgroups per CU)
+// CM (chunk-major partition): the tile's list is not contiguous -- it is gathered from the tile's column of the directory
+// (col_*), the 16 sub-tile lists go wherever the header's cursor says, and a skewed tile only books its space and its split
+// segments here (kf_segcount_cm / kf_split_place<true> do the work: the segments are not known before this kernel runs).
+template <bool CM>
+__global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(8, 8))) void kf_split_whole(TileP q, CmP cm, SeqTab S) // (64 VGPRs: two workgroups per CU)
 {
     constexpr int RPT = kSplitSeg / kFT; // 8 records per thread and chunk of 8192
-    __shared__ uint32_t scnt[kFW * kWholeRow]; // [sub-tile][batch] tickets, then exclusive prefixes
+    // scnt [sub-tile][batch] tickets, then exclusive prefixes | stage: one chunk of records, sub-tile-major.  CM, while the
+    // list is gathered (before either is used): the column L | D | the position index
+    __shared__ __attribute__((aligned(16))) uint32_t pool[kFW * kWholeRow + kSplitSeg];
+    uint32_t *scnt = pool, *stage = pool + kFW * kWholeRow;
+    static_assert(2 * kColMax + 1 + kSplitWhole / 32 + 1 <= kFW * kWholeRow + kSplitSeg, "the column fits the pool");
     __shared__ uint32_t wtot[kFW][kFW];        // segment counting (4b): [wavefront][sub-tile]
     __shared__ uint32_t vtot[kFW];             // records of every sub-tile
     __shared__ uint32_t vbeg[kFW][kFW];        // [wavefront]: every wavefront's own copy of the sub-tile starts
     __shared__ uint32_t cE[kFW][kFW], cD[kFW][kFW]; // [wavefront]: per chunk, see step 4
-    __shared__ uint32_t stage[kSplitSeg];      // one chunk of records, sub-tile-major
+    __shared__ uint32_t s_start, s_first;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (q.hdr->status != 0) return;
     const int blk = (int)blockIdx.x + q.first_block;
-    if (blk >= q.pairs) { // the blocks behind the tiles: one segment of a skewed tile each (4b, counting)
+    if (!CM && blk >= q.pairs) { // the blocks behind the tiles: one segment of a skewed tile each (4b, counting)
         if (q.first_block && blk == q.pairs && tid == 0) q.sub[(long long)q.pairs * kFW] = q.base[q.pairs]; // (the last tile's block is not there to do it)
         const uint32_t nseg = q.seg0[q.pairs];
         for (uint32_t seg = (uint32_t)(blk - q.pairs); seg < nseg; seg += (uint32_t)q.seg_grid) {
@@ -836,24 +1090,73 @@ __global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         return;
     }
     const int g = blk;
-    const uint32_t beg = q.base[g], end = q.base[g + 1];
-    if (g == q.pairs - 1 && tid == 0) q.sub[(long long)q.pairs * kFW] = end; // end of the last sub-tile's list
-    if (end - beg > whole_max_of(q.pairs) || q.skip_whole) return; // a skewed tile (or a call with few tiles): left to the segment kernels below
-    if (q.tile_walk && q.hdr->unsorted[g / q.T] == 0u) return;     // split in LDS by kf_taf_tile
-    const uint32_t n = end - beg;
-    if (n == 0u) {
-        if (tid < kFW) q.sub[(long long)g * kFW + tid] = beg;
-        return;
-    }
-    // 1. the whole list into registers (indices clamped: no load sits under a lane condition)
+    uint32_t beg, n;
     uint32_t m[kWholeChunks][RPT];
-#pragma unroll
-    for (int c = 0; c < kWholeChunks; ++c)
-#pragma unroll
-        for (int u = 0; u < RPT; ++u) {
-            const uint32_t i = (uint32_t)(c * kSplitSeg + u * kFT + tid);
-            m[c][u] = q.rec[beg + (i < n ? i : n - 1u)];
+    if (CM) {
+        uint32_t *colL = pool, *colD = pool + kColMax + 1;
+        uint16_t *idx = (uint16_t *)(pool + 2 * kColMax + 1);
+        const int s = g / q.T, C = S.chunk0[s + 1] - S.chunk0[s];
+        // (readfirstlane: the workgroup-uniform values that come out of LDS are uniform for the COMPILER too -- as vector values
+        // they turned every "is this chunk of the list there at all" test below into divergent control flow, and 19 of the 32
+        // records were spilled)
+        n = col_load<kFT>(cm, S, s, g - s * q.T, colL, colD, &wtot[0][0]);
+        if (n == 0u) {
+            if (tid < kFW) { q.sub[(long long)g * kFW + tid] = 0u; q.sub_end[(long long)g * kFW + tid] = 0u; }
+            return;
         }
+        const bool hot = n > q.tile_max;
+        if (tid == 0) {
+            s_start = atomicAdd(&q.hdr->rec_cursor, n); // the tile's 16 lists: n records of rec2[] from here
+            if (hot) s_first = atomicAdd(&q.hdr->seg_cursor, (n + kSplitSeg - 1) / kSplitSeg);
+        }
+        if (hot) { // a skewed tile (or a call with few tiles): cut into segments of 8192 list positions, one workgroup each
+            __syncthreads();
+            const uint32_t nseg = (n + kSplitSeg - 1) / kSplitSeg, first = s_first;
+            if (tid == 0) { cm.hot_start[g] = s_start; cm.hot_seg0[g] = first; }
+            for (uint32_t k = tid; k < nseg; k += kFT)
+                if (first + k < (uint32_t)cm.max_segs) cm.segdesc[first + k] = (uint32_t)g;
+            return;
+        }
+        col_index<kFT>(colL, C, 0u, n, idx);
+        __syncthreads();
+        // 1. the whole list into registers: list position -> chunk through the index + a walk over at most a few run boundaries
+        // (two sweeps: every index first -- LDS work only, nothing in flight -- then the loads through one buffer descriptor with
+        // 32-bit offsets: with 64-bit addresses next to the 32 records the compiler spilled 19 of them, each spill waiting for
+        // its load)
+        {
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)cm.rec, 0, 0xffffffffu, 0x00020000);
+#pragma unroll
+            for (int c = 0; c < kWholeChunks; ++c) {
+#pragma unroll
+                for (int u = 0; u < RPT; ++u) {
+                    const uint32_t i = (uint32_t)(c * kSplitSeg + u * kFT + tid), ic = i < n ? i : n - 1u;
+                    const uint32_t off = (uint32_t)(c * kSplitSeg) < n ? col_addr(colL, colD, idx[ic >> 4], ic) : 0u;
+                    m[c][u] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(off << 2), 0, 0);
+                }
+            }
+        }
+        beg = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_start);
+        __syncthreads(); // the column is dead: its space becomes scnt / stage
+    } else {
+        beg = q.base[g];
+        const uint32_t end = q.base[g + 1];
+        if (g == q.pairs - 1 && tid == 0) q.sub[(long long)q.pairs * kFW] = end; // end of the last sub-tile's list
+        if (end - beg > whole_max_of(q.pairs) || q.skip_whole) return; // a skewed tile (or a call with few tiles): left to the segment kernels below
+        if (q.tile_walk && q.hdr->unsorted[g / q.T] == 0u) return;     // split in LDS by kf_taf_tile
+        n = end - beg;
+        if (n == 0u) {
+            if (tid < kFW) q.sub[(long long)g * kFW + tid] = beg;
+            return;
+        }
+        // 1. the whole list into registers (indices clamped: no load sits under a lane condition)
+#pragma unroll
+        for (int c = 0; c < kWholeChunks; ++c)
+#pragma unroll
+            for (int u = 0; u < RPT; ++u) {
+                const uint32_t i = (uint32_t)(c * kSplitSeg + u * kFT + tid);
+                m[c][u] = q.rec[beg + (i < n ? i : n - 1u)];
+            }
+    }
     for (int i = tid; i < kFW * kWholeRow; i += kFT) scnt[i] = 0u;
     __syncthreads();
     // 2. tickets: batch (c, u, wv) of the stream, counter [sub-tile][batch]; packed four to a register (a ticket is < 64)
@@ -900,7 +1203,10 @@ __global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         }
         if (lane < kFW) {
             vbeg[wv][lane] = beg + inc - t;
-            if (wv == 0) q.sub[(long long)g * kFW + lane] = beg + inc - t;
+            if (wv == 0) {
+                q.sub[(long long)g * kFW + lane] = beg + inc - t;
+                if (CM) q.sub_end[(long long)g * kFW + lane] = beg + inc;
+            }
         }
         LDS_FENCE();
     }
@@ -973,20 +1279,47 @@ struct PlaceLds {
     uint32_t stage[kSplitSeg];          // the segment's records, sub-tile-major
 };
 
-__device__ __forceinline__ void split_place_segment(const TileP &q, uint32_t seg, PlaceLds &L)
+// CM: the chunk-major partition's form -- the segment is 8192 positions of the tile's list, gathered through the tile's column
+// of the directory (cl: L | D | position index, loaded per segment); the tile's space and segment ids were booked by
+// kf_split_whole<true>.
+struct ColLds {
+    uint32_t L[kColMax + 1], D[kColMax];
+    uint16_t idx[kSplitSeg / 16];
+    uint32_t wsum[kFW + 1];
+};
+
+template <bool CM>
+__device__ __forceinline__ void split_place_segment(const TileP &q, uint32_t seg, PlaceLds &L, const CmP &cm, const SeqTab &S, ColLds *cl)
 {
     constexpr int RPT = kSplitRpt, NE = RPT * kFW;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int g = pair_of_segment(q.seg0, q.pairs, seg);
-    const uint32_t beg = q.base[g] + (seg - q.seg0[g]) * (uint32_t)kSplitSeg;
-    const uint32_t end = q.base[g + 1] - beg < (uint32_t)kSplitSeg ? q.base[g + 1] : beg + kSplitSeg;
-    const uint32_t nrec = end - beg;
+    int g;
+    uint32_t beg, nrec, seg_first, seg_last, tile_start;
+    if (CM) {
+        g = __builtin_amdgcn_readfirstlane((int)cm.segdesc[seg]);
+        const int s = g / q.T;
+        const uint32_t n = col_load<kFT>(cm, S, s, g - s * q.T, cl->L, cl->D, cl->wsum);
+        seg_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)cm.hot_seg0[g]);
+        seg_last = seg_first + (n + kSplitSeg - 1) / kSplitSeg;
+        beg = (seg - seg_first) * (uint32_t)kSplitSeg; // a list position
+        nrec = n - beg < (uint32_t)kSplitSeg ? n - beg : (uint32_t)kSplitSeg;
+        tile_start = (uint32_t)__builtin_amdgcn_readfirstlane((int)cm.hot_start[g]);
+        col_index<kFT>(cl->L, S.chunk0[s + 1] - S.chunk0[s], beg, beg + nrec, cl->idx);
+    } else {
+        g = pair_of_segment(q.seg0, q.pairs, seg);
+        beg = q.base[g] + (seg - q.seg0[g]) * (uint32_t)kSplitSeg;
+        const uint32_t end = q.base[g + 1] - beg < (uint32_t)kSplitSeg ? q.base[g + 1] : beg + kSplitSeg;
+        nrec = end - beg;
+        seg_first = q.seg0[g];
+        seg_last = q.seg0[g + 1];
+        tile_start = q.base[g];
+    }
     for (int i = tid; i < RPT * kFW * kFW; i += kFT) (&L.scnt[0][0][0])[i] = 0u;
     // where this segment's records of sub-tile v (= this wavefront) go: v's list starts behind the lists of the
     // sub-tiles before it, and the earlier segments of the tile come first inside it.  Every workgroup adds up the
     // tile's segment counts for itself (<= a few hundred segments x 16 values, L2-resident).
     uint32_t before = 0, total = 0;
-    for (uint32_t sg = q.seg0[g] + lane; sg < q.seg0[g + 1]; sg += kWave) {
+    for (uint32_t sg = seg_first + lane; sg < seg_last; sg += kWave) {
         const uint32_t c = q.segcnt[(long long)sg * kFW + wv];
         total += c;
         if (sg < seg) before += c;
@@ -994,15 +1327,24 @@ __device__ __forceinline__ void split_place_segment(const TileP &q, uint32_t seg
 #pragma unroll
     for (int o2 = 32; o2 >= 1; o2 >>= 1) { before += __shfl_xor(before, o2); total += __shfl_xor(total, o2); }
     if (lane == 0) L.vtot[wv] = total;
-    __syncthreads();
-    uint32_t vstart = q.base[g];
+    __syncthreads(); // (CM: also orders col_index's writes before the reads below)
+    uint32_t vstart = tile_start;
     for (int k = 0; k < wv; ++k) vstart += L.vtot[k];
-    if (seg == q.seg0[g] && lane == 0) q.sub[(long long)g * kFW + wv] = vstart; // the tile's first segment publishes sub[]
+    if (seg == seg_first && lane == 0) { // the tile's first segment publishes sub[]
+        q.sub[(long long)g * kFW + wv] = vstart;
+        if (CM) q.sub_end[(long long)g * kFW + wv] = vstart + total;
+    }
     uint32_t m[RPT], rk[RPT];
 #pragma unroll
     for (int u = 0; u < RPT; ++u) {
         const uint32_t i = (uint32_t)(u * kFT + tid);
-        m[u] = i < nrec ? q.rec[beg + i] : 0u;
+        if (CM) {
+            const uint32_t ic = i < nrec ? i : nrec - 1u; // (nrec >= 1: a segment is never empty)
+            const uint32_t v = cm.rec[col_addr(cl->L, cl->D, cl->idx[ic >> 4], beg + ic)];
+            m[u] = i < nrec ? v : 0u;
+        } else {
+            m[u] = i < nrec ? q.rec[beg + i] : 0u;
+        }
     }
 #pragma unroll
     for (int u = 0; u < RPT; ++u) {
@@ -1056,16 +1398,60 @@ __device__ __forceinline__ void split_place_segment(const TileP &q, uint32_t seg
     }
 }
 
-__global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(8, 8))) void kf_split_place(TileP q)
+template <bool CM>
+__global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(8, 8))) void kf_split_place(TileP q, CmP cm, SeqTab S)
 {
     __shared__ PlaceLds L;
+    __shared__ typename std::conditional<CM, ColLds, uint32_t>::type clmem; // the column: only the chunk-major form has one
+    ColLds *cl = reinterpret_cast<ColLds *>(&clmem);
     if (q.hdr->status != 0) return;
-    const uint32_t nseg = q.seg0[q.pairs];
+    uint32_t nseg = CM ? q.hdr->seg_cursor : q.seg0[q.pairs];
+    if (CM && nseg > (uint32_t)cm.max_segs) nseg = (uint32_t)cm.max_segs;
     for (uint32_t seg = blockIdx.x; seg < nseg; seg += gridDim.x) { // (workgroup-uniform: most calls have no segment at all)
-        split_place_segment(q, seg, L);
+        split_place_segment<CM>(q, seg, L, cm, S, cl);
         __syncthreads(); // the LDS image is reused
     }
 }
+
+// chunk-major partition: records of every sub-tile in every split segment (kf_split_whole<false> does this in its spare
+// workgroups; here the segments only exist once kf_split_whole<true> has run).  Most calls have none: the workgroups leave
+// after one load.
+__global__ __launch_bounds__(kFT) void kf_segcount_cm(TileP q, CmP cm, SeqTab S)
+{
+    __shared__ ColLds cl;
+    __shared__ uint32_t wtot[kFW][kFW];
+    const int tid = threadIdx.x, wv = tid >> 6;
+    if (q.hdr->status != 0) return;
+    uint32_t nseg = q.hdr->seg_cursor;
+    if (nseg > (uint32_t)cm.max_segs) nseg = (uint32_t)cm.max_segs;
+    for (uint32_t seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
+        const int g = __builtin_amdgcn_readfirstlane((int)cm.segdesc[seg]), s = g / q.T;
+        const uint32_t n = col_load<kFT>(cm, S, s, g - s * q.T, cl.L, cl.D, cl.wsum);
+        const uint32_t beg = (seg - (uint32_t)__builtin_amdgcn_readfirstlane((int)cm.hot_seg0[g])) * (uint32_t)kSplitSeg;
+        const uint32_t nrec = n - beg < (uint32_t)kSplitSeg ? n - beg : (uint32_t)kSplitSeg;
+        col_index<kFT>(cl.L, S.chunk0[s + 1] - S.chunk0[s], beg, beg + nrec, cl.idx);
+        if (tid < kFW * kFW) (&wtot[0][0])[tid] = 0u;
+        __syncthreads();
+        uint32_t v[kSplitRpt];
+#pragma unroll
+        for (int u = 0; u < kSplitRpt; ++u) {
+            const uint32_t i = (uint32_t)(u * kFT + tid), ic = i < nrec ? i : nrec - 1u;
+            v[u] = cm.rec[col_addr(cl.L, cl.D, cl.idx[ic >> 4], beg + ic)];
+        }
+#pragma unroll
+        for (int u = 0; u < kSplitRpt; ++u)
+            if ((uint32_t)(u * kFT + tid) < nrec) atomicAdd(&wtot[wv][(v[u] & (kCells - 1)) >> 8], 1u);
+        __syncthreads();
+        if (tid < kFW) {
+            uint32_t t = 0;
+#pragma unroll
+            for (int w = 0; w < kFW; ++w) t += wtot[w][tid];
+            q.segcnt[(long long)seg * kFW + tid] = t;
+        }
+        __syncthreads(); // the column and wtot are reused
+    }
+}
+
 
 // 5. One workgroup of eight wavefronts per (sequence, tile, sub-tile of 256 cells).  The per-window sums of a cell do
 // not depend on each other -- only the FIFO steps that consume them are sequential -- so the eight wavefronts take ONE
@@ -1093,8 +1479,15 @@ constexpr int kWalkThreads = kWalkWaves * kWave;
 constexpr int kWalkRpt = 4;                 // records per lane and pass
 constexpr int kWalkChunk = kWalkRpt * kWave;
 
-template <bool K8>
-__global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void kf_taf_walk(TileP q)
+// CMD (chunk-major partition, direct mode: the partition's bins ARE the sub-tiles): the sub-tile's list does not exist yet --
+// its runs sit in the chunks' stretches of rec[].  The workgroup reads its column of the directory, books the list's space
+// through the header's cursor, copies the runs there in chunk order (a pure copy: groups of 16 lanes take a run each) and then
+// walks the contiguous list like any other; no gather kernel, no second launch.
+constexpr int kColDirect = 2047; // chunks per sequence the walk's column fits (the space of res_sum / res_cnt)
+constexpr int kWalkListCap = 4096; // records of a sub-tile's list kept in LDS by the CMD walk (16 KB): no trip to memory between
+                                   // the gather and the two sweeps over the list; longer lists are copied to rec2[]
+template <bool K8, bool CMD = false>
+__global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void kf_taf_walk(TileP q, CmP cm, SeqTab S)
 {
     __shared__ uint32_t s_cnt[kWalkWaves][kSubCells / 2];   // two 16-bit ticket counters per word
     __shared__ uint16_t s_off[kWalkWaves][kSubCells];
@@ -1104,6 +1497,7 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_waves_per_eu(8,
     __shared__ uint32_t wstart[FRLW_MAX_WINDOWS + 1];
     __shared__ uint32_t thr[kLeakyLevels];
     __shared__ int s_unsorted;
+    __shared__ uint32_t s_list[CMD ? kWalkListCap : 1]; // CMD: the gathered list, when it fits (else it goes to rec2[])
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int sg = blockIdx.x, g = sg / kFW, sub = sg - g * kFW;
     const int s = g / q.T, tile = g - s * q.T;
@@ -1113,8 +1507,55 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_waves_per_eu(8,
     const int NW = q.n_windows;
     for (int i = tid; i < kLeakyLevels; i += kWalkThreads) thr[i] = q.leaky_thr[i];
     for (int i = lane; i < kSubCells / 2; i += kWave) s_cnt[wv][i] = 0u;
-    // (sub[] of the NEXT pair is only written if that pair went through a split kernel: take the tile's own end)
-    const uint32_t beg = q.sub[sg], end = (sub == kFW - 1 && !q.direct) ? q.base[g + 1] : q.sub[sg + 1];
+    uint32_t beg, end;
+    const uint32_t *list = q.rec2; // where the sweeps below read the list (CMD: LDS when the list fits)
+    if (CMD) {
+        uint32_t *colL = (uint32_t *)&res_sum[0][0], *colD = &res_cnt[0][0]; // (free until the first window's sums are stored)
+        static_assert(kColDirect + 1 <= kWalkWaves * kSubCells, "the column fits");
+        const int C = S.chunk0[s + 1] - S.chunk0[s];
+        const uint32_t n = col_load<kWalkThreads>(cm, S, s, sg - s * cm.TB, colL, colD, wstart);
+        const bool in_lds = n <= (uint32_t)kWalkListCap; // workgroup-uniform
+        uint32_t *dstl;
+        if (in_lds) {
+            beg = 0u;
+            dstl = s_list;
+            list = s_list;
+        } else {
+            if (tid == 0) wstart[0] = atomicAdd(&q.hdr->rec_cursor, n);
+            __syncthreads();
+            beg = (uint32_t)__builtin_amdgcn_readfirstlane((int)wstart[0]);
+            dstl = q.rec2 + beg;
+        }
+        end = beg + n;
+        // runs -> list: every group of 16 lanes takes runs g16, g16 + 32, ...; four runs' loads in flight before their stores
+        const int g16 = tid >> 4, l16 = tid & 15;
+        for (int c0 = g16; c0 < C; c0 += 4 * (kWalkThreads / 16)) {
+            uint32_t v[4], at[4], cnt[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = c0 + u * (kWalkThreads / 16), cc = c < C ? c : C - 1;
+                const uint32_t lo = colL[cc];
+                cnt[u] = c < C ? colL[cc + 1] - lo : 0u;
+                at[u] = lo;
+                // (clamped index: a lane behind the run's end re-reads an address that exists; runs longer than 16 loop below)
+                v[u] = cm.rec[colD[cc] + lo + ((uint32_t)l16 < cnt[u] ? (uint32_t)l16 : 0u)];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if ((uint32_t)l16 < cnt[u]) dstl[at[u] + l16] = v[u];
+                if (cnt[u] > 16u) { // (wave-divergent, rare for the short runs of a direct-mode call)
+                    const int c = c0 + u * (kWalkThreads / 16);
+                    const uint32_t d = colD[c];
+                    for (uint32_t j = 16u + l16; j < cnt[u]; j += 16u) dstl[at[u] + j] = cm.rec[d + at[u] + j];
+                }
+            }
+        }
+        __syncthreads(); // the list is complete (and visible to the workgroup); the column's space is free again
+    } else {
+        // (sub[] of the NEXT pair is only written if that pair went through a split kernel: take the tile's own end)
+        beg = q.sub[sg];
+        end = q.sub_end ? q.sub_end[sg] : ((sub == kFW - 1 && !q.direct) ? q.base[g + 1] : q.sub[sg + 1]);
+    }
     for (int i = tid; i <= NW; i += kWalkThreads) wstart[i] = end;
     if (tid == 0) s_unsorted = 0;
     const unsigned long long wmask = q.hdr->wmask[s];
@@ -1129,8 +1570,8 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_waves_per_eu(8,
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const uint32_t i = c0 + (uint32_t)(u * kWalkThreads + tid), ic = i < end ? i : end - 1u;
-            cw[u] = q.rec2[ic];
-            pw[u] = q.rec2[ic > beg ? ic - 1u : beg];
+            cw[u] = list[ic];
+            pw[u] = list[ic > beg ? ic - 1u : beg];
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -1196,7 +1637,7 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_waves_per_eu(8,
 #pragma unroll
                 for (int u = 0; u < kWalkRpt; ++u) {
                     const uint32_t i = ptr + (uint32_t)(u * kWave + lane);
-                    m[u] = i < hi ? q.rec2[i] : 0xffffffffu;
+                    m[u] = i < hi ? list[i] : 0xffffffffu;
                 }
 #pragma unroll
                 for (int u = 0; u < kWalkRpt; ++u) {
@@ -1742,6 +2183,7 @@ struct EvTileP {
     const uint32_t *rec2; // sub-tile-major (segment split), for the tiles the tile walk leaves alone
     const uint32_t *base; // [pairs + 1]
     const uint32_t *sub;  // [pairs * 16 + 1]
+    const uint32_t *sub_end; // TileP::sub_end
     int pairs;
     int direct;           // TileP::direct
     uint32_t tile_max;    // tiles with more records go through the segment split + kf_ev_sub
@@ -1906,12 +2348,19 @@ __global__ __launch_bounds__(NW *kWave) void kf_ev_tile(EvTileP q)
 
 // After the segment split (kf_split_whole's counting blocks + kf_split_place): one wavefront per sub-tile walks its own
 // contiguous list -- the skewed tiles of any call, and every tile of a call with few (sequence, tile) pairs.
-template <int BINS>
-__global__ __launch_bounds__(4 * kWave) void kf_ev_sub(EvTileP q, int all_tiles)
+// CMD (chunk-major partition, direct mode): the wavefront first gathers its sub-tile's runs from the chunks' stretches of rec[]
+// -- its column of the directory, scanned 64 chunks at a time, then groups of 16 lanes copy a run each -- into LDS when the list
+// fits (kEvListCap records), else into rec2[] at the header's cursor; everything after that is the walk over one contiguous list.
+constexpr int kColEv = 511;       // chunks per sequence a wavefront's column holds
+constexpr int kEvListCap = 2048;  // records of a sub-tile's list kept in LDS per wavefront
+template <int BINS, bool CMD = false>
+__global__ __launch_bounds__(4 * kWave) void kf_ev_sub(EvTileP q, int all_tiles, CmP cm, SeqTab S)
 {
     __shared__ uint32_t s_cnt[4][kSubCells / 2];
     __shared__ uint16_t s_off[4][kSubCells];
     __shared__ __attribute__((aligned(8))) float s_sorted[4][2 * kSubCells + 2];
+    __shared__ uint32_t s_colL[CMD ? 4 : 1][CMD ? kColEv + 1 : 1], s_colD[CMD ? 4 : 1][CMD ? kColEv : 1];
+    __shared__ uint32_t s_list[CMD ? 4 : 1][CMD ? kEvListCap : 1];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (lane < 2) s_sorted[wv][2 * kSubCells + lane] = 0.0f; // the all-zero pair behind the segments
     const int sg = blockIdx.x * 4 + wv;
@@ -1929,14 +2378,69 @@ __global__ __launch_bounds__(4 * kWave) void kf_ev_sub(EvTileP q, int all_tiles)
     for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int k = 0; k < BINS; ++k) acc[j][k] = 0.0f;
-    // (sub[] of the NEXT pair is only written if that pair went through a split kernel: take the tile's own end)
-    const uint32_t beg = q.sub[sg], end = (sub == kFW - 1 && !q.direct) ? q.base[g + 1] : q.sub[sg + 1];
+    uint32_t beg, end;
+    const uint32_t *list = q.rec2;
+    if (CMD) {
+        uint32_t *colL = s_colL[wv], *colD = s_colD[wv];
+        const int c0 = S.chunk0[s], C = S.chunk0[s + 1] - c0, b = sg - s * cm.TB;
+        const uint32_t out0 = (uint32_t)(S.ev0[s] - S.ev0[0]);
+        uint32_t n = 0;
+        for (int cb = 0; cb < C; cb += kWave) { // the column, 64 chunks per step (wave-uniform trip count)
+            const int c = cb + lane;
+            const uint32_t v = cm.dir[(long long)(c0 + (c < C ? c : C - 1)) * cm.TB + b];
+            const uint32_t e = c < C ? v : 0u, cnt = e >> 16;
+            const uint32_t inc = wave_incl_scan(cnt), run = n + inc - cnt;
+            if (c < C) { colL[c] = run; colD[c] = out0 + (uint32_t)c * (uint32_t)cm.chunk_ev + (e & 0xffffu) - run; }
+            n += (uint32_t)__builtin_amdgcn_readlane((int)inc, kWave - 1);
+        }
+        if (lane == 0) colL[C] = n;
+        LDS_FENCE();
+        uint32_t *dstl;
+        if (n <= (uint32_t)kEvListCap) { // wave-uniform
+            beg = 0u;
+            dstl = s_list[wv];
+            list = s_list[wv];
+        } else {
+            uint32_t at = 0;
+            if (lane == 0) at = atomicAdd(&q.hdr->rec_cursor, n);
+            beg = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+            dstl = const_cast<uint32_t *>(q.rec2) + beg;
+        }
+        end = beg + n;
+        const int g16 = lane >> 4, l16 = lane & 15;
+        constexpr int RU = 8;
+        for (int cc0 = g16; cc0 < C; cc0 += 4 * RU) { // four groups of 16 lanes, eight runs each per step: the loads first, then the stores
+            uint32_t v[RU], at[RU], cnt[RU];
+#pragma unroll
+            for (int u = 0; u < RU; ++u) {
+                const int c = cc0 + 4 * u, cc = c < C ? c : C - 1;
+                const uint32_t lo = colL[cc];
+                cnt[u] = c < C ? colL[cc + 1] - lo : 0u;
+                at[u] = lo;
+                v[u] = cm.rec[colD[cc] + lo + ((uint32_t)l16 < cnt[u] ? (uint32_t)l16 : 0u)];
+            }
+#pragma unroll
+            for (int u = 0; u < RU; ++u) {
+                if ((uint32_t)l16 < cnt[u]) dstl[at[u] + l16] = v[u];
+                if (cnt[u] > 16u) {
+                    const uint32_t d = colD[cc0 + 4 * u];
+                    for (uint32_t j = 16u + l16; j < cnt[u]; j += 16u) dstl[at[u] + j] = cm.rec[d + at[u] + j];
+                }
+            }
+        }
+        __threadfence_block(); // (the wavefront reads back what its own lanes wrote: LDS in order; rec2[] through the fence)
+        LDS_FENCE();
+    } else {
+        // (sub[] of the NEXT pair is only written if that pair went through a split kernel: take the tile's own end)
+        beg = q.sub[sg];
+        end = q.sub_end ? q.sub_end[sg] : ((sub == kFW - 1 && !q.direct) ? q.base[g + 1] : q.sub[sg + 1]);
+    }
     uint32_t nx[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const uint32_t i = beg + (uint32_t)(u * kWave + lane);
         nx[u] = 0xffffffffu;
-        if (end > beg) { const uint32_t v = q.rec2[i < end ? i : end - 1u]; nx[u] = i < end ? v : 0xffffffffu; }
+        if (end > beg) { const uint32_t v = list[i < end ? i : end - 1u]; nx[u] = i < end ? v : 0xffffffffu; }
     }
     LDS_FENCE();
     for (uint32_t p0 = beg; p0 < end; p0 += 256) {
@@ -1945,7 +2449,7 @@ __global__ __launch_bounds__(4 * kWave) void kf_ev_sub(EvTileP q, int all_tiles)
         for (int u = 0; u < 4; ++u) {
             pm[u] = nx[u];
             const uint32_t i = p0 + 256u + (uint32_t)(u * kWave + lane);
-            const uint32_t v = q.rec2[i < end ? i : end - 1u];
+            const uint32_t v = list[i < end ? i : end - 1u];
             nx[u] = i < end ? v : 0xffffffffu;
         }
         ev_pass<BINS>(P, pm, lane, q, use_mul, rcp, binsf, acc);
@@ -2034,6 +2538,95 @@ void launch_fast(const FastGeom &G, const SeqTab &S, const FastPlan &p, char *w8
         hipLaunchKernelGGL((kf_scatter<HAS_MAP, EV, false>), dim3(p.chunks), dim3(kFT), lds_sc, st, G, S, counts, slabtot, base, records, hdr);
 }
 
+// the chunk-major partition: a memset node for the header (status, window masks, cursors) + ONE kernel
+template <bool HAS_MAP, bool EV = false>
+int launch_fast_cm(const FastGeom &G, const SeqTab &S, const FastPlan &p, char *w8, hipStream_t st)
+{
+    FastHeader *hdr = (FastHeader *)w8;
+    uint32_t *dir = (uint32_t *)(w8 + p.off_counts);
+    float *tlut = (float *)(w8 + p.off_tlut);
+    uint32_t *records = (uint32_t *)(w8 + p.off_records);
+    const size_t lds_sc = scatter_cm_lds_bytes(p.TB, p.chunk);
+    static std::atomic<uint32_t> g_epoch{0};
+    uint32_t epoch = g_epoch.fetch_add(1u, std::memory_order_relaxed) + 1u;
+    if (epoch == 0u) epoch = g_epoch.fetch_add(1u, std::memory_order_relaxed) + 1u; // (0 is what frlw_workspace_init leaves behind)
+    const bool simple = !HAS_MAP && G.simple != 0;
+    if (simple) {
+        if (lds_sc > 64 * 1024)
+            (void)hipFuncSetAttribute((const void *)kf_scatter_cm<false, EV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc);
+        hipLaunchKernelGGL((kf_scatter_cm<false, EV, true>), dim3(p.chunks), dim3(kFT), lds_sc, st, G, S, dir, records, hdr, tlut, epoch);
+    } else {
+        if (lds_sc > 64 * 1024)
+            (void)hipFuncSetAttribute((const void *)kf_scatter_cm<HAS_MAP, EV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc);
+        hipLaunchKernelGGL((kf_scatter_cm<HAS_MAP, EV, false>), dim3(p.chunks), dim3(kFT), lds_sc, st, G, S, dir, records, hdr, tlut, epoch);
+    }
+    return FRLW_OK;
+}
+
+// chunk-major partition or histogram partition?  frlw_tuning_t::chunk_major forces either (1 still gives way where a consumer
+// could not hold a sequence's column of the directory in LDS, and to the tile walk, which wants contiguous tile lists).
+// Default, from the measurements in DESIGN.md 3.6: chunk-major for direct-mode calls (TAF and Event Volume: two launches
+// instead of five) and for every Event Volume batch (64 x 1 M events: 720-743 us against 784-804); TAF calls with tile bins keep
+// the histogram partition (10 M events at 1280x720: 180 against 177 us, 64 GEN1 streams 853 against 849 -- a tie that the
+// skewed variants lose: 319 against 287 us).
+enum : int { CM_OFF = 0, CM_AUTO = -1, CM_ON = 1 };
+inline bool cm_fits(const FastPlan &p, bool ev)
+{
+    const int col = p.direct ? (ev ? kColEv : kColDirect) : kColMax;
+    return p.max_seq_chunks <= col && p.chunk <= 65535;
+}
+
+// plan + layout of one call: tries the chunk-major plan first where the knob allows it
+inline int plan_call(const frlw_tuning_t *tu, bool ev, bool tile_walk_wanted, long long n, int n_seq, int H, int W,
+                     const int64_t *seq_offsets, const int64_t *t0, uint32_t win, FastPlan &p, SeqTab &S, bool &cm)
+{
+    const int knob = tuning_knob(tu, &frlw_tuning_t::chunk_major, CM_AUTO);
+    const int bpw = tuning_knob(tu, &frlw_tuning_t::batches_per_wave, 0);
+    const int dmode = [&] {
+        const int direct = tuning_knob(tu, &frlw_tuning_t::direct_bins, -1);
+        if (direct >= 0) return direct != 0 ? (int)DIRECT_FORCE : (int)DIRECT_OFF;
+        return tile_walk_wanted ? (int)DIRECT_OFF : (int)DIRECT_AUTO;
+    }();
+    cm = false;
+    if (knob != CM_OFF && !tile_walk_wanted) {
+        if (!fast_plan(n, n_seq, H, W, p, dmode, bpw, true)) return FRLW_ERR_UNSUPPORTED;
+        if (!fast_layout(seq_offsets, t0, n_seq, p, S, win)) return FRLW_ERR_ARG;
+        cm = cm_fits(p, ev) && (knob == CM_ON || p.direct || ev);
+        if (cm) return FRLW_OK;
+    }
+    if (!fast_plan(n, n_seq, H, W, p, dmode, bpw, false)) return FRLW_ERR_UNSUPPORTED;
+    if (!fast_layout(seq_offsets, t0, n_seq, p, S, win)) return FRLW_ERR_ARG;
+    return FRLW_OK;
+}
+
+inline CmP cm_params(const FastPlan &p, char *w8)
+{
+    CmP cm;
+    cm.dir = (const uint32_t *)(w8 + p.off_counts);
+    cm.rec = (const uint32_t *)(w8 + p.off_records);
+    cm.TB = p.TB;
+    cm.chunk_ev = p.chunk;
+    cm.hot_start = (uint32_t *)(w8 + p.off_base);
+    cm.hot_seg0 = (uint32_t *)(w8 + p.off_seg0);
+    cm.segdesc = (uint32_t *)(w8 + p.off_segdesc);
+    cm.max_segs = p.max_segs;
+    return cm;
+}
+
+// second level of the chunk-major partition: q.rec2 / q.sub / q.sub_end afterwards describe one contiguous list per sub-tile
+inline void launch_split_cm(TileP &q, const FastPlan &p, const SeqTab &S, char *w8, hipStream_t st)
+{
+    const CmP cm = cm_params(p, w8);
+    q.rec2 = (uint32_t *)(w8 + p.off_records2);
+    q.sub = (uint32_t *)(w8 + p.off_sub);
+    q.sub_end = (uint32_t *)(w8 + p.off_sub_end);
+    // (direct mode never comes here: its consumers gather their own lists)
+    const int seg_grid = p.max_segs < 256 ? p.max_segs : 256; // (they stride over the segments; most calls have none)
+    hipLaunchKernelGGL(kf_split_whole<true>, dim3(p.pairs), dim3(kFT), 0, st, q, cm, S);
+    hipLaunchKernelGGL(kf_segcount_cm, dim3(seg_grid), dim3(kFT), 0, st, q, cm, S);
+    hipLaunchKernelGGL(kf_split_place<true>, dim3(seg_grid), dim3(kFT), 0, st, q, cm, S);
+}
+
 // ---- one-time check of the hardware property this file rests on ------------------------------------------------------
 // 0 = not yet tested on this device, 1 = lanes of one returning LDS atomic are served in lane order, 2 = they are not
 // (a new stepping / compiler): the fast path then refuses (FRLW_ERR_UNSUPPORTED) and callers take the general path.
@@ -2093,10 +2686,11 @@ size_t frlw_taf_batch_workspace_bytes(int64_t n_events, int n_seq, int H, int W,
 {
     if (window_us < 1 || window_us >= (1ll << 20)) return 0;
     size_t need = 0;
-    for (int direct = 0; direct < 2; ++direct) { // the larger of the two partition modes (the call's tuning picks one)
+    for (int mode = 0; mode < 4; ++mode) { // the largest of the partition modes (the call's tuning and size pick one)
+        const int direct = mode & 1, cm = mode >> 1;
         FastPlan p;
-        if (!fast_plan(n_events, n_seq, H, W, p, direct ? DIRECT_FORCE : DIRECT_OFF)) return 0;
-        if (direct && !p.direct) break;
+        if (!fast_plan(n_events, n_seq, H, W, p, direct ? DIRECT_FORCE : DIRECT_OFF, 0, cm != 0)) return 0;
+        if (direct && !p.direct) continue;
         // the layout depends on how the events are spread over the sequences only through the chunk count: every sequence
         // can add one partly filled chunk and one partly filled slab
         const size_t chunks = (size_t)(n_events + p.chunk - 1) / p.chunk + n_seq;
@@ -2112,6 +2706,8 @@ size_t frlw_taf_batch_workspace_bytes(int64_t n_events, int n_seq, int H, int W,
         off = align_up(off + (size_t)(window_us + 1) * 4, 256);
         off = align_up(off + (size_t)(n_events > 0 ? n_events : 1) * 4, 256);
         off = align_up(off + (size_t)(n_events > 0 ? n_events : 1) * 4, 256);
+        off = align_up(off + ((size_t)p.pairs * kFW + 1) * 4, 256);
+        off = align_up(off + (2 * (size_t)(n_events / kSplitSeg) + 1) * 4, 256);
         if (off > need) need = off;
     }
     return need;
@@ -2121,16 +2717,6 @@ size_t frlw_taf_batch_workspace_bytes(int64_t n_events, int n_seq, int H, int W,
 
 namespace {
 enum : int { PHASE_PARTITION = 1, PHASE_FINISH = 2 };
-
-// frlw_tuning_t: direct_bins 0 / 1 forces the partition mode (FastPlan::direct); taf_tile_walk = 1 asks for the in-LDS split,
-// which needs tile bins; default: direct where the frame allows it
-inline int direct_allowed(const frlw_tuning_t *tu)
-{
-    const int direct = tuning_knob(tu, &frlw_tuning_t::direct_bins, -1);
-    if (direct >= 0) return direct != 0 ? DIRECT_FORCE : DIRECT_OFF;
-    const bool walk = tuning_knob(tu, &frlw_tuning_t::taf_tile_walk, kTafTileWalk ? 1 : 0) != 0;
-    return walk ? DIRECT_OFF : DIRECT_AUTO;
-}
 
 // The batch encode in two halves: PARTITION = kf_hist, scans, kf_scatter (leaves the per-sequence window masks in the
 // workspace header), FINISH = split + walk (reads them).  A row stripe [y_lo, y_lo + H) of an H_full-row frame runs the two
@@ -2155,9 +2741,14 @@ int taf_batch_run(int phases, const frlw_events_t *ev, const int64_t *seq_offset
     if (kCellBits + wb + rb > 32 || (long long)n_windows * window_us >= (1ll << 32)) return FRLW_ERR_UNSUPPORTED;
     const long long n = seq_offsets[n_seq] - seq_offsets[0];
     FastPlan p;
-    if (!fast_plan(n, n_seq, H, W, p, direct_allowed(ev->tuning))) return FRLW_ERR_UNSUPPORTED;
     SeqTab S;
-    if (!fast_layout(seq_offsets, t_start, n_seq, p, S, (uint32_t)window_us)) return FRLW_ERR_ARG;
+    bool cm = false;
+    const bool walk_wanted = tuning_knob(ev->tuning, &frlw_tuning_t::taf_tile_walk, kTafTileWalk ? 1 : 0) != 0 &&
+                             tuning_knob(ev->tuning, &frlw_tuning_t::direct_bins, -1) <= 0;
+    {
+        const int rc = plan_call(ev->tuning, false, walk_wanted, n, n_seq, H, W, seq_offsets, t_start, (uint32_t)window_us, p, S, cm);
+        if (rc != FRLW_OK) return rc;
+    }
     if (workspace_bytes < p.bytes) return FRLW_ERR_WORKSPACE;
     if (scatter_lds_bytes(p.TB, p.chunk) > 160 * 1024) return FRLW_ERR_UNSUPPORTED;
 
@@ -2191,7 +2782,10 @@ int taf_batch_run(int phases, const frlw_events_t *ev, const int64_t *seq_offset
         if (ok != FRLW_OK) return ok;
     }
     if (phases & PHASE_PARTITION) {
-        if (ev->xmap) launch_fast<true>(G, S, p, w8, st);
+        if (cm) {
+            const int rc = ev->xmap ? launch_fast_cm<true>(G, S, p, w8, st) : launch_fast_cm<false>(G, S, p, w8, st);
+            if (rc != FRLW_OK) return rc;
+        } else if (ev->xmap) launch_fast<true>(G, S, p, w8, st);
         else launch_fast<false>(G, S, p, w8, st);
     }
     if (!(phases & PHASE_FINISH)) { HIP_TRY(hipGetLastError()); return FRLW_OK; }
@@ -2215,20 +2809,30 @@ int taf_batch_run(int phases, const frlw_events_t *ev, const int64_t *seq_offset
     q.hdr = (FastHeader *)w8;
     q.state = state; q.view_f32 = view_f32; q.out_u8 = out_u8;
     q.direct = p.direct;
-    if (p.direct) { // kf_scatter's bins were the sub-tiles: its output IS the sub-tile-major list, base[] its sub[]
+    q.sub_end = nullptr;
+    if (cm && p.direct) {
+        q.rec2 = (uint32_t *)(w8 + p.off_records2); // (kf_taf_walk<.., true> books and fills its own list)
+    } else if (cm) {
+        launch_split_cm(q, p, S, w8, st);
+    } else if (p.direct) { // kf_scatter's bins were the sub-tiles: its output IS the sub-tile-major list, base[] its sub[]
         q.rec2 = (uint32_t *)(w8 + p.off_records);
         q.sub = (uint32_t *)(w8 + p.off_base);
     } else {
-        hipLaunchKernelGGL(kf_split_whole, dim3(p.pairs + q.seg_grid), dim3(kFT), 0, st, q); // tiles, then segment counts
-        hipLaunchKernelGGL(kf_split_place, dim3(q.seg_grid), dim3(kFT), 0, st, q);
+        const CmP none = {};
+        hipLaunchKernelGGL(kf_split_whole<false>, dim3(p.pairs + q.seg_grid), dim3(kFT), 0, st, q, none, S); // tiles, then segment counts
+        hipLaunchKernelGGL(kf_split_place<false>, dim3(q.seg_grid), dim3(kFT), 0, st, q, none, S);
     }
     if (q.tile_walk) { // tiles of window-sorted sequences below the skew limit: split in LDS by the kernel that consumes them
         const int grid = (p.pairs + 7) / 8 * 8;
         if (K == 8) hipLaunchKernelGGL((kf_taf_tile<kFW, true>), dim3(grid), dim3(kFT), 0, st, q);
         else hipLaunchKernelGGL((kf_taf_tile<kFW, false>), dim3(grid), dim3(kFT), 0, st, q);
     }
-    if (K == 8) hipLaunchKernelGGL(kf_taf_walk<true>, dim3(p.pairs * kFW), dim3(kWalkThreads), 0, st, q);
-    else hipLaunchKernelGGL(kf_taf_walk<false>, dim3(p.pairs * kFW), dim3(kWalkThreads), 0, st, q);
+    const CmP cmq = cm ? cm_params(p, w8) : CmP{};
+    if (cm && p.direct) { // the walk gathers its own list (no gather kernel)
+        if (K == 8) hipLaunchKernelGGL((kf_taf_walk<true, true>), dim3(p.pairs * kFW), dim3(kWalkThreads), 0, st, q, cmq, S);
+        else hipLaunchKernelGGL((kf_taf_walk<false, true>), dim3(p.pairs * kFW), dim3(kWalkThreads), 0, st, q, cmq, S);
+    } else if (K == 8) hipLaunchKernelGGL((kf_taf_walk<true, false>), dim3(p.pairs * kFW), dim3(kWalkThreads), 0, st, q, cmq, S);
+    else hipLaunchKernelGGL((kf_taf_walk<false, false>), dim3(p.pairs * kFW), dim3(kWalkThreads), 0, st, q, cmq, S);
     HIP_TRY(hipGetLastError());
     return FRLW_OK;
 }
@@ -2286,11 +2890,16 @@ int frlw_ev_encode_batch(const frlw_events_t *ev, const int64_t *seq_offsets, co
     if (kCellBits + rb > 32) return FRLW_ERR_UNSUPPORTED;
     const long long n = seq_offsets[n_seq] - seq_offsets[0];
     FastPlan p;
-    if (!fast_plan(n, n_seq, H, W, p, direct_allowed(ev->tuning))) return FRLW_ERR_UNSUPPORTED;
     SeqTab S;
     int64_t t_begin[kMaxSeq];
     for (int s = 0; s < n_seq; ++s) t_begin[s] = t_end[s] - window_us; // generate_eventvolume.py:139-141
-    if (!fast_layout(seq_offsets, t_begin, n_seq, p, S, (uint32_t)window_us)) return FRLW_ERR_ARG;
+    bool cm = false;
+    const bool walk_wanted = tuning_knob(ev->tuning, &frlw_tuning_t::taf_tile_walk, kTafTileWalk ? 1 : 0) != 0 &&
+                             tuning_knob(ev->tuning, &frlw_tuning_t::direct_bins, -1) <= 0;
+    {
+        const int rc = plan_call(ev->tuning, true, walk_wanted, n, n_seq, H, W, seq_offsets, t_begin, (uint32_t)window_us, p, S, cm);
+        if (rc != FRLW_OK) return rc;
+    }
     if (workspace_bytes < p.bytes) return FRLW_ERR_WORKSPACE;
     if (scatter_lds_bytes(p.TB, p.chunk) > 160 * 1024) return FRLW_ERR_UNSUPPORTED;
 
@@ -2315,7 +2924,10 @@ int frlw_ev_encode_batch(const frlw_events_t *ev, const int64_t *seq_offsets, co
         const int ok = lds_order_ok(w8, st); // cached per device after the first call
         if (ok != FRLW_OK) return ok;
     }
-    if (ev->xmap) launch_fast<true, true>(G, S, p, w8, st);
+    if (cm) {
+        const int rc = ev->xmap ? launch_fast_cm<true, true>(G, S, p, w8, st) : launch_fast_cm<false, true>(G, S, p, w8, st);
+        if (rc != FRLW_OK) return rc;
+    } else if (ev->xmap) launch_fast<true, true>(G, S, p, w8, st);
     else launch_fast<false, true>(G, S, p, w8, st);
     // Second-level split: kf_split_whole + kf_ev_sub by default; the tile walk (kf_ev_tile, 3.4: the split in LDS, 2.44x instead
     // of 2.8x HBM traffic) on request -- it was the default until kf_split_whole became a one-pass kernel, which made the two-kernel
@@ -2337,16 +2949,22 @@ int frlw_ev_encode_batch(const frlw_events_t *ev, const int64_t *seq_offsets, co
     q.hdr = (FastHeader *)w8;
     q.first_block = tile_walk ? p.pairs : 0; // with the tile walk only the segment-counting blocks have work
     q.seg_grid = p.max_segs < 2048 ? p.max_segs : 2048;
-    if (p.direct) { // kf_scatter's bins were the sub-tiles: its output IS the sub-tile-major list, base[] its sub[]
+    q.tile_max = whole_max_of(p.pairs);
+    if (cm && p.direct) {
+        q.rec2 = (uint32_t *)(w8 + p.off_records2); // (kf_ev_sub<.., true> books and fills its own lists)
+    } else if (cm) {
+        launch_split_cm(q, p, S, w8, st);
+    } else if (p.direct) { // kf_scatter's bins were the sub-tiles: its output IS the sub-tile-major list, base[] its sub[]
         q.rec2 = (uint32_t *)(w8 + p.off_records);
         q.sub = (uint32_t *)(w8 + p.off_base);
     } else {
-        hipLaunchKernelGGL(kf_split_whole, dim3(p.pairs + q.seg_grid - q.first_block), dim3(kFT), 0, st, q); // tiles, then segment counts
-        hipLaunchKernelGGL(kf_split_place, dim3(q.seg_grid), dim3(kFT), 0, st, q);
+        const CmP none = {};
+        hipLaunchKernelGGL(kf_split_whole<false>, dim3(p.pairs + q.seg_grid - q.first_block), dim3(kFT), 0, st, q, none, S); // tiles, then segment counts
+        hipLaunchKernelGGL(kf_split_place<false>, dim3(q.seg_grid), dim3(kFT), 0, st, q, none, S);
     }
     EvTileP e;
     e.H = H; e.W = W; e.twl = p.twl; e.thl = p.thl; e.tiles_x = p.tiles_x; e.T = p.T; e.bins = bins; e.win = (uint32_t)window_us; e.rcp = G.rcp;
-    e.rec = q.rec; e.rec2 = q.rec2; e.base = q.base; e.sub = q.sub; e.pairs = p.pairs; e.tile_max = whole_max_of(p.pairs); e.direct = p.direct;
+    e.rec = q.rec; e.rec2 = q.rec2; e.base = q.base; e.sub = q.sub; e.sub_end = q.sub_end; e.pairs = p.pairs; e.tile_max = whole_max_of(p.pairs); e.direct = p.direct;
     e.tlut = (const float *)(w8 + p.off_tlut); e.hdr = (FastHeader *)w8; e.out_f32 = out_f32; e.out_u8 = out_u8;
     const int sub_grid = (p.pairs * kFW + 3) / 4;
     if (tile_walk) {
@@ -2358,8 +2976,12 @@ int frlw_ev_encode_batch(const frlw_events_t *ev, const int64_t *seq_offsets, co
         if (bins <= 5) hipLaunchKernelGGL((kf_ev_tile<NW, 5>), dim3(grid), dim3(NW * kWave), 0, st, e);
         else hipLaunchKernelGGL((kf_ev_tile<NW, kMaxK>), dim3(grid), dim3(NW * kWave), 0, st, e);
     }
-    if (bins <= 5) hipLaunchKernelGGL((kf_ev_sub<5>), dim3(sub_grid), dim3(4 * kWave), 0, st, e, tile_walk ? 0 : 1);
-    else hipLaunchKernelGGL((kf_ev_sub<kMaxK>), dim3(sub_grid), dim3(4 * kWave), 0, st, e, tile_walk ? 0 : 1);
+    const CmP cmq = cm ? cm_params(p, w8) : CmP{};
+    if (cm && p.direct) { // the sub-tile wavefronts gather their own lists
+        if (bins <= 5) hipLaunchKernelGGL((kf_ev_sub<5, true>), dim3(sub_grid), dim3(4 * kWave), 0, st, e, 1, cmq, S);
+        else hipLaunchKernelGGL((kf_ev_sub<kMaxK, true>), dim3(sub_grid), dim3(4 * kWave), 0, st, e, 1, cmq, S);
+    } else if (bins <= 5) hipLaunchKernelGGL((kf_ev_sub<5, false>), dim3(sub_grid), dim3(4 * kWave), 0, st, e, tile_walk ? 0 : 1, cmq, S);
+    else hipLaunchKernelGGL((kf_ev_sub<kMaxK, false>), dim3(sub_grid), dim3(4 * kWave), 0, st, e, tile_walk ? 0 : 1, cmq, S);
     HIP_TRY(hipGetLastError());
     return FRLW_OK;
 }

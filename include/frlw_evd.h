@@ -77,6 +77,10 @@ typedef struct frlw_tuning {
                                * wherever the frame allows it (at most 64 tiles: the 304x240 class) -- no second-level split pass
                                * at all; 0 = always tile bins + split pass; default: sub-tile bins for calls with fewer than 512
                                * (sequence, tile) pairs and more than 8192 events per pair on average */
+    int32_t chunk_major;      /* frlw_taf_encode_batch / frlw_ev_encode_batch: 1 = the chunk-major partition (no histogram pass: the
+                               * scatter writes every chunk sorted by bin where it stands plus a directory row, the consumers
+                               * gather -- the default wherever a sequence has at most 4096 chunks), 0 = histogram + scans +
+                               * bin-major scatter (the only form for longer sequences and for the tile walk) */
 } frlw_tuning_t;
 
 typedef struct frlw_events {

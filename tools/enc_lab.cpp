@@ -126,7 +126,7 @@ struct Outputs {
     bool ran = false;
 };
 
-static frlw_tuning_t g_tuning = {(int32_t)sizeof(frlw_tuning_t), -1, -1, -1, -1, -1, -1, -1, -1};
+static frlw_tuning_t g_tuning = {(int32_t)sizeof(frlw_tuning_t), -1, -1, -1, -1, -1, -1, -1, -1, -1};
 static bool g_use_tuning = false;
 
 static Outputs run_cfg(const Lib &L, const Cfg &c, const uint64_t *dat_d, const std::vector<int64_t> &offs, int reps)
@@ -232,6 +232,9 @@ int main(int argc, char **argv)
         if (!strcmp(argv[i], "--cfg") && i + 1 < argc) only = argv[++i];
         else if (!strcmp(argv[i], "--reps") && i + 1 < argc) reps = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--tile-walk")) { g_tuning.taf_tile_walk = 1; g_use_tuning = true; } // TAF through kf_taf_tile
+        else if (!strcmp(argv[i], "--bpw") && i + 1 < argc) { g_tuning.batches_per_wave = atoi(argv[++i]); g_use_tuning = true; } // larger partition chunks
+        else if (!strcmp(argv[i], "--no-cm")) { g_tuning.chunk_major = 0; g_use_tuning = true; } // histogram + scans + bin-major scatter
+        else if (!strcmp(argv[i], "--direct")) { g_tuning.direct_bins = 1; g_use_tuning = true; } // sub-tile bins wherever the frame allows
         else if (!strcmp(argv[i], "--no-direct")) { g_tuning.direct_bins = 0; g_use_tuning = true; } // tile bins + split pass also on small frames
         else libs.push_back(load(argv[i]));
     }
