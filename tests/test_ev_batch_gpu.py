@@ -131,7 +131,8 @@ def test_direct_bins_equal_tile_bins(er, n_seq, monkeypatch):
     offs = np.concatenate([[0], np.cumsum([len(r) for r in recs])])
     dat = to_dev(np.concatenate(recs))
     outs = []
-    for direct in (1, 0):
-        monkeypatch.setattr(er, "TUNING", _lib.FrlwTuning(direct_bins=direct))
+    for direct, cmaj in ((1, 1), (1, 0), (0, 1), (0, 0)):  # x the chunk-major partition (the sub-tile wavefronts gather their own lists)
+        monkeypatch.setattr(er, "TUNING", _lib.FrlwTuning(direct_bins=direct, chunk_major=cmaj))
         outs.append(er.encode_ev_batch(dat, offs, (H, W), win, win, 5, want_u8=True))
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    for o in outs[1:]:
+        assert torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1])

@@ -436,10 +436,64 @@ def test_direct_bins_equal_tile_bins(n_seq, monkeypatch):
     offs = np.concatenate([[0], np.cumsum([len(r) for r in recs])])
     dat = torch.from_numpy(np.ascontiguousarray(np.concatenate(recs)).view(np.uint8).reshape(-1, 8).copy()).cuda()
     outs = []
-    for direct in (1, 0):
-        monkeypatch.setattr(er, "TUNING", _lib.FrlwTuning(direct_bins=direct))
+    # (direct, chunk_major): sub-tile / tile bins x the chunk-major partition (no histogram pass; the direct-mode walk gathers
+    # its own list) / histogram + scans + bin-major scatter -- four ways to the same bits
+    for direct, cmaj in ((1, 1), (1, 0), (0, 1), (0, 0)):
+        monkeypatch.setattr(er, "TUNING", _lib.FrlwTuning(direct_bins=direct, chunk_major=cmaj))
         st = torch.full((n_seq, H, W, 2, K), -6000.0, device="cuda")
         u8, view = er.encode_taf_batch(dat, offs, (H, W), st, 0, win, n_win, K, want_view=True)
         outs.append((st, u8, view))
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("shape,n_seq,n,hot", [((720, 1280), 1, 3_000_000, True), ((240, 304), 3, 900_000, True),
+                                                ((97, 131), 5, 70_000, False), ((240, 304), 2, 0, False)])
+def test_chunk_major_equals_histogram_partition(shape, n_seq, n, hot, monkeypatch):
+    """frlw_tuning_t::chunk_major 1 against 0 at the library's own choice of bins: a 1280x720 stream with a hot spot (tile bins:
+    whole-tile split through the directory columns AND the segment kernels for the skewed tiles), GEN1 sequences above and
+    below the walk's LDS list (a hot sub-tile's list goes through rec2[]), tiny frames, empty sequences; state, view and uint8
+    volume bit for bit, with a state carried over from a first call."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from frlw_evd_amd import _lib, event_representation as er, synth
+    H, W = shape
+    K, win, n_win = 8, 10_000, 8
+    recs = [synth.to_dat8(synth.synth_events(1400 + j, n // (1 + 3 * (j == 1)), W, H, n_win * win, hotspot=hot)) for j in range(n_seq)]
+    offs = np.concatenate([[0], np.cumsum([len(r) for r in recs])])
+    dat = torch.from_numpy(np.ascontiguousarray(np.concatenate(recs)).view(np.uint8).reshape(-1, 8).copy()).cuda()
+    outs = []
+    for cmaj in (1, 0):
+        monkeypatch.setattr(er, "TUNING", _lib.FrlwTuning(chunk_major=cmaj))
+        st = torch.full((n_seq, H, W, 2, K), -6000.0, device="cuda")
+        for _ in range(2):  # second call: the FIFO state of the first carried over
+            u8, view = er.encode_taf_batch(dat, offs, (H, W), st, 0, win, n_win, K, want_view=True)
+        outs.append((st, u8, view))
     for a, b in zip(outs[0], outs[1]):
         assert torch.equal(a, b)
+
+
+def test_chunk_major_error_leaves_everything_untouched(monkeypatch):
+    """The chunk-major scatter is also the validator (there is no histogram pass in front of it): an event behind the span sets
+    the status, nothing is written, the deferred word carries it, and the next clean call on the workspace starts clean."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from frlw_evd_amd import _lib, event_representation as er, synth
+    H, W, K = 240, 304, 8
+    rec = synth.to_dat8(synth.synth_events(1500, 300_000, W, H, 80_000))
+    bad = rec.copy()
+    bad["t"][-3:] += 1_000_000
+    dev = lambda r: torch.from_numpy(np.ascontiguousarray(r).view(np.uint8).reshape(-1, 8).copy()).cuda()
+    er.raise_deferred()
+    for cmaj in (1, 0):
+        monkeypatch.setattr(er, "TUNING", _lib.FrlwTuning(chunk_major=cmaj))
+        st = torch.full((1, H, W, 2, K), -6000.0, device="cuda")
+        with pytest.raises(ValueError):
+            er.encode_taf_batch(dev(bad), [0, len(bad)], (H, W), st, 0, 10_000, 8, K)
+        assert float((st != -6000.0).sum()) == 0.0
+        er.encode_taf_batch(dev(bad), [0, len(bad)], (H, W), st, 0, 10_000, 8, K, check=False)
+        with pytest.raises(ValueError):
+            er.raise_deferred()
+        er.encode_taf_batch(dev(rec), [0, len(rec)], (H, W), st, 0, 10_000, 8, K)  # clean: the header was reset by the call itself
+        assert float((st != -6000.0).sum()) > 0.0

@@ -39,7 +39,8 @@ def main():
         if tile_walk and rng.random() < 0.7:
             B, H, W = int(rng.choice([8, 16, 33])), int(rng.integers(150, 260)), int(rng.integers(250, 420))
         # the others: the partition mode at random (library's choice / sub-tile bins forced where the frame allows / tile bins)
-        er.TUNING = _lib.FrlwTuning(taf_tile_walk=1) if tile_walk else [None, _lib.FrlwTuning(direct_bins=1), _lib.FrlwTuning(direct_bins=0)][int(rng.integers(0, 3))]
+        cmaj = int(rng.integers(-1, 2))  # the partition: library's choice / histogram + scans / chunk-major
+        er.TUNING = _lib.FrlwTuning(taf_tile_walk=1) if tile_walk else [_lib.FrlwTuning(chunk_major=cmaj), _lib.FrlwTuning(direct_bins=1, chunk_major=cmaj), _lib.FrlwTuning(direct_bins=0, chunk_major=cmaj)][int(rng.integers(0, 3))]
         K = int(rng.choice([8, 8, 8, 5, 4, 1, 7]))
         n_win = int(rng.choice([1, 2, 3, 8, 8, 13, 64]))
         win = int(rng.choice([1_000, 10_000, 10_000, 7_777, 50_000]))
