@@ -1119,6 +1119,7 @@ __global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         }
         col_index<kFT>(colL, C, 0u, n, idx);
         __syncthreads();
+        const uint32_t wvs = (uint32_t)__builtin_amdgcn_readfirstlane(wv); // (the wavefront index as a scalar: uniform branches below)
         // 1. the whole list into registers: list position -> chunk through the index + a walk over at most a few run boundaries
         // (two sweeps: every index first -- LDS work only, nothing in flight -- then the loads through one buffer descriptor with
         // 32-bit offsets: with 64-bit addresses next to the 32 records the compiler spilled 19 of them, each spill waiting for
@@ -1130,7 +1131,18 @@ __global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 #pragma unroll
                 for (int u = 0; u < RPT; ++u) {
                     const uint32_t i = (uint32_t)(c * kSplitSeg + u * kFT + tid), ic = i < n ? i : n - 1u;
-                    const uint32_t off = (uint32_t)(c * kSplitSeg) < n ? col_addr(colL, colD, idx[ic >> 4], ic) : 0u;
+                    // the wavefront's 64 positions i0 .. i0 + 63: mostly inside ONE run when the runs are long (64 sequences of
+                    // 1 M events: 226 records per run) -- then the run is found once, with scalar compares, and a lane only adds
+                    const uint32_t i0 = (uint32_t)(c * kSplitSeg + u * kFT) + wvs * kWave;
+                    uint32_t off = 0u;
+                    if (i0 < n) { // wave-uniform
+                        const uint32_t last = i0 + 63u < n ? i0 + 63u : n - 1u;
+                        uint32_t cs = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx[i0 >> 4]);
+                        uint32_t lnext = (uint32_t)__builtin_amdgcn_readfirstlane((int)colL[cs + 1]);
+                        while (lnext <= i0) { ++cs; lnext = (uint32_t)__builtin_amdgcn_readfirstlane((int)colL[cs + 1]); }
+                        if (lnext > last) off = (uint32_t)__builtin_amdgcn_readfirstlane((int)colD[cs]) + ic;
+                        else off = col_addr(colL, colD, idx[ic >> 4], ic);
+                    }
                     m[c][u] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(off << 2), 0, 0);
                 }
             }

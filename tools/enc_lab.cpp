@@ -233,6 +233,7 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[i], "--reps") && i + 1 < argc) reps = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--tile-walk")) { g_tuning.taf_tile_walk = 1; g_use_tuning = true; } // TAF through kf_taf_tile
         else if (!strcmp(argv[i], "--bpw") && i + 1 < argc) { g_tuning.batches_per_wave = atoi(argv[++i]); g_use_tuning = true; } // larger partition chunks
+        else if (!strcmp(argv[i], "--cm")) { g_tuning.chunk_major = 1; g_use_tuning = true; } // the chunk-major partition wherever it is possible
         else if (!strcmp(argv[i], "--no-cm")) { g_tuning.chunk_major = 0; g_use_tuning = true; } // histogram + scans + bin-major scatter
         else if (!strcmp(argv[i], "--direct")) { g_tuning.direct_bins = 1; g_use_tuning = true; } // sub-tile bins wherever the frame allows
         else if (!strcmp(argv[i], "--no-direct")) { g_tuning.direct_bins = 0; g_use_tuning = true; } // tile bins + split pass also on small frames
