@@ -38,9 +38,14 @@ class model(nn.Module):
         """Identity + in-place version of every parameter and buffer: changes on optimizer steps, load_state_dict(),
         BatchNorm running-statistics updates and .to() / .cuda()."""
         ts = self.__dict__.get("_sig_tensors")
-        if ts is None:  # the module tree is walked once per engine lifetime, not on every eval forward
+        calls = self.__dict__["_sig_calls"] = self.__dict__.get("_sig_calls", 0) + 1
+        if ts is None or calls % 32 == 0:
+            # The module tree is walked once per engine lifetime and then every 32nd eval forward: train() / _apply() /
+            # load_state_dict() on THIS module drop the cache, but a tensor can also be replaced behind its back
+            # (`net.backbone.cuda()`, a new nn.Parameter assigned to a sub-module, a parametrization) -- the periodic walk
+            # notices the new objects within 32 forwards instead of never.
             ts = self.__dict__["_sig_tensors"] = list(self.parameters()) + list(self.buffers())
-        return tuple((t.data_ptr(), t._version) for t in ts)
+        return tuple((id(t), t.data_ptr(), t._version) for t in ts)
 
     def engine(self):
         """The gfx950 engine for the CURRENT weights.  The engine folds BatchNorm into the convolutions and keeps its

@@ -343,3 +343,13 @@ def test_engine_follows_the_weights(gpu):
     with torch.no_grad():
         assert rel_err(m.engine().raw_outputs(x[..., 0, 0]), raw0) <= 1e-6
     copy.deepcopy(m)  # the engine's ctypes handle must not break copying / pickling
+    # a tensor replaced BEHIND the top module's back (a new nn.Parameter on a sub-module: no train() / _apply() /
+    # load_state_dict() of the model sees it): the periodic re-walk of the signature notices within 32 forwards
+    with torch.no_grad():
+        e2 = m.engine()
+        conv = m.head.cls_preds[0]
+        conv.bias = torch.nn.Parameter(conv.bias.detach() + 3.0)
+        for _ in range(33):
+            e3 = m.engine()
+        assert e3 is not e2
+        assert rel_err(e3.raw_outputs(x[..., 0, 0]), m.reference_outputs(x[..., 0])) <= TOL
