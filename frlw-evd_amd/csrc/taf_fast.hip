@@ -55,6 +55,7 @@ constexpr int kMaxBinPairs = 65536;       // (sequence, bin) pairs per call in t
 constexpr int kFastSlab = 32;             // chunks per slab of the two-level column scan
 constexpr int ST_MULBAD = 8;              // per-chunk flag next to the ST_* error bits (not an error)
 constexpr int kSplitSeg = 8192;           // records one workgroup of the sub-tile split handles
+constexpr int kBigBpw = 20;               // 64-event batches per wavefront of the one-workgroup-per-CU form of kf_scatter_cm
 #ifndef FRLW_WHOLE_SEGS
 #define FRLW_WHOLE_SEGS 4 /* measured: 8 -> 4 takes 7 % (TAF hot spot at 10 M events) to 15 % (Event Volume batch with hot spots) off skewed calls, uniform calls unchanged; 3 sends ordinary 25 000-record GEN1 tiles through the segments (+9 %) */
 #endif
@@ -121,6 +122,7 @@ struct FastPlan {
     // is not run at all.  Possible while a sequence has at most kMaxFastTiles bins (the scatter workgroup keeps 16 counters
     // per bin in LDS): the GEN1 / 304x240 class of frames (36 tiles = 576 bins), not 1280x720 (450 tiles = 7200 bins).
     int direct, TB, bin_shift, pairs_b; // bins per sequence (T or 16 T), log2 of bins per tile, (sequence, bin) pairs
+    int big;                            // chunk-major partition with chunks above 8192 events (kf_scatter_cm<.., kBigBpw>)
     int bpw, chunk;
     int chunks, slabs, pairs;
     size_t off_counts, off_slabtot, off_base, off_sub, off_seg0, off_segcnt, off_errs, off_tlut, off_records, off_records2, bytes;
@@ -164,14 +166,24 @@ bool fast_plan(long long n, int n_seq, int H, int W, FastPlan &p, int direct_mod
     // Chunk size: the partition kernels run two workgroups per CU (512 at a time), and a grid that is not a whole number
     // of such rounds ends on a part-filled one (10 M events in chunks of 8192 = 2.4 rounds: the last one 38 % full).  So
     // the stream is cut into 512 * k chunks with the smallest k whose chunks fit the 8192-event staging area.
-    long long cap = (long long)kFT * kMaxBpw;
+    // (cm with min_bpw above kMaxBpw: the one-workgroup-per-CU form of kf_scatter_cm, chunks up to kBigBpw batches per
+    // wavefront in 256 * k chunks -- tile bins only, and only while staging area + counters fit the CU's LDS)
+    // Default: frames with many tiles and streams long enough to fill two rounds of 256 such chunks -- where the ordinary chunks
+    // would leave a consumer runs of a dozen records (10 M events at 1280x720: 164 us against 171 with 8192-event chunks and 177
+    // with the histogram partition; 3 M events: 113 against 111 -- hence the lower bound; 64 GEN1 streams have 200-record runs
+    // either way and lose 1.5 % to the lower occupancy)
+    const bool big = cm && !p.direct && (min_bpw > kMaxBpw || (min_bpw == 0 && p.TB >= 256 && n >= 6000000)) &&
+                     (long long)kFW * p.TB * 4 + (p.TB + 2) * 4 + (long long)kFT * kBigBpw * 4 + 64 <= 150 * 1024;
+    p.big = big ? 1 : 0;
+    long long cap = (long long)kFT * (big ? kBigBpw : kMaxBpw);
+    const long long round = big ? 256 : 512;
     if (p.direct) { // 16 counters per bin: shorter chunks keep the scatter workgroup at two per CU (78 KB of LDS)
         const long long lds_cap = ((79ll * 1024 - 16 - (long long)kFW * p.TB * 4 - (p.TB + 2) * 4) / 6) / 16 * 16;
         if (lds_cap >= 2048 && lds_cap < cap) cap = lds_cap;
     }
-    long long k = (n + 512 * cap - 1) / (512 * cap);
+    long long k = (n + round * cap - 1) / (round * cap);
     if (k < 1) k = 1;
-    long long ce = (n + 512 * k - 1) / (512 * k);
+    long long ce = (n + round * k - 1) / (round * k);
     ce = (ce + 15) / 16 * 16;
     // cm: a consumer gathers one run per chunk, so a call that cannot fill 512 workgroups anyway takes the largest chunks there are
     // (one GEN1 stream: 144 chunks of 6944 events instead of 509 of 1968: 32 us against 50)
@@ -732,8 +744,12 @@ __host__ __device__ inline size_t scatter_cm_lds_bytes(int T, int chunk)
     return (size_t)kFW * T * 4 + (size_t)(T + 2) * 4 + (size_t)chunk * 4 + 16;
 }
 
-template <bool HAS_MAP, bool EV = false, bool SIMPLE = false>
-__global__ __launch_bounds__(kFT) void kf_scatter_cm(FastGeom G, SeqTab S, uint32_t *dir, uint32_t *records, FastHeader *hdr, float *tlut_w,
+// MAXB: 64-event batches per wavefront the registers hold.  8: 64 VGPRs, two workgroups per CU, chunks up to 8192 events.
+// kBigBpw: 128 VGPRs, ONE workgroup per CU, chunks up to 20 480 events (LDS: 80 KB of staging + the counters) -- for large
+// calls with tile bins, where a consumer gathers one run per chunk: 10 M events at 1280x720 leave 512 chunks with 43-record
+// runs instead of 1536 with 14-record ones.
+template <bool HAS_MAP, bool EV = false, bool SIMPLE = false, int MAXB = kMaxBpw>
+__global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(MAXB > kMaxBpw ? 4 : 8, MAXB > kMaxBpw ? 4 : 8))) void kf_scatter_cm(FastGeom G, SeqTab S, uint32_t *dir, uint32_t *records, FastHeader *hdr, float *tlut_w,
                                                      uint32_t epoch)
 {
     extern __shared__ uint32_t lds[];
@@ -767,11 +783,11 @@ __global__ __launch_bounds__(kFT) void kf_scatter_cm(FastGeom G, SeqTab S, uint3
     const long long left = S.ev0[s + 1] - wave_begin;
     const uint32_t nloc = left < (long long)G.run ? (uint32_t)(left < 0 ? 0 : left) : (uint32_t)G.run;
     const long long t0 = S.t0[s];
-    uint2 q[kMaxBpw];
+    uint2 q[MAXB];
     if (nloc > 0) { // wave-uniform; no load under a lane condition: lanes behind the run's end re-read its last event
         const uint2 *src = G.data + wave_begin;
 #pragma unroll
-        for (int j = 0; j < kMaxBpw; ++j) {
+        for (int j = 0; j < MAXB; ++j) {
             const uint32_t i = (uint32_t)(j * kWave + lane);
             q[j] = src[i < nloc ? i : nloc - 1u];
         }
@@ -790,11 +806,11 @@ __global__ __launch_bounds__(kFT) void kf_scatter_cm(FastGeom G, SeqTab S, uint3
     }
     __syncthreads();
     // ---- phase A: stream rank of every event inside (wavefront, bin), one returning LDS atomic each (lane order = stream order)
-    uint32_t where[kMaxBpw], word[kMaxBpw];
+    uint32_t where[MAXB], word[MAXB];
     unsigned long long wseen = 0ull;
     int err = 0;
 #pragma unroll
-    for (int j = 0; j < kMaxBpw; ++j) {
+    for (int j = 0; j < MAXB; ++j) {
         where[j] = 0xffffffffu;
         word[j] = 0u;
         if (j < G.bpw) {
@@ -839,7 +855,7 @@ __global__ __launch_bounds__(kFT) void kf_scatter_cm(FastGeom G, SeqTab S, uint3
     __syncthreads();
     // ---- phase C: stage the chunk bin-major in LDS
 #pragma unroll
-    for (int j = 0; j < kMaxBpw; ++j) {
+    for (int j = 0; j < MAXB; ++j) {
         if (j < G.bpw && where[j] != 0xffffffffu) {
             const uint32_t b = where[j] >> 16;
             stage[loff[b] + wcnt[b] + (where[j] & 0xffffu)] = word[j];
@@ -951,6 +967,23 @@ __device__ __forceinline__ void col_index(const uint32_t *L, int C, uint32_t lo,
         const uint32_t a = L[c] > lo ? L[c] : lo, z = L[c + 1] < hi ? L[c + 1] : hi;
         for (uint32_t i = (a + 15u) & ~15u; i < z; i += 16u) idx[(i - lo) >> 4] = (uint16_t)c;
     }
+}
+
+__device__ __forceinline__ uint32_t col_addr(const uint32_t *L, const uint32_t *D, uint32_t c, uint32_t i); // below
+
+// The same for one wavefront's 64 consecutive positions lo + r0 .. lo + r0 + 63 of a range [lo, lo + nr) indexed by idx (this
+// lane: lo + ric): when they all lie inside ONE run -- the rule for the long runs of a skewed tile -- the run is found once,
+// with scalar compares, and a lane only adds.
+__device__ __forceinline__ uint32_t col_addr_wave(const uint32_t *L, const uint32_t *D, const uint16_t *idx, uint32_t lo, uint32_t r0,
+                                                  uint32_t ric, uint32_t nr)
+{
+    if (r0 >= nr) return D[0] + L[0]; // (wave-uniform: nothing of this wavefront's batch is inside the range; any address that exists)
+    const uint32_t i0 = lo + r0, last = lo + (r0 + 63u < nr ? r0 + 63u : nr - 1u);
+    uint32_t cs = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx[r0 >> 4]);
+    uint32_t lnext = (uint32_t)__builtin_amdgcn_readfirstlane((int)L[cs + 1]);
+    while (lnext <= i0) { ++cs; lnext = (uint32_t)__builtin_amdgcn_readfirstlane((int)L[cs + 1]); }
+    if (lnext > last) return (uint32_t)__builtin_amdgcn_readfirstlane((int)D[cs]) + lo + ric;
+    return col_addr(L, D, idx[ric >> 4], lo + ric);
 }
 
 __device__ __forceinline__ uint32_t col_addr(const uint32_t *L, const uint32_t *D, uint32_t c, uint32_t i) // c: a chunk at or in front of i's
@@ -1347,12 +1380,13 @@ __device__ __forceinline__ void split_place_segment(const TileP &q, uint32_t seg
         if (CM) q.sub_end[(long long)g * kFW + wv] = vstart + total;
     }
     uint32_t m[RPT], rk[RPT];
+    const uint32_t wvs = (uint32_t)__builtin_amdgcn_readfirstlane(wv);
 #pragma unroll
     for (int u = 0; u < RPT; ++u) {
         const uint32_t i = (uint32_t)(u * kFT + tid);
         if (CM) {
             const uint32_t ic = i < nrec ? i : nrec - 1u; // (nrec >= 1: a segment is never empty)
-            const uint32_t v = cm.rec[col_addr(cl->L, cl->D, cl->idx[ic >> 4], beg + ic)];
+            const uint32_t v = cm.rec[col_addr_wave(cl->L, cl->D, cl->idx, beg, (uint32_t)(u * kFT) + wvs * kWave, ic, nrec)];
             m[u] = i < nrec ? v : 0u;
         } else {
             m[u] = i < nrec ? q.rec[beg + i] : 0u;
@@ -1445,10 +1479,11 @@ __global__ __launch_bounds__(kFT) void kf_segcount_cm(TileP q, CmP cm, SeqTab S)
         if (tid < kFW * kFW) (&wtot[0][0])[tid] = 0u;
         __syncthreads();
         uint32_t v[kSplitRpt];
+        const uint32_t wvs = (uint32_t)__builtin_amdgcn_readfirstlane(wv);
 #pragma unroll
         for (int u = 0; u < kSplitRpt; ++u) {
             const uint32_t i = (uint32_t)(u * kFT + tid), ic = i < nrec ? i : nrec - 1u;
-            v[u] = cm.rec[col_addr(cl.L, cl.D, cl.idx[ic >> 4], beg + ic)];
+            v[u] = cm.rec[col_addr_wave(cl.L, cl.D, cl.idx, beg, (uint32_t)(u * kFT) + wvs * kWave, ic, nrec)];
         }
 #pragma unroll
         for (int u = 0; u < kSplitRpt; ++u)
@@ -2563,7 +2598,13 @@ int launch_fast_cm(const FastGeom &G, const SeqTab &S, const FastPlan &p, char *
     uint32_t epoch = g_epoch.fetch_add(1u, std::memory_order_relaxed) + 1u;
     if (epoch == 0u) epoch = g_epoch.fetch_add(1u, std::memory_order_relaxed) + 1u; // (0 is what frlw_workspace_init leaves behind)
     const bool simple = !HAS_MAP && G.simple != 0;
-    if (simple) {
+    if (p.big && simple) {
+        (void)hipFuncSetAttribute((const void *)kf_scatter_cm<false, EV, true, kBigBpw>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc);
+        hipLaunchKernelGGL((kf_scatter_cm<false, EV, true, kBigBpw>), dim3(p.chunks), dim3(kFT), lds_sc, st, G, S, dir, records, hdr, tlut, epoch);
+    } else if (p.big) {
+        (void)hipFuncSetAttribute((const void *)kf_scatter_cm<HAS_MAP, EV, false, kBigBpw>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc);
+        hipLaunchKernelGGL((kf_scatter_cm<HAS_MAP, EV, false, kBigBpw>), dim3(p.chunks), dim3(kFT), lds_sc, st, G, S, dir, records, hdr, tlut, epoch);
+    } else if (simple) {
         if (lds_sc > 64 * 1024)
             (void)hipFuncSetAttribute((const void *)kf_scatter_cm<false, EV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc);
         hipLaunchKernelGGL((kf_scatter_cm<false, EV, true>), dim3(p.chunks), dim3(kFT), lds_sc, st, G, S, dir, records, hdr, tlut, epoch);
@@ -2575,12 +2616,13 @@ int launch_fast_cm(const FastGeom &G, const SeqTab &S, const FastPlan &p, char *
     return FRLW_OK;
 }
 
-// chunk-major partition or histogram partition?  frlw_tuning_t::chunk_major forces either (1 still gives way where a consumer
-// could not hold a sequence's column of the directory in LDS, and to the tile walk, which wants contiguous tile lists).
-// Default, from the measurements in DESIGN.md 3.6: chunk-major for direct-mode calls (TAF and Event Volume: two launches
-// instead of five) and for every Event Volume batch (64 x 1 M events: 720-743 us against 784-804); TAF calls with tile bins keep
-// the histogram partition (10 M events at 1280x720: 180 against 177 us, 64 GEN1 streams 853 against 849 -- a tie that the
-// skewed variants lose: 319 against 287 us).
+// chunk-major partition or histogram partition?  frlw_tuning_t::chunk_major = 0 forces the histogram partition; otherwise the
+// chunk-major one runs wherever a consumer can hold a sequence's column of the directory in LDS (cm_fits) and nobody asked for
+// the tile walk, which wants contiguous tile lists.  Measured (us, chunk-major against histogram partition): one
+// GEN1 stream 32 / 42, 5 x 70 k events on 97x131 34 / 55, 3 M events at 1280x720 111 / 133, 10 M events 164 / 177, 64 GEN1
+// streams 808 / 861, Event Volume x64 736 / 787; the skewed variants give some of it back (25 % of 10 M events in one blob:
+// 298 / 287 -- the split segments of a skewed tile are only known after the split kernel, so their counting pass is a launch
+// of its own).
 enum : int { CM_OFF = 0, CM_AUTO = -1, CM_ON = 1 };
 inline bool cm_fits(const FastPlan &p, bool ev)
 {
@@ -2603,7 +2645,7 @@ inline int plan_call(const frlw_tuning_t *tu, bool ev, bool tile_walk_wanted, lo
     if (knob != CM_OFF && !tile_walk_wanted) {
         if (!fast_plan(n, n_seq, H, W, p, dmode, bpw, true)) return FRLW_ERR_UNSUPPORTED;
         if (!fast_layout(seq_offsets, t0, n_seq, p, S, win)) return FRLW_ERR_ARG;
-        cm = cm_fits(p, ev) && (knob == CM_ON || p.direct || ev);
+        cm = cm_fits(p, ev);
         if (cm) return FRLW_OK;
     }
     if (!fast_plan(n, n_seq, H, W, p, dmode, bpw, false)) return FRLW_ERR_UNSUPPORTED;

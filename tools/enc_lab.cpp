@@ -112,6 +112,9 @@ static const Cfg kCfgs[] = {
     {"gen1x64", 0, 240, 304, 64, 1000000, 80000, 8, 10000, 8, false},
     {"e2e64", 0, 240, 304, 64, 1000000, 80000, 8, 10000, 8, true},
     {"small", 0, 97, 131, 5, 70000, 30000, 3, 10000, 4, true},
+    {"e2e64s", 0, 240, 304, 64, 125000, 80000, 8, 10000, 8, false},    // the batch of bench.py's encode + train row: 64 x 8 x 15 625 events
+    {"gen1x8", 0, 240, 304, 8, 1000000, 80000, 8, 10000, 8, false},
+    {"mpx3", 0, 720, 1280, 1, 3000000, 80000, 8, 10000, 8, false},
     {"ev1", 1, 240, 304, 1, 1000000, 250000, 1, 250000, 5, false},
     {"evb1", 2, 240, 304, 1, 1000000, 250000, 1, 250000, 5, false},
     {"evb64", 2, 240, 304, 64, 1000000, 250000, 1, 250000, 5, false},
