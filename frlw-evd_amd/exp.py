@@ -4,8 +4,9 @@
 same checkpoint files and dict layout (``saveCheckpoint`` :198-210, ``loadCheckpoint`` :155-165), so checkpoints
 interchange with the reference's -- pinned by tests/golden/entry_points.json.
 
-Data: the reference reads pre-encoded ``uint8`` files through DataLoader workers (out of scope).
-Here a run without ``--data_path`` draws SYNTHETIC event streams and encodes them on the GPU every step
+Data: with ``--bbox_path`` / ``--data_path`` the pre-encoded ``uint8`` files of the ``generate_*.py`` commands are read by
+``frlw_evd_amd.dataset`` (the reference's dataset classes and ``Loader``: uint8 batches over PCIe, the sample transform as
+one kernel on the GPU).  A run without them draws SYNTHETIC event streams and encodes them on the GPU every step
 (``e2e.SyntheticTafSource``), which is BASELINE.json's config 5.  The evaluator hand-off is the real one
 (``frlw_evd_amd.evaluator``); COCO mAP needs pycocotools and is reported only when a ``metric_fn`` is injected.
 """
@@ -76,13 +77,48 @@ class basicExp:
     def _classes(self):
         return GEN1_CLASSES if self.settings.dataset_name == "gen1" else GEN4_CLASSES
 
-    def _require_synthetic(self):
-        if not self.settings.synthetic:
-            raise NotImplementedError("--data_path / --bbox_path: real-dataset loading is outside this build's hot path "
-                                      "(SURVEY.md section 2 #9); omit both for the synthetic GPU-encoded run")
+    def _dataset(self, mode, augment, clipping):
+        """core/exp.py:60-84: ``propheseeDataset`` over the representation files the ``generate_*.py`` commands wrote."""
+        from .dataset import propheseeDataset
+        s = self.settings
+        return propheseeDataset(s.bbox_path, s.data_path, s.dataset_name, s.input_img_size, s.img_size, s.event_volume_bins,
+                                s.infer_time, s.train_memory_steps, mode, augment, clipping)
+
+    def _disk_loaders(self, test_only=False):
+        """core/exp.py:56-124 (and :401-466 / :593-660 for the TAF datasets): datasets + ``Loader``s from ``--bbox_path`` /
+        ``--data_path``; the training split goes through a DistributedSampler like the reference's."""
+        from .dataset import Loader
+        s = self.settings
+        if s.bbox_path is None or s.data_path is None:
+            raise ValueError("--bbox_path and --data_path come together (omit both for the synthetic GPU-encoded run)")
+        if test_only:
+            val = self._dataset("test", False, False)
+            self.object_classes = val.object_classes
+            self.val_loader = Loader(val, batch_size=s.batch_size, device=s.gpu_device, num_workers=s.num_cpu_workers,
+                                     pin_memory=False, shuffle=False)
+        else:
+            train = self._dataset("train", s.augment, s.clipping if self._clip_train else False)
+            self.object_classes = train.object_classes
+            val = self._dataset("val", False, False)
+            sampler = torch.utils.data.distributed.DistributedSampler(train) if dist.is_initialized() else None
+            self.train_loader = Loader(train, batch_size=s.batch_size, device=s.gpu_device, num_workers=s.num_cpu_workers,
+                                       pin_memory=True, sampler=sampler)
+            vs = torch.utils.data.distributed.DistributedSampler(val) if (dist.is_initialized() and self._shard_val) else None
+            self.val_loader = Loader(val, batch_size=s.batch_size, device=s.gpu_device, num_workers=s.num_cpu_workers,
+                                     pin_memory=True, shuffle=False, sampler=vs)
+            print(f"train_loader_len: {len(self.train_loader)}, test_loader_len: {len(self.val_loader)}")
+            self.nr_train_epochs = len(self.train_loader)
+        if test_only:
+            print(f"test_loader_len: {len(self.val_loader)}")
+        self.nr_val_epochs = len(self.val_loader)
+        self.ori_width, self.ori_height = val.width, val.height
+
+    _clip_train = True   # basicExp passes settings.clipping to the training split (core/exp.py:70), the TAF exps False (:414)
+    _shard_val = True    # basicExp gives the validation split a DistributedSampler (core/exp.py:87), the TAF exps do not (:430-435)
 
     def createDatasets(self):
-        self._require_synthetic()
+        if not self.settings.synthetic:
+            return self._disk_loaders()
         self.object_classes = self._classes()
         rank = dist.get_rank() if dist.is_initialized() else 0
         self.train_loader = SyntheticLoader(self.settings, self.synthetic_batches, seed=1005 + 1000 * rank)
@@ -91,7 +127,8 @@ class basicExp:
         self.ori_width, self.ori_height = (304, 240) if self.settings.dataset_name == "gen1" else (1280, 720)
 
     def createDatasetsTest(self):
-        self._require_synthetic()
+        if not self.settings.synthetic:
+            return self._disk_loaders(test_only=True)
         self.object_classes = self._classes()
         rank = dist.get_rank() if dist.is_initialized() else 0
         self.val_loader = SyntheticLoader(self.settings, self.synthetic_batches, seed=2005 + 1000 * rank, with_track=True)
@@ -274,6 +311,16 @@ class yoloxtafBFM(yolox):
         super().__init__(settings)
         from .yolox.bfm import Temporal_Active_Focus_connect
         self.input_layer = Temporal_Active_Focus_connect
+
+    _clip_train = False
+    _shard_val = False
+
+    def _dataset(self, mode, augment, clipping):
+        """core/exp.py:593-660: ``propheseeTafDataset`` (bins4 + bins8 files of ``generate_taf.py``)."""
+        from .dataset import propheseeTafDataset
+        s = self.settings
+        return propheseeTafDataset(s.bbox_path, s.data_path, s.dataset_name, s.input_img_size, s.img_size, s.infer_time,
+                                   s.event_volume_bins, mode, augment, clipping)
 
 
 EXPERIMENTS = {"yolox": yolox, "yolox_taf_bfm": yoloxtafBFM}

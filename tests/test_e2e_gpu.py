@@ -135,3 +135,45 @@ def test_encode_ahead_feeds_the_same_batches():
         assert got == want, (graph, got, want)
     with pytest.raises(RuntimeError):
         ahead.take()
+
+
+@pytest.mark.parametrize("recipe", ["yolox_taf_bfm", "yolox"])
+def test_raw_files_to_checkpoint_to_evaluation(tmp_path, recipe):
+    """The whole offline flow of README.md:56-170 on a fabricated GEN1 dataset, every step through the product's entry points:
+    ``*_td.dat`` + ``*_bbox.npy``  ->  ``generate_taf.py`` / ``generate_eventvolume.py`` (uint8 representation files)  ->
+    ``train.py --bbox_path --data_path`` (disk datasets, one epoch, checkpoints)  ->  ``test.py --record`` (summarise.npz)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import os
+    import shutil
+    import socket
+    import subprocess
+    import sys
+    import harness_data
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    raw, lab = harness_data.build(str(tmp_path / "dataset"))
+    for d in (raw, lab):  # a validation split: the training sequence once more
+        shutil.copytree(os.path.join(d, "train"), os.path.join(d, "val"))
+    target = str(tmp_path / "processed")
+    gen, sub, bins = (("generate_taf.py", "taf", "4") if recipe == "yolox_taf_bfm" else ("generate_eventvolume.py", "EventVolume250000", "5"))
+    r = subprocess.run([sys.executable, os.path.join(root, gen), "-raw_dir", raw, "-label_dir", lab, "-target_dir", target,
+                        "-dataset", "gen1"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, FRLW_MAX_EPOCHS="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0")
+    log = str(tmp_path / "log") + "/"
+    common = ["--dataset", "gen1", "--exp_type", recipe, "--event_volume_bins", bins, "--nodes", "1", "--log_path", log,
+              "--bbox_path", lab, "--data_path", os.path.join(target, sub), "--num_cpu_workers", "2"]
+    r = subprocess.run([sys.executable, os.path.join(root, "train.py"), "--batch_size", "2", "--augmentation", "True",
+                        "--exp_name", "R"] + common, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "train_loader_len: 1, test_loader_len: 1" in r.stdout and "trainloss" in r.stdout
+    assert os.path.exists(os.path.join(log, "R", "checkpoints", "best_epoch.pth"))
+    r = subprocess.run([sys.executable, os.path.join(root, "test.py"), "--batch_size", "4", "--record", "True", "--resume_exp", "R"]
+                       + common, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "test_loader_len: 2" in r.stdout and os.path.exists(os.path.join(log, "R", "summarise.npz"))  # 7 labelled frames, batch 4
