@@ -181,10 +181,12 @@ class Loader:
     def _read(self, batch):
         ds = self.dataset
         H, W = ds.img_size
-        buf = torch.empty((len(batch), ds.channels if not ds.reference_mean_quirk else int(2 * ds.time_channels), H, W),
-                          dtype=torch.uint8, pin_memory=self.pin)
-        view = buf.numpy()
-        list(self._pool.map(lambda j: ds.load_u8(batch[j], view[j]), range(len(batch))))
+        if ds.reference_mean_quirk:  # data/dataset.py:245 as shipped: numpy's float32 channel mean, stacked twice, on the host
+            buf = torch.from_numpy(np.stack(list(self._pool.map(lambda i: ds.load_data(i), batch))))
+        else:
+            buf = torch.empty((len(batch), ds.channels, H, W), dtype=torch.uint8, pin_memory=self.pin)
+            view = buf.numpy()
+            list(self._pool.map(lambda j: ds.load_u8(batch[j], view[j]), range(len(batch))))
         labels, params = zip(*[ds.labels(i) for i in batch])  # (host arithmetic on a handful of boxes; draws in sample order)
         return buf, np.stack(labels), list(params), [ds.file_name[i] for i in batch], np.array([ds.sequence_end_t[i] for i in batch])
 
@@ -200,9 +202,8 @@ class Loader:
                 if k + 1 < len(batches):
                     nxt = ahead.submit(self._read, batches[k + 1])  # read while this batch trains
                 u8 = buf.to(self.device, non_blocking=True)
-                if self.dataset.reference_mean_quirk:  # data/dataset.py:245 as shipped: the channel mean, stacked twice
-                    m = u8.float().mean(1, keepdim=True)
-                    imgs = self._transform_f32(torch.cat([m, m], 1), params)
+                if self.dataset.reference_mean_quirk:
+                    imgs = self._transform_f32(u8, params)
                 else:
                     imgs = transforms.transform_images(u8, params)
                 yield [imgs, torch.from_numpy(labels).to(self.device, non_blocking=True), names, stamps]
