@@ -201,17 +201,16 @@ class Loader:
                 buf, labels, params, names, stamps = nxt.result()
                 if k + 1 < len(batches):
                     nxt = ahead.submit(self._read, batches[k + 1])  # read while this batch trains
-                u8 = buf.to(self.device, non_blocking=True)
-                if self.dataset.reference_mean_quirk:
-                    imgs = self._transform_f32(u8, params)
+                if self.dataset.reference_mean_quirk:  # the HEAD line's path stays on the host end to end, with the reference's
+                    imgs = self._transform_f32(buf, params).to(self.device, non_blocking=True)  # own torch-CPU operations
                 else:
-                    imgs = transforms.transform_images(u8, params)
+                    imgs = transforms.transform_images(buf.to(self.device, non_blocking=True), params)
                 yield [imgs, torch.from_numpy(labels).to(self.device, non_blocking=True), names, stamps]
 
     @staticmethod
     def _transform_f32(vol, params):
-        """The image half of ``__getitem__`` on float32 volumes with plain torch ops (only the HEAD quirk's path needs it:
-        its mean is not a uint8 any more)."""
+        """The image half of ``__getitem__`` on float32 volumes with plain torch ops ON THE HOST (only the HEAD quirk's path
+        needs it: its mean is not a uint8 any more, and torch's GPU division is not the correctly rounded one of the CPU)."""
         B, C, H, W = vol.shape
         out = torch.empty((B, C, H, W, 1, 1), dtype=torch.float32, device=vol.device)
         for b, p in enumerate(params):
