@@ -129,6 +129,9 @@ SYMBOLS = {
     "frlw_pred_bwd": (_I, [_P, _P, _P, _I64, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
     "frlw_simota_workspace_bytes": (_SZ, [_I, _I, _I]),
     "frlw_simota_assign": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, C.c_float, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "frlw_yolox_loss_workspace_bytes": (_SZ, [_I, _I, _I]),
+    "frlw_yolox_loss_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _I, C.c_float, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "frlw_yolox_loss_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
 }
 
 _lib = None

@@ -2,9 +2,11 @@
 (reference: core/yolox/models/yolo_head.py:237-256,305-707, core/yolox/models/losses.py:9-53,
 core/yolox/utils/boxes.py:79-102).
 
-Host logic on ROCm tensors with plain torch ops (the assignment is per-image
-Python with ``.item()`` syncs in the reference too).  Dtype behaviour is kept: labels arrive as float64
-(data/dataset.py:216), so IoUs, costs and the total loss are float64 while predictions stay float32.
+Three forms of the same loss: the reference's per-image procedure with plain torch ops (``get_assignments`` -- CPU tensors,
+and the yardstick of the GPU tests), the batched one (native SimOTA + masked torch terms, ``yolox_losses_batched``) and the
+native one (``_YoloxLoss``: decode, assignment, terms and gradient in csrc/simota.hip), which is what ROCm tensors take.
+Dtype behaviour is kept in all three: labels arrive as float64 (data/dataset.py:216), so IoUs, costs and the total loss
+are float64 while predictions stay float32.
 """
 import torch
 import torch.nn.functional as F
@@ -193,12 +195,88 @@ def yolox_losses_batched(outputs, x_shifts, y_shifts, strides_all, labels, num_c
     return loss, reg_weight * loss_iou, loss_obj, loss_cls, 0.0, num_fg / nlabel.sum().clamp(min=1)
 
 
+_LOSS_WS = {}
+_FORCE_TORCH_LOSS = False  # tests flip this to compare the native loss (value and gradients) with the autograd one above
+
+
+def _level_arrays(rows, strides):
+    """HOST arrays of frlw_yolox_loss_*: device pointers, grid shapes and strides of the levels."""
+    import ctypes as C
+    n = len(rows)
+    return ((C.c_void_p * n)(*[r.data_ptr() for r in rows]), (C.c_int32 * n)(*[r.shape[1] for r in rows]),
+            (C.c_int32 * n)(*[r.shape[2] for r in rows]), (C.c_float * n)(*[float(s) for s in strides]))
+
+
+class _YoloxLoss(torch.autograd.Function):
+    """``get_losses`` (yolo_head.py:305-473) as one native forward and one native backward (csrc/simota.hip,
+    frlw_yolox_loss_fwd / _bwd): returns the (6,) float64 tensor {loss, 5 * loss_iou, loss_obj, loss_cls, num_fg / num_gt, num_fg}."""
+
+    @staticmethod
+    def forward(ctx, labels, strides, num_classes, radius, *levels):
+        import ctypes as C
+        from .. import _lib, _pins
+        lib = _lib.load()
+        dev = levels[0].device
+        # (B, h, w, 5 + nc) rows: what train_ops.pred_level produced (no copy); NCHW outputs of the torch convolutions are
+        # re-laid once
+        rows = [o.detach().float().permute(0, 2, 3, 1).contiguous() for o in levels]
+        B, P = rows[0].shape[0], rows[0].shape[3]
+        A = sum(r.shape[1] * r.shape[2] for r in rows)
+        lab = labels.detach().to(device=dev, dtype=torch.float64).contiguous()
+        G = lab.shape[1]
+        preds = torch.empty((B, A, P), dtype=torch.float32, device=dev)
+        fg = torch.empty((B, A), dtype=torch.uint8, device=dev)
+        matched_gt = torch.empty((B, A), dtype=torch.int32, device=dev)
+        matched_iou = torch.empty((B, A), dtype=torch.float64, device=dev)
+        result = torch.empty((6,), dtype=torch.float64, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        need = lib.frlw_yolox_loss_workspace_bytes(B, A, G)
+        key = (dev.index, stream)
+        ws = _LOSS_WS.get(key)
+        if ws is None or ws.numel() < need:
+            _pins.retire(ws)  # a live HIP graph may still launch kernels on the old workspace
+            ws = _LOSS_WS[key] = torch.empty(need, dtype=torch.uint8, device=dev)
+        raw, hs, wd, st = _level_arrays(rows, strides)
+        _lib.check(lib.frlw_yolox_loss_fwd(raw, hs, wd, st, len(rows), B, num_classes, lab.data_ptr(), G, C.c_float(radius),
+                                           preds.data_ptr(), fg.data_ptr(), matched_gt.data_ptr(), matched_iou.data_ptr(),
+                                           result.data_ptr(), ws.data_ptr(), ws.numel(), stream), "frlw_yolox_loss_fwd")
+        ctx.save_for_backward(lab, fg, matched_gt, matched_iou, result, *rows)
+        ctx.meta = (tuple(float(s) for s in strides), num_classes)
+        return result
+
+    @staticmethod
+    def backward(ctx, grad):
+        import ctypes as C
+        from .. import _lib
+        lib = _lib.load()
+        lab, fg, matched_gt, matched_iou, result, *rows = ctx.saved_tensors
+        strides, num_classes = ctx.meta
+        dev = rows[0].device
+        grad = grad.detach().to(torch.float64).contiguous()
+        grads = [torch.empty_like(r) for r in rows]
+        raw, hs, wd, st = _level_arrays(rows, strides)
+        out = (C.c_void_p * len(rows))(*[g.data_ptr() for g in grads])
+        _lib.check(lib.frlw_yolox_loss_bwd(raw, hs, wd, st, len(rows), rows[0].shape[0], num_classes, lab.data_ptr(),
+                                           lab.shape[1], fg.data_ptr(), matched_gt.data_ptr(), matched_iou.data_ptr(),
+                                           result.data_ptr(), grad.data_ptr(), out,
+                                           torch.cuda.current_stream(dev).cuda_stream), "frlw_yolox_loss_bwd")
+        return (None, None, None, None, *[g.permute(0, 3, 1, 2) for g in grads])
+
+
+def yolox_losses_native(level_outputs, strides, labels, num_classes, radius):
+    """The tuple of ``yolox_losses`` from the native loss (ROCm tensors): seven launches forward, one backward."""
+    res = _YoloxLoss.apply(labels, tuple(strides), int(num_classes), float(radius), *level_outputs)
+    return res[0], res[1], res[2], res[3], 0.0, res[4]
+
+
 def yolox_losses(level_outputs, strides, labels, num_classes, radius):
     """``get_losses`` (yolo_head.py:305-473) on the raw per-level outputs cat[reg, obj, cls] (B, 5 + nc, h, w).
 
-    Returns (loss, 5 * loss_iou, loss_obj, loss_cls, loss_l1 = 0.0, num_fg / num_gt).  On ROCm tensors the
-    assignment runs in the HIP library (one launch sequence per batch); on CPU tensors -- the gloo tests and
-    the golden checks -- it is the reference's per-image procedure."""
+    Returns (loss, 5 * loss_iou, loss_obj, loss_cls, loss_l1 = 0.0, num_fg / num_gt).  On ROCm tensors the whole
+    loss -- decode, assignment, the three terms and their gradient -- runs in the HIP library (``_YoloxLoss``); on CPU
+    tensors -- the gloo tests and the golden checks -- it is the reference's per-image procedure."""
+    if level_outputs[0].is_cuda and not (_FORCE_LOOP or _FORCE_TORCH_LOSS) and len(level_outputs) <= 4:
+        return yolox_losses_native(level_outputs, strides, labels, num_classes, radius)
     outs, xs, ys, ss = [], [], [], []
     for o, stride in zip(level_outputs, strides):
         dec, grid = output_and_grid(o, stride)

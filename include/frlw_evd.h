@@ -398,12 +398,36 @@ int frlw_spp_train_bwd(const float *dout, const uint16_t *argmax, int B, int H, 
  * outputs (caller-allocated):
  *   fg (B, A) u8, matched_gt (B, A) i32 (-1 = background), matched_iou (B, A) f64 (IoU of the prediction
  *   with its matched box, the class target), num_fg (B) i32, nlabel (B) i32 (may be NULL).
- * The losses proper stay autograd-side (frlw-evd_amd/yolox/losses.py). */
+ * (frlw_yolox_loss_fwd below runs this assignment as a part of the whole loss.) */
 size_t frlw_simota_workspace_bytes(int B, int A, int G);
 int frlw_simota_assign(const float *preds, const double *labels, const float *x_shifts, const float *y_shifts,
                        const float *strides, int B, int A, int G, int num_classes, float radius, uint8_t *fg,
                        int32_t *matched_gt, double *matched_iou, int32_t *num_fg, int32_t *nlabel, void *workspace,
                        size_t workspace_bytes, frlw_stream_t stream);
+
+/* The training loss of a batch on the raw level outputs (core/yolox/models/yolo_head.py:237-256 get_output_and_grid,
+ * :305-473 get_losses; core/yolox/models/losses.py:16-36 IOUloss "iou"; nn.BCEWithLogitsLoss for objectness and class):
+ * decode + concatenation, the SimOTA assignment above, the three loss sums and -- in _bwd -- the gradient of the raw
+ * outputs, as six + one launches with no host synchronisation.
+ *   raw, h, w, strides  HOST arrays of n_levels (<= 4) entries: device pointer to the level's (B, h, w, 5 + nc) f32 rows
+ *                       cat[reg, obj, cls] (no sigmoid), its grid shape and stride
+ *   labels (B, G, 5) f64 as for frlw_simota_assign
+ * _fwd outputs (caller-allocated, kept for _bwd): preds (B, A, 5 + nc) f32 decoded, A = sum h*w; fg, matched_gt,
+ *   matched_iou as above; result (6) f64 = {loss, 5 * loss_iou, loss_obj, loss_cls, num_fg / max(num_gt, 1),
+ *   max(num_fg, 1)} -- the tuple get_losses returns (its loss_l1 is the constant 0.0) and the divisor.
+ * _bwd: grad_result (4+) f64 on the device = upstream gradient of result[0..3]; grad_raw: HOST array of n_levels device
+ *   pointers, each receives the (B, h, w, 5 + nc) f32 gradient of its level (every element written).
+ * Dtypes as in the reference: IoU and class terms float64 (float64 labels), objectness float32; sums in float64 in a
+ * fixed order (bit-reproducible). */
+size_t frlw_yolox_loss_workspace_bytes(int B, int A, int G);
+int frlw_yolox_loss_fwd(const float *const *raw, const int32_t *h, const int32_t *w, const float *strides, int n_levels,
+                        int B, int num_classes, const double *labels, int G, float radius, float *preds, uint8_t *fg,
+                        int32_t *matched_gt, double *matched_iou, double *result, void *workspace,
+                        size_t workspace_bytes, frlw_stream_t stream);
+int frlw_yolox_loss_bwd(const float *const *raw, const int32_t *h, const int32_t *w, const float *strides, int n_levels,
+                        int B, int num_classes, const double *labels, int G, const uint8_t *fg,
+                        const int32_t *matched_gt, const double *matched_iou, const double *result,
+                        const double *grad_result, float *const *grad_raw, frlw_stream_t stream);
 
 /* Sample transform of the training loader for a batch (data/dataset.py:217-231 in propheseeDataset.__getitem__):
  * (B, C, H, W) uint8 -> (B, C, H, W) f32 = flip(crop(nearest_resize(x, (Hr, Wr)) / 255)).

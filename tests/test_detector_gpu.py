@@ -265,6 +265,43 @@ def test_simota_batched_equals_per_image_procedure(gpu, seed, B):
     assert float(got.detach()) == pytest.approx(float(want.detach()), rel=1e-6)  # float32 sum of the objectness term in another order
 
 
+@pytest.mark.parametrize("seed,B,nc", [(21, 4, 2), (22, 8, 2), (23, 3, 7)])
+def test_native_loss_equals_autograd_loss(gpu, seed, B, nc):
+    """frlw_yolox_loss_fwd / _bwd (decode + SimOTA + the three terms + hand-derived gradient, csrc/simota.hip) against the
+    same loss written with torch ops and differentiated by autograd (yolox_losses_batched): every element of the returned
+    tuple and the gradient of every raw level output, for upstream gradients on several tuple elements at once."""
+    from frlw_evd_amd.yolox import losses
+    m = build_yolox(10, nc)
+    m.load_state_dict(recipe_state_dict(m, seed=1004 + seed))
+    m = m.to(gpu).train()
+    x = detector_input(seed, B).to(gpu)
+    labels = _random_labels(seed, B).to(gpu)
+    if nc > 2:
+        labels[:, :, 0] = torch.randint(0, nc, labels.shape[:2], device=gpu).double() * (labels[:, :, 3] > 0)
+    with torch.no_grad():
+        level = [o.clone() for o in m.head.train_outputs(m.neck(m.backbone(x[..., 0])))]
+
+    def run(force_torch):
+        leaves = [o.clone().requires_grad_(True) for o in level]
+        try:
+            losses._FORCE_TORCH_LOSS = force_torch
+            tup = losses.yolox_losses(leaves, m.head.strides, labels, nc, m.head.radius)
+        finally:
+            losses._FORCE_TORCH_LOSS = False
+        (tup[0] + 0.5 * tup[1] + 2.0 * tup[2] - 0.25 * tup[3]).backward()
+        return [float(torch.as_tensor(v).detach()) for v in tup], [l.grad for l in leaves]
+
+    want, gwant = run(True)
+    got, ggot = run(False)
+    assert want[0] > 0 and want[5] > 0
+    assert got == pytest.approx(want, rel=1e-6)  # the float32 objectness sum is a float64 sum here
+    for a, b in zip(ggot, gwant):
+        assert a.shape == b.shape
+        assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())
+        assert rel_err(a, b) <= 1e-6
+    assert any(float(g[:, :4].abs().max()) > 0 for g in gwant)  # box gradients are exercised
+
+
 @pytest.mark.parametrize("tag,C", [("bfm8", 8), ("bfm16", 16)])
 def test_bfm_stem_engine_vs_golden_and_torch(gpu, golden_dir, tag, C):
     """yolox_taf_bfm (core/exp.py:588-591): fused BFM stem kernel + the usual plan against the reference-generated
