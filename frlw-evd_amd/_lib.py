@@ -88,6 +88,9 @@ SYMBOLS = {
     "frlw_det_num_ops": (_I, [_P]),
     "frlw_det_set_scratch": (_I, [_P, _I, _I64]),
     "frlw_det_set_lane": (_I, [_P, _I]),
+    "frlw_det_set_precision": (_I, [_P, _I]),
+    "frlw_conv_split_operand_bytes": (_SZ, [_I, _I]),
+    "frlw_conv_split_operand": (_I, [_P, _I, _I, _P, _P]),
     "frlw_det_add_fork": (_I, [_P]),
     "frlw_det_add_join": (_I, [_P]),
     "frlw_det_add_focus": (_I, [_P, _I, _I, _I, _I, _I]),

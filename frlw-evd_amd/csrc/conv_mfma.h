@@ -8,6 +8,10 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 template <int V> struct ConvIC { static constexpr int value = V; }; // compile-time step index for asm immediates
 
 // Launch heuristics are compile-time constants in the product library: it reads no environment and prints nothing.  A
@@ -36,7 +40,37 @@ struct ConvArgs {
     uint32_t x_bytes, w_bytes; // extents of the x view and of w for the buffer descriptors (set by launch_conv)
     int group_n;       // grouped convolution: output columns [g * group_n, (g + 1) * group_n) read input channels x_co + g * Cin ...; 0: one group
     int y_rp;          // output row pitch in floats (0: dense, pixel p at p * y_cs); else pixel (oy, ox) at oy * y_rp + ox * y_cs
+    int prec;          // 0: float32 MFMA on the [K][Npad] float32 operand; 1: three bf16 MFMAs per product on the split operand (below)
 };
+
+// ---- float32 products from three bf16 MFMAs (prec = 1) ---------------------------------------------------------------------
+// x = hi + lo + e with hi = bf16(x), lo = bf16(x - hi), |e| <= 2^-18 |x|; a * b ~ a_hi b_hi + a_hi b_lo + a_lo b_hi (the dropped
+// a_lo b_lo is <= 2^-18 |a b|): three v_mfma_f32_32x32x16_bf16 (32 cycles each) per 16 k instead of eight
+// v_mfma_f32_32x32x2_f32 (64 cycles each) -- 5.3 x the matrix rate at ~1e-5 relative error per product, float32 accumulation.
+// The gathered operand stays float32 in memory and in LDS and is split in registers (six VALU instructions per pair of values,
+// hidden beside the MFMAs); the weight operand is split once, by its layout kernel, into the image the fragment reads want:
+//   [k-tile of 16][lane half h][hi | lo][Npad columns] records of eight bf16 (16 bytes): element j of record (kt, h, part, n)
+//   = part(W[16 kt + kmem(h, j)][n]),  kmem(h, j) = 4 h + j (j < 4), 8 + 4 h + (j - 4) (j >= 4)
+// -- the k a lane finds in its two 16-byte reads of the gathered row.  Same bytes as the float32 operand (K padded to 16).
+__host__ __device__ inline int conv_split_kmem(int h, int j) { return j < 4 ? 4 * h + j : 8 + 4 * h + (j - 4); }
+__device__ __forceinline__ uint32_t conv_bf16_pair(float a, float b) // {bf16(a), bf16(b)} (round to nearest even), a low
+{
+    f32x2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+// eight float32 (two quads) -> hi and lo fragments
+__device__ __forceinline__ void conv_split8(const f32x4 &q0, const f32x4 &q1, u32x4 &hi, u32x4 &lo)
+{
+    const float x[8] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const uint32_t h = conv_bf16_pair(x[2 * e], x[2 * e + 1]);
+        const float r0 = x[2 * e] - __builtin_bit_cast(float, h << 16);
+        const float r1 = x[2 * e + 1] - __builtin_bit_cast(float, h & 0xFFFF0000u);
+        hi[e] = h;
+        lo[e] = conv_bf16_pair(r0, r1);
+    }
+}
 
 #ifndef CONV_BK_BIG
 #define CONV_BK_BIG 16
@@ -82,7 +116,7 @@ __device__ __forceinline__ float4 conv_load16(__amdgpu_buffer_rsrc_t r, uint32_t
 // BM x BN output tile, 4 wavefronts arranged WROWS x WCOLS, each owning TM x TN MFMA tiles of 32 x 32.
 // UT ("uniform taps"): Cin % BK == 0, so a k-tile lies inside one filter tap and the tap changes for the whole
 // workgroup at once: the gather offsets are recomputed only then, a k-tile costs one add per load.
-template <int BM, int BN, int WROWS, int WCOLS, int BK, bool UT, int D = 2>
+template <int BM, int BN, int WROWS, int WCOLS, int BK, bool UT, int D = 2, int P = 0>
 __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
 {
     constexpr int TM = BM / (32 * WROWS), TN = BN / (32 * WCOLS);
@@ -153,8 +187,13 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
 #pragma unroll
     for (int i = 0; i < B_F4; ++i) {
         const int e = tid + 256 * i;
-        const int kr = e / BN4, n4 = (e - kr * BN4) * 4;
-        b_off[i] = (kr < BK && n0 + n4 < a.Npad) ? (uint32_t)((((long long)kt0 * BK + kr) * a.Npad + n0 + n4) * 4) : kOob;
+        if (P == 1) { // 16-byte record e of the tile image [h][hi | lo][BN]
+            const int hp = e / BN, n = e - hp * BN;
+            b_off[i] = (hp < 4 && n0 + n < a.Npad) ? (uint32_t)((((long long)kt0 * 4 + hp) * a.Npad + n0 + n) * 16) : kOob;
+        } else {
+            const int kr = e / BN4, n4 = (e - kr * BN4) * 4;
+            b_off[i] = (kr < BK && n0 + n4 < a.Npad) ? (uint32_t)((((long long)kt0 * BK + kr) * a.Npad + n0 + n4) * 4) : kOob;
+        }
     }
     // tap tracker of the NEXT k-tile to load.  UT: (s_ky, s_kx, s_ci) are workgroup-uniform, a_pix[] holds the rows'
     // offsets under that tap.  Otherwise every thread tracks the tap of its own float4.
@@ -244,6 +283,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
     // byte addresses in ring slot 0: A quad (2 j + h) ^ swizzle of row fm (second tile: + 32 rows = 2048 B), B row 4 h
     const uint32_t a_lds[2] = {lds0 + (uint32_t)(fm * BK + ((0 + fh) ^ fsw) * 4) * 4, lds0 + (uint32_t)(fm * BK + ((2 + fh) ^ fsw) * 4) * 4};
     const uint32_t b_lds = lds0 + (uint32_t)(NA * BK * BM + 4 * fh * LDB + fn) * 4;
+    const uint32_t b3_lds = lds0 + (uint32_t)(NA * BK * BM) * 4 + (uint32_t)(2 * fh * BN + fn) * 16; // prec 1: record (h, hi, column fn)
     int buf = 0, bufb = 0; // ring slots of tile kt: A (kt % NA), B (kt % NB)
     for (int kt = 0; kt < nk; ++kt) {
         if (kt + D - 1 < nk) load_b(bufb == 0 ? NB - 1 : bufb - 1);          // (kt + D - 1) % NB: read last in iteration kt - 1
@@ -254,53 +294,83 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
         // drain the prefetch.  LDS returns in order, so "all but the newest N reads" is exactly lgkmcnt(N); the empty asm
         // statements after a wait make the consuming MFMAs depend on it.
         f32x4 fa[2][TM];
-        float fb[2][TN];
         const uint32_t a_addr0 = a_lds[0] + (uint32_t)buf * (BM * BK * 4), a_addr1 = a_lds[1] + (uint32_t)buf * (BM * BK * 4);
-        const uint32_t b_addr = b_lds + (uint32_t)bufb * (BK * LDB * 4);
         auto read_a = [&](auto jc) {
             constexpr int j = decltype(jc)::value;
             asm volatile("ds_read_b128 %0, %1" : "=v"(fa[j][0]) : "v"(j ? a_addr1 : a_addr0));
             if (TM > 1) asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(fa[j][TM - 1]) : "v"(j ? a_addr1 : a_addr0));
         };
-        auto read_b = [&](auto stc) {
-            constexpr int st = decltype(stc)::value;
-            constexpr int off = (8 * (st >> 2) + (st & 3)) * LDB * 4;
-            asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(fb[st & 1][0]) : "v"(b_addr), "n"(off));
-            if (TN > 1) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(fb[st & 1][TN - 1]) : "v"(b_addr), "n"(off + 128));
-        };
-        auto step = [&](auto stc) {
-            constexpr int st = decltype(stc)::value;
-            if (st + 1 < 8) {
-                read_b(ConvIC<(st + 1 < 8 ? st + 1 : 7)>{});
-                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(st == 0 ? TM + TN : TN) : "memory");
-            } else {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (P == 1) {
+            // one k-tile = ONE bf16 k-step: the lane's eight gathered values (two quads) and its hi / lo weight records
+            u32x4 bh[TN], bl[TN];
+            const uint32_t b_addr = b3_lds + (uint32_t)bufb * (BK * LDB * 4);
+            read_a(ConvIC<0>{});
+            read_a(ConvIC<1>{});
+            asm volatile("ds_read_b128 %0, %1" : "=v"(bh[0]) : "v"(b_addr));
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bl[0]) : "v"(b_addr), "n"(BN * 16));
+            if (TN > 1) {
+                asm volatile("ds_read_b128 %0, %1 offset:512" : "=v"(bh[TN - 1]) : "v"(b_addr));
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bl[TN - 1]) : "v"(b_addr), "n"(BN * 16 + 512));
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int jn = 0; jn < TN; ++jn) asm volatile("" : "+v"(fb[st & 1][jn]));
-            if ((st & 3) == 0) {
+            for (int i = 0; i < TM; ++i) { asm volatile("" : "+v"(fa[0][i])); asm volatile("" : "+v"(fa[1][i])); }
 #pragma unroll
-                for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(fa[st >> 2][i]));
-            }
+            for (int jn = 0; jn < TN; ++jn) { asm volatile("" : "+v"(bh[jn])); asm volatile("" : "+v"(bl[jn])); }
+            u32x4 ah[TM], al[TM];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const float af = fa[st >> 2][i][st & 3];
+            for (int i = 0; i < TM; ++i) conv_split8(fa[0][i], fa[1][i], ah[i], al[i]);
 #pragma unroll
-                for (int jn = 0; jn < TN; ++jn)
-                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, fb[st & 1][jn], acc[i][jn], 0, 0, 0);
-            }
-        };
-        read_a(ConvIC<0>{});
-        read_b(ConvIC<0>{});
-        read_a(ConvIC<1>{});
-        step(ConvIC<0>{});
-        step(ConvIC<1>{});
-        step(ConvIC<2>{});
-        step(ConvIC<3>{});
-        step(ConvIC<4>{});
-        step(ConvIC<5>{});
-        step(ConvIC<6>{});
-        step(ConvIC<7>{});
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int jn = 0; jn < TN; ++jn) { // the small terms first
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[i]), __builtin_bit_cast(bf16x8, bh[jn]), acc[i][jn], 0, 0, 0);
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bl[jn]), acc[i][jn], 0, 0, 0);
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bh[jn]), acc[i][jn], 0, 0, 0);
+                }
+        } else {
+            float fb[2][TN];
+            const uint32_t b_addr = b_lds + (uint32_t)bufb * (BK * LDB * 4);
+            auto read_b = [&](auto stc) {
+                constexpr int st = decltype(stc)::value;
+                constexpr int off = (8 * (st >> 2) + (st & 3)) * LDB * 4;
+                asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(fb[st & 1][0]) : "v"(b_addr), "n"(off));
+                if (TN > 1) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(fb[st & 1][TN - 1]) : "v"(b_addr), "n"(off + 128));
+            };
+            auto step = [&](auto stc) {
+                constexpr int st = decltype(stc)::value;
+                if (st + 1 < 8) {
+                    read_b(ConvIC<(st + 1 < 8 ? st + 1 : 7)>{});
+                    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(st == 0 ? TM + TN : TN) : "memory");
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+#pragma unroll
+                for (int jn = 0; jn < TN; ++jn) asm volatile("" : "+v"(fb[st & 1][jn]));
+                if ((st & 3) == 0) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(fa[st >> 2][i]));
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const float af = fa[st >> 2][i][st & 3];
+#pragma unroll
+                    for (int jn = 0; jn < TN; ++jn)
+                        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, fb[st & 1][jn], acc[i][jn], 0, 0, 0);
+                }
+            };
+            read_a(ConvIC<0>{});
+            read_b(ConvIC<0>{});
+            read_a(ConvIC<1>{});
+            step(ConvIC<0>{});
+            step(ConvIC<1>{});
+            step(ConvIC<2>{});
+            step(ConvIC<3>{});
+            step(ConvIC<4>{});
+            step(ConvIC<5>{});
+            step(ConvIC<6>{});
+            step(ConvIC<7>{});
+        }
         wait_next_tile(kt + D < nk);            // tile kt + 1 has landed (this wavefront's pieces) ...
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();           // ... everybody's have, and everybody is done reading tile kt
@@ -649,9 +719,39 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(ConvArgs a)
 
 inline int conv_grid_1d(long long n) { long long g = (n + 255) / 256; if (g > 4096) g = 4096; if (g < 1) g = 1; return (int)g; }
 
+// the split image of a [K][Npad] float32 operand for prec = 1 (layout: see conv_split_kmem); one thread per 16-byte record
+__global__ __launch_bounds__(256) void k_conv_split_operand(const float *w, int K, int Npad, uint4 *out)
+{
+    const long long nrec = (long long)((K + 15) / 16) * 4 * Npad;
+    for (long long r = blockIdx.x * (long long)blockDim.x + threadIdx.x; r < nrec; r += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(r % Npad);
+        const int hp = (int)((r / Npad) & 3), h = hp >> 1, part = hp & 1;
+        const long long kt = r / (4ll * Npad);
+        uint32_t o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const long long k = kt * 16 + conv_split_kmem(h, 2 * e + q);
+                const float x = k < K ? w[k * Npad + n] : 0.0f;
+                const float hi = __builtin_bit_cast(float, conv_bf16_pair(x, 0.0f) << 16);
+                v[q] = part ? x - hi : x;
+            }
+            o[e] = conv_bf16_pair(v[0], v[1]);
+        }
+        out[r] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 template <int BM, int BN, int WROWS, int WCOLS, int BK, int D = 2>
 inline void launch_conv_tile(const ConvArgs &c, dim3 grid, hipStream_t s)
 {
+    if (c.prec == 1) {
+        if (c.Cin % BK == 0) hipLaunchKernelGGL((k_conv_mfma<BM, BN, WROWS, WCOLS, BK, true, D, 1>), grid, dim3(256), 0, s, c);
+        else hipLaunchKernelGGL((k_conv_mfma<BM, BN, WROWS, WCOLS, BK, false, D, 1>), grid, dim3(256), 0, s, c);
+        return;
+    }
     if (c.Cin % BK == 0) hipLaunchKernelGGL((k_conv_mfma<BM, BN, WROWS, WCOLS, BK, true, D>), grid, dim3(256), 0, s, c);
     else hipLaunchKernelGGL((k_conv_mfma<BM, BN, WROWS, WCOLS, BK, false, D>), grid, dim3(256), 0, s, c);
 }
@@ -677,7 +777,7 @@ inline bool launch_conv(ConvArgs &c, float *scratch, long long scratch_floats, h
     }
     if (x_bytes > kMaxViewBytes || (long long)c.K * c.Npad * 4 > kMaxViewBytes) return false;
     c.x_bytes = (uint32_t)x_bytes;
-    c.w_bytes = (uint32_t)((long long)c.K * c.Npad * 4);
+    c.w_bytes = (uint32_t)((long long)(c.prec == 1 ? (c.K + 15) / 16 * 16 : c.K) * c.Npad * 4);
     c.splits = 1;
     c.partial = nullptr;
     const long long big = (long long)((c.M + 127) / 128) * ((c.Npad + 127) / 128);

@@ -579,6 +579,7 @@ struct frlw_detector {
     int scratch_buf = -1;        // split-K partial sums: (1 + kSideLanes) regions of scratch_floats
     long long scratch_floats = 0;
     int cur_lane = 0;
+    int prec = 0;                // convolution operands added from now on: 0 float32 [K][Npad], 1 the split bf16 image
     bool have_side = false;
     hipStream_t side[kSideLanes] = {};
     hipEvent_t ev_fork = nullptr, ev_join[kSideLanes] = {};
@@ -650,6 +651,29 @@ int frlw_det_set_lane(frlw_detector_t *d, int lane)
 {
     if (!d || lane < 0 || lane > kSideLanes) return FRLW_ERR_ARG;
     d->cur_lane = lane;
+    return FRLW_OK;
+}
+
+int frlw_det_set_precision(frlw_detector_t *d, int precision)
+{
+    if (!d || precision < 0 || precision > 1) return FRLW_ERR_ARG;
+    d->prec = precision;
+    return FRLW_OK;
+}
+
+size_t frlw_conv_split_operand_bytes(int K, int Npad)
+{
+    if (K < 1 || Npad < 1) return 0;
+    return (size_t)((K + 15) / 16) * 4 * (size_t)Npad * 16;
+}
+
+int frlw_conv_split_operand(const float *w, int K, int Npad, void *out, frlw_stream_t stream)
+{
+    (void)hipGetLastError();
+    if (!w || !out || K < 1 || Npad < 1) return FRLW_ERR_ARG;
+    const long long nrec = (long long)((K + 15) / 16) * 4 * Npad;
+    hipLaunchKernelGGL(k_conv_split_operand, dim3(conv_grid_1d(nrec)), dim3(256), 0, (hipStream_t)stream, w, K, Npad, (uint4 *)out);
+    if (hipGetLastError() != hipSuccess) return FRLW_ERR_HIP;
     return FRLW_OK;
 }
 
@@ -777,6 +801,7 @@ int frlw_det_add_conv(frlw_detector_t *d, int src_buf, int src_cs, int src_co, i
     c.y_cs = dst_cs; c.y_co = dst_co; c.y_bs = dst_bs > 0 ? dst_bs : (long long)c.Ho * c.Wo * dst_cs;
     c.r_cs = res_cs; c.r_co = res_co; c.r_bs = (long long)c.Ho * c.Wo * res_cs;
     c.act = act; c.sig_from = sig_from; c.K = k * k * Cin; c.group_n = group_n;
+    c.prec = d->prec;
     op.lane = d->cur_lane;
     d->ops.push_back(op);
     return FRLW_OK;

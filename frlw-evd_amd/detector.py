@@ -9,6 +9,7 @@ channel slices of the consumer's NHWC buffer.  There is no fallback: a missing l
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -44,12 +45,26 @@ def gemm_weight(w):
     return m.contiguous(), npad
 
 
+def default_precision():
+    """Convolution arithmetic of new engines: ``FRLW_CONV_PRECISION`` = ``f32`` (float32 MFMA, exact products) or ``bf16x3``
+    (float32 products from three bf16 MFMAs, the default: include/frlw_evd.h, frlw_det_set_precision)."""
+    v = os.environ.get("FRLW_CONV_PRECISION", "bf16x3").strip().lower()
+    if v not in PRECISIONS:
+        raise ValueError(f"FRLW_CONV_PRECISION={v!r}: expected one of {sorted(PRECISIONS)}")
+    return v
+
+
+PRECISIONS = {"f32": 0, "bf16x3": 1}
+
+
 class DetectorEngine:
-    def __init__(self, net, device=None):
+    def __init__(self, net, device=None, precision=None):
         self.lib = _lib.load()
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.net = net
+        self.precision = precision or default_precision()
         self.handle = self.lib.frlw_det_create()
+        _lib.check(self.lib.frlw_det_set_precision(self.handle, PRECISIONS[self.precision]), "frlw_det_set_precision")
         self._keep = []      # device weights referenced by the plan
         self._shapes = []    # per buffer: floats per image (index 0 = the NCHW input, set per call)
         self._bufs = {}      # batch size -> list of tensors
@@ -75,6 +90,18 @@ class DetectorEngine:
         self._keep.append(t)
         return C.c_void_p(t.data_ptr())
 
+    def _operand(self, wm):
+        """The [K][Npad] float32 GEMM operand on the device, in the form the plan's arithmetic reads."""
+        if self.precision == "f32" or self.device.type != "cuda":  # (a plan on "cpu" is never run: tools read its op list)
+            return self._dev(wm)
+        K, npad = wm.shape
+        w = wm.to(self.device).contiguous()
+        out = torch.empty(self.lib.frlw_conv_split_operand_bytes(K, npad), dtype=torch.uint8, device=self.device)
+        _lib.check(self.lib.frlw_conv_split_operand(w.data_ptr(), K, npad, out.data_ptr(),
+                                                    torch.cuda.current_stream(self.device).cuda_stream), "frlw_conv_split_operand")
+        self._keep.append(out)
+        return C.c_void_p(out.data_ptr())
+
     def _conv_raw(self, weight, bias, src, dst, k, stride, act, res=None, dst_bs=0, sig_from=0, groups=1):
         """``groups`` > 1: ``weight`` is (Cout, Cin / groups, k, k) as torch lays out a grouped convolution."""
         wm, npad = gemm_weight(weight)
@@ -82,7 +109,7 @@ class DetectorEngine:
         assert cin * groups == src.c and cout == dst.c and cout % groups == 0, (cin, src.c, cout, dst.c, groups)
         group_n = cout // groups if groups > 1 else 0
         rb, rcs, rco = (res.buf, res.cs, res.co) if res is not None else (-1, 0, 0)
-        rc = self.lib.frlw_det_add_conv(self.handle, src.buf, src.cs, src.co, cin, src.h, src.w, self._dev(wm),
+        rc = self.lib.frlw_det_add_conv(self.handle, src.buf, src.cs, src.co, cin, src.h, src.w, self._operand(wm),
                                         self._dev(bias) if bias is not None else None, cout, npad, k, stride,
                                         dst.buf, dst.cs, dst.co, dst_bs, rb, rcs, rco, act, sig_from, group_n)
         _lib.check(rc, "frlw_det_add_conv")

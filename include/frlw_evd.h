@@ -284,6 +284,17 @@ int frlw_det_num_ops(const frlw_detector_t *d);
  * with l in 1..2 are launched on library-owned side streams between a fork (side streams wait for everything
  * launched so far on the caller's stream) and a join (the caller's stream waits for the side streams). */
 int frlw_det_set_lane(frlw_detector_t *d, int lane);
+
+/* Arithmetic of the convolutions added from now on (default 0):
+ *   0  v_mfma_f32_32x32x2_f32 on float32 operands: every product exact, the float32 MFMA rate (157 TFLOP/s peak);
+ *   1  float32 products from THREE bf16 MFMAs: x = hi + lo with hi = bf16(x), lo = bf16(x - hi);
+ *      a * b ~ a_hi b_hi + a_hi b_lo + a_lo b_hi, float32 accumulation -- <= 2^-16 relative error per product (observed
+ *      3e-6 of max |y| per layer; the detector's stated tolerance is 1e-3), 5.3 x the matrix rate.  The activations stay
+ *      float32 in memory (split in registers); `w_dev` of frlw_det_add_conv is then the SPLIT IMAGE of the [K][Npad]
+ *      operand, made by frlw_conv_split_operand (frlw_conv_split_operand_bytes(K, Npad) bytes, caller-allocated). */
+int frlw_det_set_precision(frlw_detector_t *d, int precision);
+size_t frlw_conv_split_operand_bytes(int K, int Npad);
+int frlw_conv_split_operand(const float *w, int K, int Npad, void *out, frlw_stream_t stream);
 int frlw_det_add_fork(frlw_detector_t *d);
 int frlw_det_add_join(frlw_detector_t *d);
 

@@ -34,6 +34,7 @@ int main(int argc, char **argv)
     const int B = argc > 1 ? atoi(argv[1]) : 32;
     const int reps = argc > 2 ? atoi(argv[2]) : 20;
     const int nshapes = argc > 3 ? atoi(argv[3]) : 1000;
+    const int prec = argc > 4 ? atoi(argv[4]) : 0; // 1: three bf16 MFMAs per product (split weight operand); prints the error against prec 0
     int done = 0;
     const Shape shapes[] = {{32, 40, 256, 256, 3, 1}, {16, 20, 256, 256, 3, 1}, {8, 10, 256, 256, 3, 1}, {16, 20, 128, 128, 3, 1},
                             {32, 40, 64, 64, 3, 1}, {16, 20, 256, 256, 1, 1}, {32, 40, 128, 128, 1, 1}, {64, 80, 64, 64, 1, 1},
@@ -56,6 +57,13 @@ int main(int argc, char **argv)
         c.w = w; c.bias = nullptr; c.Cout = sh.Cout; c.Npad = npad; c.k = sh.k; c.stride = sh.s; c.pad = sh.k / 2;
         c.y = y; c.Ho = Ho; c.Wo = Wo; c.y_cs = sh.Cout; c.y_co = 0; c.y_bs = (long long)Ho * Wo * sh.Cout;
         c.res = nullptr; c.act = ACT_SILU; c.sig_from = 0; c.M = B * Ho * Wo; c.K = K; c.tstride = 0; c.kw = 0; c.y_rp = 0;
+        float *yref = nullptr; uint4 *wsplit = nullptr;
+        if (prec == 1) {
+            CK(hipMalloc(&yref, ny * 4)); CK(hipMalloc(&wsplit, (long long)(K + 15) / 16 * 4 * npad * 16));
+            c.y = yref; launch_conv(c, scratch, scratch_floats, st); c.y = y;
+            k_conv_split_operand<<<1024, 256, 0, st>>>(w, K, npad, wsplit);
+            c.w = (const float *)wsplit; c.prec = 1;
+        }
         for (int i = 0; i < 3; ++i) launch_conv(c, scratch, scratch_floats, st);
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         CK(hipEventRecord(e0, st));
@@ -98,6 +106,14 @@ int main(int argc, char **argv)
             CK(hipFree(pr)); CK(hipFree(pt)); CK(hipFree(pe));
         }
 #endif
+        if (prec == 1) {
+            std::vector<float> a(ny), b(ny);
+            CK(hipMemcpy(a.data(), y, ny * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(b.data(), yref, ny * 4, hipMemcpyDeviceToHost));
+            double md = 0, mx = 0;
+            for (long long i = 0; i < ny; ++i) { md = fmax(md, fabs((double)a[i] - b[i])); mx = fmax(mx, fabs((double)b[i])); }
+            printf("   prec 1 vs float32 MFMA: max |diff| %.3e of max |y| %.3e = %.2e\n", md, mx, md / mx);
+            CK(hipFree(yref)); CK(hipFree(wsplit));
+        }
         const double fl = 2.0 * c.M * sh.Cout * K;
         printf("%3dx%-3d %4d->%-4d k%d: %8.1f us %7.1f TFLOP/s  splits %d  checksum %.6e\n", sh.H, sh.W, sh.Cin, sh.Cout, sh.k, ms * 1e3,
                fl / ms / 1e9, c.splits, h);
