@@ -40,44 +40,79 @@ namespace {
 // `parity` != 0 (stride-2, k = 3): the data-gradient operand is grouped by output parity class (py, px) in the order
 // (0,0) (0,1) (1,0) (1,1) with 1, 2, 2, 4 taps -- row blocks starting at 0, 1, 3, 5 times Cout; inside a class the rows
 // are (t_ky, t_kx, co) where tap t reads dz[o' + t] and stands for kernel index 1 (parity 0) or 2, 0 (parity 1, t = 0, 1).
+// element (row, col) of the forward (which = 0) or data-gradient (which = 1) operand; zero in the padding (rows past K too)
+__device__ __forceinline__ float weight_operand_value(const float *w, int Cout, int Cin, int k, int which, int parity, long long row, int col)
+{
+    const int kk = k * k;
+    if (which == 0) {
+        const int ci = (int)(row % Cin), tap = (int)(row / Cin);
+        return (col < Cout && tap < kk) ? w[((long long)col * Cin + ci) * kk + tap] : 0.0f;
+    }
+    const int co = (int)(row % Cout), tapf = (int)(row / Cout); // tapf = flipped tap index
+    if (tapf >= kk || col >= Cin) return 0.0f;
+    int tap = kk - 1 - tapf;
+    if (parity) {
+        const int cls = tapf < 1 ? 0 : (tapf < 3 ? 1 : (tapf < 5 ? 2 : 3));
+        const int tl = tapf - (cls == 0 ? 0 : (cls == 1 ? 1 : (cls == 2 ? 3 : 5)));
+        const int py = cls >> 1, px = cls & 1, kwc = px ? 2 : 1;
+        const int t_ky = tl / kwc, t_kx = tl - t_ky * kwc;
+        const int ky = py ? (t_ky == 0 ? 2 : 0) : 1, kx = px ? (t_kx == 0 ? 2 : 0) : 1;
+        tap = ky * 3 + kx;
+    }
+    return w[((long long)co * Cin + col) * kk + tap];
+}
+
+__host__ __device__ inline long long operand_rows(long long K, int prec) { return prec == 1 ? (K + 15) / 16 * 16 : K; }
+
+// float32 operands: one thread per element i of [forward | data gradient]
 __device__ __forceinline__ void weight_layout_elem(const float *w, int Cout, int Cin, int k, float *fwd, int np_f, float *dgr, int np_d,
                                                    int parity, long long nf, long long i)
 {
-    const int kk = k * k;
-    if (i < nf) {
-        const int co = (int)(i % np_f);
-        const long long row = i / np_f;
-        const int ci = (int)(row % Cin), tap = (int)(row / Cin);
-        fwd[i] = co < Cout ? w[((long long)co * Cin + ci) * kk + tap] : 0.0f;
-    } else {
-        const long long e = i - nf;
-        const int ci = (int)(e % np_d);
-        const long long row = e / np_d;
-        const int co = (int)(row % Cout), tapf = (int)(row / Cout); // tapf = flipped tap index
-        int tap = kk - 1 - tapf;
-        if (parity) {
-            const int cls = tapf < 1 ? 0 : (tapf < 3 ? 1 : (tapf < 5 ? 2 : 3));
-            const int tl = tapf - (cls == 0 ? 0 : (cls == 1 ? 1 : (cls == 2 ? 3 : 5)));
-            const int py = cls >> 1, px = cls & 1, kwc = px ? 2 : 1;
-            const int t_ky = tl / kwc, t_kx = tl - t_ky * kwc;
-            const int ky = py ? (t_ky == 0 ? 2 : 0) : 1, kx = px ? (t_kx == 0 ? 2 : 0) : 1;
-            tap = ky * 3 + kx;
-        }
-        dgr[e] = ci < Cin ? w[((long long)co * Cin + ci) * kk + tap] : 0.0f;
-    }
+    if (i < nf) fwd[i] = weight_operand_value(w, Cout, Cin, k, 0, 0, i / np_f, (int)(i % np_f));
+    else dgr[i - nf] = weight_operand_value(w, Cout, Cin, k, 1, parity, (i - nf) / np_d, (int)((i - nf) % np_d));
 }
 
-__global__ void k_weight_layouts(const float *w, int Cout, int Cin, int k, float *fwd, int np_f, float *dgr, int np_d, int parity)
+// split operands (conv_mfma.h, prec = 1): one thread per 16-byte record = float-equivalents i .. i + 3 of [forward | data gradient],
+// each operand ceil16(K) rows
+__device__ __forceinline__ void weight_layout_record(const float *w, int Cout, int Cin, int k, float *fwd, int np_f, float *dgr, int np_d,
+                                                     int parity, long long nf, long long i)
+{
+    const int which = i < nf ? 0 : 1;
+    const long long r = (which ? i - nf : i) >> 2;
+    const int np = which ? np_d : np_f;
+    const int n = (int)(r % np), hp = (int)((r / np) & 3), h = hp >> 1, part = hp & 1;
+    const long long kt = r / (4ll * np);
+    uint32_t o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float v[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float x = weight_operand_value(w, Cout, Cin, k, which, parity, kt * 16 + conv_split_kmem(h, 2 * e + q), n);
+            const float hi = __builtin_bit_cast(float, conv_bf16_pair(x, 0.0f) << 16);
+            v[q] = part ? x - hi : x;
+        }
+        o[e] = conv_bf16_pair(v[0], v[1]);
+    }
+    ((uint4 *)(which ? dgr : fwd))[r] = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+__global__ void k_weight_layouts(const float *w, int Cout, int Cin, int k, float *fwd, int np_f, float *dgr, int np_d, int parity, int prec)
 {
     const int kk = k * k;
-    const long long nf = fwd ? (long long)kk * Cin * np_f : 0, nd = dgr ? (long long)kk * Cout * np_d : 0;
+    const long long nf = fwd ? operand_rows((long long)kk * Cin, prec) * np_f : 0, nd = dgr ? operand_rows((long long)kk * Cout, prec) * np_d : 0;
+    if (prec == 1) {
+        for (long long i = 4 * (blockIdx.x * (long long)blockDim.x + threadIdx.x); i < nf + nd; i += 4ll * gridDim.x * blockDim.x)
+            weight_layout_record(w, Cout, Cin, k, fwd, np_f, dgr, np_d, parity, nf, i);
+        return;
+    }
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nf + nd; i += (long long)gridDim.x * blockDim.x)
         weight_layout_elem(w, Cout, Cin, k, fwd, np_f, dgr, np_d, parity, nf, i);
 }
 
 // every weight of a model in one launch: element i belongs to the entry with the largest `first` <= i.  A workgroup walks
 // tiles of 2048 consecutive elements and looks the entry of a tile's first element up ONCE (wave-uniform: scalar loads);
-// only the elements of a tile that straddles two entries search again.
+// only the elements of a tile that straddles two entries search again.  (Entries with split operands: 512 records per tile.)
 __global__ __launch_bounds__(256) void k_weight_layouts_batch(const frlw_weight_layout_item_t *items, int n, long long total)
 {
     constexpr int kTile = 2048;
@@ -100,9 +135,13 @@ __global__ __launch_bounds__(256) void k_weight_layouts_batch(const frlw_weight_
                 it = items[j];
             }
             const int np_f = (it.Cout + 31) / 32 * 32, np_d = (it.Cin + 31) / 32 * 32;
-            const long long nf = it.w_fwd ? (long long)it.k * it.k * it.Cin * np_f : 0;
-            weight_layout_elem(it.w, it.Cout, it.Cin, it.k, it.w_fwd, np_f, it.w_dgrad, np_d, (it.dgrad_parity && it.k == 3) ? 1 : 0, nf,
-                               i - it.first);
+            const long long nf = it.w_fwd ? operand_rows((long long)it.k * it.k * it.Cin, it.precision) * np_f : 0;
+            const int parity = (it.dgrad_parity && it.k == 3) ? 1 : 0;
+            if (it.precision == 1) { // every fourth thread-slot lays a record (entries start at multiples of 32 elements)
+                if ((i & 3) == 0) weight_layout_record(it.w, it.Cout, it.Cin, it.k, it.w_fwd, np_f, it.w_dgrad, np_d, parity, nf, i - it.first);
+            } else {
+                weight_layout_elem(it.w, it.Cout, it.Cin, it.k, it.w_fwd, np_f, it.w_dgrad, np_d, parity, nf, i - it.first);
+            }
         }
     }
 }
@@ -398,15 +437,28 @@ int frlw_conv2d_dgrad_parity(int k, int stride, int H, int W)
     return (stride == 2 && k == 3 && !(H & 1) && !(W & 1)) ? 1 : 0;
 }
 
+// precision 1 (split operands) needs the parity classes of the data-gradient operand to start on k-tiles of 16 rows
+static inline bool precision_ok(int precision, int Cout, int dgrad_parity)
+{
+    return precision == 0 || (precision == 1 && (!dgrad_parity || Cout % 16 == 0));
+}
+
+int64_t frlw_conv_operand_floats(int K, int N, int precision)
+{
+    if (K < 1 || N < 1) return 0;
+    return operand_rows(K, precision) * (int64_t)npad32(N);
+}
+
 int frlw_conv_weight_layouts(const float *w, int Cout, int Cin, int k, int dgrad_parity, float *w_fwd, float *w_dgrad,
-                             frlw_stream_t stream)
+                             int precision, frlw_stream_t stream)
 {
     (void)hipGetLastError(); // other libraries in the process (torch's BLAS look-ups) leave stale errors behind
     if (!w || Cout < 1 || Cin < 1 || k < 1 || (!w_fwd && !w_dgrad)) return FRLW_ERR_ARG;
+    if (!precision_ok(precision, Cout, dgrad_parity && w_dgrad)) return FRLW_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
-    const long long total = (w_fwd ? (long long)k * k * Cin * npad32(Cout) : 0) + (w_dgrad ? (long long)k * k * Cout * npad32(Cin) : 0);
-    hipLaunchKernelGGL(k_weight_layouts, dim3(conv_grid_1d(total)), dim3(256), 0, s, w, Cout, Cin, k, w_fwd, npad32(Cout),
-                       w_dgrad, npad32(Cin), (dgrad_parity && k == 3) ? 1 : 0);
+    const long long total = (w_fwd ? frlw_conv_operand_floats(k * k * Cin, Cout, precision) : 0) + (w_dgrad ? frlw_conv_operand_floats(k * k * Cout, Cin, precision) : 0);
+    hipLaunchKernelGGL(k_weight_layouts, dim3(conv_grid_1d(precision == 1 ? total / 4 : total)), dim3(256), 0, s, w, Cout, Cin, k, w_fwd, npad32(Cout),
+                       w_dgrad, npad32(Cin), (dgrad_parity && k == 3) ? 1 : 0, precision);
     TRY_HIP(hipGetLastError());
     return FRLW_OK;
 }
@@ -422,8 +474,9 @@ int frlw_conv_weight_layouts_batch(const frlw_weight_layout_item_t *items, int n
 }
 
 static int conv_common(const float *x, int B, int H, int W, int Cin, const float *w_gemm, int Cout, int k, int stride,
-                       int tstride, int Ho, int Wo, float *y, float *scratch, int64_t scratch_floats, hipStream_t s)
+                       int tstride, int Ho, int Wo, float *y, float *scratch, int64_t scratch_floats, int precision, hipStream_t s)
 {
+    if (precision != 0 && precision != 1) return FRLW_ERR_ARG;
     (void)hipGetLastError(); // other libraries in the process (torch's BLAS look-ups) leave stale errors behind
     if (!x || !w_gemm || !y || B < 1 || H < 1 || W < 1 || Cin < 4 || (Cin & 3) || Cout < 1 || k < 1) return FRLW_ERR_ARG;
     ConvArgs c = {};
@@ -433,23 +486,25 @@ static int conv_common(const float *x, int B, int H, int W, int Cin, const float
     c.res = nullptr; c.act = ACT_NONE; c.sig_from = 0;
     c.M = B * Ho * Wo; c.K = k * k * Cin;
     c.tstride = tstride;
+    c.prec = precision;
     if (!launch_conv(c, scratch, scratch ? scratch_floats : 0, s)) return FRLW_ERR_UNSUPPORTED;
     if (hipGetLastError() != hipSuccess) return FRLW_ERR_HIP;
     return FRLW_OK;
 }
 
 int frlw_conv2d_fwd(const float *x, int B, int H, int W, int Cin, const float *w_fwd, int Cout, int k, int stride, float *z,
-                    float *scratch, int64_t scratch_floats, frlw_stream_t stream)
+                    float *scratch, int64_t scratch_floats, int precision, frlw_stream_t stream)
 {
     if (stride != 1 && stride != 2) return FRLW_ERR_UNSUPPORTED;
     const int pad = (k - 1) / 2;
     const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
-    return conv_common(x, B, H, W, Cin, w_fwd, Cout, k, stride, 0, Ho, Wo, z, scratch, scratch_floats, (hipStream_t)stream);
+    return conv_common(x, B, H, W, Cin, w_fwd, Cout, k, stride, 0, Ho, Wo, z, scratch, scratch_floats, precision, (hipStream_t)stream);
 }
 
 int frlw_conv2d_dgrad(const float *dz, int B, int Ho, int Wo, int Cout, const float *w_dgrad, int Cin, int k, int stride,
-                      int H, int W, float *dx, float *scratch, int64_t scratch_floats, frlw_stream_t stream)
+                      int H, int W, float *dx, float *scratch, int64_t scratch_floats, int precision, frlw_stream_t stream)
 {
+    if (precision != 0 && precision != 1) return FRLW_ERR_ARG;
     // dx[iy][ix][ci] = sum dz[(iy + pad - ky) / s][(ix + pad - kx) / s][co] * w[co][ci][ky][kx]: a stride-1 convolution of
     // dz (transposed gather for s = 2) with the flipped operand and padding k - 1 - pad = pad (odd k)
     if (stride != 1 && stride != 2) return FRLW_ERR_UNSUPPORTED;
@@ -459,6 +514,7 @@ int frlw_conv2d_dgrad(const float *dz, int B, int Ho, int Wo, int Cout, const fl
         // multiplications by the zeros of the up-sampled gradient); class (py, px) writes dx[2 o' + (py, px)]
         if (Ho * 2 != H || Wo * 2 != W) return FRLW_ERR_ARG;
         if (!dz || !w_dgrad || !dx || B < 1 || Cout < 4 || (Cout & 3) || Cin < 1) return FRLW_ERR_ARG;
+        if (!precision_ok(precision, Cout, 1)) return FRLW_ERR_UNSUPPORTED;
         (void)hipGetLastError();
         static const int row0[4] = {0, 1, 3, 5};
         for (int cls = 0; cls < 4; ++cls) {
@@ -470,6 +526,7 @@ int frlw_conv2d_dgrad(const float *dz, int B, int Ho, int Wo, int Cout, const fl
             c.y = dx; c.Ho = Ho; c.Wo = Wo; c.y_cs = 2 * Cin; c.y_rp = 2 * W * Cin; c.y_co = (py * W + px) * Cin;
             c.y_bs = (long long)H * W * Cin;
             c.res = nullptr; c.act = ACT_NONE;
+            c.prec = precision;
             c.M = B * Ho * Wo; c.K = kh * kwc * Cout;
             if (!launch_conv(c, scratch, scratch ? scratch_floats : 0, (hipStream_t)stream)) return FRLW_ERR_UNSUPPORTED;
         }
@@ -477,7 +534,7 @@ int frlw_conv2d_dgrad(const float *dz, int B, int Ho, int Wo, int Cout, const fl
         return FRLW_OK;
     }
     return conv_common(dz, B, Ho, Wo, Cout, w_dgrad, Cin, k, 1, stride == 2 ? 2 : 0, H, W, dx, scratch, scratch_floats,
-                       (hipStream_t)stream);
+                       precision, (hipStream_t)stream);
 }
 
 int64_t frlw_conv2d_wgrad_scratch_floats(int B, int Ho, int Wo, int Cin, int Cout, int k)
@@ -504,11 +561,13 @@ static long long wgrad_splits_for(long long scratch_floats, long long per, long 
 }
 
 int frlw_conv2d_wgrad(const float *x, int B, int H, int W, int Cin, const float *dz, int Ho, int Wo, int Cout, int k,
-                      int stride, float *dw, float *scratch, int64_t scratch_floats, frlw_stream_t stream)
+                      int stride, float *dw, float *scratch, int64_t scratch_floats, int precision, frlw_stream_t stream)
 {
     (void)hipGetLastError(); // other libraries in the process (torch's BLAS look-ups) leave stale errors behind
     if (!x || !dz || !dw || !scratch || B < 1 || (Cin & 3) || (Cout & 3) || Cin < 4 || Cout < 4) return FRLW_ERR_ARG;
+    if (precision != 0 && precision != 1) return FRLW_ERR_ARG;
     WgradArgs a = {};
+    a.prec = precision;
     a.x = x; a.H = H; a.W = W; a.Cin = Cin; a.x_bs = (long long)H * W * Cin; a.x_cs = Cin;
     a.dz = dz; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.dz_bs = (long long)Ho * Wo * Cout; a.dz_cs = Cout;
     a.k = k; a.stride = stride; a.pad = (k - 1) / 2;
@@ -597,9 +656,9 @@ int frlw_bn_silu_bwd(const float *dy, const float *z, int64_t M, int C, const fl
 }
 
 /* ---- one call per BaseConv and direction (the per-operator entry points above stay for tests / other callers) ---- */
-int64_t frlw_baseconv_weight_cache_floats(int Cin, int Cout, int k)
+int64_t frlw_baseconv_weight_cache_floats(int Cin, int Cout, int k, int precision)
 {
-    return (int64_t)k * k * Cin * npad32(Cout) + (int64_t)k * k * Cout * npad32(Cin);
+    return frlw_conv_operand_floats(k * k * Cin, Cout, precision) + frlw_conv_operand_floats(k * k * Cout, Cin, precision);
 }
 
 int64_t frlw_baseconv_train_scratch_bytes(int B, int H, int W, int Cin, int Cout, int k, int stride)
@@ -608,8 +667,8 @@ int64_t frlw_baseconv_train_scratch_bytes(int B, int H, int W, int Cin, int Cout
     const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
     const int64_t M = (int64_t)B * Ho * Wo;
     int64_t bytes = 0;
-    bytes += sizeof(float) * (int64_t)k * k * Cin * npad32(Cout);   // forward operand
-    bytes += sizeof(float) * (int64_t)k * k * Cout * npad32(Cin);   // data-gradient operand
+    bytes += sizeof(float) * frlw_conv_operand_floats(k * k * Cin, Cout, 1);   // forward operand (either precision fits)
+    bytes += sizeof(float) * frlw_conv_operand_floats(k * k * Cout, Cin, 1);   // data-gradient operand
     bytes += sizeof(double) * frlw_bn_scratch_doubles(M, Cout);     // reduction partials
     bytes += sizeof(float) * 2 * Cout;                              // sums
     bytes += sizeof(float) * frlw_conv2d_wgrad_scratch_floats(B, Ho, Wo, Cin, Cout, k);
@@ -624,8 +683,8 @@ inline TrainScratch carve(void *scratch, int B, int Ho, int Wo, int Cin, int Cou
     char *p = (char *)scratch;
     auto take = [&](int64_t bytes) { char *r = p; p += (bytes + 255) / 256 * 256; return r; };
     TrainScratch t;
-    t.w_fwd = (float *)take(sizeof(float) * (int64_t)k * k * Cin * npad32(Cout));
-    t.w_dg = (float *)take(sizeof(float) * (int64_t)k * k * Cout * npad32(Cin));
+    t.w_fwd = (float *)take(sizeof(float) * frlw_conv_operand_floats(k * k * Cin, Cout, 1));
+    t.w_dg = (float *)take(sizeof(float) * frlw_conv_operand_floats(k * k * Cout, Cin, 1));
     t.red = (double *)take(sizeof(double) * frlw_bn_scratch_doubles((int64_t)B * Ho * Wo, Cout));
     t.sums = (float *)take(sizeof(float) * 2 * Cout);
     t.wgrad_floats = frlw_conv2d_wgrad_scratch_floats(B, Ho, Wo, Cin, Cout, k);
@@ -642,7 +701,7 @@ int frlw_baseconv_train_fwd(const float *x, const float *w, const float *gamma, 
                             int W, int Cin, int Cout, int k, int stride, float *z, float *y, float *mean, float *var,
                             float *invstd, float *running_mean, float *running_var, float momentum,
                             int64_t *num_batches_tracked, float *w_cache, void *scratch, int64_t scratch_bytes,
-                            frlw_stream_t stream)
+                            int precision, frlw_stream_t stream)
 {
     if (!x || (!w && !w_cache) || !gamma || !beta || !z || !y || !mean || !var || !invstd || !scratch) return FRLW_ERR_ARG;
     if (scratch_bytes < frlw_baseconv_train_scratch_bytes(B, H, W, Cin, Cout, k, stride)) return FRLW_ERR_WORKSPACE;
@@ -655,11 +714,11 @@ int frlw_baseconv_train_fwd(const float *x, const float *w, const float *gamma, 
     if (w_cache && !w) { // the caller has laid both operands out already (frlw_conv_weight_layouts_batch)
         w_fwd = w_cache;
     } else if (w_cache) { // both operands in ONE launch, kept by the caller: the backward of this step finds its operand ready
-        float *w_dg = w_cache + (int64_t)k * k * Cin * npad32(Cout);
-        if ((rc = frlw_conv_weight_layouts(w, Cout, Cin, k, frlw_conv2d_dgrad_parity(k, stride, H, W), w_cache, w_dg, stream)) != FRLW_OK) return rc;
+        float *w_dg = w_cache + frlw_conv_operand_floats(k * k * Cin, Cout, precision);
+        if ((rc = frlw_conv_weight_layouts(w, Cout, Cin, k, frlw_conv2d_dgrad_parity(k, stride, H, W), w_cache, w_dg, precision, stream)) != FRLW_OK) return rc;
         w_fwd = w_cache;
-    } else if ((rc = frlw_conv_weight_layouts(w, Cout, Cin, k, 0, t.w_fwd, nullptr, stream)) != FRLW_OK) return rc;
-    if ((rc = frlw_conv2d_fwd(x, B, H, W, Cin, w_fwd, Cout, k, stride, z, t.splitk, t.splitk_floats, stream)) != FRLW_OK) return rc;
+    } else if ((rc = frlw_conv_weight_layouts(w, Cout, Cin, k, 0, t.w_fwd, nullptr, precision, stream)) != FRLW_OK) return rc;
+    if ((rc = frlw_conv2d_fwd(x, B, H, W, Cin, w_fwd, Cout, k, stride, z, t.splitk, t.splitk_floats, precision, stream)) != FRLW_OK) return rc;
     if ((rc = bn_stats_impl(z, M, Cout, eps, mean, var, invstd, t.red, running_mean, running_mean ? running_var : nullptr,
                             momentum, (long long *)num_batches_tracked, stream)) != FRLW_OK) return rc;
     return frlw_bn_silu_fwd(z, M, Cout, gamma, beta, mean, invstd, y, stream);
@@ -669,7 +728,7 @@ int frlw_baseconv_train_fwd(const float *x, const float *w, const float *gamma, 
 int frlw_baseconv_train_bwd(const float *dy, const float *x, const float *z, const float *w, const float *gamma,
                             const float *beta, const float *mean, const float *invstd, int B, int H, int W, int Cin,
                             int Cout, int k, int stride, float *dz, float *dx, float *dw, float *dgamma, float *dbeta,
-                            const float *w_cache, void *scratch, int64_t scratch_bytes, frlw_stream_t stream)
+                            const float *w_cache, void *scratch, int64_t scratch_bytes, int precision, frlw_stream_t stream)
 {
     if (!dy || !x || !z || !w || !gamma || !beta || !mean || !invstd || !dz || !dw || !dgamma || !dbeta || !scratch)
         return FRLW_ERR_ARG;
@@ -682,11 +741,11 @@ int frlw_baseconv_train_bwd(const float *dy, const float *x, const float *z, con
     if ((rc = frlw_bn_silu_bwd(dy, z, M, Cout, gamma, beta, mean, invstd, dz, dgamma, dbeta, t.red, t.sums, stream)) != FRLW_OK) return rc;
     if (dx) {
         const float *w_dg = t.w_dg;
-        if (w_cache) w_dg = w_cache + (int64_t)k * k * Cin * npad32(Cout); // laid out by the forward of this step
-        else if ((rc = frlw_conv_weight_layouts(w, Cout, Cin, k, frlw_conv2d_dgrad_parity(k, stride, H, W), nullptr, t.w_dg, stream)) != FRLW_OK) return rc;
-        if ((rc = frlw_conv2d_dgrad(dz, B, Ho, Wo, Cout, w_dg, Cin, k, stride, H, W, dx, t.splitk, t.splitk_floats, stream)) != FRLW_OK) return rc;
+        if (w_cache) w_dg = w_cache + frlw_conv_operand_floats(k * k * Cin, Cout, precision); // laid out by the forward of this step
+        else if ((rc = frlw_conv_weight_layouts(w, Cout, Cin, k, frlw_conv2d_dgrad_parity(k, stride, H, W), nullptr, t.w_dg, precision, stream)) != FRLW_OK) return rc;
+        if ((rc = frlw_conv2d_dgrad(dz, B, Ho, Wo, Cout, w_dg, Cin, k, stride, H, W, dx, t.splitk, t.splitk_floats, precision, stream)) != FRLW_OK) return rc;
     }
-    return frlw_conv2d_wgrad(x, B, H, W, Cin, dz, Ho, Wo, Cout, k, stride, dw, t.wgrad, t.wgrad_floats, stream);
+    return frlw_conv2d_wgrad(x, B, H, W, Cin, dz, Ho, Wo, Cout, k, stride, dw, t.wgrad, t.wgrad_floats, precision, stream);
 }
 
 } // extern "C"

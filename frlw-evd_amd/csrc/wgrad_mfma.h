@@ -13,6 +13,7 @@ struct WgradArgs {
     int splits;
     float *partial; // [splits][R][Cout]
     uint32_t x_bytes, dz_bytes; // extents for the buffer descriptors (set by launch_wgrad_tiles)
+    int prec;       // 0: float32 MFMA; 1: three bf16 MFMAs per product (operands split in registers)
 };
 
 // BM = 64 or 128 rows (r) x BN = 32, 64 or 128 columns (co) per workgroup; the 4 wavefronts are WR x WC (2 x 2, or 4 x 1 for
@@ -24,7 +25,9 @@ struct WgradArgs {
 // waits and raw barriers, fragment reads as asm statements with hand-counted lgkmcnt (see conv_mfma.h for why).
 // LDS image of a stage: one [16 pixels][64 channels] block per 64-wide channel group (lane-linear for the DMA: a
 // wave-instruction brings 4 pixels x 64 channels = 1 KB).
-template <int BM, int BN, int NBUF, int WR = 2, int WC = 2>
+// P = 1: float32 products from three bf16 MFMAs (conv_mfma.h): BOTH operands are activations here, so both are split in
+// registers -- a lane's eight pixels of a k-tile (2 j + h, j = 0..7: the pairing of the float32 k-steps) make one bf16 k-step.
+template <int BM, int BN, int NBUF, int WR = 2, int WC = 2, int P = 0>
 __global__ __launch_bounds__(256) void k_wgrad_mfma(WgradArgs a)
 {
     static_assert(WR * WC == 4 && BM % (32 * WR) == 0 && BN % (32 * WC) == 0, "four wavefronts");
@@ -113,36 +116,72 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(WgradArgs a)
     int stage = 0;
     for (int kt = 0; kt < nk; ++kt) {
         if (kt + NBUF - 1 < nk) load_tiles(stage == 0 ? NBUF - 1 : stage - 1); // the stage read last in iteration kt - 1
-        float fa[2][TM], fb[2][TN];
-        const uint32_t a_addr = a_lds + (uint32_t)stage * (kStage * 4), b_addr = b_lds + (uint32_t)stage * (kStage * 4);
-        auto read_frags = [&](auto stc) { // k-step st: pixels 2 st + h
-            constexpr int st = decltype(stc)::value;
-            asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(fa[st & 1][0]) : "v"(a_addr), "n"(st * 512));
-            if (TM > 1) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(fa[st & 1][TM - 1]) : "v"(a_addr), "n"(st * 512 + 128));
-            asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(fb[st & 1][0]) : "v"(b_addr), "n"(st * 512));
-            if (TN > 1) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(fb[st & 1][TN - 1]) : "v"(b_addr), "n"(st * 512 + 128));
-        };
-        auto step = [&](auto stc) {
-            constexpr int st = decltype(stc)::value;
-            if (st + 1 < 8) {
-                read_frags(ConvIC<(st + 1 < 8 ? st + 1 : 7)>{});
-                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TM + TN) : "memory");
-            } else {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (P == 1) {
+            const uint32_t a_addr = a_lds + (uint32_t)stage * (kStage * 4), b_addr = b_lds + (uint32_t)stage * (kStage * 4);
+            float fa[TM][8], fb[TN][8];
+            auto read8 = [&](auto stc) { // element st of the lane's fragments: pixel 2 st + h
+                constexpr int st = decltype(stc)::value;
+                asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(fa[0][st]) : "v"(a_addr), "n"(st * 512));
+                if (TM > 1) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(fa[TM - 1][st]) : "v"(a_addr), "n"(st * 512 + 128));
+                asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(fb[0][st]) : "v"(b_addr), "n"(st * 512));
+                if (TN > 1) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(fb[TN - 1][st]) : "v"(b_addr), "n"(st * 512 + 128));
+            };
+            read8(ConvIC<0>{}); read8(ConvIC<1>{}); read8(ConvIC<2>{}); read8(ConvIC<3>{});
+            read8(ConvIC<4>{}); read8(ConvIC<5>{}); read8(ConvIC<6>{}); read8(ConvIC<7>{});
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            u32x4 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(fa[i][e]));
+                conv_split8(f32x4{fa[i][0], fa[i][1], fa[i][2], fa[i][3]}, f32x4{fa[i][4], fa[i][5], fa[i][6], fa[i][7]}, ah[i], al[i]);
             }
 #pragma unroll
-            for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(fa[st & 1][i]));
+            for (int j = 0; j < TN; ++j) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(fb[st & 1][j]));
+                for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(fb[j][e]));
+                conv_split8(f32x4{fb[j][0], fb[j][1], fb[j][2], fb[j][3]}, f32x4{fb[j][4], fb[j][5], fb[j][6], fb[j][7]}, bh[j], bl[j]);
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[st & 1][i], fb[st & 1][j], acc[i][j], 0, 0, 0);
-        };
-        read_frags(ConvIC<0>{});
-        step(ConvIC<0>{}); step(ConvIC<1>{}); step(ConvIC<2>{}); step(ConvIC<3>{});
-        step(ConvIC<4>{}); step(ConvIC<5>{}); step(ConvIC<6>{}); step(ConvIC<7>{});
+                for (int j = 0; j < TN; ++j) { // the small terms first
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[i]), __builtin_bit_cast(bf16x8, bh[j]), acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bl[j]), acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bh[j]), acc[i][j], 0, 0, 0);
+                }
+        } else {
+            float fa[2][TM], fb[2][TN];
+            const uint32_t a_addr = a_lds + (uint32_t)stage * (kStage * 4), b_addr = b_lds + (uint32_t)stage * (kStage * 4);
+            auto read_frags = [&](auto stc) { // k-step st: pixels 2 st + h
+                constexpr int st = decltype(stc)::value;
+                asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(fa[st & 1][0]) : "v"(a_addr), "n"(st * 512));
+                if (TM > 1) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(fa[st & 1][TM - 1]) : "v"(a_addr), "n"(st * 512 + 128));
+                asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(fb[st & 1][0]) : "v"(b_addr), "n"(st * 512));
+                if (TN > 1) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(fb[st & 1][TN - 1]) : "v"(b_addr), "n"(st * 512 + 128));
+            };
+            auto step = [&](auto stc) {
+                constexpr int st = decltype(stc)::value;
+                if (st + 1 < 8) {
+                    read_frags(ConvIC<(st + 1 < 8 ? st + 1 : 7)>{});
+                    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TM + TN) : "memory");
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(fa[st & 1][i]));
+#pragma unroll
+                for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(fb[st & 1][j]));
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[st & 1][i], fb[st & 1][j], acc[i][j], 0, 0, 0);
+            };
+            read_frags(ConvIC<0>{});
+            step(ConvIC<0>{}); step(ConvIC<1>{}); step(ConvIC<2>{}); step(ConvIC<3>{});
+            step(ConvIC<4>{}); step(ConvIC<5>{}); step(ConvIC<6>{}); step(ConvIC<7>{});
+        }
         wait_next_tile(kt + NBUF - 1 < nk ? 1 : 0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -188,6 +227,17 @@ inline bool launch_wgrad_tiles(WgradArgs &a, hipStream_t s) // a.splits and a.pa
     if (xb > kMaxViewBytes || zb > kMaxViewBytes) return false; // 32-bit buffer offsets
     a.x_bytes = (uint32_t)xb;
     a.dz_bytes = (uint32_t)zb;
+    if (a.prec == 1) {
+        if (wgrad_wide(a.R, a.Cout))
+            hipLaunchKernelGGL((k_wgrad_mfma<128, 128, WGRAD_NBUF, 2, 2, 1>), dim3((a.R + 127) / 128, (a.Cout + 127) / 128, a.splits), dim3(256), 0, s, a);
+        else if (a.R > 64 && a.Cout <= 32)
+            hipLaunchKernelGGL((k_wgrad_mfma<128, 32, WGRAD_NBUF, 4, 1, 1>), dim3((a.R + 127) / 128, 1, a.splits), dim3(256), 0, s, a);
+        else if (a.R > 64)
+            hipLaunchKernelGGL((k_wgrad_mfma<128, 64, WGRAD_NBUF, 2, 2, 1>), dim3((a.R + 127) / 128, (a.Cout + 63) / 64, a.splits), dim3(256), 0, s, a);
+        else
+            hipLaunchKernelGGL((k_wgrad_mfma<64, 64, WGRAD_NBUF, 2, 2, 1>), dim3((a.R + 63) / 64, (a.Cout + 63) / 64, a.splits), dim3(256), 0, s, a);
+        return true;
+    }
     if (wgrad_wide(a.R, a.Cout))
         hipLaunchKernelGGL((k_wgrad_mfma<128, 128, WGRAD_NBUF>), dim3((a.R + 127) / 128, (a.Cout + 127) / 128, a.splits), dim3(256), 0, s, a);
     else if (a.R > 64 && a.Cout <= 32)

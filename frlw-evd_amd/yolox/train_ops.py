@@ -21,11 +21,30 @@ _WCACHE = {}  # id(weight parameter) -> (weakref, operand cache): forward + data
 _WCACHE_GEOM = {}  # id(weight parameter) -> what the data-gradient layout in the cache was laid out for: (version, parity)
 
 
+PRECISIONS = {"f32": 0, "bf16x3": 1}
+
+
+def conv_precision():
+    """Arithmetic of the native contractions of the train step: ``FRLW_CONV_PRECISION`` = ``bf16x3`` (default: float32
+    products from three bf16 MFMAs, <= 2^-16 relative error per product, float32 accumulation) or ``f32`` (float32 MFMA)."""
+    v = os.environ.get("FRLW_CONV_PRECISION", "bf16x3").strip().lower()
+    if v not in PRECISIONS:
+        raise ValueError(f"FRLW_CONV_PRECISION={v!r}: expected one of {sorted(PRECISIONS)}")
+    return PRECISIONS[v]
+
+
+def layer_precision(Cout, k, stride):
+    """Per layer: the split data-gradient operand of a stride-2 3x3 layer is grouped by parity class in blocks of Cout rows,
+    which must be whole k-tiles of 16 (every width of the shipped networks is); other widths keep the float32 MFMA."""
+    p = conv_precision()
+    return p if (p == 0 or not (k == 3 and stride == 2) or Cout % 16 == 0) else 0
+
+
 def _weight_cache(lib, weight, Cin, Cout, k):
     import weakref
     key = id(weight)
     hit = _WCACHE.get(key)
-    n = lib.frlw_baseconv_weight_cache_floats(Cin, Cout, k)
+    n = lib.frlw_baseconv_weight_cache_floats(Cin, Cout, k, 1)  # room for either precision
     if hit is None or hit[0]() is not weight or hit[1].numel() < n or hit[1].device != weight.device:
         buf = torch.empty(int(n), dtype=torch.float32, device=weight.device)
         if hit is not None:
@@ -41,9 +60,10 @@ _PLANS = {}  # id(model) -> (weakref, item table on the device, total elements, 
 
 def _layout_plan(model):
     """One table entry per natively trained BaseConv weight of `model` whose operand cache exists (= that has run one
-    forward): frlw_weight_layout_item_t {w, w_fwd, w_dgrad, Cout, Cin, k, parity, first}."""
+    forward): frlw_weight_layout_item_t {w, w_fwd, w_dgrad, Cout, Cin, k, parity, precision, reserved, first}."""
     import struct
     import weakref
+    lib = _lib.load()
     rows, blob, first = [], b"", 0
     for mod in model.modules():
         conv, bn = getattr(mod, "conv", None), getattr(mod, "bn", None)
@@ -55,10 +75,11 @@ def _layout_plan(model):
             continue
         Cout, Cin, k, _ = w.shape
         cache = hit[1]
-        n_f, n_d = k * k * Cin * pad32(Cout), k * k * Cout * pad32(Cin)
-        blob += struct.pack("<QQQiiiiq", w.data_ptr(), cache.data_ptr(), cache.data_ptr() + 4 * n_f, Cout, Cin, k, geom[1], first)
+        prec = geom[2]
+        n_f, n_d = lib.frlw_conv_operand_floats(k * k * Cin, Cout, prec), lib.frlw_conv_operand_floats(k * k * Cout, Cin, prec)
+        blob += struct.pack("<QQQiiiiiiq", w.data_ptr(), cache.data_ptr(), cache.data_ptr() + 4 * n_f, Cout, Cin, k, geom[1], prec, 0, first)
         first += n_f + n_d
-        rows.append((w, geom[1], cache, w.data_ptr()))
+        rows.append((w, (geom[1], prec), cache, w.data_ptr()))
     if not rows:
         return None
     import numpy as np
@@ -75,9 +96,9 @@ def layout_all_weights(model):
     plan = _PLANS.get(id(model))
     stale = plan is None or plan[0]() is not model
     if not stale:
-        for w, parity, cache, ptr in plan[3]:
+        for w, parity, cache, ptr in plan[3]:  # parity = (parity class, precision) the entry was written for
             hit, geom = _WCACHE.get(id(w)), _WCACHE_GEOM.get(id(w))
-            if hit is None or hit[1] is not cache or geom is None or geom[1] != parity or w.data_ptr() != ptr:
+            if hit is None or hit[1] is not cache or geom is None or geom[1:] != parity or w.data_ptr() != ptr:
                 stale = True
                 break
     if stale:
@@ -93,7 +114,7 @@ def layout_all_weights(model):
     _lib.check(lib.frlw_conv_weight_layouts_batch(table.data_ptr(), len(rows), total, _stream(table.device)), "weight_layouts_batch")
     for w, parity, cache, _ptr in rows:
         _WREADY[id(w)] = (w._version, parity, cache.data_ptr())
-        _WCACHE_GEOM[id(w)] = (w._version, parity)
+        _WCACHE_GEOM[id(w)] = (w._version, *parity)
     return True
 
 
@@ -150,20 +171,21 @@ class _BaseConvTrain(torch.autograd.Function):
         sc = _scratch(dev, "block", lib.frlw_baseconv_train_scratch_bytes(B, H, W, Cin, Cout, k, stride), torch.uint8)
         wc = _weight_cache(lib, weight, Cin, Cout, k)  # both GEMM operands of this weight, laid out once per step
         parity = int(lib.frlw_conv2d_dgrad_parity(k, stride, H, W))
-        # laid out already by layout_all_weights() for exactly this weight version, parity class and buffer?
-        ready = _WREADY.get(id(weight)) == (weight._version, parity, wc.data_ptr()) and w.data_ptr() == weight.data_ptr()
+        prec = layer_precision(Cout, k, stride)
+        # laid out already by layout_all_weights() for exactly this weight version, parity class, precision and buffer?
+        ready = _WREADY.get(id(weight)) == (weight._version, (parity, prec), wc.data_ptr()) and w.data_ptr() == weight.data_ptr()
         _lib.check(lib.frlw_baseconv_train_fwd(x.data_ptr(), None if ready else w.data_ptr(), g.data_ptr(), b.data_ptr(), C.c_float(eps), B, H, W,
                                                Cin, Cout, k, stride, z.data_ptr(), y.data_ptr(), stats[0].data_ptr(),
                                                stats[1].data_ptr(), stats[2].data_ptr(),
                                                run_mean.data_ptr() if run_mean is not None else None,
                                                run_var.data_ptr() if run_var is not None else None, C.c_float(momentum),
                                                tracked.data_ptr() if tracked is not None else None,
-                                               wc.data_ptr(), sc.data_ptr(), sc.numel(), _stream(dev)), "baseconv_train_fwd")
+                                               wc.data_ptr(), sc.data_ptr(), sc.numel(), prec, _stream(dev)), "baseconv_train_fwd")
         ctx.wcache = wc
         # the data-gradient half of the cache depends on the parity class of (k, stride, H, W): a second forward of the same
         # layer on an input of another parity (shared layer, multi-scale graph) re-lays it -- remember what THIS forward wrote
-        ctx.wparity = parity
-        _WCACHE_GEOM[id(weight)] = (weight._version, ctx.wparity)
+        ctx.wparity = (parity, prec)
+        _WCACHE_GEOM[id(weight)] = (weight._version, parity, prec)
         ctx.wversion = weight._version
         ctx.weight_ref = weight
         ctx.save_for_backward(x, z, w, g, b, stats)
@@ -187,13 +209,13 @@ class _BaseConvTrain(torch.autograd.Function):
         # since: a second forward of the same layer before this backward would have overwritten it with the same
         # weights' layout (fine), an in-place weight update in between would not (then lay out again)
         fresh = (ctx.weight_ref._version == ctx.wversion and _WCACHE.get(id(ctx.weight_ref), (None, None))[1] is ctx.wcache
-                 and _WCACHE_GEOM.get(id(ctx.weight_ref)) == (ctx.wversion, ctx.wparity))
+                 and _WCACHE_GEOM.get(id(ctx.weight_ref)) == (ctx.wversion, *ctx.wparity))
         _lib.check(lib.frlw_baseconv_train_bwd(dy.data_ptr(), x.data_ptr(), z.data_ptr(), w.data_ptr(), g.data_ptr(),
                                                b.data_ptr(), stats[0].data_ptr(), stats[2].data_ptr(), B, H, W, Cin, Cout, k,
                                                stride, dz.data_ptr(), dx.data_ptr() if dx is not None else None,
                                                dw.data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(),
                                                ctx.wcache.data_ptr() if fresh else None, sc.data_ptr(),
-                                               sc.numel(), _stream(dev)), "baseconv_train_bwd")
+                                               sc.numel(), ctx.wparity[1], _stream(dev)), "baseconv_train_bwd")
         return dx, dw, dgb[0], dgb[1], None, None, None, None, None, None
 
 

@@ -459,38 +459,45 @@ int frlw_eval_transform_dt(const float *dets, const int32_t *img_of_row, const i
  * (core/yolox/models/network_blocks.py:33-65) for the train step of core/exp.py:283-315: forward, data gradient,
  * weight gradient, BatchNorm + SiLU forward / backward.  All tensors NHWC float32 (= torch channels_last storage),
  * dense (pixel stride = channels).  Cin % 4 == 0 and Cout % 4 == 0.  `scratch` buffers are caller-owned.
+ * `precision` (every contraction below): 0 = float32 MFMA, 1 = float32 products from three bf16 MFMAs (see
+ * frlw_det_set_precision; the weight operands are then split images of ceil16(K) rows -- frlw_conv_operand_floats --
+ * and the data-gradient operand of a parity-grouped layer needs Cout % 16 == 0, else FRLW_ERR_UNSUPPORTED: use 0 there).
  * ------------------------------------------------------------------------------------------- */
+/* floats (4-byte units) of a GEMM operand with K rows and N columns: rows(K, precision) * pad32(N). */
+int64_t frlw_conv_operand_floats(int K, int N, int precision);
 /* torch weight (Cout, Cin, k, k) -> forward operand (k*k*Cin, pad32(Cout)) and / or data-gradient operand
  * (k*k*Cout, pad32(Cin)) with flipped taps; with dgrad_parity = frlw_conv2d_dgrad_parity(k, stride, H, W) != 0 the
  * rows of the latter are grouped by output parity class (see frlw_conv2d_dgrad).  pad32(n) = n rounded up to 32.
  * Either output may be NULL. */
 int frlw_conv2d_dgrad_parity(int k, int stride, int H, int W);
 int frlw_conv_weight_layouts(const float *w, int Cout, int Cin, int k, int dgrad_parity, float *w_fwd, float *w_dgrad,
-                             frlw_stream_t stream);
+                             int precision, frlw_stream_t stream);
 /* The same for MANY weights in one launch (the ~74 BaseConv weights of the detector after an optimizer step: 74 launches
  * of ~5 us each otherwise).  `items`: DEVICE array of n entries, `first` = running sum of the entries' element counts
- * (k*k*Cin*pad32(Cout) + k*k*Cout*pad32(Cin) each; either operand pointer may be NULL and then counts 0), `total` = the sum. */
+ * (frlw_conv_operand_floats(k*k*Cin, Cout, precision) + frlw_conv_operand_floats(k*k*Cout, Cin, precision) each; either
+ * operand pointer may be NULL and then counts 0), `total` = the sum. */
 typedef struct frlw_weight_layout_item {
     const float *w;
     float *w_fwd, *w_dgrad;
     int32_t Cout, Cin, k, dgrad_parity;
+    int32_t precision, reserved;
     int64_t first;
 } frlw_weight_layout_item_t;
 int frlw_conv_weight_layouts_batch(const frlw_weight_layout_item_t *items, int n, int64_t total, frlw_stream_t stream);
 /* z (B, Ho, Wo, Cout) = conv2d(x (B, H, W, Cin), w), padding (k - 1) / 2, stride 1 or 2.  scratch: optional split-K
  * partial sums (scratch_floats floats; NULL = never split). */
 int frlw_conv2d_fwd(const float *x, int B, int H, int W, int Cin, const float *w_fwd, int Cout, int k, int stride, float *z,
-                    float *scratch, int64_t scratch_floats, frlw_stream_t stream);
+                    float *scratch, int64_t scratch_floats, int precision, frlw_stream_t stream);
 /* dx (B, H, W, Cin) = gradient of the convolution above with respect to x, from dz (B, Ho, Wo, Cout).  Stride 2 with
  * k = 3 and even H, W (frlw_conv2d_dgrad_parity) runs as four stride-1 convolutions, one per output parity class
  * (1 / 2 / 2 / 4 taps) and needs the parity-grouped operand; other stride-2 shapes use a transposed gather. */
 int frlw_conv2d_dgrad(const float *dz, int B, int Ho, int Wo, int Cout, const float *w_dgrad, int Cin, int k, int stride,
-                      int H, int W, float *dx, float *scratch, int64_t scratch_floats, frlw_stream_t stream);
+                      int H, int W, float *dx, float *scratch, int64_t scratch_floats, int precision, frlw_stream_t stream);
 /* dw in torch's (Cout, Cin, k, k) layout = gradient with respect to the weight; scratch is REQUIRED
  * (frlw_conv2d_wgrad_scratch_floats floats for full parallelism; fewer = fewer splits). */
 int64_t frlw_conv2d_wgrad_scratch_floats(int B, int Ho, int Wo, int Cin, int Cout, int k);
 int frlw_conv2d_wgrad(const float *x, int B, int H, int W, int Cin, const float *dz, int Ho, int Wo, int Cout, int k,
-                      int stride, float *dw, float *scratch, int64_t scratch_floats, frlw_stream_t stream);
+                      int stride, float *dw, float *scratch, int64_t scratch_floats, int precision, frlw_stream_t stream);
 /* Per-channel batch statistics of z viewed as (M, C): mean, biased variance, invstd = 1 / sqrt(var + eps).
  * scratch: frlw_bn_scratch_doubles(M, C) doubles. */
 int64_t frlw_bn_scratch_doubles(int64_t M, int C);
@@ -511,22 +518,22 @@ int frlw_bn_silu_bwd(const float *dy, const float *z, int64_t M, int C, const fl
  * nn.BatchNorm2d: r = (1 - momentum) r + momentum * {mean, unbiased variance}; num_batches_tracked (device int64, may be
  * NULL) is incremented by one in the same launch sequence.
  * scratch: frlw_baseconv_train_scratch_bytes(...) bytes, reusable between calls.
- * w_cache (may be NULL): frlw_baseconv_weight_cache_floats(Cin, Cout, k) floats owned by the caller, one per layer: the
+ * w_cache (may be NULL): frlw_baseconv_weight_cache_floats(Cin, Cout, k, precision) floats owned by the caller, one per layer: the
  * forward then lays the weight out for itself AND for the data gradient in one launch, and the backward of the same
  * step (weights unchanged in between) reuses it instead of laying the weight out again.  w == NULL with a w_cache in
  * the forward: the cache holds both operands of the current weights already (frlw_conv_weight_layouts_batch: forward
- * operand first, the data-gradient operand k*k*Cin*pad32(Cout) floats behind it) and no layout kernel is launched. */
-int64_t frlw_baseconv_weight_cache_floats(int Cin, int Cout, int k);
+ * operand first, the data-gradient operand frlw_conv_operand_floats(k*k*Cin, Cout, precision) floats behind it) and no layout kernel is launched. */
+int64_t frlw_baseconv_weight_cache_floats(int Cin, int Cout, int k, int precision);
 int64_t frlw_baseconv_train_scratch_bytes(int B, int H, int W, int Cin, int Cout, int k, int stride);
 int frlw_baseconv_train_fwd(const float *x, const float *w, const float *gamma, const float *beta, float eps, int B, int H,
                             int W, int Cin, int Cout, int k, int stride, float *z, float *y, float *mean, float *var,
                             float *invstd, float *running_mean, float *running_var, float momentum,
                             int64_t *num_batches_tracked, float *w_cache, void *scratch, int64_t scratch_bytes,
-                            frlw_stream_t stream);
+                            int precision, frlw_stream_t stream);
 int frlw_baseconv_train_bwd(const float *dy, const float *x, const float *z, const float *w, const float *gamma,
                             const float *beta, const float *mean, const float *invstd, int B, int H, int W, int Cin,
                             int Cout, int k, int stride, float *dz, float *dx, float *dw, float *dgamma, float *dbeta,
-                            const float *w_cache, void *scratch, int64_t scratch_bytes, frlw_stream_t stream);
+                            const float *w_cache, void *scratch, int64_t scratch_bytes, int precision, frlw_stream_t stream);
 
 /* Measurement aid: a bare loop of v_mfma_f32_32x32x2_f32 (the instruction of every convolution here) on `blocks`
  * workgroups of four wavefronts, iters x 32 MFMAs (= iters x 131072 FLOP) per wavefront, operands = the 256 floats of

@@ -11,6 +11,7 @@ from frlw_evd_amd import _lib  # noqa: E402
 
 lib = _lib.load()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+PREC = int(sys.argv[2]) if len(sys.argv) > 2 else 1  # 0: float32 MFMA, 1: three bf16 MFMAs per product
 SHAPES = [(32, 40, 256, 256, 3, 1), (16, 20, 256, 256, 3, 1), (8, 10, 256, 256, 3, 1), (16, 20, 128, 128, 3, 1),
           (32, 40, 64, 64, 3, 1), (128, 160, 40, 32, 3, 1), (16, 20, 256, 256, 1, 1), (32, 40, 128, 128, 1, 1),
           (64, 80, 64, 64, 1, 1), (32, 40, 256, 128, 1, 1)]
@@ -21,14 +22,14 @@ for H, W, Cin, Cout, k, s in SHAPES:
     x = torch.randn(B, H, W, Cin, device="cuda")
     w = torch.randn(Cout, Cin, k, k, device="cuda") * 0.05
     npad = (Cout + 31) // 32 * 32
-    wf = torch.empty(k * k * Cin, npad, device="cuda")
-    _lib.check(lib.frlw_conv_weight_layouts(w.data_ptr(), Cout, Cin, k, 0, wf.data_ptr(), None, st))
+    wf = torch.empty(lib.frlw_conv_operand_floats(k * k * Cin, Cout, PREC), device="cuda")
+    _lib.check(lib.frlw_conv_weight_layouts(w.data_ptr(), Cout, Cin, k, 0, wf.data_ptr(), None, PREC, st))
     Ho, Wo = H // s, W // s
     z = torch.empty(B, Ho, Wo, Cout, device="cuda")
 
     def run():
         _lib.check(lib.frlw_conv2d_fwd(x.data_ptr(), B, H, W, Cin, wf.data_ptr(), Cout, k, s, z.data_ptr(), scratch.data_ptr(),
-                                       scratch.numel(), st))
+                                       scratch.numel(), PREC, st))
     for _ in range(3):
         run()
     torch.cuda.synchronize()
