@@ -117,27 +117,30 @@ __device__ __forceinline__ float4 conv_load16(__amdgpu_buffer_rsrc_t r, uint32_t
 // UT ("uniform taps"): Cin % BK == 0, so a k-tile lies inside one filter tap and the tap changes for the whole
 // workgroup at once: the gather offsets are recomputed only then, a k-tile costs one add per load.
 template <int BM, int BN, int WROWS, int WCOLS, int BK, bool UT, int D = 2, int P = 0>
-__global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
+__global__ __launch_bounds__(64 * WROWS * WCOLS) void k_conv_mfma(ConvArgs a)
 {
+    constexpr int NT = 64 * WROWS * WCOLS; // four wavefronts (eight for the 128 x 256 tile)
     constexpr int TM = BM / (32 * WROWS), TN = BN / (32 * WCOLS);
     constexpr int KQ = BK / 4;        // float4 per A row of the k-tile
-    constexpr int RPP = 256 / KQ;     // A rows staged per pass of the 256 threads
+    constexpr int RPP = NT / KQ;      // A rows staged per pass of the NT threads
     // Both operand tiles arrive by LDS-DMA (buffer_load ... lds: no registers, no ds_write), so their LDS images are
     // lane-linear: weights [BK][BN], gathered rows [BM][BK] with the four 16-byte quads of a row XOR-swizzled by
     // (row >> 2) & 3 on the SOURCE side, which makes the ds_read_b128 fragment reads conflict-free.
-    static_assert(BK == 16, "the A image is four quads per row");
+    static_assert(BK == 16 || (BK == 32 && P == 1), "the A image is four quads per row (eight with the bf16 k-steps: two per k-tile)");
+    constexpr int KS = BK / 16;       // bf16 k-steps per k-tile (P == 1)
     constexpr int LDB = BN;
-    constexpr int A_F4 = BM * BK / 4 / 256;   // float4 loads per thread for the A tile
-    constexpr int B_F4 = (BN * BK / 4 + 255) / 256;
+    constexpr int A_F4 = BM * BK / 4 / NT;    // float4 loads per thread for the A tile
+    constexpr int B_F4 = (BN * BK / 4 + NT - 1) / NT;
     constexpr int EPLD = 36;                          // row pitch of the epilogue staging (16-byte aligned rows)
     // LDS rings.  The gathered operand streams from HBM / the far L2: its tile t + D is requested while tile t is
     // computed (D + 1 slots).  The weights are L2-resident and shared by every workgroup: D - 1 tiles ahead (D slots).
     // D = 2 where many workgroups share a CU (they hide each other's latency and LDS is what limits their number);
     // D = 4 for launches that leave a workgroup alone on its CU: its k-tile then costs latency / D, not latency / 2.
     constexpr int NA = D + 1, NB = D;
-    static_assert(D == 2 || (BN * BK / 4) % 256 == 0, "deeper rings count on every wavefront issuing the same DMAs");
+    static_assert((BM * BK / 4) % NT == 0, "whole passes over the gathered tile");
+    static_assert(D == 2 || (BN * BK / 4) % NT == 0, "deeper rings count on every wavefront issuing the same DMAs");
     constexpr int kTileFloats = BK * (NA * BM + NB * LDB);
-    constexpr int kEpiFloats = 4 * 32 * EPLD;         // one 32 x 32 MFMA tile per wavefront
+    constexpr int kEpiFloats = (NT / 64) * 32 * EPLD; // one 32 x 32 MFMA tile per wavefront
     __shared__ __attribute__((aligned(16))) float smem[kTileFloats > kEpiFloats ? kTileFloats : kEpiFloats];
     float (*As)[BM][BK] = (float (*)[BM][BK])smem;
     float (*Bs)[BK][LDB] = (float (*)[BK][LDB])(smem + NA * BK * BM);
@@ -155,7 +158,9 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
     const __amdgpu_buffer_rsrc_t rx = conv_rsrc(a.x, a.x_bytes), rw = conv_rsrc(a.w, a.w_bytes);
 
     // ---- A staging: thread -> A_F4 rows m, one float4 of 4 consecutive k
-    const int a_k4 = ((tid & 3) ^ ((tid >> 4) & 3)) * 4; // the quad this lane FETCHES; it lands in slot tid & 3 of its row
+    // the quad this lane FETCHES; it lands in slot tid % KQ of its row (row tid / KQ): slot ^ f(row), f = (row >> 2) & 3 for
+    // 64-byte rows, (row >> 1) & 7 for 128-byte rows -- the 16 lanes of a ds_read_b128 pass then cover all 64 banks
+    const int a_k4 = (KQ == 4 ? ((tid & 3) ^ ((tid >> 4) & 3)) : ((tid & 7) ^ ((tid >> 4) & 7))) * 4;
     int a_iy0[A_F4], a_ix0[A_F4];
     uint32_t a_base[A_F4]; // byte offset of the row's image (+ channel offset); kOob for rows past M
 #pragma unroll
@@ -186,10 +191,10 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
     const int nk = kt1 - kt0;
 #pragma unroll
     for (int i = 0; i < B_F4; ++i) {
-        const int e = tid + 256 * i;
+        const int e = tid + NT * i;
         if (P == 1) { // 16-byte record e of the tile image [h][hi | lo][BN]
-            const int hp = e / BN, n = e - hp * BN;
-            b_off[i] = (hp < 4 && n0 + n < a.Npad) ? (uint32_t)((((long long)kt0 * 4 + hp) * a.Npad + n0 + n) * 16) : kOob;
+            const int hp = e / BN, n = e - hp * BN; // hp = 4 * (k-step of the tile) + 2 h + part
+            b_off[i] = (hp < BK / 4 && n0 + n < a.Npad) ? (uint32_t)((((long long)kt0 * (BK / 4) + hp) * a.Npad + n0 + n) * 16) : kOob;
         } else {
             const int kr = e / BN4, n4 = (e - kr * BN4) * 4;
             b_off[i] = (kr < BK && n0 + n4 < a.Npad) ? (uint32_t)((((long long)kt0 * BK + kr) * a.Npad + n0 + n4) * 4) : kOob;
@@ -210,13 +215,13 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) a_pix[i] = gather_off(i, s_ky, s_kx);
     }
-    // wave-instruction i of wavefront wv fills the 1 KB at float offset (wv * 64 + 256 i) * 4 of a tile
+    // wave-instruction i of wavefront wv fills the 1 KB at float offset (wv * 64 + NT i) * 4 of a tile
     auto load_a = [&](int kt, int nbuf) {
         if (UT) {
             const uint32_t cib = (uint32_t)(s_ci + a_k4) * 4;
 #pragma unroll
             for (int i = 0; i < A_F4; ++i) // kOob + cib stays out of range: zeros land in LDS
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void *)(&As[nbuf][0][0] + (wv * 64 + 256 * i) * 4),
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void *)(&As[nbuf][0][0] + (wv * 64 + NT * i) * 4),
                                                          16, (int)(a_pix[i] + cib), 0, 0, 0);
             s_ci += BK;
             if (s_ci == a.Cin) { // next tap (uniform branch, once per Cin / BK tiles)
@@ -230,7 +235,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
 #pragma unroll
             for (int i = 0; i < A_F4; ++i) {
                 const uint32_t o = gather_off(i, s_ky, s_kx);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void *)(&As[nbuf][0][0] + (wv * 64 + 256 * i) * 4),
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void *)(&As[nbuf][0][0] + (wv * 64 + NT * i) * 4),
                                                          16, (int)(in_k ? o + (uint32_t)s_ci * 4 : kOob), 0, 0, 0);
             }
             s_ci += BK; // Cin % 4 == 0: a float4 never straddles taps
@@ -240,8 +245,8 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
     auto load_b = [&](int nbuf) {
 #pragma unroll
         for (int i = 0; i < B_F4; ++i) {
-            if ((BN * BK / 4) % 256 == 0 || wv * 64 + 256 * i < BN * BK / 4) // wave-uniform
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void *)(&Bs[nbuf][0][0] + (wv * 64 + 256 * i) * 4),
+            if ((BN * BK / 4) % NT == 0 || wv * 64 + NT * i < BN * BK / 4) // wave-uniform
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void *)(&Bs[nbuf][0][0] + (wv * 64 + NT * i) * 4),
                                                          16, (int)b_off[i], 0, 0, 0);
             b_off[i] += (uint32_t)(BK * 4) * (uint32_t)a.Npad;
         }
@@ -276,12 +281,14 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
     PROBE_PH(2);
     // MFMA k-step (j, t), j = 0..1, t = 0..3: lane half h supplies k = 8 j + 4 h + t -- any pairing of the tile's 16 k
     // works as long as both operands use it; this one lets a lane take its four A values of a j from ONE 16-byte read.
-    static_assert(TM <= 2 && TN <= 2, "fragment reads are written out for at most two tiles per direction");
-    const int fh = lane >> 5, fsw = ((lane & 31) >> 2) & 3;
+    static_assert(TM <= 2 && (TN <= 2 || (P == 1 && TN <= 4)), "fragment reads are written out for at most two tiles per direction (four columns of tiles with the bf16 k-steps)");
+    const int fh = lane >> 5, fsw = KQ == 4 ? ((lane & 31) >> 2) & 3 : ((lane & 31) >> 1) & 7;
     const int fm = wr * TM * 32 + (lane & 31), fn = wc * TN * 32 + (lane & 31);
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float *)smem;
     // byte addresses in ring slot 0: A quad (2 j + h) ^ swizzle of row fm (second tile: + 32 rows = 2048 B), B row 4 h
-    const uint32_t a_lds[2] = {lds0 + (uint32_t)(fm * BK + ((0 + fh) ^ fsw) * 4) * 4, lds0 + (uint32_t)(fm * BK + ((2 + fh) ^ fsw) * 4) * 4};
+    uint32_t a_lds[2 * KS]; // quad 4 s + 2 j + h of row fm, swizzled
+#pragma unroll
+    for (int q = 0; q < 2 * KS; ++q) a_lds[q] = lds0 + (uint32_t)(fm * BK + ((2 * q + fh) ^ fsw) * 4) * 4;
     const uint32_t b_lds = lds0 + (uint32_t)(NA * BK * BM + 4 * fh * LDB + fn) * 4;
     const uint32_t b3_lds = lds0 + (uint32_t)(NA * BK * BM) * 4 + (uint32_t)(2 * fh * BN + fn) * 16; // prec 1: record (h, hi, column fn)
     int buf = 0, bufb = 0; // ring slots of tile kt: A (kt % NA), B (kt % NB)
@@ -293,41 +300,55 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
         // it can see while an LDS-DMA is in flight (it cannot tell that the DMA writes another ring slot), which would
         // drain the prefetch.  LDS returns in order, so "all but the newest N reads" is exactly lgkmcnt(N); the empty asm
         // statements after a wait make the consuming MFMAs depend on it.
-        f32x4 fa[2][TM];
-        const uint32_t a_addr0 = a_lds[0] + (uint32_t)buf * (BM * BK * 4), a_addr1 = a_lds[1] + (uint32_t)buf * (BM * BK * 4);
-        auto read_a = [&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            asm volatile("ds_read_b128 %0, %1" : "=v"(fa[j][0]) : "v"(j ? a_addr1 : a_addr0));
-            if (TM > 1) asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(fa[j][TM - 1]) : "v"(j ? a_addr1 : a_addr0));
+        f32x4 fa[2 * KS][TM];
+        const uint32_t a_slot = (uint32_t)buf * (BM * BK * 4);
+        auto read_a = [&](auto jc) { // quad pair index q = 2 s + j
+            constexpr int q = decltype(jc)::value;
+            asm volatile("ds_read_b128 %0, %1" : "=v"(fa[q][0]) : "v"(a_lds[q] + a_slot));
+            if (TM > 1) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[q][TM - 1]) : "v"(a_lds[q] + a_slot), "n"(32 * BK * 4));
         };
         if constexpr (P == 1) {
-            // one k-tile = ONE bf16 k-step: the lane's eight gathered values (two quads) and its hi / lo weight records
-            u32x4 bh[TN], bl[TN];
+            // a bf16 k-step = 16 k: the lane's eight gathered values (two quads) and its hi / lo weight records; KS per k-tile
+            u32x4 bh[KS][TN], bl[KS][TN];
             const uint32_t b_addr = b3_lds + (uint32_t)bufb * (BK * LDB * 4);
-            read_a(ConvIC<0>{});
-            read_a(ConvIC<1>{});
-            asm volatile("ds_read_b128 %0, %1" : "=v"(bh[0]) : "v"(b_addr));
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bl[0]) : "v"(b_addr), "n"(BN * 16));
-            if (TN > 1) {
-                asm volatile("ds_read_b128 %0, %1 offset:512" : "=v"(bh[TN - 1]) : "v"(b_addr));
-                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bl[TN - 1]) : "v"(b_addr), "n"(BN * 16 + 512));
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            auto read_b3 = [&bh, &bl, b_addr](auto sc, auto jc) {
+                constexpr int st = decltype(sc)::value, jn = decltype(jc)::value;
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bh[st][jn]) : "v"(b_addr), "n"(st * 4 * BN * 16 + jn * 512));
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bl[st][jn]) : "v"(b_addr), "n"(st * 4 * BN * 16 + BN * 16 + jn * 512));
+            };
+            auto read_step = [&](auto sc) {
+                constexpr int st = decltype(sc)::value;
+                read_a(ConvIC<2 * st>{});
+                read_a(ConvIC<2 * st + 1>{});
+                read_b3(sc, ConvIC<0>{});
+                if constexpr (TN > 1) read_b3(sc, ConvIC<1>{});
+                if constexpr (TN > 2) read_b3(sc, ConvIC<2>{});
+                if constexpr (TN > 3) read_b3(sc, ConvIC<3>{});
+            };
+            auto mma_step = [&](auto sc) {
+                constexpr int st = decltype(sc)::value;
+                constexpr int later = (KS - 1 - st) * (2 * TM + 2 * TN); // reads of the later k-steps still in flight
+                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(later) : "memory");
 #pragma unroll
-            for (int i = 0; i < TM; ++i) { asm volatile("" : "+v"(fa[0][i])); asm volatile("" : "+v"(fa[1][i])); }
+                for (int i = 0; i < TM; ++i) { asm volatile("" : "+v"(fa[2 * st][i])); asm volatile("" : "+v"(fa[2 * st + 1][i])); }
 #pragma unroll
-            for (int jn = 0; jn < TN; ++jn) { asm volatile("" : "+v"(bh[jn])); asm volatile("" : "+v"(bl[jn])); }
-            u32x4 ah[TM], al[TM];
+                for (int jn = 0; jn < TN; ++jn) { asm volatile("" : "+v"(bh[st][jn])); asm volatile("" : "+v"(bl[st][jn])); }
+                u32x4 ah[TM], al[TM];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) conv_split8(fa[0][i], fa[1][i], ah[i], al[i]);
+                for (int i = 0; i < TM; ++i) conv_split8(fa[2 * st][i], fa[2 * st + 1][i], ah[i], al[i]);
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int jn = 0; jn < TN; ++jn) { // the small terms first
-                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[i]), __builtin_bit_cast(bf16x8, bh[jn]), acc[i][jn], 0, 0, 0);
-                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bl[jn]), acc[i][jn], 0, 0, 0);
-                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bh[jn]), acc[i][jn], 0, 0, 0);
-                }
+                    for (int jn = 0; jn < TN; ++jn) { // the small terms first
+                        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[i]), __builtin_bit_cast(bf16x8, bh[st][jn]), acc[i][jn], 0, 0, 0);
+                        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bl[st][jn]), acc[i][jn], 0, 0, 0);
+                        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bh[st][jn]), acc[i][jn], 0, 0, 0);
+                    }
+            };
+            read_step(ConvIC<0>{});
+            if (KS > 1) read_step(ConvIC<KS - 1>{});
+            mma_step(ConvIC<0>{});
+            if (KS > 1) mma_step(ConvIC<KS - 1>{});
         } else {
             float fb[2][TN];
             const uint32_t b_addr = b_lds + (uint32_t)bufb * (BK * LDB * 4);
@@ -747,13 +768,31 @@ __global__ __launch_bounds__(256) void k_conv_split_operand(const float *w, int 
 template <int BM, int BN, int WROWS, int WCOLS, int BK, int D = 2>
 inline void launch_conv_tile(const ConvArgs &c, dim3 grid, hipStream_t s)
 {
+    const dim3 block(64 * WROWS * WCOLS);
     if (c.prec == 1) {
-        if (c.Cin % BK == 0) hipLaunchKernelGGL((k_conv_mfma<BM, BN, WROWS, WCOLS, BK, true, D, 1>), grid, dim3(256), 0, s, c);
-        else hipLaunchKernelGGL((k_conv_mfma<BM, BN, WROWS, WCOLS, BK, false, D, 1>), grid, dim3(256), 0, s, c);
+#ifdef FRLW_DEV_BUILD // lab: k-tiles of 32 (two bf16 k-steps per barrier) -- measured, no net gain: DESIGN.md section 4
+        static const long long bk32 = dev_knob("FRLW_CONV_BK32", 0ll); // bit 0: 64 x 64 tiles, bit 1: 64 x 128, bit 2: 128 x 128, bit 3: others
+        const int bit = BM == 64 ? (BN == 64 ? 1 : 2) : (BN == 128 ? 4 : 8);
+        if ((bk32 & bit) && c.Cin % 32 == 0) {
+            hipLaunchKernelGGL((k_conv_mfma<BM, BN, WROWS, WCOLS, 32, true, D, 1>), grid, block, 0, s, c);
+            return;
+        }
+#endif
+        if (c.Cin % BK == 0) hipLaunchKernelGGL((k_conv_mfma<BM, BN, WROWS, WCOLS, BK, true, D, 1>), grid, block, 0, s, c);
+        else hipLaunchKernelGGL((k_conv_mfma<BM, BN, WROWS, WCOLS, BK, false, D, 1>), grid, block, 0, s, c);
         return;
     }
-    if (c.Cin % BK == 0) hipLaunchKernelGGL((k_conv_mfma<BM, BN, WROWS, WCOLS, BK, true, D>), grid, dim3(256), 0, s, c);
-    else hipLaunchKernelGGL((k_conv_mfma<BM, BN, WROWS, WCOLS, BK, false, D>), grid, dim3(256), 0, s, c);
+    if (c.Cin % BK == 0) hipLaunchKernelGGL((k_conv_mfma<BM, BN, WROWS, WCOLS, BK, true, D>), grid, block, 0, s, c);
+    else hipLaunchKernelGGL((k_conv_mfma<BM, BN, WROWS, WCOLS, BK, false, D>), grid, block, 0, s, c);
+}
+
+// tiles that exist with the bf16 k-steps only
+template <int BM, int BN, int WROWS, int WCOLS>
+inline void launch_conv_tile_p1(const ConvArgs &c, dim3 grid, hipStream_t s)
+{
+    const dim3 block(64 * WROWS * WCOLS);
+    if (c.Cin % 16 == 0) hipLaunchKernelGGL((k_conv_mfma<BM, BN, WROWS, WCOLS, 16, true, 2, 1>), grid, block, 0, s, c);
+    else hipLaunchKernelGGL((k_conv_mfma<BM, BN, WROWS, WCOLS, 16, false, 2, 1>), grid, block, 0, s, c);
 }
 
 // Tile choice and split-K for one convolution; `scratch` (scratch_floats floats, may be NULL) holds split-K partials.
@@ -785,8 +824,18 @@ inline bool launch_conv(ConvArgs &c, float *scratch, long long scratch_floats, h
     static const long long split_target = dev_knob("FRLW_CONV_SPLIT_TARGET", 1280ll);
     static const long long big_min = dev_knob("FRLW_CONV_BIG_MIN", 1200ll);
     static const long long wide_min = dev_knob("FRLW_CONV_WIDE_MIN", 1200ll);
-    if (c.Npad <= 32) { // small N (prediction convs, the stem's data gradient)
+    static const long long t256_min = dev_knob("FRLW_CONV_T256_MIN", 100000ll);
+    static const long long row4_min = dev_knob("FRLW_CONV_ROW4_MIN", 600ll);
+    if (c.prec == 1 && c.Npad >= 256 && (long long)((c.M + 127) / 128) * ((c.Npad + 255) / 256) >= t256_min) {
+        // 128 x 256 on eight wavefronts: with the matrix work 5 x shorter these layers are bound by the L2's request rate --
+        // half the weight reads of the 64-row tile and half the gathered reads of the 128-column one
+        launch_conv_tile_p1<128, 256, 2, 4>(c, dim3((c.M + 127) / 128, (c.Npad + 255) / 256), s);
+    } else if (c.Npad <= 32) { // small N (prediction convs, the stem's data gradient)
         launch_conv_tile<128, 32, 4, 1, 16>(c, dim3((c.M + 127) / 128, 1), s);
+    } else if (c.prec == 1 && c.Npad >= 128 && big >= row4_min) {
+        // bf16 k-steps: the four wavefronts side by side in M, each 32 rows x 128 columns -- a wavefront splits its gathered
+        // values (24 VALU instructions per k-step) once for FOUR column tiles; with 2 x 2 the split cost as much issue time as the MFMAs
+        launch_conv_tile_p1<128, 128, 4, 1>(c, dim3((c.M + 127) / 128, (c.Npad + 127) / 128), s);
     } else if (big >= big_min && c.Npad >= 128) {
         launch_conv_tile<128, 128, 2, 2, CONV_BK_BIG>(c, dim3((c.M + 127) / 128, (c.Npad + 127) / 128), s);
     } else if (c.Npad >= 128 && (long long)((c.M + 63) / 64) * ((c.Npad + 127) / 128) >= wide_min) {

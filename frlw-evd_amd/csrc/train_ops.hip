@@ -72,29 +72,28 @@ __device__ __forceinline__ void weight_layout_elem(const float *w, int Cout, int
     else dgr[i - nf] = weight_operand_value(w, Cout, Cin, k, 1, parity, (i - nf) / np_d, (int)((i - nf) % np_d));
 }
 
-// split operands (conv_mfma.h, prec = 1): one thread per 16-byte record = float-equivalents i .. i + 3 of [forward | data gradient],
-// each operand ceil16(K) rows
+// split operands (conv_mfma.h, prec = 1): one thread per PAIR of 16-byte records (hi and lo of the same eight values) =
+// float-equivalents i .. i + 7 of [forward | data gradient], each operand ceil16(K) rows; i % 8 == 0
 __device__ __forceinline__ void weight_layout_record(const float *w, int Cout, int Cin, int k, float *fwd, int np_f, float *dgr, int np_d,
                                                      int parity, long long nf, long long i)
 {
     const int which = i < nf ? 0 : 1;
-    const long long r = (which ? i - nf : i) >> 2;
+    const long long r2 = (which ? i - nf : i) >> 3;
     const int np = which ? np_d : np_f;
-    const int n = (int)(r % np), hp = (int)((r / np) & 3), h = hp >> 1, part = hp & 1;
-    const long long kt = r / (4ll * np);
-    uint32_t o[4];
+    const int n = (int)(r2 % np), h = (int)((r2 / np) & 1);
+    const long long kt = r2 / (2ll * np);
+    uint32_t hi[4], lo[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        float v[2];
+        float x[2];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const float x = weight_operand_value(w, Cout, Cin, k, which, parity, kt * 16 + conv_split_kmem(h, 2 * e + q), n);
-            const float hi = __builtin_bit_cast(float, conv_bf16_pair(x, 0.0f) << 16);
-            v[q] = part ? x - hi : x;
-        }
-        o[e] = conv_bf16_pair(v[0], v[1]);
+        for (int q = 0; q < 2; ++q) x[q] = weight_operand_value(w, Cout, Cin, k, which, parity, kt * 16 + conv_split_kmem(h, 2 * e + q), n);
+        hi[e] = conv_bf16_pair(x[0], x[1]);
+        lo[e] = conv_bf16_pair(x[0] - __builtin_bit_cast(float, hi[e] << 16), x[1] - __builtin_bit_cast(float, hi[e] & 0xFFFF0000u));
     }
-    ((uint4 *)(which ? dgr : fwd))[r] = make_uint4(o[0], o[1], o[2], o[3]);
+    uint4 *out = (uint4 *)(which ? dgr : fwd) + ((kt * 2 + h) * 2) * np + n;
+    out[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    out[np] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
 }
 
 __global__ void k_weight_layouts(const float *w, int Cout, int Cin, int k, float *fwd, int np_f, float *dgr, int np_d, int parity, int prec)
@@ -102,7 +101,7 @@ __global__ void k_weight_layouts(const float *w, int Cout, int Cin, int k, float
     const int kk = k * k;
     const long long nf = fwd ? operand_rows((long long)kk * Cin, prec) * np_f : 0, nd = dgr ? operand_rows((long long)kk * Cout, prec) * np_d : 0;
     if (prec == 1) {
-        for (long long i = 4 * (blockIdx.x * (long long)blockDim.x + threadIdx.x); i < nf + nd; i += 4ll * gridDim.x * blockDim.x)
+        for (long long i = 8 * (blockIdx.x * (long long)blockDim.x + threadIdx.x); i < nf + nd; i += 8ll * gridDim.x * blockDim.x)
             weight_layout_record(w, Cout, Cin, k, fwd, np_f, dgr, np_d, parity, nf, i);
         return;
     }
@@ -124,6 +123,13 @@ __global__ __launch_bounds__(256) void k_weight_layouts_batch(const frlw_weight_
         }
         const frlw_weight_layout_item_t cur = items[lo];
         const long long next = lo + 1 < n ? items[lo + 1].first : total;
+        if (cur.precision == 1 && base + kTile <= next) { // a whole tile of one split entry: one record pair per thread
+            const int np_f = (cur.Cout + 31) / 32 * 32, np_d = (cur.Cin + 31) / 32 * 32;
+            const long long nf = cur.w_fwd ? operand_rows((long long)cur.k * cur.k * cur.Cin, 1) * np_f : 0;
+            weight_layout_record(cur.w, cur.Cout, cur.Cin, cur.k, cur.w_fwd, np_f, cur.w_dgrad, np_d, (cur.dgrad_parity && cur.k == 3) ? 1 : 0, nf,
+                                 base - cur.first + 8 * threadIdx.x);
+            continue;
+        }
 #pragma unroll
         for (int u = 0; u < kTile / 256; ++u) {
             const long long i = base + u * 256 + threadIdx.x;
@@ -137,8 +143,8 @@ __global__ __launch_bounds__(256) void k_weight_layouts_batch(const frlw_weight_
             const int np_f = (it.Cout + 31) / 32 * 32, np_d = (it.Cin + 31) / 32 * 32;
             const long long nf = it.w_fwd ? operand_rows((long long)it.k * it.k * it.Cin, it.precision) * np_f : 0;
             const int parity = (it.dgrad_parity && it.k == 3) ? 1 : 0;
-            if (it.precision == 1) { // every fourth thread-slot lays a record (entries start at multiples of 32 elements)
-                if ((i & 3) == 0) weight_layout_record(it.w, it.Cout, it.Cin, it.k, it.w_fwd, np_f, it.w_dgrad, np_d, parity, nf, i - it.first);
+            if (it.precision == 1) { // every eighth thread-slot lays a record pair (entries start at multiples of 32 elements)
+                if ((i & 7) == 0) weight_layout_record(it.w, it.Cout, it.Cin, it.k, it.w_fwd, np_f, it.w_dgrad, np_d, parity, nf, i - it.first);
             } else {
                 weight_layout_elem(it.w, it.Cout, it.Cin, it.k, it.w_fwd, np_f, it.w_dgrad, np_d, parity, nf, i - it.first);
             }
@@ -457,7 +463,7 @@ int frlw_conv_weight_layouts(const float *w, int Cout, int Cin, int k, int dgrad
     if (!precision_ok(precision, Cout, dgrad_parity && w_dgrad)) return FRLW_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     const long long total = (w_fwd ? frlw_conv_operand_floats(k * k * Cin, Cout, precision) : 0) + (w_dgrad ? frlw_conv_operand_floats(k * k * Cout, Cin, precision) : 0);
-    hipLaunchKernelGGL(k_weight_layouts, dim3(conv_grid_1d(precision == 1 ? total / 4 : total)), dim3(256), 0, s, w, Cout, Cin, k, w_fwd, npad32(Cout),
+    hipLaunchKernelGGL(k_weight_layouts, dim3(conv_grid_1d(precision == 1 ? total / 8 : total)), dim3(256), 0, s, w, Cout, Cin, k, w_fwd, npad32(Cout),
                        w_dgrad, npad32(Cin), (dgrad_parity && k == 3) ? 1 : 0, precision);
     TRY_HIP(hipGetLastError());
     return FRLW_OK;
