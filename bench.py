@@ -43,6 +43,28 @@ WORKLOADS = {
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, f32 in / f32 accumulate
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f32_32x32x16_bf16: 32 cycles per SIMD)
+
+
+def mfma_roofline(tflops, precision, kernel, **extra):
+    """The ``roofline`` object of a convolution workload.  ``tflops`` = ALGORITHMIC rate (2 x MACs of the float32 convolutions
+    / device time).  precision "f32": one v_mfma_f32_32x32x2_f32 per product, peak 157.3.  precision "bf16x3" (the default
+    of the library): every float32 product is three bf16 MFMAs (hi/lo split operands, f32 accumulate), so the peak of the
+    ALGORITHMIC rate is a third of the dense bf16 peak; the executed matrix rate and the ratio to the float32-MFMA peak -- what the
+    same float32 work could reach at best on the float32 instruction -- are listed beside it."""
+    if precision == "bf16x3":
+        peak = BF16_MFMA_PEAK_TFLOPS / 3.0
+        r = {"bound": "mfma", "kernel": kernel, "achieved": round(tflops, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+             "frac": round(tflops / peak, 4), "executed_bf16_TFLOPs": round(3 * tflops, 1), "executed_peak": BF16_MFMA_PEAK_TFLOPS,
+             "x_f32_mfma_peak": round(tflops / FP32_MFMA_PEAK_TFLOPS, 3),
+             "mfma": "3 x v_mfma_f32_32x32x16_bf16 per 16 k: x = hi + lo (bf16 each), a*b ~ a_hi*b_hi + a_hi*b_lo + a_lo*b_hi, f32 "
+                     "accumulate -- float32 products to <= 2^-16 relative (observed 3e-6 of max |y| per layer; tolerance 1e-3); "
+                     "peak = dense bf16 peak / 3; FRLW_CONV_PRECISION=f32 selects v_mfma_f32_32x32x2_f32 (exact products)"}
+    else:
+        r = {"bound": "mfma", "kernel": kernel, "achieved": round(tflops, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+             "frac": round(tflops / FP32_MFMA_PEAK_TFLOPS, 4), "mfma": "v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate)"}
+    r.update(extra)
+    return r
 
 
 def taf_algorithmic_bytes(n, H, W, K):
@@ -417,6 +439,11 @@ def main():
         flat["detector_batch_per_gpu"] = d["batch_per_gpu"]
         flat["detector_TFLOPs"] = d["roofline"]["achieved"]
         flat["detector_frac"] = d["roofline"]["frac"]
+        flat["detector_x_f32_mfma_peak"] = d["roofline"].get("x_f32_mfma_peak", d["roofline"]["frac"])
+        if "f32_mfma" in d:
+            flat["detector_f32mfma_frames_per_s"] = d["f32_mfma"]["value"]
+            flat["detector_f32mfma_frac"] = d["f32_mfma"]["roofline"]["frac"]
+            flat["detector_bf16x3_vs_f32mfma_max_rel_diff"] = d["f32_mfma"]["max_rel_diff_of_outputs"]
         if "shape_1mpx" in d:
             flat["detector_1mpx_frames_per_s"] = d["shape_1mpx"]["value"]
             flat["detector_1mpx_frac"] = d["shape_1mpx"]["roofline"]["frac"]
@@ -429,6 +456,10 @@ def main():
             flat["train_ms"] = t["ms_per_step"]
             flat["train_TFLOPs"] = t["roofline"]["achieved"]
             flat["train_frac"] = t["roofline"]["frac"]
+            flat["train_x_f32_mfma_peak"] = t["roofline"].get("x_f32_mfma_peak", t["roofline"]["frac"])
+            if "f32_mfma" in t:
+                flat["train_f32mfma_ms"] = t["f32_mfma"]["ms_per_step"]
+                flat["train_f32mfma_frac"] = t["f32_mfma"]["roofline"]["frac"]
             if "encode_plus_train_step" in t:
                 flat["encode_plus_train_ms"] = t["encode_plus_train_step"]["ms_per_step"]
                 flat["encode_plus_train_frames_per_s"] = t["encode_plus_train_step"]["value"]
@@ -598,13 +629,22 @@ def bench_detector(args, torch, world, rank, timer):
         tflops = eng.flops_per_image * B / (dev_ms * 1e-3) / 1e12
         row = {
             "value": round(world * B / per, 1), "unit": "frames/s", "batch_per_gpu": B,
-            "input": f"(B, 10, {Hd}, {Wd}) f32, recipe weights", "steps": steps, "ms_per_batch": round(per * 1e3, 3), "dtype": "f32",
+            "input": f"(B, 10, {Hd}, {Wd}) f32, recipe weights", "steps": steps, "ms_per_batch": round(per * 1e3, 3),
+            "dtype": "f32" if eng.precision == "f32" else "f32 storage and accumulation, products from 3 bf16 MFMAs (bf16x3)",
             "ms_per_batch_runs": [round(r[0] * 1e3, 3) for r in runs], "value_is": "the median of the three timed regions listed",
-            "roofline": {"bound": "mfma", "kernel": f"k_conv_mfma ({eng.n_conv} launches per forward)", "achieved": round(tflops, 2),
-                         "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / FP32_MFMA_PEAK_TFLOPS, 4),
-                         "flops_per_image": eng.flops_per_image, "device_ms_per_batch": round(dev_ms, 3),
-                         "mfma": "v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate)"},
+            "roofline": mfma_roofline(tflops, eng.precision, f"k_conv_mfma ({eng.n_conv} launches per forward)",
+                                      flops_per_image=eng.flops_per_image, device_ms_per_batch=round(dev_ms, 3)),
         }
+        if tag == "gen1" and eng.precision != "f32":  # the same forward on the float32 MFMA (exact products), one region
+            from frlw_evd_amd.detector import DetectorEngine
+            e32 = DetectorEngine(net, precision="f32")
+            per32, dev32, _r = one_region(timer, lambda: e32.raw_outputs(x), steps, 10)
+            tf32 = e32.flops_per_image * B / (dev32 * 1e-3) / 1e12
+            row["f32_mfma"] = {"value": round(world * B / per32, 1), "unit": "frames/s", "ms_per_batch": round(per32 * 1e3, 3),
+                               "roofline": mfma_roofline(tf32, "f32", "k_conv_mfma", device_ms_per_batch=round(dev32, 3)),
+                               "max_rel_diff_of_outputs": float((e32.raw_outputs(x) - eng.raw_outputs(x)).abs().max()
+                                                                / e32.raw_outputs(x).abs().max())}
+            del e32
         for _ in range(2):
             eng.detect(x)
         torch.cuda.synchronize()
@@ -647,8 +687,8 @@ def bench_detector(args, torch, world, rank, timer):
     # the bare v_mfma_f32_32x32x2_f32 loop of this box (measured AFTER the forwards: it is the chip's highest power draw)
     sustained = mfma_sustained(torch)
     for r in (out["roofline"], out["shape_1mpx"]["roofline"]):
-        r["bare_mfma_loop_TFLOPs"] = round(sustained, 1)
-        r["frac_of_bare_loop"] = round(r["achieved"] / sustained, 4)
+        r["bare_f32_mfma_loop_TFLOPs"] = round(sustained, 1)  # what the float32 instruction sustains on this box
+        r["x_bare_f32_mfma_loop"] = round(r["achieved"] / sustained, 4)
     return out
 
 
@@ -727,6 +767,8 @@ def bench_train(args, torch, world, rank, local_rank, timer):
                                                            graph=use_graph)
     loss = state["loss"]
     from frlw_evd_amd.detector import DetectorEngine
+    from frlw_evd_amd.yolox import train_ops as _tops
+    precision = {v: k for k, v in _tops.PRECISIONS.items()}[_tops.conv_precision()]
     probe = DetectorEngine(e2e.build_model(16, 2, device="cpu").eval(), device="cpu")
     probe.build((16, 256, 320))  # the plan builder counts the convolution MACs of the 16-channel network
     # forward + data gradient + weight gradient of every convolution, EXCEPT the data gradient of the stem: the network input
@@ -740,12 +782,12 @@ def bench_train(args, torch, world, rank, local_rank, timer):
            "loss": round(loss, 4), "parallelism": f"ddp{world}" if world > 1 else "single", "scaling": "weak",
            "launch": "one HIP graph per step (Trainer(graph=True): ~1 200 kernel nodes, the loss read back after every replay "
                      "like core/exp.py:303)" if use_graph else "eager launches (DDP ranks)",
-           "convolutions": "csrc/train_ops.hip (fp32 MFMA fwd / dgrad / wgrad, BatchNorm + SiLU fwd / bwd), SimOTA csrc/simota.hip",
-           "roofline": {"bound": "mfma", "kernel": "k_conv_mfma (fwd + dgrad) + k_wgrad_mfma", "achieved": round(tflops, 2),
-                        "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / FP32_MFMA_PEAK_TFLOPS, 4),
-                        "flops_per_step": flops, "flops_model": "(3 x conv MACs x 2 of the 16-channel forward - the stem's data gradient, which "
-                        "is never computed: the network input needs none) x batch = forward + data gradient + weight gradient",
-                        "stem_fraction_of_forward": round(stem_fl / probe.flops_per_image, 4), "device_ms_per_step": round(dev_ms, 3)}}
+           "convolutions": "csrc/train_ops.hip (MFMA fwd / dgrad / wgrad, BatchNorm + SiLU fwd / bwd), SimOTA + losses csrc/simota.hip",
+           "dtype": "f32" if precision == "f32" else "f32 storage and accumulation, products from 3 bf16 MFMAs (bf16x3)",
+           "roofline": mfma_roofline(tflops, precision, "k_conv_mfma (fwd + dgrad) + k_wgrad_mfma", flops_per_step=flops,
+                                     flops_model="(3 x conv MACs x 2 of the 16-channel forward - the stem's data gradient, which "
+                                     "is never computed: the network input needs none) x batch = forward + data gradient + weight gradient",
+                                     stem_fraction_of_forward=round(stem_fl / probe.flops_per_image, 4), device_ms_per_step=round(dev_ms, 3))}
     if world > 1:
         out["allreduce"] = _allreduce_rows(torch, timer, world, rank, local_rank, B, per, steps)
     # BASELINE.json configs[4]: the same step fed by the TAF encode of its batch (B GEN1-shaped streams of 8 x 125 000
@@ -794,6 +836,21 @@ def bench_train(args, torch, world, rank, local_rank, timer):
                                               "launch": "eager", "native_speedup": round(per_t / per_e, 3),
                                               "native_graph_speedup": round(per_t / per, 3)}
         del tr_e, one_e, _xy
+        if precision != "f32":  # the same graph-replayed step with every contraction on the float32 MFMA (exact products)
+            prev = os.environ.get("FRLW_CONV_PRECISION")
+            os.environ["FRLW_CONV_PRECISION"] = "f32"
+            try:
+                per32, dev32, tr32, st32, *_ = _train_variant(torch, timer, world, rank, local_rank, B, False, None, steps, graph=True)
+            finally:
+                if prev is None:
+                    os.environ.pop("FRLW_CONV_PRECISION", None)
+                else:
+                    os.environ["FRLW_CONV_PRECISION"] = prev
+            out["f32_mfma"] = {"value": round(B / per32, 1), "ms_per_step": round(per32 * 1e3, 3), "loss": round(st32["loss"], 4),
+                               "roofline": mfma_roofline(flops / (dev32 * 1e-3) / 1e12, "f32", "k_conv_mfma + k_wgrad_mfma",
+                                                         device_ms_per_step=round(dev32, 3)),
+                               "speedup_of_bf16x3": round(per32 / per, 3)}
+            del tr32
     del tr, one, x, lab
     torch.cuda.empty_cache()
     # ---- the reference's semantics: GLOBAL batch 64 (settings.py:41: 64 / nodes per GPU) -> strong scaling over N
@@ -808,8 +865,7 @@ def bench_train(args, torch, world, rank, local_rank, timer):
             del tr_g
             g64 = {"value": round(G / per_g, 1), "ms_per_step": round(per_g * 1e3, 3), "device_ms_per_step": round(dev_g, 3)}
             tf = flops_img * b / (dev_g * 1e-3) / 1e12
-            g64["roofline"] = {"bound": "mfma", "achieved": round(tf, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4)}
+            g64["roofline"] = mfma_roofline(tf, precision, "k_conv_mfma + k_wgrad_mfma")
             if world > 1:
                 g64["allreduce"] = _allreduce_rows(torch, timer, world, rank, local_rank, b, per_g, steps)
         out["global64"] = dict({"workload": f"global batch {G} over {world} GPU(s) = {b} per GPU (settings.py:41), DDP "

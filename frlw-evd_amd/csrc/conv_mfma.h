@@ -832,7 +832,7 @@ inline bool launch_conv(ConvArgs &c, float *scratch, long long scratch_floats, h
         launch_conv_tile_p1<128, 256, 2, 4>(c, dim3((c.M + 127) / 128, (c.Npad + 255) / 256), s);
     } else if (c.Npad <= 32) { // small N (prediction convs, the stem's data gradient)
         launch_conv_tile<128, 32, 4, 1, 16>(c, dim3((c.M + 127) / 128, 1), s);
-    } else if (c.prec == 1 && c.Npad >= 128 && big >= row4_min) {
+    } else if (c.prec == 1 && c.Npad >= 128 && big >= row4_min && c.K >= 512) {
         // bf16 k-steps: the four wavefronts side by side in M, each 32 rows x 128 columns -- a wavefront splits its gathered
         // values (24 VALU instructions per k-step) once for FOUR column tiles; with 2 x 2 the split cost as much issue time as the MFMAs
         launch_conv_tile_p1<128, 128, 4, 1>(c, dim3((c.M + 127) / 128, (c.Npad + 127) / 128), s);
@@ -842,7 +842,11 @@ inline bool launch_conv(ConvArgs &c, float *scratch, long long scratch_floats, h
         // 64 x 128: half the im2col gathers per output of the 64 x 64 tile, still > 4 workgroups per CU
         launch_conv_tile<64, 128, 2, 2, 16>(c, dim3((c.M + 63) / 64, (c.Npad + 127) / 128), s);
     } else {
-        const long long wgs = (long long)((c.M + 63) / 64) * ((c.Npad + 63) / 64);
+        static const long long w2 = dev_knob("FRLW_CONV_W2", 0ll); // bf16 k-steps, two wavefronts of 32 x 64 (bit 0) / 32 x 128 (bit 1) per workgroup
+        static const long long ring4 = dev_knob("FRLW_CONV_RING4", 0ll), ring3 = dev_knob("FRLW_CONV_RING3", 0ll);
+        const bool w2n128 = c.prec == 1 && (w2 & 2) && c.Npad >= 128, w2n64 = c.prec == 1 && (w2 & 1) && !w2n128;
+        const int bn = w2n128 ? 128 : 64;
+        const long long wgs = (long long)((c.M + 63) / 64) * ((c.Npad + bn - 1) / bn);
         const int nk = (c.K + kSplitBK - 1) / kSplitBK;
         // small feature maps leave most CUs idle: split the contraction over blockIdx.z
         if (wgs < split_below && nk >= 64 && scratch) { // (contractions shorter than 1024 gained nothing from splitting: measured)
@@ -862,7 +866,11 @@ inline bool launch_conv(ConvArgs &c, float *scratch, long long scratch_floats, h
             return true;
         }
 #endif
-        launch_conv_tile<64, 64, 2, 2, CONV_BK_SMALL>(c, dim3((c.M + 63) / 64, (c.Npad + 63) / 64, c.splits), s);
+        if (w2n128) launch_conv_tile_p1<64, 128, 2, 1>(c, dim3((c.M + 63) / 64, (c.Npad + 127) / 128, c.splits), s);
+        else if (w2n64) launch_conv_tile_p1<64, 64, 2, 1>(c, dim3((c.M + 63) / 64, (c.Npad + 63) / 64, c.splits), s);
+        else if (c.prec == 1 && ring4) launch_conv_tile<64, 64, 2, 2, CONV_BK_SMALL, 4>(c, dim3((c.M + 63) / 64, (c.Npad + 63) / 64, c.splits), s);
+        else if (c.prec == 1 && ring3) launch_conv_tile<64, 64, 2, 2, CONV_BK_SMALL, 3>(c, dim3((c.M + 63) / 64, (c.Npad + 63) / 64, c.splits), s);
+        else launch_conv_tile<64, 64, 2, 2, CONV_BK_SMALL>(c, dim3((c.M + 63) / 64, (c.Npad + 63) / 64, c.splits), s);
         if (c.splits > 1) {
             const bool vec = ((c.Cout | c.Npad | c.y_cs | c.y_co | c.r_cs | c.r_co | c.y_rp) & 3) == 0 && (c.y_bs & 3) == 0 && (c.r_bs & 3) == 0;
             if (vec) hipLaunchKernelGGL(k_splitk_reduce<true>, dim3(conv_grid_1d((long long)c.M * c.Cout / 4)), dim3(256), 0, s, c);

@@ -63,6 +63,25 @@ def test_batch_workspace_queries_are_host_only():
     assert lib.frlw_taf_batch_workspace_bytes(1_000, 1, 4000, 4000, 10_000) == 0       # more tiles than the scatter's LDS holds
 
 
+def test_operand_size_queries_and_precision_arguments_are_host_only():
+    """Sizes of the GEMM operands in both arithmetics (float32: K rows; split bf16 image: ceil16(K) rows -- the same bytes per
+    row) and argument checks of the precision switches, without a GPU."""
+    lib = _lib.load()
+    assert lib.frlw_conv_operand_floats(360, 32, 0) == 360 * 32
+    assert lib.frlw_conv_operand_floats(360, 32, 1) == 368 * 32
+    assert lib.frlw_conv_operand_floats(2304, 200, 1) == 2304 * 224
+    assert lib.frlw_conv_split_operand_bytes(360, 32) == 368 * 32 * 4
+    assert lib.frlw_baseconv_weight_cache_floats(64, 128, 3, 0) == 9 * 64 * 128 + 9 * 128 * 64
+    assert lib.frlw_baseconv_weight_cache_floats(40, 32, 3, 1) == 368 * 32 + 288 * 64
+    assert lib.frlw_det_set_precision(None, 1) == _lib.FRLW_ERR_ARG
+    d = lib.frlw_det_create()
+    try:
+        assert lib.frlw_det_set_precision(d, 1) == 0 and lib.frlw_det_set_precision(d, 0) == 0
+        assert lib.frlw_det_set_precision(d, 2) == _lib.FRLW_ERR_ARG
+    finally:
+        lib.frlw_det_destroy(d)
+
+
 def test_product_path_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "frlw-evd_amd")
     for dirpath, _, files in os.walk(pkg):

@@ -35,14 +35,20 @@ def rel_err(got, want):
     return float((got - want).abs().max() / want.abs().max())
 
 
+@pytest.mark.parametrize("precision", ["bf16x3", "f32"])
 @pytest.mark.parametrize("tag,C", [("ev10", 10), ("taf16", 16)])
-def test_raw_outputs_vs_golden_and_torch(gpu, golden_dir, tag, C):
+def test_raw_outputs_vs_golden_and_torch(gpu, golden_dir, tag, C, precision):
+    """Both arithmetics of the convolutions (frlw_det_set_precision): float32 products from three bf16 MFMAs (the default)
+    and the float32 MFMA, against the reference-generated head tensor."""
+    from frlw_evd_amd.detector import DetectorEngine, default_precision
+    assert default_precision() == "bf16x3"
     g = np.load(os.path.join(golden_dir, "detector.npz"))
     m = build_yolox(C, 2)
     m.load_state_dict(recipe_state_dict(m, seed=1004))
     m.eval()
     x = detector_input(1004, 2, C)
-    eng = m.engine()
+    eng = DetectorEngine(m, precision=precision)
+    assert eng.precision == precision
     raw = eng.raw_outputs(x[..., 0].to(gpu)).cpu()
     want = torch.from_numpy(g[f"{tag}_raw"])
     assert rel_err(raw, want) <= TOL, rel_err(raw, want)
@@ -51,6 +57,44 @@ def test_raw_outputs_vs_golden_and_torch(gpu, golden_dir, tag, C):
     with torch.no_grad():
         ref = m.reference_outputs(x[..., 0])
     assert rel_err(raw, ref) <= TOL
+    assert rel_err(raw, want) <= (2e-5 if precision == "f32" else 1e-4)  # observed
+
+
+def test_split_operand_image(gpu):
+    """frlw_conv_split_operand: the bf16 hi / lo image of a [K][Npad] float32 operand, bit for bit against a host statement of
+    the layout in include/frlw_evd.h (records [k-tile of 16][lane half h][hi | lo][column] of eight bf16; hi = bf16(x) round
+    to nearest even, lo = bf16(x - hi); rows past K are zero)."""
+    from frlw_evd_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(7)
+    for K, npad in ((40, 32), (576, 64), (23, 96)):
+        w = (rng.standard_normal((K, npad)) * rng.choice([1e-3, 1.0, 300.0], size=(K, npad))).astype(np.float32)
+        w[0, 0], w[1, 1] = 0.0, -0.0
+        wd = torch.from_numpy(w).to(gpu)
+        nbytes = lib.frlw_conv_split_operand_bytes(K, npad)
+        assert nbytes == (K + 15) // 16 * 16 * npad * 4
+        out = torch.empty(nbytes, dtype=torch.uint8, device=gpu)
+        _lib.check(lib.frlw_conv_split_operand(wd.data_ptr(), K, npad, out.data_ptr(), torch.cuda.current_stream().cuda_stream), "split")
+        got = out.cpu().numpy().view(np.uint16).reshape(-1, 2, 2, npad, 8)  # [kt][h][part][n][j]
+
+        def bf16(x):  # round to nearest even on the float32 bits
+            u = x.astype(np.float32).view(np.uint32).astype(np.uint64)
+            return (((u + 0x7FFF + ((u >> 16) & 1)) >> 16) & 0xFFFF).astype(np.uint16)
+
+        def widen(b):
+            return (b.astype(np.uint32) << 16).view(np.float32)
+
+        kt_n = (K + 15) // 16
+        wp = np.zeros((kt_n * 16, npad), np.float32)
+        wp[:K] = w
+        hi = bf16(wp)
+        lo = bf16(wp - widen(hi))
+        for h in range(2):
+            for j in range(8):
+                kmem = 4 * h + j if j < 4 else 8 + 4 * h + (j - 4)
+                rows = np.arange(kt_n) * 16 + kmem
+                assert np.array_equal(got[:, h, 0, :, j], hi[rows]), (K, npad, h, j, "hi")
+                assert np.array_equal(got[:, h, 1, :, j], lo[rows]), (K, npad, h, j, "lo")
 
 
 def test_batch_32_vs_torch_gpu(gpu):

@@ -1,6 +1,7 @@
 """Training-mode BaseConv kernels (csrc/train_ops.hip) against torch autograd of the same module in FLOAT64:
 forward, input gradient, weight / gamma / beta gradients, running statistics.  Tolerance L3 (1e-3, SURVEY.md
-section 8c); the kernels are exact-f32 MFMA with float64 statistics, observed ~1e-6.
+section 8c); both arithmetics of the contractions -- float32 MFMA (exact products) and float32 products from three bf16
+MFMAs (FRLW_CONV_PRECISION, the default) -- with float64 statistics, observed ~1e-6 / ~1e-5.
 
 The judge is float64 because MIOpen's float32 BatchNorm backward is itself off by 7-12 % in dgamma / dbeta when
 H * W is odd (measured against float64, tools/fuzz_train_ops.py) -- not a regime of the detector (H, W are multiples of
@@ -27,12 +28,18 @@ def rel(a, b):
     (4, 16, 9, 7, 20, 3, 1),
     (2, 24, 15, 13, 28, 3, 2),     # stride 2 on odd sizes: transposed-gather data gradient instead of parity classes
     (1, 292, 21, 53, 128, 1, 1),   # H * W odd: the shape where float32 MIOpen BatchNorm backward is wrong
+    (2, 32, 16, 20, 24, 3, 2),     # parity-grouped data gradient with Cout % 16 != 0: this layer keeps the float32 MFMA
 ])
-def test_base_conv_train_vs_torch(B, Cin, H, W, Cout, k, stride):
+@pytest.mark.parametrize("precision", ["bf16x3", "f32"])
+def test_base_conv_train_vs_torch(B, Cin, H, W, Cout, k, stride, precision, monkeypatch):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from frlw_evd_amd.yolox.network_blocks import BaseConv
     from frlw_evd_amd.yolox import train_ops
+    monkeypatch.setenv("FRLW_CONV_PRECISION", precision)
+    assert train_ops.conv_precision() == train_ops.PRECISIONS[precision]
+    if (B, Cout, stride) == (2, 24, 2):
+        assert train_ops.layer_precision(Cout, k, stride) == 0
     torch.manual_seed(B * 1000 + Cin)
     mine = BaseConv(Cin, Cout, k, stride, act="silu").cuda().train()
     with torch.no_grad():
@@ -56,7 +63,7 @@ def test_base_conv_train_vs_torch(B, Cin, H, W, Cout, k, stride):
             rel(d(mine.bn.running_mean), ref.bn.running_mean), rel(d(mine.bn.running_var), ref.bn.running_var)]
     assert max(errs) <= TOL, errs
     assert int(mine.bn.num_batches_tracked) == 1
-    assert max(errs) <= 2e-5, errs  # observed accuracy (exact-f32 contraction, float64 statistics)
+    assert max(errs) <= (2e-5 if precision == "f32" else 5e-5), errs  # observed accuracy (float64 statistics)
 
 
 @pytest.mark.parametrize("B,C,H,W,nc", [(2, 256, 8, 10, 2), (3, 128, 16, 20, 7), (1, 64, 5, 7, 1), (2, 512, 4, 5, 11), (64, 256, 8, 10, 2)])
