@@ -292,6 +292,73 @@ __global__ __launch_bounds__(64 * WROWS * WCOLS) void k_conv_mfma(ConvArgs a)
     const uint32_t b_lds = lds0 + (uint32_t)(NA * BK * BM + 4 * fh * LDB + fn) * 4;
     const uint32_t b3_lds = lds0 + (uint32_t)(NA * BK * BM) * 4 + (uint32_t)(2 * fh * BN + fn) * 16; // prec 1: record (h, hi, column fn)
     int buf = 0, bufb = 0; // ring slots of tile kt: A (kt % NA), B (kt % NB)
+    if constexpr (P == 1 && BK == 16 && TM * TN == 1) { // (wider wavefront tiles lose a wavefront per SIMD to the second register set: measured slower)
+        // bf16 k-steps, software-pipelined: with the matrix work of a k-tile down to TM * TN * 3 MFMAs of 32 cycles, a wavefront's
+        // chain "fragment reads -> wait -> split -> MFMAs -> barrier" is what a thin layer's workgroup spends its time on (one
+        // or two workgroups per CU, nobody to hide it).  The fragments of tile t + 1 are therefore requested right after the
+        // barrier that publishes it, BEFORE the MFMAs of tile t are issued: the LDS latency and the MFMA chain overlap.  Two
+        // register sets for the fragments, the loop unrolled by two.
+        f32x4 fa[2][2][TM];
+        u32x4 bh[2][TN], bl[2][TN];
+        auto read_frags = [&fa, &bh, &bl, &a_lds, b3_lds](auto pc, int slot_a, int slot_b) {
+            constexpr int p = decltype(pc)::value;
+            const uint32_t a_slot = (uint32_t)slot_a * (BM * BK * 4), b_addr = b3_lds + (uint32_t)slot_b * (BK * LDB * 4);
+            asm volatile("ds_read_b128 %0, %1" : "=v"(fa[p][0][0]) : "v"(a_lds[0] + a_slot));
+            asm volatile("ds_read_b128 %0, %1" : "=v"(fa[p][1][0]) : "v"(a_lds[1] + a_slot));
+            if constexpr (TM > 1) {
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[p][0][TM - 1]) : "v"(a_lds[0] + a_slot), "n"(32 * BK * 4));
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[p][1][TM - 1]) : "v"(a_lds[1] + a_slot), "n"(32 * BK * 4));
+            }
+            asm volatile("ds_read_b128 %0, %1" : "=v"(bh[p][0]) : "v"(b_addr));
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bl[p][0]) : "v"(b_addr), "n"(BN * 16));
+            if constexpr (TN > 1) {
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bh[p][1]) : "v"(b_addr), "n"(512));
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bl[p][1]) : "v"(b_addr), "n"(BN * 16 + 512));
+            }
+            if constexpr (TN > 2) {
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bh[p][2]) : "v"(b_addr), "n"(1024));
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bl[p][2]) : "v"(b_addr), "n"(BN * 16 + 1024));
+            }
+            if constexpr (TN > 3) {
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bh[p][3]) : "v"(b_addr), "n"(1536));
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bl[p][3]) : "v"(b_addr), "n"(BN * 16 + 1536));
+            }
+        };
+        auto iteration = [&](auto pc, int kt) {
+            constexpr int p = decltype(pc)::value;
+            if (kt + D - 1 < nk) load_b(bufb == 0 ? NB - 1 : bufb - 1);
+            if (kt + D < nk) load_a(kt0 + kt + D, buf == 0 ? NA - 1 : buf - 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the fragments of tile kt (set p) are in registers
+#pragma unroll
+            for (int i = 0; i < TM; ++i) { asm volatile("" : "+v"(fa[p][0][i])); asm volatile("" : "+v"(fa[p][1][i])); }
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn) { asm volatile("" : "+v"(bh[p][jn])); asm volatile("" : "+v"(bl[p][jn])); }
+            u32x4 ah[TM], al[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) conv_split8(fa[p][0][i], fa[p][1][i], ah[i], al[i]);
+            wait_next_tile(kt + D < nk);            // tile kt + 1 has landed (this wavefront's pieces) ...
+            __builtin_amdgcn_s_barrier();           // ... everybody's have, and everybody has tile kt in registers
+            buf = buf == NA - 1 ? 0 : buf + 1;
+            bufb = bufb == NB - 1 ? 0 : bufb + 1;
+            if (kt + 1 < nk) read_frags(ConvIC<1 - p>{}, buf, bufb);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int jn = 0; jn < TN; ++jn) { // the small terms first
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[i]), __builtin_bit_cast(bf16x8, bh[p][jn]), acc[i][jn], 0, 0, 0);
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bl[p][jn]), acc[i][jn], 0, 0, 0);
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bh[p][jn]), acc[i][jn], 0, 0, 0);
+                }
+        };
+        if (nk > 0) read_frags(ConvIC<0>{}, 0, 0);
+        int kt = 0;
+        for (; kt + 1 < nk; kt += 2) {
+            iteration(ConvIC<0>{}, kt);
+            iteration(ConvIC<1>{}, kt + 1);
+        }
+        if (kt < nk) iteration(ConvIC<0>{}, kt);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    } else
     for (int kt = 0; kt < nk; ++kt) {
         if (kt + D - 1 < nk) load_b(bufb == 0 ? NB - 1 : bufb - 1);          // (kt + D - 1) % NB: read last in iteration kt - 1
         if (kt + D < nk) load_a(kt0 + kt + D, buf == 0 ? NA - 1 : buf - 1);  // (kt + D) % NA: likewise
@@ -826,11 +893,15 @@ inline bool launch_conv(ConvArgs &c, float *scratch, long long scratch_floats, h
     static const long long wide_min = dev_knob("FRLW_CONV_WIDE_MIN", 1200ll);
     static const long long t256_min = dev_knob("FRLW_CONV_T256_MIN", 100000ll);
     static const long long row4_min = dev_knob("FRLW_CONV_ROW4_MIN", 600ll);
+    (void)t256_min;
+#ifdef FRLW_DEV_BUILD
     if (c.prec == 1 && c.Npad >= 256 && (long long)((c.M + 127) / 128) * ((c.Npad + 255) / 256) >= t256_min) {
-        // 128 x 256 on eight wavefronts: with the matrix work 5 x shorter these layers are bound by the L2's request rate --
-        // half the weight reads of the 64-row tile and half the gathered reads of the 128-column one
+        // lab: 128 x 256 on eight wavefronts (half the L2 requests per FLOP of the 128 x 128 tile): 264 us against 204 on the
+        // 40960 x 256 x 2304 layer -- the requests were not the limit, the issue slots of the SIMDs were
         launch_conv_tile_p1<128, 256, 2, 4>(c, dim3((c.M + 127) / 128, (c.Npad + 255) / 256), s);
-    } else if (c.Npad <= 32) { // small N (prediction convs, the stem's data gradient)
+    } else
+#endif
+    if (c.Npad <= 32) { // small N (prediction convs, the stem's data gradient)
         launch_conv_tile<128, 32, 4, 1, 16>(c, dim3((c.M + 127) / 128, 1), s);
     } else if (c.prec == 1 && c.Npad >= 128 && big >= row4_min && c.K >= 512) {
         // bf16 k-steps: the four wavefronts side by side in M, each 32 rows x 128 columns -- a wavefront splits its gathered
@@ -845,6 +916,7 @@ inline bool launch_conv(ConvArgs &c, float *scratch, long long scratch_floats, h
         static const long long w2 = dev_knob("FRLW_CONV_W2", 0ll); // bf16 k-steps, two wavefronts of 32 x 64 (bit 0) / 32 x 128 (bit 1) per workgroup
         static const long long ring4 = dev_knob("FRLW_CONV_RING4", 0ll), ring3 = dev_knob("FRLW_CONV_RING3", 0ll);
         const bool w2n128 = c.prec == 1 && (w2 & 2) && c.Npad >= 128, w2n64 = c.prec == 1 && (w2 & 1) && !w2n128;
+        (void)ring4; (void)ring3; (void)w2n64;
         const int bn = w2n128 ? 128 : 64;
         const long long wgs = (long long)((c.M + 63) / 64) * ((c.Npad + bn - 1) / bn);
         const int nk = (c.K + kSplitBK - 1) / kSplitBK;
@@ -866,11 +938,14 @@ inline bool launch_conv(ConvArgs &c, float *scratch, long long scratch_floats, h
             return true;
         }
 #endif
+#ifdef FRLW_DEV_BUILD // lab variants, all measured without a net gain: two-wavefront workgroups, deeper rings
         if (w2n128) launch_conv_tile_p1<64, 128, 2, 1>(c, dim3((c.M + 63) / 64, (c.Npad + 127) / 128, c.splits), s);
         else if (w2n64) launch_conv_tile_p1<64, 64, 2, 1>(c, dim3((c.M + 63) / 64, (c.Npad + 63) / 64, c.splits), s);
         else if (c.prec == 1 && ring4) launch_conv_tile<64, 64, 2, 2, CONV_BK_SMALL, 4>(c, dim3((c.M + 63) / 64, (c.Npad + 63) / 64, c.splits), s);
         else if (c.prec == 1 && ring3) launch_conv_tile<64, 64, 2, 2, CONV_BK_SMALL, 3>(c, dim3((c.M + 63) / 64, (c.Npad + 63) / 64, c.splits), s);
-        else launch_conv_tile<64, 64, 2, 2, CONV_BK_SMALL>(c, dim3((c.M + 63) / 64, (c.Npad + 63) / 64, c.splits), s);
+        else
+#endif
+        launch_conv_tile<64, 64, 2, 2, CONV_BK_SMALL>(c, dim3((c.M + 63) / 64, (c.Npad + 63) / 64, c.splits), s);
         if (c.splits > 1) {
             const bool vec = ((c.Cout | c.Npad | c.y_cs | c.y_co | c.r_cs | c.r_co | c.y_rp) & 3) == 0 && (c.y_bs & 3) == 0 && (c.r_bs & 3) == 0;
             if (vec) hipLaunchKernelGGL(k_splitk_reduce<true>, dim3(conv_grid_1d((long long)c.M * c.Cout / 4)), dim3(256), 0, s, c);
