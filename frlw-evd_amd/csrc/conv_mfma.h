@@ -41,6 +41,8 @@ struct ConvArgs {
     int group_n;       // grouped convolution: output columns [g * group_n, (g + 1) * group_n) read input channels x_co + g * Cin ...; 0: one group
     int y_rp;          // output row pitch in floats (0: dense, pixel p at p * y_cs); else pixel (oy, ox) at oy * y_rp + ox * y_cs
     int prec;          // 0: float32 MFMA on the [K][Npad] float32 operand; 1: three bf16 MFMAs per product on the split operand (below)
+    double *stats;     // train forward (act NONE, no bias): per slab of BM output rows and channel {sum, sum of squares} of the
+    int stats_rows;    // outputs -- [stats_rows][Cout][2]; set by launch_conv (0 / NULL: the launch does not produce them)
 };
 
 // ---- float32 products from three bf16 MFMAs (prec = 1) ---------------------------------------------------------------------
@@ -497,6 +499,39 @@ __global__ __launch_bounds__(64 * WROWS * WCOLS) void k_conv_mfma(ConvArgs a)
         // runs with no MFMA left to overlap (all workgroups of a layer finish together): it is store-ISSUE bound.
         float *epw = smem + wv * 32 * EPLD; // the last k-tile's barrier has freed the operand tiles
         const int er = lane >> 3, ec = (lane & 7) * 4; // this lane's rows er, er + 8, er + 16, er + 24; columns ec..ec+3
+        if (a.stats) { // (workgroup-uniform)
+            // BatchNorm statistics of the train step straight from the accumulators: the column sums of the workgroup's BM rows
+            // (rows past M are zero) -- float32 inside a wavefront's 32 * TM rows, float64 across the wavefronts and in the
+            // stored slab -- so the separate pass over z (k_bn_stats_partial) goes away
+            float2 *stg = (float2 *)smem; // [wavefront][TN * 32 columns]: the operand tiles are free after the last barrier
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                float cs = 0.0f, cq = 0.0f;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { cs += acc[i][j][r]; cq += acc[i][j][r] * acc[i][j][r]; }
+                cs += __shfl_xor(cs, 32);
+                cq += __shfl_xor(cq, 32);
+                if (lane < 32) stg[(wv * TN + j) * 32 + lane] = make_float2(cs, cq);
+            }
+            __syncthreads();
+            if (wr == 0 && lane < 32) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    double ds = 0.0, dq = 0.0;
+#pragma unroll
+                    for (int w = 0; w < WROWS; ++w) { // wavefront (w, wc) = w * WCOLS + wc
+                        const float2 v = stg[((w * WCOLS + wc) * TN + j) * 32 + lane];
+                        ds += (double)v.x;
+                        dq += (double)v.y;
+                    }
+                    const int n = n0 + wc * TN * 32 + 32 * j + lane;
+                    if (n < a.Cout) *(double2 *)(a.stats + ((long long)blockIdx.x * a.Cout + n) * 2) = make_double2(ds, dq);
+                }
+            }
+            __syncthreads(); // the staging area below overlaps stg
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int tm0 = m0 + wr * TM * 32 + 32 * i;
@@ -871,10 +906,14 @@ inline bool launch_conv(ConvArgs &c, float *scratch, long long scratch_floats, h
     const long long x_bytes = (((long long)(nb - 1) * c.x_bs) + ((long long)c.H * c.W - 1) * c.x_cs + c.x_co + (long long)c.Cin * n_groups) * 4;
     if (x_bytes > kMaxViewBytes && nb > 1 && c.M == nb * howo) { // 32-bit buffer offsets: run the batch in two halves
         ConvArgs h = c;
+        h.stats = nullptr; // (two launches would write the same slabs: the caller runs its own statistics pass)
+        c.stats = nullptr;
+        c.stats_rows = 0;
         const int b0 = nb / 2;
         h.M = b0 * howo;
         if (!launch_conv(h, scratch, scratch_floats, s)) return false;
         h = c;
+        h.stats = nullptr;
         h.M = (nb - b0) * howo;
         h.x = c.x + (long long)b0 * c.x_bs;
         h.y = c.y + (long long)b0 * c.y_bs;
@@ -886,6 +925,11 @@ inline bool launch_conv(ConvArgs &c, float *scratch, long long scratch_floats, h
     c.w_bytes = (uint32_t)((long long)(c.prec == 1 ? (c.K + 15) / 16 * 16 : c.K) * c.Npad * 4);
     c.splits = 1;
     c.partial = nullptr;
+    double *const stats_req = c.stats; // wanted by the caller; granted per tile below (never with split-K or the scalar epilogue)
+    c.stats = nullptr;
+    c.stats_rows = 0;
+    const bool stats_ok = stats_req && ((c.Cout | c.y_cs | c.y_co | c.r_cs | c.r_co) & 3) == 0 && (c.y_bs & 3) == 0 && (c.r_bs & 3) == 0 && c.y_rp == 0;
+    auto grant_stats = [&](int bm) { if (stats_ok && c.splits == 1) { c.stats = stats_req; c.stats_rows = (c.M + bm - 1) / bm; } };
     const long long big = (long long)((c.M + 127) / 128) * ((c.Npad + 127) / 128);
     static const long long split_below = dev_knob("FRLW_CONV_SPLIT_BELOW", 700ll);
     static const long long split_target = dev_knob("FRLW_CONV_SPLIT_TARGET", 1280ll);
@@ -902,15 +946,19 @@ inline bool launch_conv(ConvArgs &c, float *scratch, long long scratch_floats, h
     } else
 #endif
     if (c.Npad <= 32) { // small N (prediction convs, the stem's data gradient)
+        grant_stats(128);
         launch_conv_tile<128, 32, 4, 1, 16>(c, dim3((c.M + 127) / 128, 1), s);
     } else if (c.prec == 1 && c.Npad >= 128 && big >= row4_min && c.K >= 512) {
         // bf16 k-steps: the four wavefronts side by side in M, each 32 rows x 128 columns -- a wavefront splits its gathered
         // values (24 VALU instructions per k-step) once for FOUR column tiles; with 2 x 2 the split cost as much issue time as the MFMAs
+        grant_stats(128);
         launch_conv_tile_p1<128, 128, 4, 1>(c, dim3((c.M + 127) / 128, (c.Npad + 127) / 128), s);
     } else if (big >= big_min && c.Npad >= 128) {
+        grant_stats(128);
         launch_conv_tile<128, 128, 2, 2, CONV_BK_BIG>(c, dim3((c.M + 127) / 128, (c.Npad + 127) / 128), s);
     } else if (c.Npad >= 128 && (long long)((c.M + 63) / 64) * ((c.Npad + 127) / 128) >= wide_min) {
         // 64 x 128: half the im2col gathers per output of the 64 x 64 tile, still > 4 workgroups per CU
+        grant_stats(64);
         launch_conv_tile<64, 128, 2, 2, 16>(c, dim3((c.M + 63) / 64, (c.Npad + 127) / 128), s);
     } else {
         static const long long w2 = dev_knob("FRLW_CONV_W2", 0ll); // bf16 k-steps, two wavefronts of 32 x 64 (bit 0) / 32 x 128 (bit 1) per workgroup
@@ -932,12 +980,13 @@ inline bool launch_conv(ConvArgs &c, float *scratch, long long scratch_floats, h
 #ifdef FRLW_DEV_BUILD
         static const long long thin16 = dev_knob("FRLW_CONV_THIN16", 0ll); // lab: 1 = the 64 x 32 / 16x16x4 variant, no split-K
         if (thin16 && c.group_n == 0) {
-            c.splits = 1; c.partial = nullptr;
+            c.splits = 1; c.partial = nullptr; c.stats = nullptr; c.stats_rows = 0;
             if (c.Cin % 16 == 0) hipLaunchKernelGGL((k_conv_mfma16<true>), dim3((c.M + 63) / 64, (c.Npad + 31) / 32, 1), dim3(256), 0, s, c);
             else hipLaunchKernelGGL((k_conv_mfma16<false>), dim3((c.M + 63) / 64, (c.Npad + 31) / 32, 1), dim3(256), 0, s, c);
             return true;
         }
 #endif
+        grant_stats(64);
 #ifdef FRLW_DEV_BUILD // lab variants, all measured without a net gain: two-wavefront workgroups, deeper rings
         if (w2n128) launch_conv_tile_p1<64, 128, 2, 1>(c, dim3((c.M + 63) / 64, (c.Npad + 127) / 128, c.splits), s);
         else if (w2n64) launch_conv_tile_p1<64, 64, 2, 1>(c, dim3((c.M + 63) / 64, (c.Npad + 63) / 64, c.splits), s);

@@ -480,7 +480,8 @@ int frlw_conv_weight_layouts_batch(const frlw_weight_layout_item_t *items, int n
 }
 
 static int conv_common(const float *x, int B, int H, int W, int Cin, const float *w_gemm, int Cout, int k, int stride,
-                       int tstride, int Ho, int Wo, float *y, float *scratch, int64_t scratch_floats, int precision, hipStream_t s)
+                       int tstride, int Ho, int Wo, float *y, float *scratch, int64_t scratch_floats, int precision, hipStream_t s,
+                       double *stats = nullptr, int *stats_rows = nullptr)
 {
     if (precision != 0 && precision != 1) return FRLW_ERR_ARG;
     (void)hipGetLastError(); // other libraries in the process (torch's BLAS look-ups) leave stale errors behind
@@ -493,7 +494,9 @@ static int conv_common(const float *x, int B, int H, int W, int Cin, const float
     c.M = B * Ho * Wo; c.K = k * k * Cin;
     c.tstride = tstride;
     c.prec = precision;
+    c.stats = stats;
     if (!launch_conv(c, scratch, scratch ? scratch_floats : 0, s)) return FRLW_ERR_UNSUPPORTED;
+    if (stats_rows) *stats_rows = c.stats ? c.stats_rows : 0;
     if (hipGetLastError() != hipSuccess) return FRLW_ERR_HIP;
     return FRLW_OK;
 }
@@ -602,12 +605,14 @@ int frlw_conv2d_wgrad(const float *x, int B, int H, int W, int Cin, const float 
 int64_t frlw_bn_scratch_doubles(int64_t M, int C)
 {
     const int rows = bn_rows_per_wg(M);
-    return ((M + rows - 1) / rows) * (int64_t)C * 2;
+    const int64_t pass = ((M + rows - 1) / rows) * (int64_t)C * 2;
+    const int64_t fused = ((M + 63) / 64) * (int64_t)C * 2; // the convolution epilogue's slabs of >= 64 rows (conv_mfma.h: ConvArgs::stats)
+    return pass > fused ? pass : fused;
 }
 
 static int bn_stats_impl(const float *z, int64_t M, int C, float eps, float *mean, float *var, float *invstd,
                          double *scratch, float *run_mean, float *run_var, float momentum, long long *batches_tracked,
-                         frlw_stream_t stream);
+                         frlw_stream_t stream, int have_partials = 0);
 
 int frlw_bn_stats(const float *z, int64_t M, int C, float eps, float *mean, float *var, float *invstd, double *scratch,
                   frlw_stream_t stream)
@@ -617,13 +622,14 @@ int frlw_bn_stats(const float *z, int64_t M, int C, float eps, float *mean, floa
 
 static int bn_stats_impl(const float *z, int64_t M, int C, float eps, float *mean, float *var, float *invstd,
                          double *scratch, float *run_mean, float *run_var, float momentum, long long *batches_tracked,
-                         frlw_stream_t stream)
+                         frlw_stream_t stream, int have_partials)
 {
     (void)hipGetLastError(); // other libraries in the process (torch's BLAS look-ups) leave stale errors behind
     if (!z || !mean || !var || !invstd || !scratch || M < 1 || C < 4 || (C & 3)) return FRLW_ERR_ARG;
-    const int n_wg = (int)((M + bn_rows_per_wg(M) - 1) / bn_rows_per_wg(M));
+    int n_wg = (int)((M + bn_rows_per_wg(M) - 1) / bn_rows_per_wg(M));
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_bn_stats_partial, dim3(n_wg), dim3(256), 0, s, z, (long long)M, C, scratch);
+    if (have_partials > 0) n_wg = have_partials; // the convolution's epilogue has written `have_partials` slabs into scratch
+    else hipLaunchKernelGGL(k_bn_stats_partial, dim3(n_wg), dim3(256), 0, s, z, (long long)M, C, scratch);
     hipLaunchKernelGGL(k_bn_stats_final, dim3((C + kFinCh - 1) / kFinCh), dim3(256), 0, s, scratch, n_wg, C, (long long)M, eps, mean,
                        var, invstd, run_mean, run_var, momentum, batches_tracked);
     TRY_HIP(hipGetLastError());
@@ -724,9 +730,12 @@ int frlw_baseconv_train_fwd(const float *x, const float *w, const float *gamma, 
         if ((rc = frlw_conv_weight_layouts(w, Cout, Cin, k, frlw_conv2d_dgrad_parity(k, stride, H, W), w_cache, w_dg, precision, stream)) != FRLW_OK) return rc;
         w_fwd = w_cache;
     } else if ((rc = frlw_conv_weight_layouts(w, Cout, Cin, k, 0, t.w_fwd, nullptr, precision, stream)) != FRLW_OK) return rc;
-    if ((rc = frlw_conv2d_fwd(x, B, H, W, Cin, w_fwd, Cout, k, stride, z, t.splitk, t.splitk_floats, precision, stream)) != FRLW_OK) return rc;
+    if (stride != 1 && stride != 2) return FRLW_ERR_UNSUPPORTED;
+    int stat_rows = 0; // > 0: the convolution's epilogue left the column sums of its output slabs in t.red
+    if ((rc = conv_common(x, B, H, W, Cin, w_fwd, Cout, k, stride, 0, Ho, Wo, z, t.splitk, t.splitk_floats, precision, (hipStream_t)stream,
+                          t.red, &stat_rows)) != FRLW_OK) return rc;
     if ((rc = bn_stats_impl(z, M, Cout, eps, mean, var, invstd, t.red, running_mean, running_mean ? running_var : nullptr,
-                            momentum, (long long *)num_batches_tracked, stream)) != FRLW_OK) return rc;
+                            momentum, (long long *)num_batches_tracked, stream, stat_rows)) != FRLW_OK) return rc;
     return frlw_bn_silu_fwd(z, M, Cout, gamma, beta, mean, invstd, y, stream);
 }
 

@@ -57,6 +57,7 @@ int main(int argc, char **argv)
         a.dz = dz; a.Ho = Ho; a.Wo = Wo; a.Cout = sh.Cout; a.dz_bs = (long long)Ho * Wo * sh.Cout; a.dz_cs = sh.Cout;
         a.k = sh.k; a.stride = sh.s; a.pad = (sh.k - 1) / 2; a.R = sh.k * sh.k * sh.Cin; a.M = B * Ho * Wo;
         a.partial = scratch;
+        a.prec = (int)dev_knob("FRLW_WGRAD_PREC", 1); // 1: three bf16 MFMAs per product
         const int target = (int)dev_knob("FRLW_WGRAD_TARGET", 1280);
         auto run = [&]() { launch_wgrad(a, target, scratch_floats, st); };
         for (int i = 0; i < 2; ++i) run();
