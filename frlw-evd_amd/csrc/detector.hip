@@ -91,17 +91,31 @@ struct FocusStemArgs {
     const float *w, *bias;               // (9 * 4 C0, 32) rows (tap * 4 C0 + q * C0 + c), q = py + 2 px as in k_focus; bias (Cout)
     float *y; int Cout, y_cs, y_co;      // NHWC view of the output, Ho = H / 2, Wo = W / 2
     int tiles_x, tiles_y, n_tiles;
+    int prec;                            // 1: w is the split bf16 image of the operand (conv_mfma.h), three bf16 MFMAs per product
 };
 
-template <int C0>
+// floats of LDS in front of the patch: the weight operand (P = 1: its split image, ceil16(K) rows, + the quad offset table)
+template <int C0, int P> constexpr int focus_stem_w_floats()
+{
+    return P == 1 ? (9 * 4 * C0 + 15) / 16 * 16 * 32 + (9 * C0 + 7) / 4 * 4 : 9 * 4 * C0 * 32;
+}
+
+template <int C0, int P = 0>
 __global__ __launch_bounds__(256) void k_focus_stem(FocusStemArgs a)
 {
     constexpr int CF = 4 * C0, PS = CF + 4, TH = 8, TW = 16, PH = TH + 2, PW = TW + 2, KT = 9 * CF;
+    constexpr int QT = CF / 4, NQ = 9 * QT, NS = (NQ + 3) / 4; // P = 1: quads per tap, quads, bf16 k-steps of 16 k = 4 quads
     static_assert(C0 % 2 == 0, "quads are paired");
     extern __shared__ __attribute__((aligned(16))) float fs_lds[];
-    float *Ws = fs_lds, *patch = fs_lds + KT * 32;
+    float *Ws = fs_lds, *patch = fs_lds + focus_stem_w_floats<C0, P>();
+    int *qoff = (int *)(fs_lds + NS * 16 * 32); // P = 1: float offset of quad g inside the patch, relative to the tap-(0, 0) pixel
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    for (int i = tid; i < KT * 8; i += 256) ((float4 *)Ws)[i] = ((const float4 *)a.w)[i];
+    if (P == 1) {
+        for (int i = tid; i < NS * 4 * 32; i += 256) ((uint4 *)Ws)[i] = ((const uint4 *)a.w)[i];
+        for (int g = tid; g < NQ; g += 256) { const int tap = g / QT; qoff[g] = ((tap / 3) * PW + tap % 3) * PS + 4 * (g - tap * QT); }
+    } else {
+        for (int i = tid; i < KT * 8; i += 256) ((float4 *)Ws)[i] = ((const float4 *)a.w)[i];
+    }
     const int Ho = a.H / 2, Wo = a.W / 2;
     const int fh = lane >> 5, m = lane & 31, n = lane & 31;
     const int pp0 = (2 * wv + (m >> 4)) * PW + (m & 15);
@@ -144,6 +158,25 @@ __global__ __launch_bounds__(256) void k_focus_stem(FocusStemArgs a)
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        if constexpr (P == 1) {
+            // k = tap * CF + channel is cut into quads g = k / 4; bf16 k-step st takes quads 4 st + h and 4 st + 2 + h of lane half h
+            // (the pairing of conv_mfma.h: conv_split_kmem), the weights' split image has the matching records
+            const float *pbase = patch + pp0 * PS;
+            const uint4 *wrec = (const uint4 *)Ws + 2 * fh * 32 + n;
+#pragma unroll
+            for (int st = 0; st < NS; ++st) {
+                const f32x4 q0 = *(const f32x4 *)(pbase + qoff[4 * st + fh]);
+                f32x4 q1 = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (4 * st + 2 < NQ) q1 = *(const f32x4 *)(pbase + qoff[4 * st + 2 + fh]); // (compile-time: the tail step of K = 360)
+                const uint4 bh4 = wrec[st * 4 * 32], bl4 = wrec[st * 4 * 32 + 32];
+                const u32x4 bh = {bh4.x, bh4.y, bh4.z, bh4.w}, bl = {bl4.x, bl4.y, bl4.z, bl4.w};
+                u32x4 ah, al;
+                conv_split8(q0, q1, ah, al);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, bh), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bl), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bh), acc, 0, 0, 0);
+            }
+        } else
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const float *prow = patch + (pp0 + (t / 3) * PW + (t % 3)) * PS + fh * 4;
@@ -731,6 +764,7 @@ int frlw_det_add_focus_stem(frlw_detector_t *d, int src_buf, int C, int H, int W
     op.type = OP_FOCUS_STEM; op.src = src_buf; op.dst = dst_buf; op.C = C;
     FocusStemArgs &a = op.fstem;
     a.H = H; a.W = W; a.w = w_dev; a.bias = bias_dev; a.Cout = Cout; a.y_cs = dst_cs; a.y_co = dst_co;
+    a.prec = d->prec; // 1: w_dev is the split image of the (9 * 4 C, 32) operand (frlw_conv_split_operand)
     a.tiles_x = (W / 2 + 15) / 16; a.tiles_y = (H / 2 + 7) / 8;
     op.lane = d->cur_lane;
     d->ops.push_back(op);
@@ -881,16 +915,16 @@ int frlw_det_run(const frlw_detector_t *d, int B, void *const *bufs, int n_bufs,
             if (!a.x || !a.y) return FRLW_ERR_ARG;
             a.n_tiles = B * a.tiles_x * a.tiles_y;
             const int cf = 4 * op.C;
-            const size_t lds = ((size_t)9 * cf * 32 + (size_t)180 * (cf + 4)) * sizeof(float);
+            const int wfl = a.prec == 1 ? (op.C == 10 ? focus_stem_w_floats<10, 1>() : focus_stem_w_floats<16, 1>()) : 9 * cf * 32;
+            const size_t lds = ((size_t)wfl + (size_t)180 * (cf + 4)) * sizeof(float);
             const int per_cu = lds <= 80 * 1024 ? 2 : 1;
             const int grid = a.n_tiles < 256 * per_cu ? a.n_tiles : 256 * per_cu;
-            if (op.C == 10) {
-                (void)hipFuncSetAttribute((const void *)k_focus_stem<10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                hipLaunchKernelGGL(k_focus_stem<10>, dim3(grid), dim3(256), lds, s, a);
-            } else {
-                (void)hipFuncSetAttribute((const void *)k_focus_stem<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                hipLaunchKernelGGL(k_focus_stem<16>, dim3(grid), dim3(256), lds, s, a);
-            }
+            auto go = [&](auto kern) {
+                (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
+            };
+            if (op.C == 10) { if (a.prec == 1) go(k_focus_stem<10, 1>); else go(k_focus_stem<10, 0>); }
+            else { if (a.prec == 1) go(k_focus_stem<16, 1>); else go(k_focus_stem<16, 0>); }
             break;
         }
         case OP_BFM: {

@@ -199,7 +199,7 @@ class DetectorEngine:
                 w, b = fold_bn(sc.conv, sc.bn)
                 wm, npad = gemm_weight(w)
                 if npad == 32:
-                    rc = lib.frlw_det_add_focus_stem(self.handle, x_in, cin, H, W, self._dev(wm), self._dev(b), c, stem.buf,
+                    rc = lib.frlw_det_add_focus_stem(self.handle, x_in, cin, H, W, self._operand(wm), self._dev(b), c, stem.buf,
                                                      stem.cs, stem.co)
                     if rc != _lib.FRLW_ERR_UNSUPPORTED:
                         _lib.check(rc, "focus_stem")
