@@ -1,5 +1,7 @@
-// conv_mfma.h -- the fp32-MFMA implicit-GEMM convolution kernel shared by the detector plan (detector.hip) and the
-// training operators (train_ops.hip).  Included inside each translation unit's anonymous namespace.
+// conv_mfma.h -- the MFMA implicit-GEMM convolution kernel shared by the detector plan (detector.hip) and the training
+// operators (train_ops.hip), in two arithmetics: v_mfma_f32_32x32x2_f32 on float32 operands (P = 0) and float32 products from
+// three v_mfma_f32_32x32x16_bf16 on hi / lo split operands (P = 1, ConvArgs::prec).  Included inside each translation unit's
+// anonymous namespace.
 //
 //   Y[M = B*Ho*Wo][N = Cout] = A[M][K] * W[K][N],  K = (ky, kx, ci),  A gathered on the fly from an NHWC view.
 //   tstride = 2 turns the gather into that of a transposed (stride-2) convolution: input coordinate
@@ -67,8 +69,16 @@ __device__ __forceinline__ void conv_split8(const f32x4 &q0, const f32x4 &q1, u3
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const uint32_t h = conv_bf16_pair(x[2 * e], x[2 * e + 1]);
-        const float r0 = x[2 * e] - __builtin_bit_cast(float, h << 16);
-        const float r1 = x[2 * e + 1] - __builtin_bit_cast(float, h & 0xFFFF0000u);
+        // (two scalar subtractions on purpose: the compiler pairs them into one v_pk_add_f32, which beside MFMAs costs the
+        // issue time of several plain VALU instructions -- MI355X_MICROARCH.md, "packed f32 VALU: an anti-lever")
+        float r0, r1;
+#ifdef CONV_SPLIT_PK
+        r0 = x[2 * e] - __builtin_bit_cast(float, h << 16);
+        r1 = x[2 * e + 1] - __builtin_bit_cast(float, h & 0xFFFF0000u);
+#else
+        asm("v_sub_f32_e32 %0, %1, %2" : "=v"(r0) : "v"(x[2 * e]), "v"(h << 16));
+        asm("v_sub_f32_e32 %0, %1, %2" : "=v"(r1) : "v"(x[2 * e + 1]), "v"(h & 0xFFFF0000u));
+#endif
         hi[e] = h;
         lo[e] = conv_bf16_pair(r0, r1);
     }

@@ -14,8 +14,9 @@
 //   frlw_bn_silu_fwd           y = silu(gamma * (z - mean) * invstd + beta)
 //   frlw_bn_silu_bwd           dz, dgamma, dbeta from dy and z (u recomputed, nothing but z saved)
 //
-// MI355X: every contraction runs on the matrix cores with v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate), like
-// the forward; the elementwise passes are HBM-bound float4 streams over the (M, C) view of the tensor.
+// MI355X: every contraction runs on the matrix cores, like the inference forward, in the arithmetic the caller names
+// (`precision`: 0 = v_mfma_f32_32x32x2_f32, 1 = float32 products from three bf16 MFMAs on split operands: conv_mfma.h);
+// the elementwise passes are HBM-bound float4 streams over the (M, C) view of the tensor.
 
 #include <hip/hip_runtime.h>
 #include <math.h>
