@@ -69,16 +69,9 @@ __device__ __forceinline__ void conv_split8(const f32x4 &q0, const f32x4 &q1, u3
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const uint32_t h = conv_bf16_pair(x[2 * e], x[2 * e + 1]);
-        // (two scalar subtractions on purpose: the compiler pairs them into one v_pk_add_f32, which beside MFMAs costs the
-        // issue time of several plain VALU instructions -- MI355X_MICROARCH.md, "packed f32 VALU: an anti-lever")
-        float r0, r1;
-#ifdef CONV_SPLIT_PK
-        r0 = x[2 * e] - __builtin_bit_cast(float, h << 16);
-        r1 = x[2 * e + 1] - __builtin_bit_cast(float, h & 0xFFFF0000u);
-#else
-        asm("v_sub_f32_e32 %0, %1, %2" : "=v"(r0) : "v"(x[2 * e]), "v"(h << 16));
-        asm("v_sub_f32_e32 %0, %1, %2" : "=v"(r1) : "v"(x[2 * e + 1]), "v"(h & 0xFFFF0000u));
-#endif
+        // (the compiler pairs the two subtractions into one v_pk_add_f32; two v_sub_f32 measured the same)
+        const float r0 = x[2 * e] - __builtin_bit_cast(float, h << 16);
+        const float r1 = x[2 * e + 1] - __builtin_bit_cast(float, h & 0xFFFF0000u);
         hi[e] = h;
         lo[e] = conv_bf16_pair(r0, r1);
     }
