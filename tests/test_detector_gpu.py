@@ -346,6 +346,36 @@ def test_native_loss_equals_autograd_loss(gpu, seed, B, nc):
     assert any(float(g[:, :4].abs().max()) > 0 for g in gwant)  # box gradients are exercised
 
 
+def test_native_loss_without_any_label(gpu):
+    """A batch with no box at all (yolo_head.py:349-368: every image takes the empty branch, num_fg is clamped to 1): only the
+    objectness term is left; value and gradient equal the torch form, and nothing is NaN."""
+    from frlw_evd_amd.yolox import losses
+    m = build_yolox(10, 2)
+    m.load_state_dict(recipe_state_dict(m, seed=1004))
+    m = m.to(gpu).train()
+    x = detector_input(31, 3).to(gpu)
+    labels = torch.zeros(3, 80, 5, dtype=torch.float64, device=gpu)
+    with torch.no_grad():
+        level = [o.clone() for o in m.head.train_outputs(m.neck(m.backbone(x[..., 0])))]
+
+    def run(force_torch):
+        leaves = [o.clone().requires_grad_(True) for o in level]
+        try:
+            losses._FORCE_TORCH_LOSS = force_torch
+            tup = losses.yolox_losses(leaves, m.head.strides, labels, 2, m.head.radius)
+        finally:
+            losses._FORCE_TORCH_LOSS = False
+        tup[0].backward()
+        return [float(torch.as_tensor(v).detach()) for v in tup], [l.grad for l in leaves]
+
+    want, gwant = run(True)
+    got, ggot = run(False)
+    assert got == pytest.approx(want, rel=1e-6) and got[1] == 0.0 and got[3] == 0.0 and got[0] > 0
+    for a, b in zip(ggot, gwant):
+        assert bool(torch.isfinite(a).all()) and rel_err(a, b) <= 1e-6
+        assert float(a[:, :4].abs().max()) == 0.0 and float(a[:, 5:].abs().max()) == 0.0  # no box, no class gradient
+
+
 @pytest.mark.parametrize("tag,C", [("bfm8", 8), ("bfm16", 16)])
 def test_bfm_stem_engine_vs_golden_and_torch(gpu, golden_dir, tag, C):
     """yolox_taf_bfm (core/exp.py:588-591): fused BFM stem kernel + the usual plan against the reference-generated
