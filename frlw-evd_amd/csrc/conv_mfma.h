@@ -383,11 +383,16 @@ __global__ __launch_bounds__(64 * WROWS * WCOLS) void k_conv_mfma(ConvArgs a)
             // a bf16 k-step = 16 k: the lane's eight gathered values (two quads) and its hi / lo weight records; KS per k-tile
             u32x4 bh[KS][TN], bl[KS][TN];
             const uint32_t b_addr = b3_lds + (uint32_t)bufb * (BK * LDB * 4);
+            // (explicit captures: with [&] clang rejects the asm operands inside this generic lambda -- "reference to local variable
+            // declared in enclosing function" -- and with them it warns that they are not needed)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wunused-lambda-capture"
             auto read_b3 = [&bh, &bl, b_addr](auto sc, auto jc) {
                 constexpr int st = decltype(sc)::value, jn = decltype(jc)::value;
                 asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bh[st][jn]) : "v"(b_addr), "n"(st * 4 * BN * 16 + jn * 512));
                 asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bl[st][jn]) : "v"(b_addr), "n"(st * 4 * BN * 16 + BN * 16 + jn * 512));
             };
+#pragma clang diagnostic pop
             auto read_step = [&](auto sc) {
                 constexpr int st = decltype(sc)::value;
                 read_a(ConvIC<2 * st>{});
