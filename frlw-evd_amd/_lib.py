@@ -119,12 +119,12 @@ SYMBOLS = {
     "frlw_bn_scratch_doubles": (_I64, [_I64, _I]),
     "frlw_bn_stats": (_I, [_P, _I64, _I, C.c_float, _P, _P, _P, _P, _P]),
     "frlw_bn_silu_fwd": (_I, [_P, _I64, _I, _P, _P, _P, _P, _P, _P]),
-    "frlw_bn_silu_bwd": (_I, [_P, _P, _I64, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "frlw_bn_silu_bwd": (_I, [_P, _I64, _P, _I64, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "frlw_baseconv_weight_cache_floats": (_I64, [_I, _I, _I, _I]),
     "frlw_baseconv_train_scratch_bytes": (_I64, [_I, _I, _I, _I, _I, _I, _I]),
     "frlw_baseconv_train_fwd": (_I, [_P, _P, _P, _P, C.c_float, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P,
                                     C.c_float, _P, _P, _P, _I64, _I, _P]),
-    "frlw_baseconv_train_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P,
+    "frlw_baseconv_train_bwd": (_I, [_P, _I64, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P,
                                     _P, _I64, _I, _P]),
     "frlw_spp_train_fwd": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
     "frlw_spp_train_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),

@@ -381,12 +381,13 @@ __device__ __forceinline__ float dsilu_times(float dy, float u)
 }
 
 // partial[wg][c] = {sum du, sum du * zhat} in float64
-__global__ __launch_bounds__(256) void k_bn_silu_bwd_partial(const float *dy, const float *z, long long M, int C,
+// (dy_rs: floats between two rows of dy -- C when dense, more when dy is a channel slice of a wider NHWC gradient)
+__global__ __launch_bounds__(256) void k_bn_silu_bwd_partial(const float *dy, long long dy_rs, const float *z, long long M, int C,
                                                              const float *gamma, const float *beta, const float *mean,
                                                              const float *invstd, double *partial)
 {
     bn_reduce_rows<true>(M, C, partial, [=](long long r, int c, float (&o)[8]) {
-        const float4 zv = *(const float4 *)(z + r * C + c), gv = *(const float4 *)(dy + r * C + c);
+        const float4 zv = *(const float4 *)(z + r * C + c), gv = *(const float4 *)(dy + r * dy_rs + c);
         const float zz[4] = {zv.x, zv.y, zv.z, zv.w}, gg[4] = {gv.x, gv.y, gv.z, gv.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -413,13 +414,14 @@ __global__ __launch_bounds__(256) void k_bn_silu_bwd_final(const double *partial
 }
 
 // dz = gamma * invstd * (du - mean(du) - zhat * mean(du * zhat))
-__global__ void k_bn_silu_bwd_apply(const float *dy, const float *z, long long n4, int C, const float *gamma,
+__global__ void k_bn_silu_bwd_apply(const float *dy, long long dy_rs, const float *z, long long n4, int C, const float *gamma,
                                     const float *beta, const float *mean, const float *invstd, const float *sums, float *dz)
 {
     const int C4 = C >> 2;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C4) * 4;
-        const float4 zv = ((const float4 *)z)[i], gv = ((const float4 *)dy)[i];
+        const float4 zv = ((const float4 *)z)[i];
+        const float4 gv = dy_rs == C ? ((const float4 *)dy)[i] : *(const float4 *)(dy + (i / C4) * dy_rs + c);
         const float zz[4] = {zv.x, zv.y, zv.z, zv.w}, gg[4] = {gv.x, gv.y, gv.z, gv.w};
         float o[4];
 #pragma unroll
@@ -649,20 +651,22 @@ int frlw_bn_silu_fwd(const float *z, int64_t M, int C, const float *gamma, const
     return FRLW_OK;
 }
 
-int frlw_bn_silu_bwd(const float *dy, const float *z, int64_t M, int C, const float *gamma, const float *beta,
+int frlw_bn_silu_bwd(const float *dy, int64_t dy_row_stride, const float *z, int64_t M, int C, const float *gamma, const float *beta,
                      const float *mean, const float *invstd, float *dz, float *dgamma, float *dbeta, double *scratch,
                      float *sums, frlw_stream_t stream)
 {
     (void)hipGetLastError(); // other libraries in the process (torch's BLAS look-ups) leave stale errors behind
     if (!dy || !z || !dz || !dgamma || !dbeta || !scratch || !sums || M < 1 || C < 4 || (C & 3)) return FRLW_ERR_ARG;
+    const long long dy_rs = dy_row_stride > 0 ? dy_row_stride : C;
+    if (dy_rs < C || (dy_rs & 3) || ((uintptr_t)dy & 15)) return FRLW_ERR_ARG;
     const int n_wg = (int)((M + bn_rows_per_wg(M) - 1) / bn_rows_per_wg(M));
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_bn_silu_bwd_partial, dim3(n_wg), dim3(256), 0, s, dy, z, (long long)M, C, gamma, beta, mean, invstd,
+    hipLaunchKernelGGL(k_bn_silu_bwd_partial, dim3(n_wg), dim3(256), 0, s, dy, dy_rs, z, (long long)M, C, gamma, beta, mean, invstd,
                        scratch);
     hipLaunchKernelGGL(k_bn_silu_bwd_final, dim3((C + kFinCh - 1) / kFinCh), dim3(256), 0, s, scratch, n_wg, C, (long long)M, dgamma,
                        dbeta, sums);
     const long long n4 = (long long)M * C / 4;
-    hipLaunchKernelGGL(k_bn_silu_bwd_apply, dim3(conv_grid_1d(n4)), dim3(256), 0, s, dy, z, n4, C, gamma, beta, mean, invstd,
+    hipLaunchKernelGGL(k_bn_silu_bwd_apply, dim3(conv_grid_1d(n4)), dim3(256), 0, s, dy, dy_rs, z, n4, C, gamma, beta, mean, invstd,
                        sums, dz);
     TRY_HIP(hipGetLastError());
     return FRLW_OK;
@@ -741,7 +745,7 @@ int frlw_baseconv_train_fwd(const float *x, const float *w, const float *gamma, 
 }
 
 /* Gradients of the block: dx (NULL: not needed), dw (Cout, Cin, k, k), dgamma, dbeta.  dz: (B, Ho, Wo, Cout) work buffer. */
-int frlw_baseconv_train_bwd(const float *dy, const float *x, const float *z, const float *w, const float *gamma,
+int frlw_baseconv_train_bwd(const float *dy, int64_t dy_row_stride, const float *x, const float *z, const float *w, const float *gamma,
                             const float *beta, const float *mean, const float *invstd, int B, int H, int W, int Cin,
                             int Cout, int k, int stride, float *dz, float *dx, float *dw, float *dgamma, float *dbeta,
                             const float *w_cache, void *scratch, int64_t scratch_bytes, int precision, frlw_stream_t stream)
@@ -754,7 +758,7 @@ int frlw_baseconv_train_bwd(const float *dy, const float *x, const float *z, con
     const int64_t M = (int64_t)B * Ho * Wo;
     TrainScratch t = carve(scratch, B, Ho, Wo, Cin, Cout, k);
     int rc;
-    if ((rc = frlw_bn_silu_bwd(dy, z, M, Cout, gamma, beta, mean, invstd, dz, dgamma, dbeta, t.red, t.sums, stream)) != FRLW_OK) return rc;
+    if ((rc = frlw_bn_silu_bwd(dy, dy_row_stride, z, M, Cout, gamma, beta, mean, invstd, dz, dgamma, dbeta, t.red, t.sums, stream)) != FRLW_OK) return rc;
     if (dx) {
         const float *w_dg = t.w_dg;
         if (w_cache) w_dg = w_cache + frlw_conv_operand_floats(k * k * Cin, Cout, precision); // laid out by the forward of this step

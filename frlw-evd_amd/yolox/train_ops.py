@@ -143,6 +143,20 @@ def _nhwc(x):
     return x.contiguous(memory_format=torch.channels_last)
 
 
+def _rows_in_place(t):
+    """(tensor, floats between two pixel rows) of a (B, C, H, W) gradient for the kernels that read (M, C) rows: a channel
+    slice of a wider channels_last tensor -- what the backward of ``torch.cat`` hands to each of its inputs -- is read where it
+    lies (row stride = the wide tensor's channels) instead of being copied dense first; anything else becomes dense NHWC."""
+    B, Cc, H, W = t.shape
+    st = t.stride()
+    cs = st[3]
+    if (st[1] == 1 and cs >= Cc and cs % 4 == 0 and st[2] == W * cs and (B == 1 or st[0] == H * W * cs)
+            and t.data_ptr() % 16 == 0 and cs != Cc):
+        return t, cs
+    t = _nhwc(t)
+    return t, 0
+
+
 def pad32(n):
     return (n + 31) // 32 * 32
 
@@ -198,7 +212,7 @@ class _BaseConvTrain(torch.autograd.Function):
         x, z, w, g, b, stats = ctx.saved_tensors
         B, Cin, H, W, Cout, k, stride = ctx.geom
         dev = dy.device
-        dy = _nhwc(dy.float())
+        dy, dy_rs = _rows_in_place(dy.float())
         dz = torch.empty_like(z)
         dx = (torch.empty((B, Cin, H, W), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
               if ctx.needs_input_grad[0] else None)
@@ -210,7 +224,7 @@ class _BaseConvTrain(torch.autograd.Function):
         # weights' layout (fine), an in-place weight update in between would not (then lay out again)
         fresh = (ctx.weight_ref._version == ctx.wversion and _WCACHE.get(id(ctx.weight_ref), (None, None))[1] is ctx.wcache
                  and _WCACHE_GEOM.get(id(ctx.weight_ref)) == (ctx.wversion, *ctx.wparity))
-        _lib.check(lib.frlw_baseconv_train_bwd(dy.data_ptr(), x.data_ptr(), z.data_ptr(), w.data_ptr(), g.data_ptr(),
+        _lib.check(lib.frlw_baseconv_train_bwd(dy.data_ptr(), dy_rs, x.data_ptr(), z.data_ptr(), w.data_ptr(), g.data_ptr(),
                                                b.data_ptr(), stats[0].data_ptr(), stats[2].data_ptr(), B, H, W, Cin, Cout, k,
                                                stride, dz.data_ptr(), dx.data_ptr() if dx is not None else None,
                                                dw.data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(),

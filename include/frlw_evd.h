@@ -506,8 +506,10 @@ int frlw_bn_stats(const float *z, int64_t M, int C, float eps, float *mean, floa
 /* y = silu(gamma * (z - mean) * invstd + beta) */
 int frlw_bn_silu_fwd(const float *z, int64_t M, int C, const float *gamma, const float *beta, const float *mean,
                      const float *invstd, float *y, frlw_stream_t stream);
-/* dz, dgamma (C), dbeta (C) from dy and the saved z; sums: 2 C floats of scratch. */
-int frlw_bn_silu_bwd(const float *dy, const float *z, int64_t M, int C, const float *gamma, const float *beta,
+/* dz, dgamma (C), dbeta (C) from dy and the saved z; sums: 2 C floats of scratch.  dy_row_stride: floats between two rows
+ * of dy (0 or C: dense; larger: dy is a channel slice of a wider NHWC gradient -- what the backward of a concatenation hands
+ * out -- read in place; multiple of 4, dy 16-byte aligned). */
+int frlw_bn_silu_bwd(const float *dy, int64_t dy_row_stride, const float *z, int64_t M, int C, const float *gamma, const float *beta,
                      const float *mean, const float *invstd, float *dz, float *dgamma, float *dbeta, double *scratch,
                      float *sums, frlw_stream_t stream);
 
@@ -530,7 +532,7 @@ int frlw_baseconv_train_fwd(const float *x, const float *w, const float *gamma, 
                             float *invstd, float *running_mean, float *running_var, float momentum,
                             int64_t *num_batches_tracked, float *w_cache, void *scratch, int64_t scratch_bytes,
                             int precision, frlw_stream_t stream);
-int frlw_baseconv_train_bwd(const float *dy, const float *x, const float *z, const float *w, const float *gamma,
+int frlw_baseconv_train_bwd(const float *dy, int64_t dy_row_stride, const float *x, const float *z, const float *w, const float *gamma,
                             const float *beta, const float *mean, const float *invstd, int B, int H, int W, int Cin,
                             int Cout, int k, int stride, float *dz, float *dx, float *dw, float *dgamma, float *dbeta,
                             const float *w_cache, void *scratch, int64_t scratch_bytes, int precision, frlw_stream_t stream);
