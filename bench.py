@@ -463,6 +463,8 @@ def main():
             if "encode_plus_train_step" in t:
                 flat["encode_plus_train_ms"] = t["encode_plus_train_step"]["ms_per_step"]
                 flat["encode_plus_train_frames_per_s"] = t["encode_plus_train_step"]["value"]
+                flat["encode_ahead_plus_train_ms"] = t["encode_plus_train_step"]["encode_ahead"]["ms_per_step"]
+                flat["encode_ahead_plus_train_frames_per_s"] = t["encode_plus_train_step"]["encode_ahead"]["value"]
         except Exception as e:  # never lose the headline line to the extra leg
             result["train"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
