@@ -48,8 +48,8 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f
 
 def mfma_roofline(tflops, precision, kernel, **extra):
     """The ``roofline`` object of a convolution workload.  ``tflops`` = ALGORITHMIC rate (2 x MACs of the float32 convolutions
-    / device time).  precision "f32": one v_mfma_f32_32x32x2_f32 per product, peak 157.3.  precision "bf16x3" (the default
-    of the library): every float32 product is three bf16 MFMAs (hi/lo split operands, f32 accumulate), so the peak of the
+    / device time).  precision "f32" (the default): one v_mfma_f32_32x32x2_f32 per product, peak 157.3.  precision "bf16x3"
+    (opt-in, FRLW_CONV_PRECISION): every float32 product is three bf16 MFMAs (hi/lo split operands, f32 accumulate), so the peak of the
     ALGORITHMIC rate is a third of the dense bf16 peak; the executed matrix rate and the ratio to the float32-MFMA peak -- what the
     same float32 work could reach at best on the float32 instruction -- are listed beside it."""
     if precision == "bf16x3":
@@ -59,7 +59,7 @@ def mfma_roofline(tflops, precision, kernel, **extra):
              "x_f32_mfma_peak": round(tflops / FP32_MFMA_PEAK_TFLOPS, 3),
              "mfma": "3 x v_mfma_f32_32x32x16_bf16 per 16 k: x = hi + lo (bf16 each), a*b ~ a_hi*b_hi + a_hi*b_lo + a_lo*b_hi, f32 "
                      "accumulate -- float32 products to <= 2^-16 relative (observed 3e-6 of max |y| per layer; tolerance 1e-3); "
-                     "peak = dense bf16 peak / 3; FRLW_CONV_PRECISION=f32 selects v_mfma_f32_32x32x2_f32 (exact products)"}
+                     "peak = dense bf16 peak / 3; opt-in (FRLW_CONV_PRECISION=bf16x3) beside the default v_mfma_f32_32x32x2_f32 (exact products)"}
     else:
         r = {"bound": "mfma", "kernel": kernel, "achieved": round(tflops, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
              "frac": round(tflops / FP32_MFMA_PEAK_TFLOPS, 4), "mfma": "v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate)"}
@@ -439,11 +439,16 @@ def main():
         flat["detector_batch_per_gpu"] = d["batch_per_gpu"]
         flat["detector_TFLOPs"] = d["roofline"]["achieved"]
         flat["detector_frac"] = d["roofline"]["frac"]
-        flat["detector_x_f32_mfma_peak"] = d["roofline"].get("x_f32_mfma_peak", d["roofline"]["frac"])
-        if "f32_mfma" in d:
-            flat["detector_f32mfma_frames_per_s"] = d["f32_mfma"]["value"]
-            flat["detector_f32mfma_frac"] = d["f32_mfma"]["roofline"]["frac"]
-            flat["detector_bf16x3_vs_f32mfma_max_rel_diff"] = d["f32_mfma"]["max_rel_diff_of_outputs"]
+        flat["detector_dtype"] = d["dtype"]
+        if "other_arithmetic" in d:  # the opt-in bf16x3 arithmetic (or, when that was made the default, the float32 MFMA)
+            o = d["other_arithmetic"]
+            tagp = "bf16x3" if o["precision"] == "bf16x3" else "f32mfma"
+            flat[f"detector_{tagp}_frames_per_s"] = o["value"]
+            flat[f"detector_{tagp}_ms_per_batch"] = o["ms_per_batch"]
+            flat[f"detector_{tagp}_frac"] = o["roofline"]["frac"]
+            if "x_f32_mfma_peak" in o["roofline"]:
+                flat[f"detector_{tagp}_x_f32_mfma_peak"] = o["roofline"]["x_f32_mfma_peak"]
+            flat["detector_bf16x3_vs_f32_max_rel_diff"] = o["max_rel_diff_bf16x3_vs_f32"]
         if "shape_1mpx" in d:
             flat["detector_1mpx_frames_per_s"] = d["shape_1mpx"]["value"]
             flat["detector_1mpx_frac"] = d["shape_1mpx"]["roofline"]["frac"]
@@ -456,10 +461,15 @@ def main():
             flat["train_ms"] = t["ms_per_step"]
             flat["train_TFLOPs"] = t["roofline"]["achieved"]
             flat["train_frac"] = t["roofline"]["frac"]
-            flat["train_x_f32_mfma_peak"] = t["roofline"].get("x_f32_mfma_peak", t["roofline"]["frac"])
-            if "f32_mfma" in t:
-                flat["train_f32mfma_ms"] = t["f32_mfma"]["ms_per_step"]
-                flat["train_f32mfma_frac"] = t["f32_mfma"]["roofline"]["frac"]
+            flat["train_dtype"] = t["dtype"]
+            if "other_arithmetic" in t:
+                o = t["other_arithmetic"]
+                tagp = "bf16x3" if o["precision"] == "bf16x3" else "f32mfma"
+                flat[f"train_{tagp}_ms"] = o["ms_per_step"]
+                flat[f"train_{tagp}_frames_per_s"] = o["value"]
+                flat[f"train_{tagp}_frac"] = o["roofline"]["frac"]
+                if "x_f32_mfma_peak" in o["roofline"]:
+                    flat[f"train_{tagp}_x_f32_mfma_peak"] = o["roofline"]["x_f32_mfma_peak"]
             if "encode_plus_train_step" in t:
                 flat["encode_plus_train_ms"] = t["encode_plus_train_step"]["ms_per_step"]
                 flat["encode_plus_train_frames_per_s"] = t["encode_plus_train_step"]["value"]
@@ -637,16 +647,20 @@ def bench_detector(args, torch, world, rank, timer):
             "roofline": mfma_roofline(tflops, eng.precision, f"k_conv_mfma ({eng.n_conv} launches per forward)",
                                       flops_per_image=eng.flops_per_image, device_ms_per_batch=round(dev_ms, 3)),
         }
-        if tag == "gen1" and eng.precision != "f32":  # the same forward on the float32 MFMA (exact products), one region
+        if tag == "gen1":  # the same forward in the OTHER arithmetic (the opt-in bf16x3 beside the float32 default), one region
             from frlw_evd_amd.detector import DetectorEngine
-            e32 = DetectorEngine(net, precision="f32")
-            per32, dev32, _r = one_region(timer, lambda: e32.raw_outputs(x), steps, 10)
-            tf32 = e32.flops_per_image * B / (dev32 * 1e-3) / 1e12
-            row["f32_mfma"] = {"value": round(world * B / per32, 1), "unit": "frames/s", "ms_per_batch": round(per32 * 1e3, 3),
-                               "roofline": mfma_roofline(tf32, "f32", "k_conv_mfma", device_ms_per_batch=round(dev32, 3)),
-                               "max_rel_diff_of_outputs": float((e32.raw_outputs(x) - eng.raw_outputs(x)).abs().max()
-                                                                / e32.raw_outputs(x).abs().max())}
-            del e32
+            other = "bf16x3" if eng.precision == "f32" else "f32"
+            e2 = DetectorEngine(net, precision=other)
+            per2, dev2, _r = one_region(timer, lambda: e2.raw_outputs(x), steps, 10)
+            tf2 = e2.flops_per_image * B / (dev2 * 1e-3) / 1e12
+            ref32, alt = (eng, e2) if other == "bf16x3" else (e2, eng)
+            row["other_arithmetic"] = {"precision": other, "value": round(world * B / per2, 1), "unit": "frames/s",
+                                       "ms_per_batch": round(per2 * 1e3, 3),
+                                       "roofline": mfma_roofline(tf2, other, "k_conv_mfma", device_ms_per_batch=round(dev2, 3)),
+                                       "max_rel_diff_bf16x3_vs_f32": float((alt.raw_outputs(x) - ref32.raw_outputs(x)).abs().max()
+                                                                           / ref32.raw_outputs(x).abs().max()),
+                                       "speedup_vs_default": round(per / per2, 3)}
+            del e2
         for _ in range(2):
             eng.detect(x)
         torch.cuda.synchronize()
@@ -838,21 +852,23 @@ def bench_train(args, torch, world, rank, local_rank, timer):
                                               "launch": "eager", "native_speedup": round(per_t / per_e, 3),
                                               "native_graph_speedup": round(per_t / per, 3)}
         del tr_e, one_e, _xy
-        if precision != "f32":  # the same graph-replayed step with every contraction on the float32 MFMA (exact products)
-            prev = os.environ.get("FRLW_CONV_PRECISION")
-            os.environ["FRLW_CONV_PRECISION"] = "f32"
-            try:
-                per32, dev32, tr32, st32, *_ = _train_variant(torch, timer, world, rank, local_rank, B, False, None, steps, graph=True)
-            finally:
-                if prev is None:
-                    os.environ.pop("FRLW_CONV_PRECISION", None)
-                else:
-                    os.environ["FRLW_CONV_PRECISION"] = prev
-            out["f32_mfma"] = {"value": round(B / per32, 1), "ms_per_step": round(per32 * 1e3, 3), "loss": round(st32["loss"], 4),
-                               "roofline": mfma_roofline(flops / (dev32 * 1e-3) / 1e12, "f32", "k_conv_mfma + k_wgrad_mfma",
-                                                         device_ms_per_step=round(dev32, 3)),
-                               "speedup_of_bf16x3": round(per32 / per, 3)}
-            del tr32
+        # the same graph-replayed step in the OTHER arithmetic (the opt-in bf16x3 beside the float32 default)
+        other = "bf16x3" if precision == "f32" else "f32"
+        prev = os.environ.get("FRLW_CONV_PRECISION")
+        os.environ["FRLW_CONV_PRECISION"] = other
+        try:
+            per2, dev2, tr2, st2, *_ = _train_variant(torch, timer, world, rank, local_rank, B, False, None, steps, graph=True)
+        finally:
+            if prev is None:
+                os.environ.pop("FRLW_CONV_PRECISION", None)
+            else:
+                os.environ["FRLW_CONV_PRECISION"] = prev
+        out["other_arithmetic"] = {"precision": other, "value": round(B / per2, 1), "unit": "frames/s", "ms_per_step": round(per2 * 1e3, 3),
+                                   "loss": round(st2["loss"], 4),
+                                   "roofline": mfma_roofline(flops / (dev2 * 1e-3) / 1e12, other, "k_conv_mfma + k_wgrad_mfma",
+                                                             device_ms_per_step=round(dev2, 3)),
+                                   "speedup_vs_default": round(per / per2, 3)}
+        del tr2
     del tr, one, x, lab
     torch.cuda.empty_cache()
     # ---- the reference's semantics: GLOBAL batch 64 (settings.py:41: 64 / nodes per GPU) -> strong scaling over N

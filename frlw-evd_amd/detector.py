@@ -46,9 +46,10 @@ def gemm_weight(w):
 
 
 def default_precision():
-    """Convolution arithmetic of new engines: ``FRLW_CONV_PRECISION`` = ``f32`` (float32 MFMA, exact products) or ``bf16x3``
-    (float32 products from three bf16 MFMAs, the default: include/frlw_evd.h, frlw_det_set_precision)."""
-    v = os.environ.get("FRLW_CONV_PRECISION", "bf16x3").strip().lower()
+    """Convolution arithmetic of new engines: ``FRLW_CONV_PRECISION`` = ``f32`` (the default: float32 MFMA, every product
+    exact -- the reference's own arithmetic) or ``bf16x3`` (opt-in: float32 products from three bf16 MFMAs on hi / lo split
+    operands, ~1e-5 of the float32 result, 1.6 x the frames: include/frlw_evd.h, frlw_det_set_precision)."""
+    v = os.environ.get("FRLW_CONV_PRECISION", "f32").strip().lower()
     if v not in PRECISIONS:
         raise ValueError(f"FRLW_CONV_PRECISION={v!r}: expected one of {sorted(PRECISIONS)}")
     return v

@@ -1,7 +1,7 @@
 """Training-mode BaseConv kernels (csrc/train_ops.hip) against torch autograd of the same module in FLOAT64:
 forward, input gradient, weight / gamma / beta gradients, running statistics.  Tolerance L3 (1e-3, SURVEY.md
-section 8c); both arithmetics of the contractions -- float32 MFMA (exact products) and float32 products from three bf16
-MFMAs (FRLW_CONV_PRECISION, the default) -- with float64 statistics, observed ~1e-6 / ~1e-5.
+section 8c); both arithmetics of the contractions -- float32 MFMA (exact products, the default) and float32 products from
+three bf16 MFMAs (FRLW_CONV_PRECISION=bf16x3) -- with float64 statistics, observed ~1e-6 / ~1e-5.
 
 The judge is float64 because MIOpen's float32 BatchNorm backward is itself off by 7-12 % in dgamma / dbeta when
 H * W is odd (measured against float64, tools/fuzz_train_ops.py) -- not a regime of the detector (H, W are multiples of

@@ -19,13 +19,15 @@ stats lab_gen1_nocm $R/build/enc_lab $LIB --cfg gen1 --reps 20 --no-cm # ... and
 stats lab_evb64_nocm $R/build/enc_lab $LIB --cfg evb64 --reps 20 --no-cm
 stats sae python3 $R/tools/run_small_encoders.py sae 20
 stats eci python3 $R/tools/run_small_encoders.py eci 20
-stats det python3 $R/tools/time_detector.py
+stats det python3 $R/tools/time_detector.py                    # default arithmetic: float32 MFMA
 GRAPH=1 B=64 stats train python3 $R/tools/train_gaps.py run   # Trainer(graph=True): the capture, then replays
-FRLW_CONV_PRECISION=f32 stats det_f32mfma python3 $R/tools/time_detector.py   # the same two on the float32 MFMA
-FRLW_CONV_PRECISION=f32 GRAPH=1 B=64 stats train_f32mfma python3 $R/tools/train_gaps.py run
+FRLW_CONV_PRECISION=bf16x3 stats det_bf16x3 python3 $R/tools/time_detector.py   # the same two in the opt-in arithmetic
+FRLW_CONV_PRECISION=bf16x3 GRAPH=1 B=64 stats train_bf16x3 python3 $R/tools/train_gaps.py run
 (cd $R && bash tools/det_profile.sh > $K/det_layers.txt 2>&1); cd /tmp
+(cd $R && FRLW_CONV_PRECISION=bf16x3 bash tools/det_profile.sh > $K/det_layers_bf16x3.txt 2>&1); cd /tmp
 (bash $R/tools/pmc_bin.sh build/conv_lab 32 5 1 1 > $K/conv_big_pmc.txt 2>&1); cd /tmp   # counters of the 40960 x 256 x 2304 layer, both arithmetics
 (GRAPH=1 bash $R/tools/train_gaps.sh > /dev/null 2>&1; cp $R/gpurun_out/train_gaps/sequence.txt $K/train_sequence.txt; cp $R/gpurun_out/train_gaps/gaps.txt $K/train_gaps.txt); cd /tmp
+(FRLW_CONV_PRECISION=bf16x3 GRAPH=1 bash $R/tools/train_gaps.sh > /dev/null 2>&1; cp $R/gpurun_out/train_gaps/sequence.txt $K/train_bf16x3_sequence.txt); cd /tmp
 # PMC passes (separate runs, kernel-trace only)
 pmc() { # out-dir tag counters -- program args...
   local O=$1 tag=$2; shift 2; local ctrs=(); while [ "$1" != "--" ]; do ctrs+=("$1"); shift; done; shift
