@@ -84,6 +84,9 @@ __device__ __forceinline__ void conv_split8(const f32x4 &q0, const f32x4 &q1, u3
 #define CONV_BK_SMALL 16
 #endif
 constexpr int kSplitBK = 16; // granularity the split-K heuristics count k-tiles in
+#ifndef CONV_F32_PIPE
+#define CONV_F32_PIPE 1 // 0: the float32-MFMA loop without the pipelined iteration seam (A/B in tools/conv_lab.hip)
+#endif
 
 __device__ __forceinline__ float act_apply(float v, int act)
 {
@@ -356,6 +359,86 @@ __global__ __launch_bounds__(64 * WROWS * WCOLS) void k_conv_mfma(ConvArgs a)
                 }
         };
         if (nk > 0) read_frags(ConvIC<0>{}, 0, 0);
+        int kt = 0;
+        for (; kt + 1 < nk; kt += 2) {
+            iteration(ConvIC<0>{}, kt);
+            iteration(ConvIC<1>{}, kt + 1);
+        }
+        if (kt < nk) iteration(ConvIC<0>{}, kt);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    } else if constexpr (P == 0 && BK == 16 && CONV_F32_PIPE && TM * TN == 1) { // (wider wavefront tiles: within +-1 %)
+        // float32 MFMA, the iteration's seam pipelined: after the last fragment read of tile t has been issued (k-step 6 requests
+        // the B row of k-step 7) the wavefront drains its LDS reads, passes the barrier that publishes tile t + 1, requests the
+        // first fragments of tile t + 1 -- and only then issues the MFMAs of k-steps 6 and 7, which it has in registers.  The
+        // LDS latency that used to sit in front of every iteration's first MFMA (nobody to hide it on the thin layers: one or two
+        // workgroups per CU) now runs under two k-steps of matrix work.  Two register sets, the loop unrolled by two.
+        f32x4 fa[2][2][TM];
+        float fb[2][2][TN];
+        auto read_a = [&fa, &a_lds](auto pc, auto jc, int slot_a) {
+            constexpr int p = decltype(pc)::value, j = decltype(jc)::value;
+            const uint32_t ad = a_lds[j] + (uint32_t)slot_a * (BM * BK * 4);
+            asm volatile("ds_read_b128 %0, %1" : "=v"(fa[p][j][0]) : "v"(ad));
+            if constexpr (TM > 1) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[p][j][TM - 1]) : "v"(ad), "n"(32 * BK * 4));
+        };
+        auto read_b = [&fb, b_lds](auto pc, auto stc, int slot_b) {
+            constexpr int p = decltype(pc)::value, st = decltype(stc)::value;
+            constexpr int off = (8 * (st >> 2) + (st & 3)) * LDB * 4;
+            const uint32_t bd = b_lds + (uint32_t)slot_b * (BK * LDB * 4);
+            asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(fb[p][st & 1][0]) : "v"(bd), "n"(off));
+            if constexpr (TN > 1) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(fb[p][st & 1][TN - 1]) : "v"(bd), "n"(off + 128));
+        };
+        auto mma = [&](auto pc, auto stc) {
+            constexpr int p = decltype(pc)::value, st = decltype(stc)::value;
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn) asm volatile("" : "+v"(fb[p][st & 1][jn]));
+            if ((st & 3) == 0) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(fa[p][st >> 2][i]));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const float af = fa[p][st >> 2][i][st & 3];
+#pragma unroll
+                for (int jn = 0; jn < TN; ++jn)
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, fb[p][st & 1][jn], acc[i][jn], 0, 0, 0);
+            }
+        };
+        auto step = [&](auto pc, auto stc, int slot_b) { // k-steps 0 .. 5: request the B row of the next k-step, wait for this one's
+            constexpr int st = decltype(stc)::value;
+            read_b(pc, ConvIC<st + 1>{}, slot_b);
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(st == 0 ? TM + TN : TN) : "memory");
+            mma(pc, stc);
+        };
+        auto iteration = [&](auto pc, int kt) {
+            constexpr int p = decltype(pc)::value;
+            if (kt + D - 1 < nk) load_b(bufb == 0 ? NB - 1 : bufb - 1);
+            if (kt + D < nk) load_a(kt0 + kt + D, buf == 0 ? NA - 1 : buf - 1);
+            const int sb = bufb;
+            step(pc, ConvIC<0>{}, sb);
+            step(pc, ConvIC<1>{}, sb);
+            step(pc, ConvIC<2>{}, sb);
+            step(pc, ConvIC<3>{}, sb);
+            step(pc, ConvIC<4>{}, sb);
+            step(pc, ConvIC<5>{}, sb);
+            read_b(pc, ConvIC<7>{}, sb);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // every fragment of tile kt is in registers
+            wait_next_tile(kt + D < nk);                        // tile kt + 1 has landed (this wavefront's pieces) ...
+            __builtin_amdgcn_s_barrier();                       // ... everybody's have, and everybody is done reading tile kt
+            buf = buf == NA - 1 ? 0 : buf + 1;
+            bufb = bufb == NB - 1 ? 0 : bufb + 1;
+            if (kt + 1 < nk) {
+                read_a(ConvIC<1 - p>{}, ConvIC<0>{}, buf);
+                read_b(ConvIC<1 - p>{}, ConvIC<0>{}, bufb);
+                read_a(ConvIC<1 - p>{}, ConvIC<1>{}, buf);
+            }
+            mma(pc, ConvIC<6>{});
+            mma(pc, ConvIC<7>{});
+        };
+        if (nk > 0) {
+            read_a(ConvIC<0>{}, ConvIC<0>{}, 0);
+            read_b(ConvIC<0>{}, ConvIC<0>{}, 0);
+            read_a(ConvIC<0>{}, ConvIC<1>{}, 0);
+        }
         int kt = 0;
         for (; kt + 1 < nk; kt += 2) {
             iteration(ConvIC<0>{}, kt);
