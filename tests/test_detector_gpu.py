@@ -41,7 +41,8 @@ def test_raw_outputs_vs_golden_and_torch(gpu, golden_dir, tag, C, precision):
     """Both arithmetics of the convolutions (frlw_det_set_precision): the float32 MFMA (the default) and float32 products from
     three bf16 MFMAs (opt-in), against the reference-generated head tensor."""
     from frlw_evd_amd.detector import DetectorEngine, default_precision
-    assert default_precision() == "f32"
+    if "FRLW_CONV_PRECISION" not in os.environ:
+        assert default_precision() == "f32"
     g = np.load(os.path.join(golden_dir, "detector.npz"))
     m = build_yolox(C, 2)
     m.load_state_dict(recipe_state_dict(m, seed=1004))
