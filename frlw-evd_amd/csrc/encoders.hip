@@ -696,7 +696,7 @@ int frlw_encoder_status(const void *workspace, frlw_stream_t stream, int *status
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(hipMemcpyAsync(&st, workspace, sizeof(st), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    *status_out = (st & ST_INDEX) ? FRLW_ERR_INDEX : (st & ST_POLARITY) ? FRLW_ERR_POLARITY : (st & ST_SPAN) ? FRLW_ERR_SPAN : FRLW_OK;
+    *status_out = (st & ST_INDEX) ? FRLW_ERR_INDEX : (st & ST_POLARITY) ? FRLW_ERR_POLARITY : (st & ST_SPAN) ? FRLW_ERR_SPAN : (st & ST_STALL) ? FRLW_ERR_HIP : FRLW_OK;
     return FRLW_OK;
 }
 
@@ -715,7 +715,7 @@ int frlw_encoder_deferred_status(void *workspace, frlw_stream_t stream, int *sta
     HIP_TRY(hipMemcpyAsync(&st, (char *)workspace + kStickyOffset, sizeof(st), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemsetAsync((char *)workspace + kStickyOffset, 0, sizeof(st), s));
     HIP_TRY(hipStreamSynchronize(s));
-    *status_out = (st & ST_INDEX) ? FRLW_ERR_INDEX : (st & ST_POLARITY) ? FRLW_ERR_POLARITY : (st & ST_SPAN) ? FRLW_ERR_SPAN : FRLW_OK;
+    *status_out = (st & ST_INDEX) ? FRLW_ERR_INDEX : (st & ST_POLARITY) ? FRLW_ERR_POLARITY : (st & ST_SPAN) ? FRLW_ERR_SPAN : (st & ST_STALL) ? FRLW_ERR_HIP : FRLW_OK;
     return FRLW_OK;
 }
 

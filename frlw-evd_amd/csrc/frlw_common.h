@@ -54,7 +54,7 @@ constexpr int kMaxBpw = 8;        // batches of 64 events per wavefront per work
 constexpr int kSlabUnits = 32;    // workgroups per slab of the two-level column scan
 
 enum Kind : int { KIND_ECI = 0, KIND_EV = 1, KIND_SAE = 2, KIND_TAF = 3 };
-enum : int { ST_INDEX = 1, ST_POLARITY = 2, ST_SPAN = 4 };
+enum : int { ST_INDEX = 1, ST_POLARITY = 2, ST_SPAN = 4, /* 8: taf_fast.hip ST_MULBAD (not an error) */ ST_STALL = 16 /* a bounded device-side wait ran out: FRLW_ERR_HIP */ };
 
 // First kHeaderBytes of the workspace.
 constexpr int kMaxHot = 32;     // tiles per encode whose cells are split over several workgroups (skew)

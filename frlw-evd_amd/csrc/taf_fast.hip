@@ -766,11 +766,13 @@ __global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(MAXB > kMax
     uint32_t *wcnt = wcnt_all + (size_t)wv * T;
     for (int b = tid; b < kFW * T; b += kFT) wcnt_all[b] = 0;
     if (tid == 0) { wg_seen = 0ull; serr = 0; }
-    if (blockIdx.x == 0) {
+    if (blockIdx.x == 0 && epoch != 0u) {
         // The header's per-call words are reset HERE, by the workgroup the dispatcher starts first, instead of by a memset node
         // in front of the kernel.  Every other workgroup writes to the header only at its very end and only after it has seen
         // this call's epoch (published below, behind the reset): the first workgroup is resident before any other one starts,
-        // so that wait always ends.
+        // so that wait always ends (and is bounded all the same, below).  epoch == 0: the call is being captured into a graph --
+        // a host-made epoch would be baked into the node and every replay after the first would find it published already --
+        // so launch_fast_cm put a memset node in front instead and nobody resets or waits here.
         uint32_t *h32 = (uint32_t *)hdr;
         for (int i = tid; i < (int)(offsetof(FastHeader, epoch) / 4); i += kFT) h32[i] = 0u;
         __threadfence();
@@ -872,7 +874,16 @@ __global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(MAXB > kMax
     uint32_t *dst = records + (chunk_begin - S.ev0[0]);
     for (uint32_t qi = tid; qi < total; qi += kFT) dst[qi] = stage[qi];
     if (tid == 0) {
-        while (__hip_atomic_load(&hdr->epoch, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(2);
+        if (epoch != 0u) {
+            // bounded: ~2^22 polls of >= 128 cycles (a fraction of a second; the wait is normally over before it starts).  A part
+            // or a scheduler that does not start workgroup 0 first ends the call with ST_STALL (FRLW_ERR_HIP) instead of a hang.
+            uint32_t polls = 0u;
+            while (__hip_atomic_load(&hdr->epoch, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+                if (++polls > (1u << 22)) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (polls > (1u << 22)) { atomicOr(&hdr->status, ST_STALL); fold_sticky_status(hdr, ST_STALL); return; }
+        }
         const unsigned long long m = wg_seen;
         const unsigned long long have = __hip_atomic_load(&hdr->wmask[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (m & ~have) atomicOr(&hdr->wmask[s], m);
@@ -2595,8 +2606,18 @@ int launch_fast_cm(const FastGeom &G, const SeqTab &S, const FastPlan &p, char *
     uint32_t *records = (uint32_t *)(w8 + p.off_records);
     const size_t lds_sc = scatter_cm_lds_bytes(p.TB, p.chunk);
     static std::atomic<uint32_t> g_epoch{0};
-    uint32_t epoch = g_epoch.fetch_add(1u, std::memory_order_relaxed) + 1u;
-    if (epoch == 0u) epoch = g_epoch.fetch_add(1u, std::memory_order_relaxed) + 1u; // (0 is what frlw_workspace_init leaves behind)
+    uint32_t epoch = 0u;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(st, &cap);
+    if (cap != hipStreamCaptureStatusNone) {
+        // inside a stream capture the kernel arguments are frozen into the graph node: a host-made epoch would already be the
+        // published one on every replay after the first (workgroups could then OR their flags into the header BEFORE workgroup 0
+        // zeroes it).  A captured call resets the header with a memset node and passes epoch 0 = "nobody resets, nobody waits".
+        if (hipMemsetAsync(hdr, 0, offsetof(FastHeader, epoch), st) != hipSuccess) return FRLW_ERR_HIP;
+    } else {
+        epoch = g_epoch.fetch_add(1u, std::memory_order_relaxed) + 1u;
+        if (epoch == 0u) epoch = g_epoch.fetch_add(1u, std::memory_order_relaxed) + 1u; // (0 = the captured form)
+    }
     const bool simple = !HAS_MAP && G.simple != 0;
     if (p.big && simple) {
         (void)hipFuncSetAttribute((const void *)kf_scatter_cm<false, EV, true, kBigBpw>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc);

@@ -497,3 +497,55 @@ def test_chunk_major_error_leaves_everything_untouched(monkeypatch):
             er.raise_deferred()
         er.encode_taf_batch(dev(rec), [0, len(rec)], (H, W), st, 0, 10_000, 8, K)  # clean: the header was reset by the call itself
         assert float((st != -6000.0).sum()) > 0.0
+
+
+@pytest.mark.parametrize("shape,n_seq,n", [((240, 304), 2, 400_000), ((720, 1280), 1, 2_000_000)])
+def test_captured_encode_replays_against_the_oracle(er, orc, shape, n_seq, n):
+    """include/frlw_evd.h: calls can be captured into a hipGraph.  The chunk-major scatter resets the workspace header itself, keyed
+    by a host-made epoch; frozen into a graph node that epoch would already be the published one on every replay after the first
+    (stale window masks / flags).  A captured call therefore takes a memset node and epoch 0.  Here: capture ONE
+    frlw_taf_encode_batch, replay it three times with DIFFERENT records in the same buffer -- data whose empty window moves from
+    replay to replay, so a window mask that survived a replay would age cells the reference leaves alone -- and hold the carried
+    state and the uint8 volume to the oracle after every replay (direct mode and tile bins; generate_taf.py:40-41, :193-235)."""
+    H, W = shape
+    K, win, n_win = 8, 10_000, 8
+
+    def records(seed, empty_window):
+        out = []
+        for j in range(n_seq):
+            ev = synth.synth_events(seed + j, n // n_seq, W, H, n_win * win)
+            rec = synth.to_dat8(ev)
+            kept = np.flatnonzero((rec["t"] // win) != empty_window)  # one window without a single event in the whole sequence
+            # thinned to the same record count for every variant (the graph's offsets are frozen), stream order kept
+            pick = np.sort(np.random.default_rng(seed + 50 + j).choice(kept, size=(n // n_seq) * 3 // 4, replace=False))
+            out.append(rec[pick])
+        return out
+
+    variants = [records(9100, 3), records(9200, 5), records(9300, 3)]
+    counts = [len(r) for r in variants[0]]
+    for v in variants:
+        assert [len(r) for r in v] == counts
+    offs = np.concatenate([[0], np.cumsum(counts)])
+    cat = lambda v: torch.from_numpy(np.ascontiguousarray(np.concatenate(v)).view(np.uint8).reshape(-1, 8).copy())
+    side = torch.cuda.Stream()
+    dat = cat(variants[0]).cuda()
+    state = torch.full((n_seq, H, W, 2, K), -6000.0, device="cuda")
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        warm = state.clone()  # eager call on the capture stream first: workspace, self-test and threshold table exist before the capture
+        er.encode_taf_batch(dat, offs, (H, W), warm, 0, win, n_win, K)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            u8, _ = er.encode_taf_batch(dat, offs, (H, W), state, 0, win, n_win, K, check=False)
+    want = [np.full((H, W, 2, K), -6000, np.float32) for _ in range(n_seq)]
+    for v in variants:
+        dat.copy_(cat(v).cuda())
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        for j in range(n_seq):
+            _view, want[j], ou8 = oracle_taf(orc, v[j], (H, W), K, 0, win, n_win, want[j])
+            assert_bitexact(host(state[j]), want[j], f"state of sequence {j}")
+            assert_u8_budget(host(u8[j]), ou8, 1e-5, f"uint8 of sequence {j}")
+    with torch.cuda.stream(side):
+        er.raise_deferred()
