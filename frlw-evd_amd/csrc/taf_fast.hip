@@ -772,7 +772,7 @@ __global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(MAXB > kMax
         // this call's epoch (published below, behind the reset): the first workgroup is resident before any other one starts,
         // so that wait always ends (and is bounded all the same, below).  epoch == 0: the call is being captured into a graph --
         // a host-made epoch would be baked into the node and every replay after the first would find it published already --
-        // so launch_fast_cm put a memset node in front instead and nobody resets or waits here.
+        // so launch_fast_cm put a reset kernel in front instead and nobody resets or waits here.
         uint32_t *h32 = (uint32_t *)hdr;
         for (int i = tid; i < (int)(offsetof(FastHeader, epoch) / 4); i += kFT) h32[i] = 0u;
         __threadfence();
@@ -2596,7 +2596,14 @@ void launch_fast(const FastGeom &G, const SeqTab &S, const FastPlan &p, char *w8
         hipLaunchKernelGGL((kf_scatter<HAS_MAP, EV, false>), dim3(p.chunks), dim3(kFT), lds_sc, st, G, S, counts, slabtot, base, records, hdr);
 }
 
-// the chunk-major partition: a memset node for the header (status, window masks, cursors) + ONE kernel
+// the captured form's header reset (status, window masks, cursors): see launch_fast_cm
+__global__ __launch_bounds__(256) void kf_header_reset(FastHeader *hdr)
+{
+    uint32_t *h32 = (uint32_t *)hdr;
+    for (int i = threadIdx.x; i < (int)(offsetof(FastHeader, epoch) / 4); i += 256) h32[i] = 0u;
+}
+
+// the chunk-major partition: ONE kernel (its first workgroup resets the header; a reset kernel in front of it inside a capture)
 template <bool HAS_MAP, bool EV = false>
 int launch_fast_cm(const FastGeom &G, const SeqTab &S, const FastPlan &p, char *w8, hipStream_t st)
 {
@@ -2612,8 +2619,10 @@ int launch_fast_cm(const FastGeom &G, const SeqTab &S, const FastPlan &p, char *
     if (cap != hipStreamCaptureStatusNone) {
         // inside a stream capture the kernel arguments are frozen into the graph node: a host-made epoch would already be the
         // published one on every replay after the first (workgroups could then OR their flags into the header BEFORE workgroup 0
-        // zeroes it).  A captured call resets the header with a memset node and passes epoch 0 = "nobody resets, nobody waits".
-        if (hipMemsetAsync(hdr, 0, offsetof(FastHeader, epoch), st) != hipSuccess) return FRLW_ERR_HIP;
+        // zeroes it).  A captured call resets the header with a kernel node of its own and passes epoch 0 = "nobody resets, nobody waits".
+        // (a kernel node, not hipMemsetAsync: a captured memset node of this runtime wrote a stale pattern into the header from its
+        // second replay on -- measured, tests/test_taf_fast_gpu.py::test_captured_encode_replays_against_the_oracle)
+        hipLaunchKernelGGL(kf_header_reset, dim3(1), dim3(256), 0, st, hdr);
     } else {
         epoch = g_epoch.fetch_add(1u, std::memory_order_relaxed) + 1u;
         if (epoch == 0u) epoch = g_epoch.fetch_add(1u, std::memory_order_relaxed) + 1u; // (0 = the captured form)
