@@ -1536,22 +1536,25 @@ constexpr int kWalkWaves = 8;
 constexpr int kWalkThreads = kWalkWaves * kWave;
 constexpr int kWalkRpt = 4;                 // records per lane and pass
 constexpr int kWalkChunk = kWalkRpt * kWave;
+constexpr int kWalkSlots = 4;               // ranks of a cell inside one pass that have a plane of their own
+constexpr int kWalkWaveWords = kWalkSlots * kSubCells + kSubCells / 2; // LDS words per wavefront: the planes + the ticket counters
+// (two 16-bit counters per word: 36 KB of planes and counters for the eight wavefronts -- FOUR workgroups per CU; with 32-bit
+// counters the workgroup needs 41.3 KB, three fit, and the walk ran 8 % slower although it issued fewer instructions, measured)
 
 // CMD (chunk-major partition, direct mode: the partition's bins ARE the sub-tiles): the sub-tile's list does not exist yet --
 // its runs sit in the chunks' stretches of rec[].  The workgroup reads its column of the directory, books the list's space
 // through the header's cursor, copies the runs there in chunk order (a pure copy: groups of 16 lanes take a run each) and then
 // walks the contiguous list like any other; no gather kernel, no second launch.
-constexpr int kColDirect = 2047; // chunks per sequence the walk's column fits (the space of res_sum / res_cnt)
-constexpr int kWalkListCap = 4096; // records of a sub-tile's list kept in LDS by the CMD walk (16 KB): no trip to memory between
+constexpr int kColDirect = 2047; // chunks per sequence the walk's column fits (two arrays over the wavefronts' plane areas)
+constexpr int kWalkListCap = 3584; // records of a sub-tile's list kept in LDS by the CMD walk (14 KB: three workgroups per CU): no trip to memory between
                                    // the gather and the two sweeps over the list; longer lists are copied to rec2[]
 template <bool K8, bool CMD = false>
 __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void kf_taf_walk(TileP q, CmP cm, SeqTab S)
 {
-    __shared__ uint32_t s_cnt[kWalkWaves][kSubCells / 2];   // two 16-bit ticket counters per word
-    __shared__ uint16_t s_off[kWalkWaves][kSubCells];
-    __shared__ float s_sorted[kWalkWaves][kWalkChunk];
-    __shared__ __attribute__((aligned(16))) float res_sum[kWalkWaves][kSubCells]; // the uint8 staging at the end
-    __shared__ uint32_t res_cnt[kWalkWaves][kSubCells];
+    // per wavefront: kWalkSlots planes of 256 floats (plane r, cell c = the value of the cell's r-th record of the pass; +0 when
+    // there is none) + 256 ticket counters.  The (mean, count) rows phase 2 reads lie over planes 0 and 1 of their wavefront;
+    // the CMD column and the uint8 staging at the end lie over the whole area.
+    __shared__ __attribute__((aligned(16))) uint32_t s_area[kWalkWaves][kWalkWaveWords];
     __shared__ uint32_t wstart[FRLW_MAX_WINDOWS + 1];
     __shared__ uint32_t thr[kLeakyLevels];
     __shared__ int s_unsorted;
@@ -1564,12 +1567,11 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_waves_per_eu(8,
     const int K = K8 ? 8 : q.K;
     const int NW = q.n_windows;
     for (int i = tid; i < kLeakyLevels; i += kWalkThreads) thr[i] = q.leaky_thr[i];
-    for (int i = lane; i < kSubCells / 2; i += kWave) s_cnt[wv][i] = 0u;
     uint32_t beg, end;
     const uint32_t *list = q.rec2; // where the sweeps below read the list (CMD: LDS when the list fits)
     if (CMD) {
-        uint32_t *colL = (uint32_t *)&res_sum[0][0], *colD = &res_cnt[0][0]; // (free until the first window's sums are stored)
-        static_assert(kColDirect + 1 <= kWalkWaves * kSubCells, "the column fits");
+        uint32_t *colL = &s_area[0][0], *colD = colL + (kColDirect + 1); // (free until phase 1 starts: zeroed below)
+        static_assert(2 * (kColDirect + 1) <= kWalkWaves * kWalkWaveWords, "the column fits");
         const int C = S.chunk0[s + 1] - S.chunk0[s];
         const uint32_t n = col_load<kWalkThreads>(cm, S, s, sg - s * cm.TB, colL, colD, wstart);
         const bool in_lds = n <= (uint32_t)kWalkListCap; // workgroup-uniform
@@ -1616,6 +1618,12 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_waves_per_eu(8,
     }
     for (int i = tid; i <= NW; i += kWalkThreads) wstart[i] = end;
     if (tid == 0) s_unsorted = 0;
+    {   // planes and counters start at zero (CMD: the column is dead since the barrier behind the gather)
+        uint2 *z = (uint2 *)&s_area[wv][0];
+        static_assert(kWalkWaveWords % (2 * kWave) == 0, "whole 8-byte sweeps");
+#pragma unroll
+        for (int i = 0; i < kWalkWaveWords / 2 / kWave; ++i) z[i * kWave + lane] = make_uint2(0u, 0u);
+    }
     const unsigned long long wmask = q.hdr->wmask[s];
     const bool use_mul = q.hdr->mul_bad == 0u; // checked for every r of the domain by kf_hist
     const double rcp = q.rcp;
@@ -1678,109 +1686,110 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_waves_per_eu(8,
         }
     }
 
-    uint32_t *cnt = s_cnt[wv];
-    uint16_t *off = s_off[wv];
-    float *sorted = s_sorted[wv];
+    float *rplane = (float *)&s_area[wv][0];                      // [kWalkSlots][256]
+    uint32_t *cnt = &s_area[wv][kWalkSlots * kSubCells];          // [128] two 16-bit tickets per word, all zero between passes
+    const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 #pragma nounroll
     for (int g0 = 0; g0 < NW; g0 += kWalkWaves) {
-        // ---- phase 1: wavefront wv sums window g0 + wv
+        // ---- phase 1: wavefront wv sums window g0 + wv; lane l owns cells 4 l .. 4 l + 3
         const int w = g0 + wv;
         float sum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         uint32_t num[4] = {0u, 0u, 0u, 0u};
+        if (g0 > 0) { // the (mean, count) rows of the previous round lay over planes 0 and 1
+            ((float4 *)rplane)[lane] = zero4;
+            ((float4 *)rplane)[kWave + lane] = zero4;
+        }
         if (w < NW) {
             const uint32_t lo = general ? beg : wstart[w], hi = general ? end : wstart[w + 1];
 #pragma nounroll
             for (uint32_t ptr = lo; ptr < hi; ptr += kWalkChunk) {
                 uint32_t m[kWalkRpt], rk[kWalkRpt];
+                float val[kWalkRpt];
+                // (no load under a lane condition -- each would wait for its own data: lanes behind the end re-read the last record)
 #pragma unroll
                 for (int u = 0; u < kWalkRpt; ++u) {
                     const uint32_t i = ptr + (uint32_t)(u * kWave + lane);
-                    m[u] = i < hi ? list[i] : 0xffffffffu;
+                    m[u] = list[i < hi ? i : hi - 1u];
                 }
+                // the ticket = the record's stream rank inside its cell: lanes of one returning LDS atomic are served in lane
+                // order, the four instructions of a pass are in stream order
 #pragma unroll
                 for (int u = 0; u < kWalkRpt; ++u) {
                     const bool take = ptr + (uint32_t)(u * kWave + lane) < hi && (int)((m[u] >> kCellBits) & wfield) == w;
                     rk[u] = 0xffffffffu; // not taken
-                    if (take) { // 1. the ticket = stream rank inside the cell
-                        const uint32_t lc = m[u] & 255u, sh = 16u * (lc & 1u);
+                    if (take) {
+                        const uint32_t lc = m[u] & 255u, sh = (lc & 1u) << 4;
                         rk[u] = (atomicAdd(&cnt[lc >> 1], 1u << sh) >> sh) & 0xffffu;
                     }
                 }
-                LDS_FENCE();
-                // 2. counts of my four cells (64 j + lane) -> segment offsets (cells in the order lane-major, then j)
-                uint32_t n[4], o[4];
+                // the value t - 1 with t = (t - t_min) / (w + 1e-8) in f64 (generate_taf.py:215, :26), for every lane (those
+                // without a record never store theirs)
+                if (use_mul) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) n[j] = (cnt[32 * j + (lane >> 1)] >> (16 * (lane & 1))) & 0xffffu;
-                LDS_FENCE();
+                    for (int u = 0; u < kWalkRpt; ++u) val[u] = (float)((double)(m[u] >> rshift) * rcp) - 1.0f;
+                } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (!(lane & 1)) cnt[32 * j + (lane >> 1)] = 0u; // after both lanes of the word have read it
-                {
-                    const uint32_t tl = n[0] + n[1] + n[2] + n[3];
-                    const uint32_t inc = wave_incl_scan(tl);
-                    o[0] = inc - tl; o[1] = o[0] + n[0]; o[2] = o[1] + n[1]; o[3] = o[2] + n[2];
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) off[64 * j + lane] = (uint16_t)o[j];
-                LDS_FENCE();
-                // 3. values to their slots: t - 1 with t = (t - t_min) / (w + 1e-8) in f64 (generate_taf.py:215, :26)
-#pragma unroll
-                for (int u = 0; u < kWalkRpt; ++u) {
-                    if (rk[u] != 0xffffffffu) {
+                    for (int u = 0; u < kWalkRpt; ++u) {
                         const uint32_t r = m[u] >> rshift;
-                        const float v = use_mul ? (float)((double)r * rcp) - 1.0f : q.tlut[r];
-                        sorted[(uint32_t)off[m[u] & 255u] + rk[u]] = v;
+                        val[u] = q.tlut[r < q.win ? r : q.win];
                     }
                 }
                 LDS_FENCE();
-                // 4. every lane adds its segments front to back, two slots per cell in flight
-                uint32_t nmax = n[0] > n[1] ? n[0] : n[1];
-                nmax = n[2] > nmax ? n[2] : nmax;
-                nmax = n[3] > nmax ? n[3] : nmax;
+                const uint2 np = ((const uint2 *)cnt)[lane]; // the counts of cells 4 l .. 4 l + 3
+                LDS_FENCE();
+                ((uint2 *)cnt)[lane] = make_uint2(0u, 0u);
+                const uint4 nn = make_uint4(np.x & 0xffffu, np.x >> 16, np.y & 0xffffu, np.y >> 16);
+                const uint32_t n01 = nn.x > nn.y ? nn.x : nn.y, n23 = nn.z > nn.w ? nn.z : nn.w, nmax = n01 > n23 ? n01 : n23;
+                // Ranks 0 .. 3 of every cell go straight to plane[rank][cell] (no offsets, no scan, no sorted list); the owner
+                // adds its four cells' planes front to back -- a cell without a rank-r record reads +0, and x + 0 == x for every
+                // sum that can occur (sums start at +0 and never become -0) -- and clears them.  Cells with more than four
+                // records in the pass (0.06 % at 0.7 records per cell and window) cost the wavefront further rounds of four.
 #pragma nounroll
-                for (uint32_t a = 0; __ballot(a < nmax); a += 2) {
-                    float e0[4], e1[4];
+                for (uint32_t base = 0u;;) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const uint32_t at = o[j] + a; // (a slot behind the segment's end is read and not used: any in-range address does)
-                        e0[j] = sorted[at & (uint32_t)(kWalkChunk - 1)];
-                        e1[j] = sorted[(at + 1u) & (uint32_t)(kWalkChunk - 1)];
+                    for (int u = 0; u < kWalkRpt; ++u) {
+                        const uint32_t rr = rk[u] - base; // (not taken: 0xffffffff - base stays out of range)
+                        if (rr < (uint32_t)kWalkSlots) rplane[rr * kSubCells + (m[u] & 255u)] = val[u];
                     }
+                    LDS_FENCE();
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float s0 = sum[j] + e0[j]; // sum += t - 1 in stream order, generate_taf.py:26
-                        sum[j] = a < n[j] ? s0 : sum[j];
-                        const float s1 = sum[j] + e1[j];
-                        sum[j] = a + 1 < n[j] ? s1 : sum[j];
+                    for (int r = 0; r < kWalkSlots; ++r) { // sum += t - 1 in stream order, generate_taf.py:26
+                        const float4 pr = ((const float4 *)(rplane + r * kSubCells))[lane];
+                        LDS_FENCE();
+                        ((float4 *)(rplane + r * kSubCells))[lane] = zero4;
+                        sum[0] = sum[0] + pr.x;
+                        sum[1] = sum[1] + pr.y;
+                        sum[2] = sum[2] + pr.z;
+                        sum[3] = sum[3] + pr.w;
                     }
+                    base += (uint32_t)kWalkSlots;
+                    if (__ballot(nmax > base) == 0ull) break;
                 }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) num[j] += n[j];
+                num[0] += nn.x; num[1] += nn.y; num[2] += nn.z; num[3] += nn.w;
                 LDS_FENCE();
             }
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { // the mean is taken HERE, once per (cell, window): 2048 correctly rounded divisions per workgroup
-            res_sum[wv][64 * j + lane] = fifo_mean(num[j], sum[j]); // and round of windows instead of 4096 in phase 2 (both lanes of a cell)
-            res_cnt[wv][64 * j + lane] = num[j];
-        }
+        // the mean is taken HERE, once per (cell, window): 2048 correctly rounded divisions per workgroup and round of windows
+        // instead of 4096 in phase 2 (both lanes of a cell); rows over planes 0 (means) and 1 (counts)
+        ((float4 *)rplane)[lane] = make_float4(fifo_mean(num[0], sum[0]), fifo_mean(num[1], sum[1]), fifo_mean(num[2], sum[2]), fifo_mean(num[3], sum[3]));
+        ((uint4 *)(rplane + kSubCells))[lane] = make_uint4(num[0], num[1], num[2], num[3]);
         __syncthreads();
         // ---- phase 2: one cell per lane, the FIFO steps of this round's windows in order
         if (K8) {
             float (&h4)[4] = reinterpret_cast<float (&)[4]>(st);
 #pragma nounroll
             for (int ws = 0; ws < kWalkWaves && g0 + ws < NW; ++ws) // (wave-uniform condition: every lane runs the DPP move)
-                if ((wmask >> (g0 + ws)) & 1ull) fifo_step_half(h4, half != 0, true, res_cnt[ws][cell], res_sum[ws][cell]);
+                if ((wmask >> (g0 + ws)) & 1ull) fifo_step_half(h4, half != 0, true, s_area[ws][kSubCells + cell], __uint_as_float(s_area[ws][cell]));
         } else if (owner) {
 #pragma nounroll
             for (int ws = 0; ws < kWalkWaves && g0 + ws < NW; ++ws)
-                if ((wmask >> (g0 + ws)) & 1ull) fifo_step(st, K, true, res_cnt[ws][tid], res_sum[ws][tid]);
+                if ((wmask >> (g0 + ws)) & 1ull) fifo_step(st, K, true, s_area[ws][kSubCells + tid], __uint_as_float(s_area[ws][tid]));
         }
         __syncthreads();
     }
 
     // ---- write-out: state, optional f32 view (2K, H, W), optional uint8 leaky transform (K, 2, H, W)
-    uint8_t *ob = (uint8_t *)&res_sum[0][0]; // [2K planes][128 pixels of the sub-tile]
+    uint8_t *ob = (uint8_t *)&s_area[0][0]; // [2K planes][128 pixels of the sub-tile] (the last phase 2 ended with a barrier)
     const int nslot = K8 ? 4 : kMaxK, slot0 = 4 * half; // this lane's slots: slot0 .. slot0 + nslot - 1
     if (ok) {
         if (K8) {
