@@ -1532,6 +1532,17 @@ __global__ __launch_bounds__(kFT) void kf_segcount_cm(TileP q, CmP cm, SeqTab S)
 //            (generate_taf.py:27-49), skipped for windows that are empty in the whole sequence (:40-41).
 // (ds_add_f32 would do the ordered sum in one instruction -- it applies same-address lanes in lane order with v_add_f32
 // rounding, checked by the self-test below -- but runs at 192 cycles per wave-instruction per CU: measured, not used.)
+#ifdef FRLW_WALK_PROF // developer timeline of kf_taf_walk (tools/enc_lab.cpp prints it): cycles between stamps, summed over workgroups
+constexpr int kProfWgs = 131072;
+__device__ unsigned long long g_walk_prof[kProfWgs * 9];
+#define WPROF(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pd_[i] += t_ - tp_; tp_ = t_; } while (0)
+#define WPROF_INIT() unsigned long long tp_ = __builtin_amdgcn_s_memtime(), pd_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define WPROF_END() do { if (threadIdx.x == 0 && blockIdx.x < kProfWgs) for (int i_ = 0; i_ < 9; ++i_) g_walk_prof[blockIdx.x * 9 + i_] += pd_[i_]; } while (0)
+#else
+#define WPROF(i) do { } while (0)
+#define WPROF_INIT() do { } while (0)
+#define WPROF_END() do { } while (0)
+#endif
 constexpr int kWalkWaves = 8;
 constexpr int kWalkThreads = kWalkWaves * kWave;
 constexpr int kWalkRpt = 4;                 // records per lane and pass
@@ -1562,12 +1573,23 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_waves_per_eu(8,
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int sg = blockIdx.x, g = sg / kFW, sub = sg - g * kFW;
     const int s = g / q.T, tile = g - s * q.T;
-    if (q.hdr->status != 0) return; // data-dependent error: nothing is written (the caller re-runs the general path)
+    // Everything the workgroup needs from the header and the list tables is requested in ONE go, in front of the status test:
+    // each of these is a scalar load of its own round trip, and one behind a branch waits for the one in front of it.  (The
+    // tables lie at addresses the plan fixes: reading them is safe whatever the status says; the LIST is only read behind it.)
+    const int32_t status0 = q.hdr->status;
+    const unsigned long long wmask = q.hdr->wmask[s];
+    const uint32_t mul_bad0 = q.hdr->mul_bad;
+    uint32_t beg = 0u, end = 0u;
+    if (!CMD) {
+        // (sub[] of the NEXT pair is only written if that pair went through a split kernel: take the tile's own end)
+        beg = q.sub[sg];
+        end = q.sub_end ? q.sub_end[sg] : ((sub == kFW - 1 && !q.direct) ? q.base[g + 1] : q.sub[sg + 1]);
+    }
+    if (status0 != 0) return; // data-dependent error: nothing is written (the caller re-runs the general path)
+    WPROF_INIT();
     if (q.tile_walk && q.hdr->unsorted[s] == 0u && q.base[g + 1] - q.base[g] <= q.tile_max) return; // done by kf_taf_tile
     const int K = K8 ? 8 : q.K;
     const int NW = q.n_windows;
-    for (int i = tid; i < kLeakyLevels; i += kWalkThreads) thr[i] = q.leaky_thr[i];
-    uint32_t beg, end;
     const uint32_t *list = q.rec2; // where the sweeps below read the list (CMD: LDS when the list fits)
     if (CMD) {
         uint32_t *colL = &s_area[0][0], *colD = colL + (kColDirect + 1); // (free until phase 1 starts: zeroed below)
@@ -1611,55 +1633,8 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_waves_per_eu(8,
             }
         }
         __syncthreads(); // the list is complete (and visible to the workgroup); the column's space is free again
-    } else {
-        // (sub[] of the NEXT pair is only written if that pair went through a split kernel: take the tile's own end)
-        beg = q.sub[sg];
-        end = q.sub_end ? q.sub_end[sg] : ((sub == kFW - 1 && !q.direct) ? q.base[g + 1] : q.sub[sg + 1]);
     }
-    for (int i = tid; i <= NW; i += kWalkThreads) wstart[i] = end;
-    if (tid == 0) s_unsorted = 0;
-    {   // planes and counters start at zero (CMD: the column is dead since the barrier behind the gather)
-        uint2 *z = (uint2 *)&s_area[wv][0];
-        static_assert(kWalkWaveWords % (2 * kWave) == 0, "whole 8-byte sweeps");
-#pragma unroll
-        for (int i = 0; i < kWalkWaveWords / 2 / kWave; ++i) z[i * kWave + lane] = make_uint2(0u, 0u);
-    }
-    const unsigned long long wmask = q.hdr->wmask[s];
-    const bool use_mul = q.hdr->mul_bad == 0u; // checked for every r of the domain by kf_hist
-    const double rcp = q.rcp;
-    const uint32_t wfield = (1u << q.wb) - 1u;
-    const int rshift = kCellBits + q.wb;
-    __syncthreads();
-    // ---- phase 0: first record of every window; a window index that decreases = not window-sorted
-    for (uint32_t c0 = beg; c0 < end; c0 += 4 * kWalkThreads) { // (eight clamped loads in flight, then the compares)
-        uint32_t cw[4], pw[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint32_t i = c0 + (uint32_t)(u * kWalkThreads + tid), ic = i < end ? i : end - 1u;
-            cw[u] = list[ic];
-            pw[u] = list[ic > beg ? ic - 1u : beg];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint32_t i = c0 + (uint32_t)(u * kWalkThreads + tid);
-            if (i < end) {
-                const uint32_t w = (cw[u] >> kCellBits) & wfield;
-                const uint32_t wp = i > beg ? (pw[u] >> kCellBits) & wfield : 0xffffffffu;
-                if (wp == 0xffffffffu || w != wp) {
-                    if (wp != 0xffffffffu && w < wp) s_unsorted = 1;
-                    atomicMin(&wstart[w], i);
-                }
-            }
-        }
-    }
-    __syncthreads();
-    const bool general = s_unsorted != 0;
-    if (tid == 0) { // a window without records starts where the next one does
-        if (general) atomicAdd(&q.hdr->filtered_tiles, 1u);
-        for (int w = NW - 1; w >= 0; --w) if (wstart[w] > wstart[w + 1]) wstart[w] = wstart[w + 1];
-    }
-    __syncthreads();
-
+    // (the state row is requested HERE, in front of the window scan: its trip to HBM overlaps phase 0)
     // phase-2 ownership.  K = 8: cell = tid / 2, lane half tid & 1 holds slots 4 (tid & 1) .. + 3 (all 512 threads work);
     // other K: cell = tid (< 256), the whole row in one lane.  Cell c: pixel 128 sub + c / 2 of the tile, polarity c & 1.
     const int ty = tile / q.tiles_x, tx = tile - ty * q.tiles_x;
@@ -1686,6 +1661,52 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_waves_per_eu(8,
         }
     }
 
+    for (int i = tid; i <= NW; i += kWalkThreads) wstart[i] = end;
+    if (tid == 0) s_unsorted = 0;
+    {   // planes and counters start at zero (CMD: the column is dead since the barrier behind the gather)
+        uint2 *z = (uint2 *)&s_area[wv][0];
+        static_assert(kWalkWaveWords % (2 * kWave) == 0, "whole 8-byte sweeps");
+#pragma unroll
+        for (int i = 0; i < kWalkWaveWords / 2 / kWave; ++i) z[i * kWave + lane] = make_uint2(0u, 0u);
+    }
+    const bool use_mul = mul_bad0 == 0u; // checked for every r of the domain by the partition kernel
+    const double rcp = q.rcp;
+    const uint32_t wfield = (1u << q.wb) - 1u;
+    const int rshift = kCellBits + q.wb;
+    __syncthreads();
+    WPROF(0);
+    // ---- phase 0: first record of every window; a window index that decreases = not window-sorted
+    for (uint32_t c0 = beg; c0 < end; c0 += 4 * kWalkThreads) { // (eight clamped loads in flight, then the compares)
+        uint32_t cw[4], pw[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t i = c0 + (uint32_t)(u * kWalkThreads + tid), ic = i < end ? i : end - 1u;
+            cw[u] = list[ic];
+            pw[u] = list[ic > beg ? ic - 1u : beg];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t i = c0 + (uint32_t)(u * kWalkThreads + tid);
+            if (i < end) {
+                const uint32_t w = (cw[u] >> kCellBits) & wfield;
+                const uint32_t wp = i > beg ? (pw[u] >> kCellBits) & wfield : 0xffffffffu;
+                if (wp == 0xffffffffu || w != wp) {
+                    if (wp != 0xffffffffu && w < wp) s_unsorted = 1;
+                    atomicMin(&wstart[w], i);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    WPROF(1);
+    const bool general = s_unsorted != 0;
+    if (general && tid == 0) atomicAdd(&q.hdr->filtered_tiles, 1u);
+    // wstart[w'] = first record of window w', or `end` for a window without records: window w's stretch starts at the minimum over
+    // w' >= w (a window without records starts where the next one does) -- every wavefront takes that minimum for itself over
+    // the lanes (lane = window), instead of one thread walking the table between two barriers (12 % of the workgroup's life)
+    const uint32_t first_inv = ~wstart[lane < NW ? lane : NW];
+    WPROF(2);
+
     float *rplane = (float *)&s_area[wv][0];                      // [kWalkSlots][256]
     uint32_t *cnt = &s_area[wv][kWalkSlots * kSubCells];          // [128] two 16-bit tickets per word, all zero between passes
     const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -1700,7 +1721,13 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_waves_per_eu(8,
             ((float4 *)rplane)[kWave + lane] = zero4;
         }
         if (w < NW) {
-            const uint32_t lo = general ? beg : wstart[w], hi = general ? end : wstart[w + 1];
+            uint32_t lo = beg, hi = end;
+            if (!general) {
+                lo = ~wave_max_u32(lane >= w ? first_inv : 0u);
+                hi = ~wave_max_u32(lane > w ? first_inv : 0u);
+                lo = lo < end ? lo : end;
+                hi = hi < end ? hi : end;
+            }
 #pragma nounroll
             for (uint32_t ptr = lo; ptr < hi; ptr += kWalkChunk) {
                 uint32_t m[kWalkRpt], rk[kWalkRpt];
@@ -1773,7 +1800,13 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_waves_per_eu(8,
         // instead of 4096 in phase 2 (both lanes of a cell); rows over planes 0 (means) and 1 (counts)
         ((float4 *)rplane)[lane] = make_float4(fifo_mean(num[0], sum[0]), fifo_mean(num[1], sum[1]), fifo_mean(num[2], sum[2]), fifo_mean(num[3], sum[3]));
         ((uint4 *)(rplane + kSubCells))[lane] = make_uint4(num[0], num[1], num[2], num[3]);
+        // the 256 thresholds of the leaky transform come to LDS behind phase 2 (requested here, stored in front of its barrier):
+        // at the top of the kernel the load's trip was on the path of every wavefront's first barrier
+        uint32_t thr_v = 0u;
+        if (g0 == 0 && tid < kLeakyLevels) thr_v = q.leaky_thr[tid];
+        WPROF(3);
         __syncthreads();
+        WPROF(4);
         // ---- phase 2: one cell per lane, the FIFO steps of this round's windows in order
         if (K8) {
             float (&h4)[4] = reinterpret_cast<float (&)[4]>(st);
@@ -1785,7 +1818,9 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_waves_per_eu(8,
             for (int ws = 0; ws < kWalkWaves && g0 + ws < NW; ++ws)
                 if ((wmask >> (g0 + ws)) & 1ull) fifo_step(st, K, true, s_area[ws][kSubCells + tid], __uint_as_float(s_area[ws][tid]));
         }
+        if (g0 == 0 && tid < kLeakyLevels) thr[tid] = thr_v;
         __syncthreads();
+        WPROF(5);
     }
 
     // ---- write-out: state, optional f32 view (2K, H, W), optional uint8 leaky transform (K, 2, H, W)
@@ -1829,7 +1864,9 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_waves_per_eu(8,
                 }
             }
         }
+        WPROF(6);
         __syncthreads();
+        WPROF(7);
         // the (K, 2, H, W) volume leaves plane by plane in 16-pixel pieces: one 16-byte store where the row allows
         for (int c = tid; c < 2 * K * 8; c += kWalkThreads) {
             const int pl = c >> 3, part = c & 7;
@@ -1846,6 +1883,8 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_waves_per_eu(8,
             }
         }
     }
+    WPROF(8);
+    WPROF_END();
 }
 
 // =====================================================================================================================
@@ -2497,10 +2536,6 @@ __global__ __launch_bounds__(4 * kWave) void kf_ev_sub(EvTileP q, int all_tiles,
         }
         __threadfence_block(); // (the wavefront reads back what its own lanes wrote: LDS in order; rec2[] through the fence)
         LDS_FENCE();
-    } else {
-        // (sub[] of the NEXT pair is only written if that pair went through a split kernel: take the tile's own end)
-        beg = q.sub[sg];
-        end = q.sub_end ? q.sub_end[sg] : ((sub == kFW - 1 && !q.direct) ? q.base[g + 1] : q.sub[sg + 1]);
     }
     uint32_t nx[4];
 #pragma unroll
@@ -2751,6 +2786,23 @@ int lds_order_ok(char *w8, hipStream_t st)
 } // namespace
 
 extern "C" {
+
+#ifdef FRLW_WALK_PROF
+int frlw_debug_walk_prof(unsigned long long *out16)
+{
+    static unsigned long long host[kProfWgs * 9];
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_walk_prof), sizeof(host)) != hipSuccess) return FRLW_ERR_HIP;
+    for (int i = 0; i < 16; ++i) out16[i] = 0;
+    for (int w = 0; w < kProfWgs; ++w) {
+        if (host[w * 9 + 8] == 0 && host[w * 9] == 0) continue;
+        ++out16[15];
+        for (int i = 0; i < 9; ++i) out16[i] += host[w * 9 + i];
+    }
+    void *dev = nullptr;
+    if (hipGetSymbolAddress(&dev, HIP_SYMBOL(g_walk_prof)) != hipSuccess || hipMemset(dev, 0, sizeof(host)) != hipSuccess) return FRLW_ERR_HIP;
+    return FRLW_OK;
+}
+#endif
 
 #ifdef FRLW_DEV_BUILD // not in the product library: a process-wide switch has no place in its ABI
 int frlw_debug_force_lds_order(int value)

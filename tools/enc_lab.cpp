@@ -269,6 +269,15 @@ int main(int argc, char **argv)
                    dat.size() / o.us / 1e3, alg / o.us / 1e3, o.status, (unsigned long long)fnv(o.a.data(), o.a.size()),
                    (unsigned long long)fnv(o.b.data(), o.b.size()));
             res.push_back(std::move(o));
+            if (void *fp = dlsym(L.h, "frlw_debug_walk_prof")) { // -DFRLW_WALK_PROF builds: kf_taf_walk's timeline, cycles per workgroup
+                unsigned long long pr[16];
+                if (((int (*)(unsigned long long *))fp)(pr) == 0) {
+                    printf("%-10s walk timeline (sum over all encodes incl. warm-up, s_memtime ticks):", c.name);
+                    for (int i = 0; i < 9; ++i) printf(" %llu", pr[i]);
+                    printf("  workgroups %llu", pr[15]);
+                    printf("\n");
+                }
+            }
         }
         if (c.kind == 2 && res[0].ran && libs[0].ev) {
             // reference of the batched Event Volume: the general path (frlw_ev_encode), one call per sequence
