@@ -319,6 +319,42 @@ __device__ __forceinline__ void leaky_u8_lookup_n(const float (&v)[N], const uin
     }
 }
 
+// The same step function through a bucket table (kf_taf_walk): the level changes by 20.3 per octave of 1 + x at most, so a bucket
+// of 1/32 octave of x (the float's exponent and five mantissa bits) holds at most ONE threshold.  lut[b] = the level at the
+// bucket's upper end; the level of x is lut[b] + (x <= thr[lut[b] + 1]): one byte and one word from LDS, a compare and an add --
+// no transcendental, no first guess to repair.  Buckets start at 2^-6 (everything below shares bucket 0: level 254, or 255 for
+// x = 0, which thr[255] = 0 decides) and end at 2^13 (level 0 from 6002 on).  k_leaky_fill builds lut[] from thr[] itself and
+// CHECKS the one-threshold property for every bucket on the device's own table (word kLeakyOkWord); a device whose log1pf broke
+// it would take the exact routine for every value.
+constexpr int kLeakyBucketShift = 18;                         // 5 mantissa bits
+constexpr int kLeakyBucket0 = (127 - 6) << 5;                 // bits(2^-6) >> 18
+constexpr int kLeakyBuckets = ((127 + 13) << 5) - kLeakyBucket0; // 608
+constexpr int kLeakyLutWord = kLeakyLevels;                   // lut bytes, four per word, behind the 256 thresholds
+constexpr int kLeakyOkWord = kLeakyLutWord + kLeakyBuckets / 4;
+constexpr int kLeakyTableWords = kLeakyOkWord + 1;            // 409 words: what leaky_table() points at
+
+template <int N>
+__device__ __forceinline__ void leaky_u8_bucket_n(const float (&v)[N], const uint32_t *tab, uint8_t (&out)[N])
+{
+    const uint8_t *lut = (const uint8_t *)(tab + kLeakyLutWord);
+    const bool lut_ok = tab[kLeakyOkWord] != 0u; // (uniform)
+    uint32_t xb[N], k[N], t1[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        xb[i] = __float_as_uint(fabsf(v[i]));
+        int b = (int)(xb[i] >> kLeakyBucketShift) - kLeakyBucket0;
+        b = b < 0 ? 0 : (b > kLeakyBuckets - 1 ? kLeakyBuckets - 1 : b);
+        k[i] = lut[b];
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) t1[i] = tab[k[i] + 1u];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        out[i] = (uint8_t)(k[i] + (xb[i] <= t1[i] ? 1u : 0u));
+        if (!(v[i] <= 0.0f) || !lut_ok) out[i] = leaky_u8_exact(v[i], tab); // outside the table's domain (rare), or no valid lut
+    }
+}
+
 // ---- host side ---------------------------------------------------------------------------------
 struct Plan {
     int twl, tiles_x, tiles_y, n_tiles;

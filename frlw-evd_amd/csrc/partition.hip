@@ -535,11 +535,37 @@ int partition_events(const frlw_events_t *ev, int H, int W, int kind, long long 
 
 // ---- the uint8(leaky_transform(.)) threshold table: one per device, built on first use (see frlw_common.h) -----------
 namespace {
-__device__ uint32_t g_leaky_thr[kLeakyLevels];
+__device__ uint32_t g_leaky_thr[kLeakyTableWords];
 __global__ __launch_bounds__(kLeakyLevels) void k_leaky_fill()
 {
+    __shared__ uint32_t thr[kLeakyLevels];
+    __shared__ uint8_t lut[kLeakyBuckets];
+    __shared__ int bad;
     const int t = threadIdx.x;
-    g_leaky_thr[t] = t == 0 ? 0x7f800000u : leaky_threshold_bits(t); // generate_taf.py:69-76 as a 256-level step function
+    thr[t] = t == 0 ? 0x7f800000u : leaky_threshold_bits(t); // generate_taf.py:69-76 as a 256-level step function
+    if (t == 0) bad = 0;
+    __syncthreads();
+    g_leaky_thr[t] = thr[t];
+    // the bucket table of leaky_u8_bucket_n: level(x) = the largest k with x <= thr[k] (thr is non-increasing in k)
+    auto level = [&](uint32_t xb) {
+        int lo = 0, hi = kLeakyLevels; // thr[lo] >= xb always (thr[0] = +inf); first k with thr[k] < xb is in (lo, hi]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (xb <= thr[mid]) lo = mid; else hi = mid;
+        }
+        return lo;
+    };
+    for (int b = t; b < kLeakyBuckets; b += kLeakyLevels) {
+        const uint32_t lo_x = b == 0 ? 0u : (uint32_t)(b + kLeakyBucket0) << kLeakyBucketShift;
+        const uint32_t hi_x = b == kLeakyBuckets - 1 ? 0x7f800000u : (((uint32_t)(b + kLeakyBucket0 + 1)) << kLeakyBucketShift) - 1u;
+        const int k_hi = level(hi_x), k_lo = level(lo_x);
+        lut[b] = (uint8_t)k_hi;
+        if (k_lo - k_hi > 1 || k_hi > kLeakyLevels - 2) bad = 1; // more than one threshold inside the bucket: the table is not used
+    }
+    __syncthreads();
+    for (int w = t; w < kLeakyBuckets / 4; w += kLeakyLevels)
+        g_leaky_thr[kLeakyLutWord + w] = (uint32_t)lut[4 * w] | ((uint32_t)lut[4 * w + 1] << 8) | ((uint32_t)lut[4 * w + 2] << 16) | ((uint32_t)lut[4 * w + 3] << 24);
+    if (t == 0) g_leaky_thr[kLeakyOkWord] = bad ? 0u : 1u;
 }
 struct LeakyDev { int state = 0; hipEvent_t ev = nullptr; const uint32_t *ptr = nullptr; }; // 0 never filled, 1 fill queued, 2 done
 std::mutex g_leaky_mu;

@@ -1567,9 +1567,9 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_waves_per_eu(8,
     // the CMD column and the uint8 staging at the end lie over the whole area.
     __shared__ __attribute__((aligned(16))) uint32_t s_area[kWalkWaves][kWalkWaveWords];
     __shared__ uint32_t wstart[FRLW_MAX_WINDOWS + 1];
-    __shared__ uint32_t thr[kLeakyLevels];
+    __shared__ uint32_t thr[kLeakyTableWords]; // thresholds + bucket table of the leaky transform (leaky_u8_bucket_n)
     __shared__ int s_unsorted;
-    __shared__ uint32_t s_list[CMD ? kWalkListCap : 1]; // CMD: the gathered list, when it fits (else it goes to rec2[])
+    __shared__ __attribute__((aligned(16))) uint32_t s_list[CMD ? kWalkListCap : 4]; // CMD: the gathered list, when it fits (else it goes to rec2[])
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int sg = blockIdx.x, g = sg / kFW, sub = sg - g * kFW;
     const int s = g / q.T, tile = g - s * q.T;
@@ -1675,24 +1675,38 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_waves_per_eu(8,
     const int rshift = kCellBits + q.wb;
     __syncthreads();
     WPROF(0);
-    // ---- phase 0: first record of every window; a window index that decreases = not window-sorted
-    for (uint32_t c0 = beg; c0 < end; c0 += 4 * kWalkThreads) { // (eight clamped loads in flight, then the compares)
-        uint32_t cw[4], pw[4];
+    // ---- phase 0: first record of every window; a window index that decreases = not window-sorted.  A thread looks at four
+    // consecutive records -- ONE 16-byte load from the 16-byte block they share (the list's neighbours in front of `beg` and
+    // behind `end` are read and masked: the blocks lie inside rec2[] / the LDS list) -- and at the record in front of them.
+    {
+        const uint32_t n_list = end - beg;
+        for (uint32_t c0 = beg & ~3u; c0 < end; c0 += 4 * kWalkThreads) {
+            const uint32_t i0 = c0 + 4u * (uint32_t)tid, il = i0 < end ? i0 : (end - 1u) & ~3u; // (lanes behind the end repeat the last block: harmless)
+            const uint4 v4 = *(const uint4 *)(list + il);
+            const uint32_t pv = list[il > beg ? il - 1u : beg];
+            const uint32_t w0 = __builtin_amdgcn_ubfe(v4.x, kCellBits, q.wb), w1 = __builtin_amdgcn_ubfe(v4.y, kCellBits, q.wb);
+            const uint32_t w2 = __builtin_amdgcn_ubfe(v4.z, kCellBits, q.wb), w3 = __builtin_amdgcn_ubfe(v4.w, kCellBits, q.wb);
+            const uint32_t wp = il > beg ? __builtin_amdgcn_ubfe(pv, kCellBits, q.wb) : 0xffffffffu; // the record in front (none: 0xffffffff)
+            const bool full = n_list >= 4u && il - beg <= n_list - 4u; // all four records belong to the list (unsigned: false in front of beg)
+            if (full) {
+                if (w0 != wp || w1 != w0 || w2 != w1 || w3 != w2) { // a window starts here: a handful of lanes per list
+                    if (w0 != wp) { atomicMin(&wstart[w0], il); if (wp != 0xffffffffu && w0 < wp) s_unsorted = 1; }
+                    if (w1 != w0) { atomicMin(&wstart[w1], il + 1u); if (w1 < w0) s_unsorted = 1; }
+                    if (w2 != w1) { atomicMin(&wstart[w2], il + 2u); if (w2 < w1) s_unsorted = 1; }
+                    if (w3 != w2) { atomicMin(&wstart[w3], il + 3u); if (w3 < w2) s_unsorted = 1; }
+                }
+            } else { // the blocks the list's ends lie in: record by record
+                const uint32_t ws[5] = {wp, w0, w1, w2, w3};
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint32_t i = c0 + (uint32_t)(u * kWalkThreads + tid), ic = i < end ? i : end - 1u;
-            cw[u] = list[ic];
-            pw[u] = list[ic > beg ? ic - 1u : beg];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint32_t i = c0 + (uint32_t)(u * kWalkThreads + tid);
-            if (i < end) {
-                const uint32_t w = (cw[u] >> kCellBits) & wfield;
-                const uint32_t wp = i > beg ? (pw[u] >> kCellBits) & wfield : 0xffffffffu;
-                if (wp == 0xffffffffu || w != wp) {
-                    if (wp != 0xffffffffu && w < wp) s_unsorted = 1;
-                    atomicMin(&wstart[w], i);
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t k = il + (uint32_t)e;
+                    if (k - beg < n_list) {
+                        const bool first = k == beg;
+                        if (first || ws[e + 1] != ws[e]) {
+                            atomicMin(&wstart[ws[e + 1]], k);
+                            if (!first && ws[e + 1] < ws[e]) s_unsorted = 1;
+                        }
+                    }
                 }
             }
         }
@@ -1702,9 +1716,11 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_waves_per_eu(8,
     const bool general = s_unsorted != 0;
     if (general && tid == 0) atomicAdd(&q.hdr->filtered_tiles, 1u);
     // wstart[w'] = first record of window w', or `end` for a window without records: window w's stretch starts at the minimum over
-    // w' >= w (a window without records starts where the next one does) -- every wavefront takes that minimum for itself over
-    // the lanes (lane = window), instead of one thread walking the table between two barriers (12 % of the workgroup's life)
-    const uint32_t first_inv = ~wstart[lane < NW ? lane : NW];
+    // w' >= w (a window without records starts where the next one does) -- every wavefront finds that window for itself in a
+    // ballot over the lanes (lane = window), instead of one thread walking the table between two barriers (12 % of the
+    // workgroup's life)
+    const uint32_t first_w = wstart[lane < NW ? lane : NW];
+    const unsigned long long nonempty = __ballot(lane < NW && first_w != end); // (lane = window; window-sorted list: their starts ascend)
     WPROF(2);
 
     float *rplane = (float *)&s_area[wv][0];                      // [kWalkSlots][256]
@@ -1722,11 +1738,10 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_waves_per_eu(8,
         }
         if (w < NW) {
             uint32_t lo = beg, hi = end;
-            if (!general) {
-                lo = ~wave_max_u32(lane >= w ? first_inv : 0u);
-                hi = ~wave_max_u32(lane > w ? first_inv : 0u);
-                lo = lo < end ? lo : end;
-                hi = hi < end ? hi : end;
+            if (!general) { // the first window with records at or behind w (behind w) starts the stretch (ends it); none: the list's end
+                const unsigned long long at = nonempty >> w, behind = w + 1 < 64 ? nonempty >> (w + 1) : 0ull;
+                lo = at ? (uint32_t)__builtin_amdgcn_readlane((int)first_w, w + __builtin_ctzll(at)) : end;
+                hi = behind ? (uint32_t)__builtin_amdgcn_readlane((int)first_w, w + 1 + __builtin_ctzll(behind)) : end;
             }
 #pragma nounroll
             for (uint32_t ptr = lo; ptr < hi; ptr += kWalkChunk) {
@@ -1802,8 +1817,9 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_waves_per_eu(8,
         ((uint4 *)(rplane + kSubCells))[lane] = make_uint4(num[0], num[1], num[2], num[3]);
         // the 256 thresholds of the leaky transform come to LDS behind phase 2 (requested here, stored in front of its barrier):
         // at the top of the kernel the load's trip was on the path of every wavefront's first barrier
+        static_assert(kLeakyTableWords <= kWalkThreads, "one word per thread");
         uint32_t thr_v = 0u;
-        if (g0 == 0 && tid < kLeakyLevels) thr_v = q.leaky_thr[tid];
+        if (g0 == 0 && tid < kLeakyTableWords) thr_v = q.leaky_thr[tid];
         WPROF(3);
         __syncthreads();
         WPROF(4);
@@ -1818,7 +1834,7 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_waves_per_eu(8,
             for (int ws = 0; ws < kWalkWaves && g0 + ws < NW; ++ws)
                 if ((wmask >> (g0 + ws)) & 1ull) fifo_step(st, K, true, s_area[ws][kSubCells + tid], __uint_as_float(s_area[ws][tid]));
         }
-        if (g0 == 0 && tid < kLeakyLevels) thr[tid] = thr_v;
+        if (g0 == 0 && tid < kLeakyTableWords) thr[tid] = thr_v;
         __syncthreads();
         WPROF(5);
     }
@@ -1846,7 +1862,7 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_waves_per_eu(8,
             if (K8) {
                 const float (&h4)[4] = reinterpret_cast<const float (&)[4]>(st);
                 uint8_t lv[4];
-                leaky_u8_lookup_n<4>(h4, thr, lv);
+                leaky_u8_bucket_n<4>(h4, thr, lv);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int ko = q.flip ? (7 - (slot0 + k)) : slot0 + k;
@@ -1854,7 +1870,7 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_waves_per_eu(8,
                 }
             } else {
                 uint8_t lv[kMaxK];
-                leaky_u8_lookup_n<kMaxK>(st, thr, lv); // the eight table look-ups in flight together
+                leaky_u8_bucket_n<kMaxK>(st, thr, lv); // the eight table look-ups in flight together
 #pragma unroll
                 for (int k = 0; k < kMaxK; ++k) {
                     if (k < K) {
