@@ -1634,32 +1634,24 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_waves_per_eu(8,
         }
         __syncthreads(); // the list is complete (and visible to the workgroup); the column's space is free again
     }
-    // (the state row is requested HERE, in front of the window scan: its trip to HBM overlaps phase 0)
-    // phase-2 ownership.  K = 8: cell = tid / 2, lane half tid & 1 holds slots 4 (tid & 1) .. + 3 (all 512 threads work);
-    // other K: cell = tid (< 256), the whole row in one lane.  Cell c: pixel 128 sub + c / 2 of the tile, polarity c & 1.
+    // phase-2 ownership: cell = tid (< 256), the whole K-slot row in one lane (the first four wavefronts; K = 8 used to split
+    // the row over two lanes so that all 512 threads work -- but the kernel is bound by VALU issue, and a step costs a
+    // half row's lane the same 13 instructions as a whole row's).  Cell c: pixel 128 sub + c / 2 of the tile, polarity c & 1.
     const int ty = tile / q.tiles_x, tx = tile - ty * q.tiles_x;
     const int x0 = tx << q.twl, y0 = ty << q.thl, tw1 = (1 << q.twl) - 1;
     const long long plane = (long long)q.H * q.W;
-    const int cell = K8 ? tid >> 1 : tid & (kSubCells - 1);
-    const int half = K8 ? tid & 1 : 0;
+    const int cell = tid & (kSubCells - 1);
     const int pol = cell & 1;
     const int pt = sub * (kSubCells / 2) + (cell >> 1);
     const int py = y0 + (pt >> q.twl), px = x0 + (pt & tw1);
-    const bool owner = K8 || tid < kSubCells, ok = owner && py < q.H && px < q.W;
-    float *srow = q.state + (((long long)s * plane + (long long)py * q.W + px) * 2 + pol) * K + 4 * half;
-    float st[kMaxK]; // K = 8: st[0..3] only
-#pragma unroll
-    for (int k = 0; k < kMaxK; ++k) st[k] = 0.0f;
-    if (ok) {
-        if (K8) {
-            const float4 a = ((const float4 *)srow)[0];
-            st[0] = a.x; st[1] = a.y; st[2] = a.z; st[3] = a.w;
-        } else {
-#pragma unroll
-            for (int k = 0; k < kMaxK; ++k)
-                if (k < K) st[k] = srow[k];
-        }
-    }
+    const bool owner = tid < kSubCells, ok = owner && py < q.H && px < q.W;
+    float *srow = q.state + (((long long)s * plane + (long long)py * q.W + px) * 2 + pol) * K;
+    float st[kMaxK];
+    // The state rows are needed behind phase 1 (and their registers should not be alive during it) -- but their trip to HBM should
+    // overlap the window scan: one word of every row is requested HERE (a wavefront's rows are 2 KB in a row: all its lines come
+    // in) and dropped behind phase 0; the real load then finds the lines in the caches.
+    float row_touch = 0.0f;
+    if (ok) row_touch = srow[0];
 
     for (int i = tid; i <= NW; i += kWalkThreads) wstart[i] = end;
     if (tid == 0) s_unsorted = 0;
@@ -1712,6 +1704,7 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_waves_per_eu(8,
         }
     }
     __syncthreads();
+    asm volatile("" ::"v"(row_touch)); // (the touch has landed; nothing else wants the value)
     WPROF(1);
     const bool general = s_unsorted != 0;
     if (general && tid == 0) atomicAdd(&q.hdr->filtered_tiles, 1u);
@@ -1820,19 +1813,37 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_waves_per_eu(8,
         static_assert(kLeakyTableWords <= kWalkThreads, "one word per thread");
         uint32_t thr_v = 0u;
         if (g0 == 0 && tid < kLeakyTableWords) thr_v = q.leaky_thr[tid];
+        if (g0 == 0) { // the state rows: requested behind phase 1 (their registers are not alive during it), used behind the barrier
+#pragma unroll
+            for (int kk = 0; kk < kMaxK; ++kk) st[kk] = 0.0f;
+            if (ok) {
+                if (K8) {
+                    const float4 a = ((const float4 *)srow)[0], b = ((const float4 *)srow)[1];
+                    st[0] = a.x; st[1] = a.y; st[2] = a.z; st[3] = a.w; st[4] = b.x; st[5] = b.y; st[6] = b.z; st[7] = b.w;
+                } else {
+#pragma unroll
+                    for (int kk = 0; kk < kMaxK; ++kk)
+                        if (kk < K) st[kk] = srow[kk];
+                }
+            }
+        }
         WPROF(3);
         __syncthreads();
         WPROF(4);
         // ---- phase 2: one cell per lane, the FIFO steps of this round's windows in order
-        if (K8) {
-            float (&h4)[4] = reinterpret_cast<float (&)[4]>(st);
-#pragma nounroll
-            for (int ws = 0; ws < kWalkWaves && g0 + ws < NW; ++ws) // (wave-uniform condition: every lane runs the DPP move)
-                if ((wmask >> (g0 + ws)) & 1ull) fifo_step_half(h4, half != 0, true, s_area[ws][kSubCells + cell], __uint_as_float(s_area[ws][cell]));
-        } else if (owner) {
-#pragma nounroll
-            for (int ws = 0; ws < kWalkWaves && g0 + ws < NW; ++ws)
-                if ((wmask >> (g0 + ws)) & 1ull) fifo_step(st, K, true, s_area[ws][kSubCells + tid], __uint_as_float(s_area[ws][tid]));
+        if (owner) {
+            // (the eight (count, mean) pairs are requested together, in front of the steps: a step that waits for its own pair
+            // is an LDS round trip on the workgroup's critical path, eight times)
+            uint32_t rn[kWalkWaves];
+            float rm[kWalkWaves];
+#pragma unroll
+            for (int ws = 0; ws < kWalkWaves; ++ws) {
+                rn[ws] = s_area[ws][kSubCells + tid];
+                rm[ws] = __uint_as_float(s_area[ws][tid]);
+            }
+#pragma unroll
+            for (int ws = 0; ws < kWalkWaves; ++ws)
+                if (g0 + ws < NW && ((wmask >> (g0 + ws)) & 1ull)) fifo_step(st, K, true, rn[ws], rm[ws]);
         }
         if (g0 == 0 && tid < kLeakyTableWords) thr[tid] = thr_v;
         __syncthreads();
@@ -1841,10 +1852,10 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_waves_per_eu(8,
 
     // ---- write-out: state, optional f32 view (2K, H, W), optional uint8 leaky transform (K, 2, H, W)
     uint8_t *ob = (uint8_t *)&s_area[0][0]; // [2K planes][128 pixels of the sub-tile] (the last phase 2 ended with a barrier)
-    const int nslot = K8 ? 4 : kMaxK, slot0 = 4 * half; // this lane's slots: slot0 .. slot0 + nslot - 1
     if (ok) {
         if (K8) {
             ((float4 *)srow)[0] = make_float4(st[0], st[1], st[2], st[3]);
+            ((float4 *)srow)[1] = make_float4(st[4], st[5], st[6], st[7]);
         } else {
 #pragma unroll
             for (int k = 0; k < kMaxK; ++k)
@@ -1854,29 +1865,18 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_waves_per_eu(8,
             float *vw = q.view_f32 + (long long)s * 2 * K * plane + (long long)py * q.W + px;
 #pragma unroll
             for (int k = 0; k < kMaxK; ++k)
-                if (k < nslot && slot0 + k < K) vw[(long long)(2 * (slot0 + k) + pol) * plane] = st[k]; // generate_taf.py:55
+                if (k < K) vw[(long long)(2 * k + pol) * plane] = st[k]; // generate_taf.py:55
         }
     }
     if (q.out_u8) {
         if (owner) {
-            if (K8) {
-                const float (&h4)[4] = reinterpret_cast<const float (&)[4]>(st);
-                uint8_t lv[4];
-                leaky_u8_bucket_n<4>(h4, thr, lv);
+            uint8_t lv[kMaxK];
+            leaky_u8_bucket_n<kMaxK>(st, thr, lv); // the eight table look-ups in flight together
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int ko = q.flip ? (7 - (slot0 + k)) : slot0 + k;
-                    ob[(2 * ko + pol) * (kSubCells / 2) + (cell >> 1)] = lv[k];
-                }
-            } else {
-                uint8_t lv[kMaxK];
-                leaky_u8_bucket_n<kMaxK>(st, thr, lv); // the eight table look-ups in flight together
-#pragma unroll
-                for (int k = 0; k < kMaxK; ++k) {
-                    if (k < K) {
-                        const int ko = q.flip ? (K - 1 - k) : k;
-                        ob[(2 * ko + pol) * (kSubCells / 2) + (tid >> 1)] = lv[k];
-                    }
+            for (int k = 0; k < kMaxK; ++k) {
+                if (k < K) {
+                    const int ko = q.flip ? (K - 1 - k) : k;
+                    ob[(2 * ko + pol) * (kSubCells / 2) + (tid >> 1)] = lv[k];
                 }
             }
         }
@@ -2552,6 +2552,10 @@ __global__ __launch_bounds__(4 * kWave) void kf_ev_sub(EvTileP q, int all_tiles,
         }
         __threadfence_block(); // (the wavefront reads back what its own lanes wrote: LDS in order; rec2[] through the fence)
         LDS_FENCE();
+    } else {
+        // (sub[] of the NEXT pair is only written if that pair went through a split kernel: take the tile's own end)
+        beg = q.sub[sg];
+        end = q.sub_end ? q.sub_end[sg] : ((sub == kFW - 1 && !q.direct) ? q.base[g + 1] : q.sub[sg + 1]);
     }
     uint32_t nx[4];
 #pragma unroll
