@@ -2685,7 +2685,7 @@ int launch_fast_cm(const FastGeom &G, const SeqTab &S, const FastPlan &p, char *
         // published one on every replay after the first (workgroups could then OR their flags into the header BEFORE workgroup 0
         // zeroes it).  A captured call resets the header with a kernel node of its own and passes epoch 0 = "nobody resets, nobody waits".
         // (a kernel node, not hipMemsetAsync: a captured memset node of this runtime wrote a stale pattern into the header from its
-        // second replay on -- measured, tests/test_taf_fast_gpu.py::test_captured_encode_replays_against_the_oracle)
+        // second replay on -- measured; tests/test_taf_fast_gpu.py replays a captured encode three times)
         hipLaunchKernelGGL(kf_header_reset, dim3(1), dim3(256), 0, st, hdr);
     } else {
         epoch = g_epoch.fetch_add(1u, std::memory_order_relaxed) + 1u;

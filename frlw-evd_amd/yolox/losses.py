@@ -263,6 +263,9 @@ class _YoloxLoss(torch.autograd.Function):
         return (None, None, None, None, *[g.permute(0, 3, 1, 2) for g in grads])
 
 
+NATIVE_MAX_ANCHORS = 150 * 1024 // 16  # 9600: what frlw_simota_assign / frlw_yolox_loss_fwd accept (FRLW_ERR_UNSUPPORTED above)
+
+
 def yolox_losses_native(level_outputs, strides, labels, num_classes, radius):
     """The tuple of ``yolox_losses`` from the native loss (ROCm tensors): seven launches forward, one backward."""
     res = _YoloxLoss.apply(labels, tuple(strides), int(num_classes), float(radius), *level_outputs)
@@ -275,7 +278,11 @@ def yolox_losses(level_outputs, strides, labels, num_classes, radius):
     Returns (loss, 5 * loss_iou, loss_obj, loss_cls, loss_l1 = 0.0, num_fg / num_gt).  On ROCm tensors the whole
     loss -- decode, assignment, the three terms and their gradient -- runs in the HIP library (``_YoloxLoss``); on CPU
     tensors -- the gloo tests and the golden checks -- it is the reference's per-image procedure."""
-    if level_outputs[0].is_cuda and not (_FORCE_LOOP or _FORCE_TORCH_LOSS) and len(level_outputs) <= 4:
+    n_anchors = sum(int(o.shape[2]) * int(o.shape[3]) for o in level_outputs)
+    # (the native assignment keeps an image's IoU and cost rows of one box in LDS: 2 * A * 8 bytes <= 150 KB, csrc/simota.hip; a
+    # 720 x 1280 input has 18 900 anchors -- such shapes take the reference's per-image procedure below instead of aborting)
+    fits = n_anchors <= NATIVE_MAX_ANCHORS
+    if level_outputs[0].is_cuda and not (_FORCE_LOOP or _FORCE_TORCH_LOSS) and len(level_outputs) <= 4 and fits:
         return yolox_losses_native(level_outputs, strides, labels, num_classes, radius)
     outs, xs, ys, ss = [], [], [], []
     for o, stride in zip(level_outputs, strides):
@@ -286,7 +293,7 @@ def yolox_losses(level_outputs, strides, labels, num_classes, radius):
         ss.append(_level_grid(o.shape[2], o.shape[3], stride, o.device, o.dtype)[1])
     outputs = torch.cat(outs, 1)
     x_shifts, y_shifts, strides_all = torch.cat(xs, 1), torch.cat(ys, 1), torch.cat(ss, 1)
-    if outputs.is_cuda and not _FORCE_LOOP:
+    if outputs.is_cuda and not _FORCE_LOOP and fits:
         return yolox_losses_batched(outputs, x_shifts, y_shifts, strides_all, labels, num_classes, radius)
     bbox_preds = outputs[:, :, :4]
     obj_preds = outputs[:, :, 4].unsqueeze(-1)

@@ -35,17 +35,16 @@ class model(nn.Module):
         return torch.cat([o.flatten(start_dim=2) for o in outs], dim=2).permute(0, 2, 1)
 
     def _weights_signature(self):
-        """Identity + in-place version of every parameter and buffer: changes on optimizer steps, load_state_dict(),
-        BatchNorm running-statistics updates and .to() / .cuda()."""
-        ts = self.__dict__.get("_sig_tensors")
-        calls = self.__dict__["_sig_calls"] = self.__dict__.get("_sig_calls", 0) + 1
-        if ts is None or calls % 32 == 0:
-            # The module tree is walked once per engine lifetime and then every 32nd eval forward: train() / _apply() /
-            # load_state_dict() on THIS module drop the cache, but a tensor can also be replaced behind its back
-            # (`net.backbone.cuda()`, a new nn.Parameter assigned to a sub-module, a parametrization) -- the periodic walk
-            # notices the new objects within 32 forwards instead of never.
-            ts = self.__dict__["_sig_tensors"] = list(self.parameters()) + list(self.buffers())
-        return tuple((id(t), t.data_ptr(), t._version) for t in ts)
+        """Identity + in-place version of every parameter and buffer the module tree holds NOW: changes on optimizer steps,
+        load_state_dict(), BatchNorm running-statistics updates, .to() / .cuda() -- and when a tensor is replaced behind this
+        module's back (``net.backbone.cuda()``, a new ``nn.Parameter`` assigned to a sub-module, a parametrization).  The tree is
+        walked on EVERY call (about 440 tensors: ~0.2 ms beside a forward of milliseconds): a cached tensor list keeps the ids of
+        the OLD objects alive and valid, so a replaced tensor would go unnoticed -- until round 4 for up to 31 forwards."""
+        return tuple((id(t), t.data_ptr(), t._version) for t in self._state_tensors())
+
+    def _state_tensors(self):
+        yield from self.parameters()
+        yield from self.buffers()
 
     def engine(self):
         """The gfx950 engine for the CURRENT weights.  The engine folds BatchNorm into the convolutions and keeps its
@@ -61,7 +60,6 @@ class model(nn.Module):
     def drop_engine(self):
         self._engine = None
         self._engine_sig = None
-        self.__dict__.pop("_sig_tensors", None)  # (.to() / .cuda() / load_state_dict(assign=True) may replace the tensors)
 
     def _apply(self, fn, *a, **k):  # .to() / .cuda() / .float(): new tensors
         self.drop_engine()
@@ -80,7 +78,6 @@ class model(nn.Module):
         d = self.__dict__.copy()
         d["_engine"] = None
         d["_engine_sig"] = None
-        d.pop("_sig_tensors", None)
         return d
 
     def detect(self, x):

@@ -241,11 +241,40 @@ def main_nms():
     print("detector_nms.npz", os.path.getsize(os.path.join(HERE, "detector_nms.npz")) // 1024, "KiB")
 
 
+def main_b32():
+    """BASELINE.json configs[3] at its full size: B = 32, (10, 256, 320), recipe weights, eval -- the REFERENCE's modules on
+    torch-CPU fp32 (373 GFLOP: a minute or two on eight threads).  The (32, 1680, 7) head tensor is kept as its sha256, its
+    per-channel |max|, three whole images and 8192 sampled values, so that the GPU engine at the bench configuration is held to
+    the reference itself and not to another GPU library (core/yolox/models/yolo_head.py:209-235)."""
+    import hashlib
+    chans = [128, 256, 512]
+    ref = RefModel(CSPDarknet(10, 0.33, 0.5, stem=Focus),
+                   YOLOPAFPN(0.33, in_features=["dark3", "dark4", "dark5"], in_channels=chans, act="silu"), None,
+                   YOLOXHead(2, in_channels=chans, act="silu", strides=[8, 16, 32], radius=5))
+    ref.load_state_dict(recipe_state_dict(build_yolox(10, 2), seed=1004))
+    ref.eval()
+    x = detector_input(1004, 32, 10)
+    with torch.no_grad():
+        ref.head.decode_in_inference = False
+        raw = ref.head(ref.neck(ref.backbone(x[..., 0]))).numpy()
+    assert raw.shape == (32, 1680, 7) and raw.dtype == np.float32
+    idx = np.sort(np.random.default_rng(3204).choice(raw.size, size=8192, replace=False))
+    out = {"b32_shape": np.array(raw.shape), "b32_sha": np.array(hashlib.sha256(raw.tobytes()).hexdigest()),
+           "b32_absmax": np.abs(raw).reshape(-1, 7).max(axis=0), "b32_idx": idx, "b32_val": raw.reshape(-1)[idx],
+           "b32_images": np.array([0, 7, 31]), "b32_img": raw[[0, 7, 31]]}
+    np.savez_compressed(os.path.join(HERE, "detector_b32.npz"), **out)
+    print("detector_b32.npz", os.path.getsize(os.path.join(HERE, "detector_b32.npz")) // 1024, "KiB")
+
+
 if __name__ == "__main__":
+    if "--b32-only" in sys.argv:
+        main_b32()
+        sys.exit(0)
     if "--nms-only" in sys.argv:
         main_nms()
         sys.exit(0)
     if "--bfm-only" not in sys.argv:
         main()
         main_nms()
+        main_b32()
     main_bfm()

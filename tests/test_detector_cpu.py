@@ -157,3 +157,23 @@ def test_decode_outputs_vs_reference_postprocessing(golden_dir, case):
     assert np.array_equal(torch.cat(dets).numpy(), g[f"{case}_dets"])  # same f32 statements -> same bits
     if case == "craft":
         assert dets[1].shape == (1, 6) and float(dets[1].abs().sum()) == 0.0 and counts[2] == 3
+
+
+def test_weights_signature_sees_tensors_replaced_behind_the_module():
+    """yolox/model.py: the eval engine is rebuilt whenever the signature of the module tree's tensors changes.  A tensor replaced
+    on a SUB-module (a new nn.Parameter, ``net.backbone.to(...)``) never passes through the top module's ``_apply`` /
+    ``load_state_dict``: the signature must be taken from the tree as it is now, on every call (the reference folds nothing,
+    so its forward always sees the current weights: core/yolox/models/yolo_head.py:209-235)."""
+    from frlw_evd_amd.yolox import build_yolox
+    net = build_yolox(10, 2).eval()
+    sig0 = net._weights_signature()
+    assert net._weights_signature() == sig0
+    conv = net.backbone.backbone.stem.conv.conv if hasattr(net.backbone, "backbone") else net.backbone.stem.conv.conv
+    conv.weight = torch.nn.Parameter(conv.weight.detach().clone() * 2)  # a new object behind the top module's back
+    sig1 = net._weights_signature()
+    assert sig1 != sig0, "a replaced parameter must change the signature on the very next call"
+    with torch.no_grad():
+        conv.weight.mul_(0.5)  # in place: the version counter moves
+    assert net._weights_signature() != sig1
+    net.head.double()  # a sub-module's _apply: new tensors for its parameters, the top module is not asked
+    assert net._weights_signature() != sig1

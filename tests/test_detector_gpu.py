@@ -118,6 +118,31 @@ def test_batch_32_vs_torch_gpu(gpu):
     assert torch.equal(again, m.engine().raw_outputs(x[..., 0]))  # deterministic run to run
 
 
+def test_batch_32_vs_reference_golden(gpu, golden_dir):
+    """BASELINE.json configs[3] at full size against the REFERENCE's own torch-CPU fp32 forward (tests/golden/detector_b32.npz,
+    make_golden_detector.py::main_b32; yolo_head.py:209-235): three whole images and 8192 sampled values of the (32, 1680, 7) head
+    tensor, max-abs-err / max-abs-ref <= 1e-3 over the tensor and per output channel, observed ~1e-5."""
+    g = np.load(os.path.join(golden_dir, "detector_b32.npz"))
+    m = build_yolox(10, 2)
+    m.load_state_dict(recipe_state_dict(m, seed=1004))
+    m.eval().to(gpu)
+    x = detector_input(1004, 32).to(gpu)
+    raw = m.engine().raw_outputs(x[..., 0]).cpu().numpy()
+    assert raw.shape == tuple(g["b32_shape"])
+    absmax = g["b32_absmax"]
+    imgs = raw[g["b32_images"]]
+    err_img = np.abs(imgs - g["b32_img"])
+    assert err_img.max() <= TOL * absmax.max(), err_img.max() / absmax.max()
+    for c in range(raw.shape[-1]):  # every head output channel on its own scale
+        assert err_img[..., c].max() <= TOL * absmax[c], (c, err_img[..., c].max() / absmax[c])
+    got = raw.reshape(-1)[g["b32_idx"]]
+    chan = g["b32_idx"] % raw.shape[-1]
+    rel = np.abs(got - g["b32_val"]) / absmax[chan]
+    assert rel.max() <= TOL, rel.max()
+    print(f"B = 32 head tensor vs the reference's CPU fp32 forward: worst per-channel relative error {max(rel.max(), (err_img / absmax).max()):.2e}")
+    assert max(rel.max(), (err_img / absmax).max()) <= 5e-5  # observed (float32 MFMA; the opt-in bf16x3 arithmetic is held to TOL above)
+
+
 def test_other_resolution(gpu):
     """1 Mpx detector shape is 512 x 640 (settings.py:22-25); here a smaller multiple of 32 with 7 classes."""
     m = build_yolox(10, 7)
@@ -345,6 +370,36 @@ def test_native_loss_equals_autograd_loss(gpu, seed, B, nc):
         assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())
         assert rel_err(a, b) <= 1e-6
     assert any(float(g[:, :4].abs().max()) > 0 for g in gwant)  # box gradients are exercised
+
+
+def test_loss_above_the_native_anchor_limit_takes_the_per_image_procedure(gpu):
+    """The native assignment keeps two float64 rows of A anchors in LDS (A <= 9600, csrc/simota.hip: FRLW_ERR_UNSUPPORTED above).
+    A 736 x 1280 input has 19 320 anchors: ``yolox_losses`` must not abort there -- it takes the reference's per-image
+    procedure (yolo_head.py:305-473) -- and the value equals that procedure forced on the same tensors."""
+    from frlw_evd_amd.yolox import losses
+    rng = np.random.default_rng(77)
+    shapes = [(92, 160), (46, 80), (23, 40)]
+    assert sum(h * w for h, w in shapes) > losses.NATIVE_MAX_ANCHORS
+    level = [torch.from_numpy(rng.normal(0, 0.5, size=(1, 7, h, w)).astype(np.float32)).to(gpu) for h, w in shapes]
+    labels = torch.zeros((1, 80, 5), dtype=torch.float64, device=gpu)
+    labels[0, 0] = torch.tensor([1.0, 400.0, 300.0, 120.0, 90.0])
+    labels[0, 1] = torch.tensor([0.0, 900.0, 500.0, 60.0, 200.0])
+
+    def run(force_loop):
+        leaves = [o.clone().requires_grad_(True) for o in level]
+        try:
+            losses._FORCE_LOOP = force_loop
+            tup = losses.yolox_losses(leaves, [8, 16, 32], labels, 2, 5.0)
+        finally:
+            losses._FORCE_LOOP = False
+        tup[0].backward()
+        return [float(torch.as_tensor(v).detach()) for v in tup], [l.grad for l in leaves]
+
+    got, ggot = run(False)
+    want, gwant = run(True)
+    assert got == pytest.approx(want, rel=1e-12) and want[0] > 0 and want[5] > 0
+    for a, b in zip(ggot, gwant):
+        assert torch.equal(a, b)
 
 
 def test_native_loss_without_any_label(gpu):

@@ -1,7 +1,7 @@
 """The four offline harnesses end to end on the GPU (frlw_evd_amd/generate.py, the root ``generate_*.py`` commands) against
 the files the REFERENCE's scripts wrote for the same fabricated dataset (tests/golden/harness.npz, make_golden_harness.py):
 same output tree, same file names; Event Count Image and Event Volume bit for bit (sha256), SAE and TAF -- behind ``exp`` /
-``log1p`` of different math libraries -- within 1 LSB in <= 1e-4 of the bytes (row sums + 32 768 sampled bytes per file, the
+``log1p`` of different math libraries -- within 1 LSB in <= 1e-5 of the bytes, SURVEY.md 8(c) L2 (row sums + 32 768 sampled bytes per file, the
 three TAF files kept in full byte by byte), including the TAF label that rounds onto its predecessor (``bins == 0``,
 generate_taf.py:181, :226-227: the stale volume is transformed twice)."""
 import hashlib
@@ -17,7 +17,7 @@ import harness_data
 torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-U8_BUDGET = 1e-4
+U8_BUDGET = 1e-5  # <= 1e-5 of the elements, by exactly 1 LSB (observed counts are printed: run with -s)
 
 
 @pytest.fixture(scope="module")
@@ -55,21 +55,27 @@ def test_transcendental_harnesses(dataset, golden_dir, tmp_path, key, fn):
     files = _files(target)
     assert files == list(g[key + "/files"]) and n == len(files)
     exact = 0
+    seen_bytes = seen_diff = 0  # over every byte the golden holds (the row sums cover ALL bytes: |difference of a row sum| counts them)
     for i, (rel, want) in enumerate(zip(files, g[key + "/sha"])):
         data = np.fromfile(os.path.join(target, rel), dtype=np.uint8)
+        seen_bytes += data.size
         if hashlib.sha256(data.tobytes()).hexdigest() == str(want):
             exact += 1
             continue
-        budget = max(1, int(U8_BUDGET * data.size))
+        budget = max(1, int(U8_BUDGET * data.size))  # of the whole file
         pos = harness_data.sample_positions(data.size)
         d = np.abs(data[pos].astype(np.int16) - g[f"{key}/sample_{i}"].astype(np.int16))
-        assert d.max() <= 1 and int((d != 0).sum()) <= budget, (rel, int(d.max()), int((d != 0).sum()))
+        assert d.max() <= 1 and int((d != 0).sum()) <= max(1, int(np.ceil(U8_BUDGET * pos.size))), (rel, int(d.max()), int((d != 0).sum()))
         rows = data.reshape(-1, 320).astype(np.int64).sum(axis=1)
         dr = np.abs(rows - g[f"{key}/rowsum_{i}"])
         assert int(dr.sum()) <= budget and dr.max() <= 2, (rel, int(dr.sum()), int(dr.max()))
+        seen_diff += int(dr.sum())
         if f"{key}/data_{i}" in g:
             full = np.abs(data.astype(np.int16) - g[f"{key}/data_{i}"].astype(np.int16))
             assert full.max() <= 1 and int((full != 0).sum()) <= budget, (rel, int(full.max()), int((full != 0).sum()))
+    print(f"{key}: {exact} of {len(files)} files byte-identical; {seen_diff} of {seen_bytes} bytes differ by 1 LSB "
+          f"({seen_diff / max(1, seen_bytes):.2e}; budget {U8_BUDGET:g})")
+    assert seen_diff <= max(1, int(U8_BUDGET * seen_bytes))
     assert exact >= len(files) // 2, f"only {exact} of {len(files)} files are byte-identical"
 
 
