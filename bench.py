@@ -563,11 +563,15 @@ def bench_also(args, torch, synth, er, timer, rank, n_gpus, copy_gbs):
     ev4 = synth.synth_events(1002 + 7919 * rank, 1_000_000, W2, H2, 250_000)
     rec4 = synth.to_dat8(ev4)
     dat4 = torch.from_numpy(rec4.view(np.uint8).reshape(-1, 8)).cuda()
-    per, dev = timer.run(lambda: er.encode_ev_dat(dat4, (H2, W2), 250_000, 250_000, volume_bins=5, check=False), steps, 3)
+    er.encode_ev_dat(dat4, (H2, W2), 250_000, 250_000, volume_bins=5, check=True, fast=True)  # data-dependent status: clean
+    per, dev = timer.run(lambda: er.encode_ev_dat(dat4, (H2, W2), 250_000, 250_000, volume_bins=5, check=False, fast=True), steps, 3)
     row = {"workload": "ev_gen1 (BASELINE.json configs[1]): Event Volume 5 bins, 1000000 events, 304x240, ONE stream",
            "value": round(n_gpus * 1_000_000 / per / 1e6, 2), "unit": "Mevents/s", "ms_per_step": round(per * 1e3, 4),
-           "roofline": roofline(ev_algorithmic_bytes(1_000_000, H2, W2, 5), dev, "frlw_ev_encode (k_ev_tile dominant)", copy_gbs,
+           "roofline": roofline(ev_algorithmic_bytes(1_000_000, H2, W2, 5), dev,
+                                "frlw_ev_encode_batch, one window, direct mode = kf_scatter_cm + kf_ev_fadd (two launches)", copy_gbs,
                                 "1000000 events")}
+    pg, dg = timer.run(lambda: er.encode_ev_dat(dat4, (H2, W2), 250_000, 250_000, volume_bins=5, check=False, fast=False), steps, 3)
+    row["general_path"] = {"ms_per_step": round(pg * 1e3, 4), "device_ms": round(dg, 4), "kernel": "frlw_ev_encode (five launches)"}
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         row["cpu_baseline"] = cpu_baseline_ev(rec4, H2, W2)
     out.append(row)

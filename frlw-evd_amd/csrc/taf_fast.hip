@@ -2380,28 +2380,33 @@ __device__ __forceinline__ void ev_pass(const WavePass &P, const uint32_t (&pm)[
     LDS_FENCE();
 }
 
+// the cells 64 j + lane of a sub-tile: scale (generate_eventvolume.py:37) and write both outputs
 template <int BINS>
-__device__ __forceinline__ void ev_store(const EvTileP &q, int s, int tile, int sub, int lane, const float (&acc)[4][BINS])
+__device__ __forceinline__ void ev_store_cells(const EvTileP &q, int s, int tile, int sub, int lane, int j, const float (&acc)[BINS])
 {
     const int ty = tile / q.tiles_x, tx = tile - ty * q.tiles_x;
     const int x0 = tx << q.twl, y0 = ty << q.thl, tw1 = (1 << q.twl) - 1;
     const long long plane = (long long)q.H * q.W;
     const int pol = lane & 1, ch = pol ? 0 : 1; // weights [p, 1 - p]: channel 0 = p == 1
+    const int pt = sub * (kSubCells / 2) + 32 * j + (lane >> 1); // cell 64 j + lane = pixel 32 j + lane / 2, polarity lane & 1
+    const int py = y0 + (pt >> q.twl), px = x0 + (pt & tw1);
+    if (py >= q.H || px >= q.W) return;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int pt = sub * (kSubCells / 2) + 32 * j + (lane >> 1); // cell 64 j + lane = pixel 32 j + lane / 2, polarity lane & 1
-        const int py = y0 + (pt >> q.twl), px = x0 + (pt & tw1);
-        if (py >= q.H || px >= q.W) continue;
-#pragma unroll
-        for (int k = 0; k < BINS; ++k) {
-            if (k < q.bins) {
-                const float v = acc[j][k] / 5.0f * 255.0f; // generate_eventvolume.py:37
-                const long long idx = ((long long)s * 2 * q.bins + (2 * k + ch)) * plane + (long long)py * q.W + px;
-                if (q.out_f32) q.out_f32[idx] = v;
-                if (q.out_u8) q.out_u8[idx] = f32_to_u8(v > 255.0f ? 255.0f : v);
-            }
+    for (int k = 0; k < BINS; ++k) {
+        if (k < q.bins) {
+            const float v = acc[k] / 5.0f * 255.0f; // generate_eventvolume.py:37
+            const long long idx = ((long long)s * 2 * q.bins + (2 * k + ch)) * plane + (long long)py * q.W + px;
+            if (q.out_f32) q.out_f32[idx] = v;
+            if (q.out_u8) q.out_u8[idx] = f32_to_u8(v > 255.0f ? 255.0f : v);
         }
     }
+}
+
+template <int BINS>
+__device__ __forceinline__ void ev_store(const EvTileP &q, int s, int tile, int sub, int lane, const float (&acc)[4][BINS])
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ev_store_cells<BINS>(q, s, tile, sub, lane, j, acc[j]);
 }
 
 // One workgroup = NW sub-tiles of one (sequence, tile) pair; see the section header.
@@ -2577,6 +2582,135 @@ __global__ __launch_bounds__(4 * kWave) void kf_ev_sub(EvTileP q, int all_tiles,
         ev_pass<BINS>(P, pm, lane, q, use_mul, rcp, binsf, acc);
     }
     ev_store<BINS>(q, s, tile, sub, lane, acc);
+}
+
+// Small direct-mode calls (ONE label window of a GEN1-shaped stream: 576 sub-tile lists of ~1 700 records): kf_ev_sub's ticket
+// sort is built for throughput and leaves such a call on a latency chain of seven dependent passes per wavefront (30 us).  Here
+// the sums are made by the LDS itself: ds_add_f32 applies the lanes of one instruction that hit one address in ascending lane
+// order with the rounding of v_add_f32 (fact 2 of DESIGN.md 3.2; the library's self-test checks it on the first call and this
+// kernel is only used where it held), a wavefront's instructions are served in program order -- so one wavefront that feeds its
+// list through `acc[bin][cell] += weight` 64 records at a time makes exactly the reference's sequential sums
+// (generate_eventvolume.py:28-32), without tickets, scans or segment walks.  It costs 192 cycles per instruction and CU (3 x the
+// ticket scheme per record), which is why only small calls come here.  Four wavefronts share a sub-tile: they gather its list
+// together, and then EACH walks the whole list but adds only into the bins k with k % 4 == its index -- every (cell, bin) sum
+// stays one wavefront's chain in stream order, and the four chains of atomics run side by side.
+// An event adds to the two bins around t* = bins * float(t): records of one instruction whose floor(t*) differ are issued run by
+// run (equal floors, lane order), because the upper weight of an earlier record and the lower weight of a later one can meet in
+// one bin -- a time-sorted stream has one run per instruction except at the five slice boundaries.
+constexpr int kFaddWaves = 4; // wavefronts per sub-tile: they gather the list together, then wavefront w owns the bins k with k % 4 == w
+template <int BINS>
+__global__ __launch_bounds__(kFaddWaves *kWave) void kf_ev_fadd(EvTileP q, CmP cm, SeqTab S)
+{
+    constexpr int NT = kFaddWaves * kWave;
+    __shared__ float s_acc[BINS][kSubCells];
+    __shared__ uint32_t s_colL[kColEv + 1], s_colD[kColEv], s_wsum[kFaddWaves + 1];
+    __shared__ uint32_t s_list[kEvListCap];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int sg = blockIdx.x;
+    if (sg >= q.pairs * kFW || q.hdr->status != 0) return;
+    const int g = sg / kFW, sub = sg - g * kFW;
+    const int s = g / q.T, tile = g - s * q.T;
+    const bool use_mul = q.hdr->mul_bad == 0u;
+    const double rcp = q.rcp;
+    const float binsf = (float)q.bins;
+    for (int i = tid; i < BINS * kSubCells; i += NT) (&s_acc[0][0])[i] = 0.0f;
+    // the list: this sub-tile's runs in the chunks' stretches of rec[] (the column of the directory, then groups of 16 lanes
+    // copy a run each: what kf_ev_sub<BINS, true> does with one wavefront, here with four)
+    const int c0 = S.chunk0[s], C = S.chunk0[s + 1] - c0, b = sg - s * cm.TB;
+    const uint32_t out0 = (uint32_t)(S.ev0[s] - S.ev0[0]);
+    uint32_t n = 0;
+    for (int cb = 0; cb < C; cb += NT) { // (workgroup-uniform trip count; C <= kColEv)
+        const int c = cb + tid;
+        const uint32_t v = cm.dir[(long long)(c0 + (c < C ? c : C - 1)) * cm.TB + b];
+        const uint32_t e = c < C ? v : 0u, cnt = e >> 16;
+        const uint32_t inc = wave_incl_scan(cnt);
+        if (lane == kWave - 1) s_wsum[wv] = inc;
+        __syncthreads();
+        uint32_t pre = 0, all = 0;
+#pragma unroll
+        for (int k = 0; k < kFaddWaves; ++k) { if (k < wv) pre += s_wsum[k]; all += s_wsum[k]; }
+        const uint32_t run = n + pre + inc - cnt;
+        if (c < C) { s_colL[c] = run; s_colD[c] = out0 + (uint32_t)c * (uint32_t)cm.chunk_ev + (e & 0xffffu) - run; }
+        n += all;
+        __syncthreads();
+    }
+    if (tid == 0) s_colL[C] = n;
+    uint32_t beg = 0u;
+    uint32_t *dstl = s_list;
+    const uint32_t *list = s_list;
+    if (n > (uint32_t)kEvListCap) { // (workgroup-uniform) a list too long for LDS goes through rec2[]
+        if (tid == 0) s_wsum[kFaddWaves] = atomicAdd(&q.hdr->rec_cursor, n);
+        __syncthreads();
+        beg = s_wsum[kFaddWaves];
+        dstl = const_cast<uint32_t *>(q.rec2) + beg;
+        list = q.rec2;
+    }
+    __syncthreads();
+    const uint32_t end = beg + n;
+    {
+        const int g16 = tid >> 4, l16 = tid & 15;
+        constexpr int RU = 10, NG = NT / 16;
+        for (int cc0 = g16; cc0 < C; cc0 += NG * RU) { // groups of 16 lanes, ten runs each per step (one step for the 144 chunks of a
+                                                       // GEN1 stream): the loads first, then the stores
+            uint32_t v[RU], at[RU], cnt[RU];
+#pragma unroll
+            for (int u = 0; u < RU; ++u) {
+                const int c = cc0 + NG * u, cc = c < C ? c : C - 1;
+                const uint32_t lo = s_colL[cc];
+                cnt[u] = c < C ? s_colL[cc + 1] - lo : 0u;
+                at[u] = lo;
+                v[u] = cm.rec[s_colD[cc] + lo + ((uint32_t)l16 < cnt[u] ? (uint32_t)l16 : 0u)];
+            }
+#pragma unroll
+            for (int u = 0; u < RU; ++u) {
+                if ((uint32_t)l16 < cnt[u]) dstl[at[u] + l16] = v[u];
+                if (cnt[u] > 16u) {
+                    const uint32_t d = s_colD[cc0 + NG * u];
+                    for (uint32_t j = 16u + l16; j < cnt[u]; j += 16u) dstl[at[u] + j] = cm.rec[d + at[u] + j];
+                }
+            }
+        }
+    }
+    __syncthreads(); // the list is complete (LDS, or rec2[] written and read on this CU)
+    // every wavefront walks the whole list in stream order and adds into ITS bins only: a (cell, bin) sum is one wavefront's chain
+    float *accl = &s_acc[0][0];
+    for (uint32_t p0 = beg; p0 < end; p0 += 4 * kWave) {
+        uint32_t pm[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { // (four instructions' records in flight; clamped index, masked below)
+            const uint32_t i = p0 + (uint32_t)(u * kWave + lane);
+            pm[u] = list[i < end ? i : end - 1u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool valid = p0 + (uint32_t)(u * kWave + lane) < end;
+            const uint32_t r = pm[u] >> kCellBits, cell = pm[u] & 255u;
+            const float tn = use_mul ? (float)((double)r * rcp) : q.tlut[r < q.win ? r : q.win]; // float((t - t0) / window), :141, :23
+            const float ts = binsf * tn;                       // t* = bins * float(t), :23
+            const int k0 = (int)ts;                            // floor (t* >= 0): the 1-based bins k0 and k0 + 1 can receive
+            const float wl = 1.0f - fabsf((float)k0 - ts), wh = 1.0f - fabsf((float)(k0 + 1) - ts); // :28
+            // :29 (a weight of zero adds nothing either); 0-based bin k0 - 1 takes wl, bin k0 takes wh
+            const bool lo_ok = valid && k0 >= 1 && k0 <= q.bins && wl > 0.0f && ((k0 - 1) & (kFaddWaves - 1)) == wv;
+            const bool hi_ok = valid && k0 + 1 <= q.bins && wh > 0.0f && (k0 & (kFaddWaves - 1)) == wv;
+            if (__ballot(lo_ok || hi_ok) == 0ull) continue; // (none of this instruction's records touches my bins)
+            const int kv = valid ? k0 : -1;
+            const int kprev = __shfl_up(kv, 1);
+            unsigned long long starts = __ballot(lane == 0 || kv != kprev); // runs of equal floor(t*), in lane order
+            while (starts) {
+                const int rb = __builtin_ctzll(starts);
+                starts &= starts - 1ull;
+                const int re = starts ? __builtin_ctzll(starts) : kWave;
+                const bool in = lane >= rb && lane < re;
+                if (in && lo_ok) atomicAdd(&accl[(k0 - 1) * kSubCells + (int)cell], wl);
+                if (in && hi_ok) atomicAdd(&accl[k0 * kSubCells + (int)cell], wh);
+            }
+        }
+    }
+    __syncthreads();
+    float acc[BINS];
+#pragma unroll
+    for (int k = 0; k < BINS; ++k) acc[k] = s_acc[k][64 * wv + lane];
+    ev_store_cells<BINS>(q, s, tile, sub, lane, wv, acc);
 }
 
 // Self-test of the two hardware properties this file rests on, for lanes of ONE wave-instruction that hit the same LDS
@@ -2780,6 +2914,7 @@ inline void launch_split_cm(TileP &q, const FastPlan &p, const SeqTab &S, char *
 // (a new stepping / compiler): the fast path then refuses (FRLW_ERR_UNSUPPORTED) and callers take the general path.
 constexpr int kMaxDevices = 64;
 std::atomic<int> g_lds_order[kMaxDevices];
+std::atomic<int> g_lds_fadd[kMaxDevices]; // 1: ds_add_f32 made the sequential f32 sums in the same self-test run (kf_ev_fadd may be used)
 
 int lds_order_ok(char *w8, hipStream_t st)
 {
@@ -2798,6 +2933,7 @@ int lds_order_ok(char *w8, hipStream_t st)
         HIP_TRY(hipMemcpyAsync(host, out, 24, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         have = (host[0] == 0ull && host[1] > 0ull) ? 1 : 2; // no rank violation among > 0 conflicting pairs
+        g_lds_fadd[dev].store((host[2] == 0ull && host[1] > 0ull) ? 1 : 0, std::memory_order_release);
         g_lds_order[dev].store(have, std::memory_order_release);
     }
     return have == 1 ? FRLW_OK : FRLW_ERR_UNSUPPORTED;
@@ -3142,7 +3278,20 @@ int frlw_ev_encode_batch(const frlw_events_t *ev, const int64_t *seq_offsets, co
         else hipLaunchKernelGGL((kf_ev_tile<NW, kMaxK>), dim3(grid), dim3(NW * kWave), 0, st, e);
     }
     const CmP cmq = cm ? cm_params(p, w8) : CmP{};
-    if (cm && p.direct) { // the sub-tile wavefronts gather their own lists
+    bool fadd = false;
+    {
+        // kf_ev_fadd: calls whose lists are few and short enough that the LDS float atomics' 192 cycles per instruction and CU
+        // stay below the ticket kernel's latency chain (measured: 1 M events in 576 lists 25 against 35 us, the whole call 40 against 50; with plain stores instead of the atomics the kernel takes 19 us: gather and decode are most of it; the ticket kernel
+        // wins from about 3 M events on), on devices where the self-test saw ds_add_f32 make the sequential sums
+        int dev = 0;
+        const bool hw_ok = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < kMaxDevices && g_lds_fadd[dev].load(std::memory_order_acquire) == 1;
+        const int knob = tuning_knob(ev->tuning, &frlw_tuning_t::ev_lds_float_atomics, -1);
+        fadd = cm && p.direct && hw_ok && (knob >= 0 ? knob != 0 : n <= 3000000ll);
+    }
+    if (fadd) {
+        if (bins <= 5) hipLaunchKernelGGL((kf_ev_fadd<5>), dim3(p.pairs * kFW), dim3(kFaddWaves * kWave), 0, st, e, cmq, S);
+        else hipLaunchKernelGGL((kf_ev_fadd<kMaxK>), dim3(p.pairs * kFW), dim3(kFaddWaves * kWave), 0, st, e, cmq, S);
+    } else if (cm && p.direct) { // the sub-tile wavefronts gather their own lists
         if (bins <= 5) hipLaunchKernelGGL((kf_ev_sub<5, true>), dim3(sub_grid), dim3(4 * kWave), 0, st, e, 1, cmq, S);
         else hipLaunchKernelGGL((kf_ev_sub<kMaxK, true>), dim3(sub_grid), dim3(4 * kWave), 0, st, e, 1, cmq, S);
     } else if (bins <= 5) hipLaunchKernelGGL((kf_ev_sub<5, false>), dim3(sub_grid), dim3(4 * kWave), 0, st, e, tile_walk ? 0 : 1, cmq, S);

@@ -81,6 +81,9 @@ typedef struct frlw_tuning {
                                * scatter writes every chunk sorted by bin where it stands plus a directory row, the consumers
                                * gather -- the default wherever a sequence has at most 4096 chunks), 0 = histogram + scans +
                                * bin-major scatter (the only form for longer sequences and for the tile walk) */
+    int32_t ev_lds_float_atomics; /* frlw_ev_encode_batch, direct mode of the chunk-major partition: 1 = one wavefront per sub-tile
+                               * sums its list with LDS float atomics in stream order (kf_ev_fadd: short latency chain, 3 x the
+                               * cycles per record -- the default up to 3 M events per call), 0 = the ticket-sort kernel */
 } frlw_tuning_t;
 
 typedef struct frlw_events {

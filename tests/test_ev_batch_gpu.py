@@ -136,3 +136,51 @@ def test_direct_bins_equal_tile_bins(er, n_seq, monkeypatch):
         outs.append(er.encode_ev_batch(dat, offs, (H, W), win, win, 5, want_u8=True))
     for o in outs[1:]:
         assert torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1])
+
+
+@pytest.mark.parametrize("bins", [1, 2, 5, 8])
+@pytest.mark.parametrize("n_seq", [1, 3])
+def test_lds_float_atomic_kernel_equals_ticket_kernel_and_oracle(er, orc, bins, n_seq, monkeypatch):
+    """kf_ev_fadd (small direct-mode calls: the sums are made by ds_add_f32 in stream order, csrc/taf_fast.hip) against the
+    ticket-sort kernel (``ev_lds_float_atomics`` 1 / 0) and the oracle, bit for bit: a time-sorted stream (one run of equal
+    floor(t*) per instruction except at the slice boundaries), a SHUFFLED one (runs of one record: the upper weight of an earlier
+    record and the lower weight of a later one meet in one bin -- the order the reference's sequential index_add_ defines,
+    generate_eventvolume.py:28-32), a hot spot (hundreds of records per cell), events exactly on the bin centres and on t_end."""
+    from frlw_evd_amd import _lib
+    H, W, win = 240, 304, 60_000
+    recs = []
+    for j in range(n_seq):
+        ev = synth.synth_events(8800 + 10 * bins + j, 260_000, W, H, win, hotspot=(j == 0), t_offset=1)
+        if j == 0:  # events exactly on the bin centres (t* integer) and on the window's end
+            ev["t"][::97] = (np.arange(len(ev["t"][::97])) % bins + 1) * (win // bins)
+            ev["t"][-5:] = win
+            ev["t"].sort()
+        if j == 1:  # not time-sorted at all
+            perm = np.random.default_rng(5).permutation(len(ev["t"]))
+            ev = {k: v[perm] for k, v in ev.items()}
+        recs.append(synth.to_dat8(ev))
+    offs = np.concatenate([[0], np.cumsum([len(r) for r in recs])])
+    dat = to_dev(np.concatenate(recs))
+    outs = []
+    for knob in (1, 0):
+        monkeypatch.setattr(er, "TUNING", _lib.FrlwTuning(ev_lds_float_atomics=knob, direct_bins=1))
+        out, u8 = er.encode_ev_batch(dat, offs, (H, W), win, win, bins, want_u8=True)
+        outs.append((out, u8))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    for j, r in enumerate(recs):
+        assert_bitexact(host(outs[0][0][j]), orc.ev_stream_dat8(r, (H, W), (H, W), bins, win, win), f"sequence {j}")
+
+
+def test_single_window_shim_takes_the_two_launch_path(er, orc):
+    """``encode_ev_dat(fast=True)`` = the batch entry point with one window; an event behind t_end makes the checked call fall back
+    to the general path, which places it like the reference (generate_eventvolume.py:139 filters only the front)."""
+    H, W, win = 240, 304, 100_000
+    rec = synth.to_dat8(synth.synth_events(8900, 300_000, W, H, win, t_offset=1))
+    want = orc.ev_stream_dat8(rec, (H, W), (H, W), 5, win, win)
+    for fast in (True, False, "auto"):
+        out, _ = er.encode_ev_dat(to_dev(rec), (H, W), win, win, 5, fast=fast)
+        assert_bitexact(host(out), want, f"fast={fast}")
+    late = rec.copy()
+    late["t"][-2:] += 7  # behind t_end: outside the batch path's contract
+    out, _ = er.encode_ev_dat(to_dev(late), (H, W), win, win, 5, fast=True)
+    assert_bitexact(host(out), orc.ev_stream_dat8(late, (H, W), (H, W), 5, win, win), "late events through the fall-back")

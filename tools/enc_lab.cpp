@@ -129,7 +129,7 @@ struct Outputs {
     bool ran = false;
 };
 
-static frlw_tuning_t g_tuning = {(int32_t)sizeof(frlw_tuning_t), -1, -1, -1, -1, -1, -1, -1, -1, -1};
+static frlw_tuning_t g_tuning = {(int32_t)sizeof(frlw_tuning_t), -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
 static bool g_use_tuning = false;
 
 static Outputs run_cfg(const Lib &L, const Cfg &c, const uint64_t *dat_d, const std::vector<int64_t> &offs, int reps)
@@ -236,6 +236,8 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[i], "--reps") && i + 1 < argc) reps = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--tile-walk")) { g_tuning.taf_tile_walk = 1; g_use_tuning = true; } // TAF through kf_taf_tile
         else if (!strcmp(argv[i], "--bpw") && i + 1 < argc) { g_tuning.batches_per_wave = atoi(argv[++i]); g_use_tuning = true; } // larger partition chunks
+        else if (!strcmp(argv[i], "--fadd")) { g_tuning.ev_lds_float_atomics = 1; g_use_tuning = true; } // Event Volume, direct mode: LDS float atomics
+        else if (!strcmp(argv[i], "--no-fadd")) { g_tuning.ev_lds_float_atomics = 0; g_use_tuning = true; } // ... the ticket-sort kernel
         else if (!strcmp(argv[i], "--cm")) { g_tuning.chunk_major = 1; g_use_tuning = true; } // the chunk-major partition wherever it is possible
         else if (!strcmp(argv[i], "--no-cm")) { g_tuning.chunk_major = 0; g_use_tuning = true; } // histogram + scans + bin-major scatter
         else if (!strcmp(argv[i], "--direct")) { g_tuning.direct_bins = 1; g_use_tuning = true; } // sub-tile bins wherever the frame allows

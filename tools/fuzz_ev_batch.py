@@ -57,7 +57,8 @@ def main():
         offs = np.concatenate([[0], np.cumsum([len(r) for r in recs])])
         # every third case: the opt-in tile walk (kf_ev_tile); the others: the partition mode at random
         er.TUNING = (_lib.FrlwTuning(taf_tile_walk=1) if case % 3 == 2 else
-                     [_lib.FrlwTuning(chunk_major=int(rng.integers(-1, 2))), _lib.FrlwTuning(direct_bins=1, chunk_major=int(rng.integers(-1, 2))),
+                     [_lib.FrlwTuning(chunk_major=int(rng.integers(-1, 2)), ev_lds_float_atomics=int(rng.integers(-1, 2))),
+                      _lib.FrlwTuning(direct_bins=1, chunk_major=int(rng.integers(-1, 2)), ev_lds_float_atomics=int(rng.integers(-1, 2))),
                       _lib.FrlwTuning(direct_bins=0, chunk_major=int(rng.integers(-1, 2)))][int(rng.integers(0, 3))])
         try:
             out, u8 = er.encode_ev_batch(dev(np.concatenate(recs)), offs, (H, W), ends, win, bins, want_u8=True)
