@@ -276,6 +276,73 @@ __global__ __launch_bounds__(NT) void k_eci_tile(const uint2 *rec, const uint32_
     }
 }
 
+// Small calls (BASELINE.json configs[0]: 100 000 events on 304x240): the five launches of the general path -- histogram, two
+// scans, scatter, tile kernel -- are 29 us of launch chain for 1.4 MB of data.  A count image needs no order at all: ONE launch in
+// which every workgroup owns 2048 consecutive pixels (4096 counters in LDS), reads the WHOLE event array (0.8 MB out of the L2,
+// 36 workgroups at 304x240) and counts the events that fall into its stretch; the 21-entry table turns the counts into the
+// image.  The first workgroup also owns the call's status.  Used while events x workgroups stays small (frlw_eci_encode).
+constexpr int kEciScanPix = 2048;
+constexpr int kEciScanThreads = 1024;
+template <bool HAS_MAP>
+__global__ __launch_bounds__(kEciScanThreads) void k_eci_scan(const uint2 *data, long long n, const uint16_t *xmap, const uint16_t *ymap,
+                                                              int map_w, int map_h, EciParams q, WsHeader *hdr)
+{
+    __shared__ uint32_t cnt[2 * kEciScanPix];
+    __shared__ int serr;
+    const int t = threadIdx.x;
+    for (int i = t; i < 2 * kEciScanPix; i += kEciScanThreads) cnt[i] = 0u;
+    if (t == 0) serr = 0;
+    __syncthreads();
+    const long long total = (long long)q.H * q.W; // (< 2^31: the host checks)
+    const long long p0 = (long long)blockIdx.x * kEciScanPix;
+    const bool check_status = blockIdx.x == 0;
+    int err = 0;
+    constexpr int RU = 16; // clamped loads in flight per thread, masked below (a workgroup's pass over the array is a chain of
+                           // dependent iterations: with four loads per iteration 100 000 events took 25 round trips, 21 us)
+    for (long long i0 = 0; i0 < n; i0 += RU * kEciScanThreads) {
+        uint2 r[RU];
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            const long long i = i0 + (long long)u * kEciScanThreads + t;
+            r[u] = data[i < n ? i : n - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            const bool live = i0 + (long long)u * kEciScanThreads + t < n;
+            int x = (int)(r[u].y & 16383u), y = (int)((r[u].y >> 14) & 16383u);
+            const uint32_t p = (r[u].y >> 28) & 1u;
+            bool ok = live;
+            if (HAS_MAP) {
+                ok = ok && x < map_w && y < map_h;
+                x = xmap[x < map_w ? x : 0];
+                y = ymap[y < map_h ? y : 0];
+            }
+            // the reference indexes the flat cell 2 x + 2 W y + p (generate_eventcountimage.py:32): x >= W aliases into the next
+            // row, only a flat pixel outside the frame raises.  (The range test below drops such an event in every workgroup; the
+            // STATUS is the first workgroup's business alone: 36 workgroups repeat this loop, every instruction counts.)
+            const uint32_t flat = (uint32_t)x + (uint32_t)q.W * (uint32_t)y, loc = flat - (uint32_t)p0;
+            if (check_status && live && (!ok || flat >= (uint32_t)total)) err |= ST_INDEX;
+            if (ok && loc < (uint32_t)kEciScanPix && flat < (uint32_t)total) atomicAdd(&cnt[(loc << 1) | p], 1u);
+        }
+    }
+    if (err) atomicOr(&serr, err);
+    __syncthreads();
+    if (blockIdx.x == 0 && t == 0) { // every workgroup has seen every event: the first one speaks for the call
+        hdr->status = serr;
+        fold_sticky_status(hdr, serr);
+    }
+    for (int i = t; i < 2 * kEciScanPix; i += kEciScanThreads) {
+        const int pol = i >= kEciScanPix ? 1 : 0;
+        const long long pix = p0 + (i - pol * kEciScanPix);
+        if (pix >= total) continue;
+        const uint32_t c = cnt[((uint32_t)(i - pol * kEciScanPix) << 1) | (uint32_t)pol];
+        const float v = q.lut[c > 20u ? 20u : c];
+        const long long idx = (long long)pol * total + pix; // view (H, W, 2) -> permute (2, H, W), :36
+        if (q.out_f32) q.out_f32[idx] = v;
+        if (q.out_u8) q.out_u8[idx] = f32_to_u8(v);
+    }
+}
+
 // ---- SAE -------------------------------------------------------------------------------------
 struct SaeParams {
     int H, W, twl, tiles_x, n_lamda;
@@ -724,11 +791,8 @@ int frlw_eci_encode(const frlw_events_t *ev, int H, int W, float *out_f32, uint8
 {
     if (!out_f32 && !out_u8) return FRLW_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    Partitioned pt;
-    int rc = partition_events(ev, H, W, KIND_ECI, 0, 1, 1, 0, workspace, workspace_bytes, s, pt);
-    if (rc != FRLW_OK) return rc;
     EciParams q;
-    q.H = H; q.W = W; q.twl = pt.plan.twl; q.tiles_x = pt.plan.tiles_x; q.out_f32 = out_f32; q.out_u8 = out_u8;
+    q.H = H; q.W = W; q.twl = 0; q.tiles_x = 0; q.out_f32 = out_f32; q.out_u8 = out_u8;
     // generate_eventcountimage.py:32-34,41: n sequential f32 adds of 0.05f, > 1 -> 1, * 255
     volatile float acc = 0.0f;
     q.lut[0] = 0.0f;
@@ -737,6 +801,28 @@ int frlw_eci_encode(const frlw_events_t *ev, int H, int W, float *out_f32, uint8
         float v = acc;
         q.lut[n] = (v > 1.0f ? 1.0f : v) * 255.0f;
     }
+    // one launch for small calls: every workgroup of 2048 pixels reads all events (k_eci_scan); at most 8 M event reads in all
+    // (36 workgroups x 100 000 events at 304x240: 29 -> ~8 us); frlw_tuning_t::staged_scatter = 0 keeps the general path (tests)
+    if (ev && workspace && workspace_bytes >= kHeaderBytes && ev->layout == FRLW_LAYOUT_DAT8 && H > 0 && W > 0 && ev->n > 0 && ev->data &&
+        tuning_valid(ev->tuning) && (ev->xmap == nullptr) == (ev->ymap == nullptr) &&
+        tuning_knob(ev->tuning, &frlw_tuning_t::staged_scatter, -1) != 0) {
+        const long long wgs = ((long long)H * W + kEciScanPix - 1) / kEciScanPix;
+        if (wgs * ev->n <= (8ll << 20) && (long long)H * W < (1ll << 31)) {
+            (void)hipGetLastError();
+            if (ev->xmap)
+                hipLaunchKernelGGL(k_eci_scan<true>, dim3((unsigned)wgs), dim3(kEciScanThreads), 0, s, (const uint2 *)ev->data, (long long)ev->n,
+                                   ev->xmap, ev->ymap, ev->map_w, ev->map_h, q, (WsHeader *)workspace);
+            else
+                hipLaunchKernelGGL(k_eci_scan<false>, dim3((unsigned)wgs), dim3(kEciScanThreads), 0, s, (const uint2 *)ev->data, (long long)ev->n,
+                                   (const uint16_t *)nullptr, (const uint16_t *)nullptr, 0, 0, q, (WsHeader *)workspace);
+            HIP_TRY(hipGetLastError());
+            return FRLW_OK;
+        }
+    }
+    Partitioned pt;
+    int rc = partition_events(ev, H, W, KIND_ECI, 0, 1, 1, 0, workspace, workspace_bytes, s, pt);
+    if (rc != FRLW_OK) return rc;
+    q.twl = pt.plan.twl; q.tiles_x = pt.plan.tiles_x;
     LAUNCH_TILE(k_eci_tile, pt.plan, s, pt.records, pt.base, q);
     HIP_TRY(hipGetLastError());
     return FRLW_OK;

@@ -454,3 +454,44 @@ def test_ev_samples_laid_out_in_one_frame_equal_their_own_encodes(er):
     for j in range(4):
         r0, c0 = (j // 2) * H, (j % 2) * W
         assert torch.equal(both[:, r0:r0 + H, c0:c0 + W], singles[j]), j
+
+
+@pytest.mark.parametrize("shape,n,maps", [((240, 304), 100_000, False), ((17, 33), 3_000, False), ((97, 131), 60_000, False),
+                                          ((512, 640), 12_000, True), ((240, 304), 1, False)])
+def test_eci_single_launch_equals_general_path_and_oracle(er, orc, shape, n, maps, monkeypatch):
+    """Small Event Count Image calls take ONE launch (k_eci_scan: every workgroup counts its 2048 pixels over all events,
+    generate_eventcountimage.py:19-41) -- against the five-launch general path (forced by the tuning knob) and the oracle, bit for
+    bit: hot pixels beyond the 20-add saturation, x >= W aliasing into the next row, down-scale maps, a single event; and an
+    event outside the frame raises IndexError on both paths."""
+    from frlw_evd_amd import _lib
+    H, W = shape
+    Hs, Ws = (720, 1280) if maps else (H, W)
+    ev = synth.synth_events(7100 + n, n, Ws, Hs, 50_000, hotspot=n > 10)
+    if n > 100:
+        ev["x"][:40] = Ws // 3  # one pixel far beyond 20 events
+        ev["y"][:40] = Hs // 3
+        ev["p"][:40] = 1
+    if not maps and n > 100:
+        ev["x"][50:60] = W + 2  # aliases into the next row like the reference's flat index
+        ev["y"][50:60] = 3
+    rec = synth.to_dat8(ev)
+    xm = ym = None
+    if maps:
+        xm, ym = er.coordinate_maps((Hs, Ws), (H, W), "cuda")
+    dat = torch.from_numpy(rec.view(np.uint8).reshape(-1, 8).copy()).cuda()
+    out1, u1 = er.encode_eci_dat(dat, (H, W), want_u8=True, xmap=xm, ymap=ym)
+    monkeypatch.setattr(er, "TUNING", _lib.FrlwTuning(staged_scatter=0))  # the general path
+    out0, u0 = er.encode_eci_dat(dat, (H, W), want_u8=True, xmap=xm, ymap=ym)
+    monkeypatch.setattr(er, "TUNING", None)
+    assert torch.equal(out1, out0) and torch.equal(u1, u0)
+    assert_bitexact(host(out1), orc.eci_stream_dat8(rec, (Hs, Ws), (H, W)), "single-launch eci vs oracle")
+    if not maps and n > 100:
+        bad = rec.copy()
+        bad["_"][7] = (np.uint32(W - 1) & 16383) | (np.uint32(H + 5) << 14)  # flat index behind the frame
+        datb = torch.from_numpy(bad.view(np.uint8).reshape(-1, 8).copy()).cuda()
+        for tun in (None, _lib.FrlwTuning(staged_scatter=0)):
+            monkeypatch.setattr(er, "TUNING", tun)
+            with pytest.raises(IndexError):
+                er.encode_eci_dat(datb, (H, W))
+        monkeypatch.setattr(er, "TUNING", None)
+        er.encode_eci_dat(dat, (H, W))  # the next clean call starts clean
