@@ -123,6 +123,29 @@ def test_bench_gpus_flag_spawns_the_ranks():
     assert line["launched_by"] == "bench.py" and line["backend"] == "gloo"
 
 
+def test_bench_eight_ranks_dry_launch():
+    """The driver's SCALE run goes to 8 ranks (README.md:160-170: one process per GPU of an 8-GPU node): the launcher, the
+    rendezvous on 127.0.0.1, the SUM / MAX reductions and rank 0's single JSON line with eight fresh ranks over gloo -- both
+    as bench.py's own launcher and under torch.distributed.run, the form the driver uses -- so that a first real 8-GPU run
+    cannot die before it measures anything."""
+    import subprocess
+    import sys
+    rc, line, err = _run_bench(["--gpus", "8", "--launch-only"], {"FRLW_DIST_BACKEND": "gloo"}, timeout=600)
+    assert rc == 0, err
+    assert line["n_gpus"] == 8 and line["rank_sum"] == 36.0 and line["max_over_ranks"] == 7.5
+    assert line["launched_by"] == "bench.py" and line["backend"] == "gloo"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FRLW_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr",
+                        "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "3",
+                        "--warmup", "1", "--launch-only"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert '"n_gpus": 8' in p.stdout and '"rank_sum": 36.0' in p.stdout and '"launched_by": "external launcher"' in p.stdout
+    assert sum(1 for ln in p.stdout.splitlines() if ln.startswith("{")) == 1  # ONE line, from rank 0
+
+
 def test_bench_single_rank_line_has_one_gpu():
     rc, line, err = _run_bench(["--launch-only"], {})
     assert rc == 0, err
