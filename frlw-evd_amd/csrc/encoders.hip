@@ -855,6 +855,12 @@ int frlw_sae_encode(const frlw_events_t *ev, int H, int W, const double *lamdas,
 {
     if (!mem_out || !lamdas || n_lamda < 0 || n_lamda > FRLW_MAX_LAMDAS) return FRLW_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
+    {   // single calls of the GEN1 class: two launches instead of five (taf_fast.hip: kf_scatter_cm<.., SAE> + kf_sae_sub)
+        float lamf[FRLW_MAX_LAMDAS];
+        for (int l = 0; l < n_lamda; ++l) lamf[l] = (float)lamdas[l];
+        const int rc2 = sae_fast_try(ev, H, W, lamf, n_lamda, mem_in, mem_out, now, window_us, out_f32, out_u8, workspace, workspace_bytes, s);
+        if (rc2 <= 0) return rc2;
+    }
     Partitioned pt;
     const int filt = window_us > 0;
     int rc = partition_events(ev, H, W, KIND_SAE, now - window_us, 1, 1, filt, workspace,

@@ -391,6 +391,12 @@ inline int tuning_knob(const frlw_tuning_t *tu, int32_t frlw_tuning_t::*f, int d
 inline bool tuning_valid(const frlw_tuning_t *tu) { return !tu || (tu->struct_size >= 8 && tu->struct_size <= 4096); }
 int hip_fail(hipError_t e, const char *what, int line);
 
+// frlw_sae_encode through the chunk-major partition of taf_fast.hip (two launches): FRLW_OK = launched, 1 = not eligible
+// (nothing launched), negative = error.
+int sae_fast_try(const frlw_events_t *ev, int H, int W, const float *lam, int n_lamda, const float *mem_in, float *mem_out,
+                 long long now, long long window_us, float *out_f32, uint8_t *out_u8, void *workspace, size_t workspace_bytes,
+                 hipStream_t st);
+
 // hist -> scans -> stable scatter: tile-major 8-byte records {window << (twl + 4) | cell, f32 bits}.
 int partition_events(const frlw_events_t *ev, int H, int W, int kind, long long t0, long long win,
                      int n_windows, int time_filter, void *ws, size_t ws_bytes, hipStream_t s,

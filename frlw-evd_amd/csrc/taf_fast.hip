@@ -258,7 +258,10 @@ struct FastEv {
 // span n_windows * win below 2^32, win >= 2 -- then the time arithmetic is 32-bit, the stripe test disappears and the window
 // needs ONE correction step after the multiply-high (floor(2^32 / win) under-estimates the quotient by less than one).  Same
 // results as the general form on such calls; 14 of the decode's 52 VALU instructions less in kf_hist and kf_scatter.
-template <bool HAS_MAP, bool EV = false, bool SIMPLE = false>
+// SAE (Surface of Active Events, generate_surfaceofactiveevents.py:72, :176-190; an EV-shaped decode): events outside the frame
+// and events at or in front of t0 = now - window are dropped without an error, there is no upper time bound, and the record's
+// time field is replaced by the caller with the event's position in its sequence (the consumer wants the LAST writer).
+template <bool HAS_MAP, bool EV = false, bool SIMPLE = false, bool SAE = false>
 __device__ __forceinline__ FastEv fast_decode(const FastGeom &G, uint2 r, long long t0)
 {
     FastEv o;
@@ -270,6 +273,7 @@ __device__ __forceinline__ FastEv fast_decode(const FastGeom &G, uint2 r, long l
         x = G.xmap[x];
         y = G.ymap[y];
     }
+    if (SAE && (x >= G.W || y >= G.H_full)) return o; // generate_surfaceofactiveevents.py:72
     if (x >= G.W || y >= G.H_full) {
         const long long flat = (long long)x + (long long)G.W * y;
         if (flat >= (long long)G.H_full * G.W) { o.err = ST_INDEX; return o; }
@@ -280,7 +284,7 @@ __device__ __forceinline__ FastEv fast_decode(const FastGeom &G, uint2 r, long l
         const uint32_t t0lo = (uint32_t)t0, relu = r.x - t0lo;
         if (EV) {
             if (r.x <= t0lo) return o; // generate_eventvolume.py:139: not an error, not encoded
-            if (relu > G.win) { o.err = ST_SPAN; return o; }
+            if (!SAE && relu > G.win) { o.err = ST_SPAN; return o; }
             const int tw1e = (1 << G.twl) - 1, th1e = (1 << G.thl) - 1;
             const uint32_t celle = (uint32_t)((((y & th1e) << G.twl) | (x & tw1e)) << 1) | p;
             o.tile = (((y >> G.thl) * G.tiles_x + (x >> G.twl)) << G.bin_shift) | (int)((celle >> 8) & (uint32_t)G.bin_mask);
@@ -304,7 +308,7 @@ __device__ __forceinline__ FastEv fast_decode(const FastGeom &G, uint2 r, long l
     const long long rel = (long long)r.x - t0;
     if (EV) {
         if (rel <= 0) return o; // generate_eventvolume.py:139: not an error, not encoded
-        if (rel > (long long)G.win) { o.err = ST_SPAN; return o; }
+        if (!SAE && rel > (long long)G.win) { o.err = ST_SPAN; return o; }
         const int tw1e = (1 << G.twl) - 1, th1e = (1 << G.thl) - 1;
         const uint32_t celle = (uint32_t)((((y & th1e) << G.twl) | (x & tw1e)) << 1) | p;
         o.tile = (((y >> G.thl) * G.tiles_x + (x >> G.twl)) << G.bin_shift) | (int)((celle >> 8) & (uint32_t)G.bin_mask);
@@ -748,7 +752,7 @@ __host__ __device__ inline size_t scatter_cm_lds_bytes(int T, int chunk)
 // kBigBpw: 128 VGPRs, ONE workgroup per CU, chunks up to 20 480 events (LDS: 80 KB of staging + the counters) -- for large
 // calls with tile bins, where a consumer gathers one run per chunk: 10 M events at 1280x720 leave 512 chunks with 43-record
 // runs instead of 1536 with 14-record ones.
-template <bool HAS_MAP, bool EV = false, bool SIMPLE = false, int MAXB = kMaxBpw>
+template <bool HAS_MAP, bool EV = false, bool SIMPLE = false, int MAXB = kMaxBpw, bool SAE = false>
 __global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(MAXB > kMaxBpw ? 4 : 8, MAXB > kMaxBpw ? 4 : 8))) void kf_scatter_cm(FastGeom G, SeqTab S, uint32_t *dir, uint32_t *records, FastHeader *hdr, float *tlut_w,
                                                      uint32_t epoch)
 {
@@ -818,12 +822,13 @@ __global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(MAXB > kMax
         if (j < G.bpw) {
             const uint32_t i = (uint32_t)(j * kWave + lane);
             if (i < nloc) {
-                const FastEv o = fast_decode<HAS_MAP, EV, SIMPLE>(G, q[j], t0);
+                const FastEv o = fast_decode<HAS_MAP, EV, SIMPLE, SAE>(G, q[j], t0);
                 err |= o.err;
                 if (o.tile >= 0) {
                     const uint32_t r = atomicAdd(&wcnt[o.tile], 1u);
                     where[j] = ((uint32_t)o.tile << 16) | r;
-                    word[j] = o.word;
+                    // SAE: the event's position in its sequence + 1 (below 2^20: the host checks; a record is never 0) in place of the time field
+                    word[j] = SAE ? ((uint32_t)(wave_begin - S.ev0[s] + (long long)i + 1) << kCellBits) | (o.word & (uint32_t)(kCells - 1)) : o.word;
                     wseen |= 1ull << o.window;
                 }
             }
@@ -2713,6 +2718,103 @@ __global__ __launch_bounds__(kFaddWaves *kWave) void kf_ev_fadd(EvTileP q, CmP c
     ev_store_cells<BINS>(q, s, tile, sub, lane, wv, acc);
 }
 
+// ---- Surface of Active Events through the chunk-major partition (small single calls) ------------------------------------
+// generate_leaky_cuda (generate_surfaceofactiveevents.py:44-80): t_img[p, y, x] = float(t) of the cell's LAST event in stream
+// order, max with the memory, exp(lambda (t_img - now)) * 255.  The general path takes five launches (41 us for 1 M events at
+// 304x240).  Here: kf_scatter_cm<.., SAE> writes records {position in the sequence << 12 | cell} chunk-major, and one workgroup
+// per sub-tile takes the maximum record per cell with LDS atomics -- straight from the runs, no list, no order needed -- reads
+// the time of that one event from the DAT array and writes memory and outputs with the arithmetic of k_sae_tile (encoders.hip).
+struct SaeFastP {
+    int H, W, twl, thl, tiles_x, T, n_lamda;
+    float lam[FRLW_MAX_LAMDAS];
+    float nowf;
+    const uint2 *data;
+    const float *mem_in;
+    float *mem_out, *out_f32;
+    uint8_t *out_u8;
+    FastHeader *hdr;
+};
+
+__global__ __launch_bounds__(kSubCells) void kf_sae_sub(SaeFastP q, CmP cm, SeqTab S)
+{
+    __shared__ uint32_t s_last[kSubCells];
+    __shared__ uint32_t s_colL[kColEv + 1], s_colD[kColEv], s_wsum[kSubCells / kWave + 1];
+    constexpr int NT = kSubCells, NWV = NT / kWave;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int sg = blockIdx.x, tile = sg / kFW, sub = sg - tile * kFW; // (one sequence)
+    if (q.hdr->status != 0) return;
+    s_last[tid] = 0u;
+    const int C = S.chunk0[1] - S.chunk0[0];
+    uint32_t n = 0;
+    for (int cb = 0; cb < C; cb += NT) { // the sub-tile's column of the directory (workgroup-uniform trip count; C <= kColEv)
+        const int c = cb + tid;
+        const uint32_t v = cm.dir[(long long)(c < C ? c : C - 1) * cm.TB + sg];
+        const uint32_t e = c < C ? v : 0u, cnt = e >> 16;
+        const uint32_t inc = wave_incl_scan(cnt);
+        if (lane == kWave - 1) s_wsum[wv] = inc;
+        __syncthreads();
+        uint32_t pre = 0, all = 0;
+#pragma unroll
+        for (int k = 0; k < NWV; ++k) { if (k < wv) pre += s_wsum[k]; all += s_wsum[k]; }
+        const uint32_t run = n + pre + inc - cnt;
+        if (c < C) { s_colL[c] = run; s_colD[c] = (uint32_t)c * (uint32_t)cm.chunk_ev + (e & 0xffffu) - run; }
+        n += all;
+        __syncthreads();
+    }
+    if (tid == 0) s_colL[C] = n;
+    __syncthreads();
+    {   // the runs: groups of 16 lanes take a run each, ten runs' loads in flight; the later record of a cell wins (position in the high bits)
+        const int g16 = tid >> 4, l16 = tid & 15;
+        constexpr int RU = 10, NG = NT / 16;
+        for (int cc0 = g16; cc0 < C; cc0 += NG * RU) {
+            uint32_t v[RU], cnt[RU];
+#pragma unroll
+            for (int u = 0; u < RU; ++u) {
+                const int c = cc0 + NG * u, cc = c < C ? c : C - 1;
+                const uint32_t lo = s_colL[cc];
+                cnt[u] = c < C ? s_colL[cc + 1] - lo : 0u;
+                v[u] = cm.rec[s_colD[cc] + lo + ((uint32_t)l16 < cnt[u] ? (uint32_t)l16 : 0u)];
+            }
+#pragma unroll
+            for (int u = 0; u < RU; ++u) {
+                if ((uint32_t)l16 < cnt[u]) atomicMax(&s_last[v[u] & 255u], v[u]);
+                if (cnt[u] > 16u) {
+                    const int c = cc0 + NG * u;
+                    const uint32_t d = s_colD[c], lo = s_colL[c];
+                    for (uint32_t j = 16u + l16; j < cnt[u]; j += 16u) {
+                        const uint32_t w = cm.rec[d + lo + j];
+                        atomicMax(&s_last[w & 255u], w);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // cell tid: pixel 128 sub + tid / 2 of the tile, polarity tid & 1
+    const int ty = tile / q.tiles_x, tx = tile - ty * q.tiles_x;
+    const int x0 = tx << q.twl, y0 = ty << q.thl, tw1 = (1 << q.twl) - 1;
+    const int pol = tid & 1, pt = sub * (kSubCells / 2) + (tid >> 1);
+    const int py = y0 + (pt >> q.twl), px = x0 + (pt & tw1);
+    if (py >= q.H || px >= q.W) return;
+    const long long plane = (long long)q.H * q.W, idx = (long long)pol * plane + (long long)py * q.W + px;
+    const uint32_t w = s_last[tid];
+    const float init = (0.0f + q.nowf) - 5000000.0f; // generate_surfaceofactiveevents.py:48
+    // (the scatter stores position + 1: a record is never 0, 0 = the cell has no event)
+    float tv = w ? (float)q.data[S.ev0[0] + (long long)(w >> kCellBits) - 1].x : init; // float(t), :76
+    if (q.mem_in) {
+        const float m = q.mem_in[idx];
+        if (!(tv > m)) tv = m; // torch.where(t_img > memory, t_img, memory), :52
+    }
+    q.mem_out[idx] = tv;
+    const float dt = tv - q.nowf;
+    for (int l = 0; l < q.n_lamda; ++l) {
+        const float v = expf(q.lam[l] * dt) * 255.0f;
+        const long long oi = (long long)l * 2 * plane + idx;
+        if (q.out_f32) q.out_f32[oi] = v;
+        if (q.out_u8) q.out_u8[oi] = f32_to_u8(v);
+    }
+}
+
 // Self-test of the two hardware properties this file rests on, for lanes of ONE wave-instruction that hit the same LDS
 // address: (1) a returning integer atomic serves them in ascending lane order (the returned count is the stream rank);
 // (2) ds_add_f32 applies them in ascending lane order with the rounding of v_add_f32, i.e. it IS the sequential
@@ -3301,3 +3403,64 @@ int frlw_ev_encode_batch(const frlw_events_t *ev, const int64_t *seq_offsets, co
 }
 
 } // extern "C"
+
+namespace frlw {
+// frlw_sae_encode's two-launch form (see kf_sae_sub).  Returns FRLW_OK when it has launched the encode, 1 when the call is not
+// eligible (nothing launched: the caller takes the general path), a negative FRLW_ERR_* on a HIP failure.
+int sae_fast_try(const frlw_events_t *ev, int H, int W, const float *lam, int n_lamda, const float *mem_in, float *mem_out,
+                 long long now, long long window_us, float *out_f32, uint8_t *out_u8, void *workspace, size_t workspace_bytes,
+                 hipStream_t st)
+{
+    if (!ev || ev->layout != FRLW_LAYOUT_DAT8 || !ev->data || !workspace || window_us <= 0) return 1;
+    if ((ev->xmap == nullptr) != (ev->ymap == nullptr) || !tuning_valid(ev->tuning)) return 1;
+    const long long n = ev->n;
+    // positions + 1 must fit the 20 bits above the 12-bit cell; tiny calls gain nothing; staged_scatter = 0 keeps the general path (tests)
+    if (n < 16384 || n >= (1ll << 20) - 1 || tuning_knob(ev->tuning, &frlw_tuning_t::staged_scatter, -1) == 0) return 1;
+    FastPlan p;
+    SeqTab S;
+    const int64_t offs[2] = {0, (int64_t)n};
+    const int64_t t0[1] = {(int64_t)(now - window_us)};
+    if (!fast_plan(n, 1, H, W, p, DIRECT_FORCE, 0, true) || !p.direct) return 1; // frames of at most 64 tiles (the 304x240 class)
+    if (!fast_layout(offs, t0, 1, p, S, 1u)) return 1;
+    if (p.max_seq_chunks > kColEv || p.chunk > 65535 || p.big || workspace_bytes < p.bytes) return 1;
+    if (scatter_cm_lds_bytes(p.TB, p.chunk) > 160 * 1024) return 1;
+    FastGeom G;
+    G.data = (const uint2 *)ev->data;
+    G.xmap = ev->xmap; G.ymap = ev->ymap; G.map_w = ev->map_w; G.map_h = ev->map_h;
+    G.H = H; G.W = W; G.twl = p.twl; G.thl = p.thl; G.tiles_x = p.tiles_x; G.T = p.TB; G.bin_shift = p.bin_shift; G.bin_mask = 15; G.bpw = p.bpw;
+    G.chunk_ev = p.chunk; G.run = p.chunk / kFW; G.n_total = n;
+    G.n_windows = 1; G.wb = 0; G.win = 0xffffffffu; G.win_magic = 0u; G.order_check = 0; G.y_lo = 0; G.H_full = H;
+    G.rcp = 0.0;
+    G.simple = (S.t0[0] >= 0 && S.t0[0] <= 0xffffffffll) ? 1 : 0;
+    G.span = 0u;
+    char *w8 = (char *)workspace;
+    FastHeader *hdr = (FastHeader *)w8;
+    uint32_t *dir = (uint32_t *)(w8 + p.off_counts);
+    uint32_t *records = (uint32_t *)(w8 + p.off_records);
+    const size_t lds_sc = scatter_cm_lds_bytes(p.TB, p.chunk);
+    (void)hipGetLastError();
+    static std::atomic<uint32_t> g_epoch_sae{0x40000000u}; // (its own range: never equal to a TAF / Event Volume call's epoch of the same process ... within 2^30 calls)
+    uint32_t epoch = 0u;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(st, &cap);
+    if (cap != hipStreamCaptureStatusNone) hipLaunchKernelGGL(kf_header_reset, dim3(1), dim3(256), 0, st, hdr);
+    else epoch = g_epoch_sae.fetch_add(1u, std::memory_order_relaxed) | 0x40000000u;
+#define SAE_SCATTER(MAP, SIMPLE_) do { \
+        if (lds_sc > 64 * 1024) (void)hipFuncSetAttribute((const void *)kf_scatter_cm<MAP, true, SIMPLE_, kMaxBpw, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc); \
+        hipLaunchKernelGGL((kf_scatter_cm<MAP, true, SIMPLE_, kMaxBpw, true>), dim3(p.chunks), dim3(kFT), lds_sc, st, G, S, dir, records, hdr, (float *)nullptr, epoch); } while (0)
+    if (ev->xmap) SAE_SCATTER(true, false);
+    else if (G.simple) SAE_SCATTER(false, true);
+    else SAE_SCATTER(false, false);
+#undef SAE_SCATTER
+    SaeFastP q;
+    q.H = H; q.W = W; q.twl = p.twl; q.thl = p.thl; q.tiles_x = p.tiles_x; q.T = p.T; q.n_lamda = n_lamda;
+    for (int l = 0; l < n_lamda; ++l) q.lam[l] = lam[l];
+    q.nowf = (float)now;
+    q.data = (const uint2 *)ev->data;
+    q.mem_in = mem_in; q.mem_out = mem_out; q.out_f32 = out_f32; q.out_u8 = out_u8; q.hdr = hdr;
+    const CmP cmq = cm_params(p, w8);
+    hipLaunchKernelGGL(kf_sae_sub, dim3(p.pairs * kFW), dim3(kSubCells), 0, st, q, cmq, S);
+    HIP_TRY(hipGetLastError());
+    return FRLW_OK;
+}
+} // namespace frlw

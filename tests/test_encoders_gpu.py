@@ -495,3 +495,42 @@ def test_eci_single_launch_equals_general_path_and_oracle(er, orc, shape, n, map
                 er.encode_eci_dat(datb, (H, W))
         monkeypatch.setattr(er, "TUNING", None)
         er.encode_eci_dat(dat, (H, W))  # the next clean call starts clean
+
+
+@pytest.mark.parametrize("shape,n,maps,shuffle", [((240, 304), 1_000_000, False, False), ((240, 304), 300_000, False, True),
+                                                  ((97, 131), 40_000, False, False), ((256, 320), 200_000, True, False)])
+def test_sae_two_launch_form_equals_general_path(er, orc, shape, n, maps, shuffle, monkeypatch):
+    """Surface of Active Events, single calls of the GEN1 class: the chunk-major scatter + kf_sae_sub (two launches) against the
+    five-launch general path (forced by the tuning knob), bit for bit in the memory AND the outputs (same expf), and against the
+    oracle's memory: last writer in STREAM order also on a shuffled stream (generate_surfaceofactiveevents.py:49), events
+    outside the frame and events at or in front of now - window dropped (:72, :176-190), memory carried over two calls, a hot
+    spot, down-scale maps."""
+    from frlw_evd_amd import _lib
+    H, W = shape
+    Hs, Ws = (720, 1280) if maps else (H, W)
+    now, win = 40_000_000, 5_541_263
+    ev = synth.synth_events(7300 + n % 1000, n, Ws, Hs, 7_000_000, hotspot=True, t_offset=33_500_000)  # some events in front of now - window
+    if not maps:
+        ev["x"][::211] = W + 3   # outside the frame: dropped, not an error
+        ev["y"][5::977] = H + 1
+    if shuffle:
+        perm = np.random.default_rng(3).permutation(n)
+        ev = {k: v[perm] for k, v in ev.items()}
+    rec = synth.to_dat8(ev)
+    xm = ym = None
+    if maps:
+        xm, ym = er.coordinate_maps((Hs, Ws), (H, W), "cuda")
+    dat = torch.from_numpy(rec.view(np.uint8).reshape(-1, 8).copy()).cuda()
+    half = n // 2
+    res = []
+    for tun in (None, _lib.FrlwTuning(staged_scatter=0)):
+        monkeypatch.setattr(er, "TUNING", tun)
+        o1, u1, m1 = er.encode_sae_dat(dat[:half], (H, W), LAMDAS, None, now - 1_000_000, win, want_u8=True, xmap=xm, ymap=ym)
+        o2, u2, m2 = er.encode_sae_dat(dat[half:], (H, W), LAMDAS, m1, now, win, want_u8=True, xmap=xm, ymap=ym)
+        res.append((o1, u1, m1, o2, u2, m2))
+    monkeypatch.setattr(er, "TUNING", None)
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
+    _, om1 = orc.sae_stream_dat8(rec[:half], (Hs, Ws), (H, W), LAMDAS, None, now - 1_000_000, win)
+    _, om2 = orc.sae_stream_dat8(rec[half:], (Hs, Ws), (H, W), LAMDAS, om1, now, win)
+    assert_bitexact(host(res[0][5]), om2, "memory after two calls")
