@@ -159,6 +159,43 @@ class Timer:
         return wall / steps, dev_ms
 
 
+GRAPHED_NOTE = {"launch": "the K timed steps are ONE HIP graph replay (launch-bound call: ~20 us of Python per eager call); "
+                          "eager_ms_per_step = the same K steps as eager calls"}
+
+
+def run_graphed(timer, fn, steps, warmup):
+    """The K steps of a SMALL encode captured into ONE HIP graph and replayed once inside the timed region (barrier + synchronize
+    on both sides as everywhere): a 100 000-event Event Count Image is 13 us of kernels behind ~20 us of Python per call, and a
+    launch-bound inner loop belongs in a graph.  Returns (seconds per step, device ms per step, eager seconds per step)."""
+    torch = timer.torch
+    eager, _ = timer.run(fn, steps, warmup)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn()  # (workspace, tables and the lane-order self-test exist on this stream before the capture)
+        side.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            for _ in range(steps):
+                fn()
+    torch.cuda.synchronize()
+    graph.replay()  # warm-up replay
+    torch.cuda.synchronize()
+    timer.fd.barrier_sync()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    graph.replay()
+    e1.record()
+    timer.fd.barrier_sync()
+    wall = time.perf_counter() - t0
+    wall, dev_ms = timer.fd.max_over_ranks([wall, e0.elapsed_time(e1) / steps])
+    with torch.cuda.stream(side):
+        if timer.er is not None:
+            timer.er.raise_deferred("bench.py graphed region")
+    return wall / steps, dev_ms, eager
+
+
 def roofline(alg_bytes, dev_ms, kernel, copy_gbs, units):
     achieved = alg_bytes / (dev_ms * 1e-3) / 1e9
     return {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -535,13 +572,14 @@ def bench_also(args, torch, synth, er, timer, rank, n_gpus, copy_gbs):
     rec2 = synth.to_dat8(ev2)
     dat2 = torch.from_numpy(rec2.view(np.uint8).reshape(-1, 8)).cuda()
     st2 = torch.full((H2, W2, 2, K2), -6000.0, device="cuda")
-    per, dev = timer.run(lambda: er.encode_taf_dat(dat2, (H2, W2), st2, 0, wu2, nw2, K2, check=False,
-                                                     fast=n2 >= er.FAST_MIN_EVENTS), steps, 3)
+    per, dev, eager = run_graphed(timer, lambda: er.encode_taf_dat(dat2, (H2, W2), st2, 0, wu2, nw2, K2, check=False,
+                                                                    fast=n2 >= er.FAST_MIN_EVENTS), steps, 3)
     row = {"workload": "taf_gen1 (the GEN1 304x240 shape BASELINE.json's metric names): TAF K=8 encode + leaky + uint8, "
                        "1000000 events, 304x240, 8 windows, ONE stream per launch sequence",
            "value": round(n_gpus * n2 / per / 1e6, 2), "unit": "Mevents/s", "ms_per_step": round(per * 1e3, 4),
            "roofline": roofline(taf_algorithmic_bytes(n2, H2, W2, K2), dev, "frlw_taf_encode_batch, one sequence, direct mode = kf_scatter_cm + kf_taf_walk<K8, direct> (two launches)" if n2 >= er.FAST_MIN_EVENTS else "frlw_taf_encode (k_taf_tile dominant)", copy_gbs,
                                 f"{n2} events")}
+    row.update(GRAPHED_NOTE, eager_ms_per_step=round(eager * 1e3, 4))
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         row["cpu_baseline"] = cpu_baseline_taf(rec2, n2, H2, W2, K2, nw2, wu2, all_cores=False)
     out.append(row)
@@ -564,13 +602,14 @@ def bench_also(args, torch, synth, er, timer, rank, n_gpus, copy_gbs):
     rec4 = synth.to_dat8(ev4)
     dat4 = torch.from_numpy(rec4.view(np.uint8).reshape(-1, 8)).cuda()
     er.encode_ev_dat(dat4, (H2, W2), 250_000, 250_000, volume_bins=5, check=True, fast=True)  # data-dependent status: clean
-    per, dev = timer.run(lambda: er.encode_ev_dat(dat4, (H2, W2), 250_000, 250_000, volume_bins=5, check=False, fast=True), steps, 3)
+    per, dev, eager = run_graphed(timer, lambda: er.encode_ev_dat(dat4, (H2, W2), 250_000, 250_000, volume_bins=5, check=False, fast=True), steps, 3)
     row = {"workload": "ev_gen1 (BASELINE.json configs[1]): Event Volume 5 bins, 1000000 events, 304x240, ONE stream",
            "value": round(n_gpus * 1_000_000 / per / 1e6, 2), "unit": "Mevents/s", "ms_per_step": round(per * 1e3, 4),
            "roofline": roofline(ev_algorithmic_bytes(1_000_000, H2, W2, 5), dev,
                                 "frlw_ev_encode_batch, one window, direct mode = kf_scatter_cm + kf_ev_fadd (two launches)", copy_gbs,
                                 "1000000 events")}
-    pg, dg = timer.run(lambda: er.encode_ev_dat(dat4, (H2, W2), 250_000, 250_000, volume_bins=5, check=False, fast=False), steps, 3)
+    row.update(GRAPHED_NOTE, eager_ms_per_step=round(eager * 1e3, 4))
+    pg, dg, _e = run_graphed(timer, lambda: er.encode_ev_dat(dat4, (H2, W2), 250_000, 250_000, volume_bins=5, check=False, fast=False), steps, 3)
     row["general_path"] = {"ms_per_step": round(pg * 1e3, 4), "device_ms": round(dg, 4), "kernel": "frlw_ev_encode (five launches)"}
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         row["cpu_baseline"] = cpu_baseline_ev(rec4, H2, W2)
@@ -601,12 +640,13 @@ def bench_also(args, torch, synth, er, timer, rank, n_gpus, copy_gbs):
 
     def sae_step():
         mem["m"] = er.encode_sae_dat(dat6, (H2, W2), LAM, mem["m"], now6, win6, check=False)[2]
-    per, dev = timer.run(sae_step, steps, 3)
+    per, dev, eager = run_graphed(timer, sae_step, steps, 3)
     row = {"tag": "sae_gen1", "workload": "sae_gen1: Surface of Active Events, 3 lambdas, 1000000 events over 5 s, 304x240, memory carried "
                                         "(frlw_sae_encode)",
            "value": round(n_gpus * 1_000_000 / per / 1e6, 2), "unit": "Mevents/s", "ms_per_step": round(per * 1e3, 4),
-           "roofline": roofline(sae_algorithmic_bytes(1_000_000, H2, W2, len(LAM)), dev, "frlw_sae_encode (k_sae_tile dominant)", copy_gbs,
-                                "1000000 events")}
+           "roofline": roofline(sae_algorithmic_bytes(1_000_000, H2, W2, len(LAM)), dev,
+                                "frlw_sae_encode = kf_scatter_cm<SAE> + kf_sae_sub (two launches)", copy_gbs, "1000000 events")}
+    row.update(GRAPHED_NOTE, eager_ms_per_step=round(eager * 1e3, 4))
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         row["cpu_baseline"] = cpu_baseline_generic(
             lambda orc: orc.sae_stream_dat8(rec6, (H2, W2), (H2, W2), LAM, None, now6, win6), len(rec6), "sae_stream_dat8")
@@ -617,11 +657,12 @@ def bench_also(args, torch, synth, er, timer, rank, n_gpus, copy_gbs):
     rec7 = synth.to_dat8(ev7)
     dat7 = torch.from_numpy(rec7.view(np.uint8).reshape(-1, 8)).cuda()
     er.encode_eci_dat(dat7, (H2, W2), check=True)
-    per, dev = timer.run(lambda: er.encode_eci_dat(dat7, (H2, W2), check=False), steps, 3)
+    per, dev, eager7 = run_graphed(timer, lambda: er.encode_eci_dat(dat7, (H2, W2), check=False), steps, 3)
     row = {"tag": "eci_gen1", "workload": "eci_gen1 (BASELINE.json configs[0]): Event Count Image, 100000 events, 304x240 (frlw_eci_encode)",
            "value": round(n_gpus * 100_000 / per / 1e6, 2), "unit": "Mevents/s", "ms_per_step": round(per * 1e3, 4),
-           "roofline": roofline(eci_algorithmic_bytes(100_000, H2, W2), dev, "frlw_eci_encode (launch-bound at this size)", copy_gbs,
-                                "100000 events")}
+           "roofline": roofline(eci_algorithmic_bytes(100_000, H2, W2), dev,
+                                "frlw_eci_encode = kf_scatter_cm<ECI> + kf_sae_sub<count> (two launches)", copy_gbs, "100000 events")}
+    row.update(GRAPHED_NOTE, eager_ms_per_step=round(eager7 * 1e3, 4))
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         row["cpu_baseline"] = cpu_baseline_generic(lambda orc: orc.eci_stream_dat8(rec7, (H2, W2), (H2, W2)), len(rec7),
                                                    "eci_stream_dat8", reps=40)

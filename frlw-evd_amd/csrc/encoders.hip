@@ -801,7 +801,13 @@ int frlw_eci_encode(const frlw_events_t *ev, int H, int W, float *out_f32, uint8
         float v = acc;
         q.lut[n] = (v > 1.0f ? 1.0f : v) * 255.0f;
     }
-    // one launch for small calls: every workgroup of 2048 pixels reads all events (k_eci_scan); at most 8 M event reads in all
+    // calls of the GEN1 class with at least 16 384 events: two launches through the chunk-major partition (taf_fast.hip:
+    // kf_scatter_cm<.., 2> + kf_sae_sub<true>: 100 000 events 21 -> 12 us)
+    if (tuning_knob(ev ? ev->tuning : nullptr, &frlw_tuning_t::staged_scatter, -1) != 0) {
+        const int rc2 = sae_fast_try(ev, H, W, q.lut, 21, nullptr, nullptr, 0, 0, out_f32, out_u8, workspace, workspace_bytes, s);
+        if (rc2 <= 0) return rc2;
+    }
+    // one launch for smaller calls: every workgroup of 2048 pixels reads all events (k_eci_scan); at most 8 M event reads in all
     // (36 workgroups x 100 000 events at 304x240: 29 -> ~8 us); frlw_tuning_t::staged_scatter = 0 keeps the general path (tests)
     if (ev && workspace && workspace_bytes >= kHeaderBytes && ev->layout == FRLW_LAYOUT_DAT8 && H > 0 && W > 0 && ev->n > 0 && ev->data &&
         tuning_valid(ev->tuning) && (ev->xmap == nullptr) == (ev->ymap == nullptr) &&

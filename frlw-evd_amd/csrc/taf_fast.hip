@@ -261,7 +261,9 @@ struct FastEv {
 // SAE (Surface of Active Events, generate_surfaceofactiveevents.py:72, :176-190; an EV-shaped decode): events outside the frame
 // and events at or in front of t0 = now - window are dropped without an error, there is no upper time bound, and the record's
 // time field is replaced by the caller with the event's position in its sequence (the consumer wants the LAST writer).
-template <bool HAS_MAP, bool EV = false, bool SIMPLE = false, bool SAE = false>
+// SAE == 2 (Event Count Image, generate_eventcountimage.py:19-41): the Event Volume decode -- x >= W aliases into the next row,
+// a flat pixel outside the frame is an error -- without any time bound (the host passes t0 = -1: every event is kept).
+template <bool HAS_MAP, bool EV = false, bool SIMPLE = false, int SAE = 0>
 __device__ __forceinline__ FastEv fast_decode(const FastGeom &G, uint2 r, long long t0)
 {
     FastEv o;
@@ -273,7 +275,7 @@ __device__ __forceinline__ FastEv fast_decode(const FastGeom &G, uint2 r, long l
         x = G.xmap[x];
         y = G.ymap[y];
     }
-    if (SAE && (x >= G.W || y >= G.H_full)) return o; // generate_surfaceofactiveevents.py:72
+    if (SAE == 1 && (x >= G.W || y >= G.H_full)) return o; // generate_surfaceofactiveevents.py:72
     if (x >= G.W || y >= G.H_full) {
         const long long flat = (long long)x + (long long)G.W * y;
         if (flat >= (long long)G.H_full * G.W) { o.err = ST_INDEX; return o; }
@@ -752,7 +754,7 @@ __host__ __device__ inline size_t scatter_cm_lds_bytes(int T, int chunk)
 // kBigBpw: 128 VGPRs, ONE workgroup per CU, chunks up to 20 480 events (LDS: 80 KB of staging + the counters) -- for large
 // calls with tile bins, where a consumer gathers one run per chunk: 10 M events at 1280x720 leave 512 chunks with 43-record
 // runs instead of 1536 with 14-record ones.
-template <bool HAS_MAP, bool EV = false, bool SIMPLE = false, int MAXB = kMaxBpw, bool SAE = false>
+template <bool HAS_MAP, bool EV = false, bool SIMPLE = false, int MAXB = kMaxBpw, int SAE = 0>
 __global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(MAXB > kMaxBpw ? 4 : 8, MAXB > kMaxBpw ? 4 : 8))) void kf_scatter_cm(FastGeom G, SeqTab S, uint32_t *dir, uint32_t *records, FastHeader *hdr, float *tlut_w,
                                                      uint32_t epoch)
 {
@@ -2726,7 +2728,7 @@ __global__ __launch_bounds__(kFaddWaves *kWave) void kf_ev_fadd(EvTileP q, CmP c
 // the time of that one event from the DAT array and writes memory and outputs with the arithmetic of k_sae_tile (encoders.hip).
 struct SaeFastP {
     int H, W, twl, thl, tiles_x, T, n_lamda;
-    float lam[FRLW_MAX_LAMDAS];
+    float lam[FRLW_MAX_LAMDAS > 21 ? FRLW_MAX_LAMDAS : 21]; // (ECI: the count -> value table)
     float nowf;
     const uint2 *data;
     const float *mem_in;
@@ -2735,6 +2737,9 @@ struct SaeFastP {
     FastHeader *hdr;
 };
 
+// ECI (template flag): the same walk over the runs COUNTS the records per cell instead; the image is the 21-entry table of
+// n sequential +0.05f adds, clamped and scaled (generate_eventcountimage.py:32-41; q.lam[] carries the table, n_lamda = 21).
+template <bool ECI>
 __global__ __launch_bounds__(kSubCells) void kf_sae_sub(SaeFastP q, CmP cm, SeqTab S)
 {
     __shared__ uint32_t s_last[kSubCells];
@@ -2777,13 +2782,13 @@ __global__ __launch_bounds__(kSubCells) void kf_sae_sub(SaeFastP q, CmP cm, SeqT
             }
 #pragma unroll
             for (int u = 0; u < RU; ++u) {
-                if ((uint32_t)l16 < cnt[u]) atomicMax(&s_last[v[u] & 255u], v[u]);
+                if ((uint32_t)l16 < cnt[u]) { if (ECI) atomicAdd(&s_last[v[u] & 255u], 1u); else atomicMax(&s_last[v[u] & 255u], v[u]); }
                 if (cnt[u] > 16u) {
                     const int c = cc0 + NG * u;
                     const uint32_t d = s_colD[c], lo = s_colL[c];
                     for (uint32_t j = 16u + l16; j < cnt[u]; j += 16u) {
                         const uint32_t w = cm.rec[d + lo + j];
-                        atomicMax(&s_last[w & 255u], w);
+                        if (ECI) atomicAdd(&s_last[w & 255u], 1u); else atomicMax(&s_last[w & 255u], w);
                     }
                 }
             }
@@ -2798,6 +2803,12 @@ __global__ __launch_bounds__(kSubCells) void kf_sae_sub(SaeFastP q, CmP cm, SeqT
     if (py >= q.H || px >= q.W) return;
     const long long plane = (long long)q.H * q.W, idx = (long long)pol * plane + (long long)py * q.W + px;
     const uint32_t w = s_last[tid];
+    if (ECI) {
+        const float v = q.lam[w > 20u ? 20u : w];
+        if (q.out_f32) q.out_f32[idx] = v;
+        if (q.out_u8) q.out_u8[idx] = f32_to_u8(v);
+        return;
+    }
     const float init = (0.0f + q.nowf) - 5000000.0f; // generate_surfaceofactiveevents.py:48
     // (the scatter stores position + 1: a record is never 0, 0 = the cell has no event)
     float tv = w ? (float)q.data[S.ev0[0] + (long long)(w >> kCellBits) - 1].x : init; // float(t), :76
@@ -3411,7 +3422,10 @@ int sae_fast_try(const frlw_events_t *ev, int H, int W, const float *lam, int n_
                  long long now, long long window_us, float *out_f32, uint8_t *out_u8, void *workspace, size_t workspace_bytes,
                  hipStream_t st)
 {
-    if (!ev || ev->layout != FRLW_LAYOUT_DAT8 || !ev->data || !workspace || window_us <= 0) return 1;
+    // (mem_out == nullptr: the Event Count Image -- lam[0 .. 20] is its count -> value table, no time filter)
+    const bool eci = mem_out == nullptr;
+    if (eci) { now = -1; window_us = 0; }
+    if (!ev || ev->layout != FRLW_LAYOUT_DAT8 || !ev->data || !workspace || (!eci && window_us <= 0)) return 1;
     if ((ev->xmap == nullptr) != (ev->ymap == nullptr) || !tuning_valid(ev->tuning)) return 1;
     const long long n = ev->n;
     // positions + 1 must fit the 20 bits above the 12-bit cell; tiny calls gain nothing; staged_scatter = 0 keeps the general path (tests)
@@ -3421,6 +3435,12 @@ int sae_fast_try(const frlw_events_t *ev, int H, int W, const float *lam, int n_
     const int64_t offs[2] = {0, (int64_t)n};
     const int64_t t0[1] = {(int64_t)(now - window_us)};
     if (!fast_plan(n, 1, H, W, p, DIRECT_FORCE, 0, true) || !p.direct) return 1; // frames of at most 64 tiles (the 304x240 class)
+    {   // at least ~64 chunks: the plan's largest-chunk rule (one GEN1 stream of 1 M events: 144 chunks) would leave a
+        // 100 000-event call with 15 scatter workgroups on 256 CUs
+        long long ce = ((n + 63) / 64 + 15) / 16 * 16;
+        if (ce < 1024) ce = 1024;
+        if (ce < p.chunk) { p.chunk = (int)ce; p.bpw = (p.chunk / kFW + kWave - 1) / kWave; }
+    }
     if (!fast_layout(offs, t0, 1, p, S, 1u)) return 1;
     if (p.max_seq_chunks > kColEv || p.chunk > 65535 || p.big || workspace_bytes < p.bytes) return 1;
     if (scatter_cm_lds_bytes(p.TB, p.chunk) > 160 * 1024) return 1;
@@ -3445,21 +3465,25 @@ int sae_fast_try(const frlw_events_t *ev, int H, int W, const float *lam, int n_
     (void)hipStreamIsCapturing(st, &cap);
     if (cap != hipStreamCaptureStatusNone) hipLaunchKernelGGL(kf_header_reset, dim3(1), dim3(256), 0, st, hdr);
     else epoch = g_epoch_sae.fetch_add(1u, std::memory_order_relaxed) | 0x40000000u;
-#define SAE_SCATTER(MAP, SIMPLE_) do { \
-        if (lds_sc > 64 * 1024) (void)hipFuncSetAttribute((const void *)kf_scatter_cm<MAP, true, SIMPLE_, kMaxBpw, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc); \
-        hipLaunchKernelGGL((kf_scatter_cm<MAP, true, SIMPLE_, kMaxBpw, true>), dim3(p.chunks), dim3(kFT), lds_sc, st, G, S, dir, records, hdr, (float *)nullptr, epoch); } while (0)
-    if (ev->xmap) SAE_SCATTER(true, false);
-    else if (G.simple) SAE_SCATTER(false, true);
-    else SAE_SCATTER(false, false);
+#define SAE_SCATTER(MAP, SIMPLE_, MODE) do { \
+        if (lds_sc > 64 * 1024) (void)hipFuncSetAttribute((const void *)kf_scatter_cm<MAP, true, SIMPLE_, kMaxBpw, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc); \
+        hipLaunchKernelGGL((kf_scatter_cm<MAP, true, SIMPLE_, kMaxBpw, MODE>), dim3(p.chunks), dim3(kFT), lds_sc, st, G, S, dir, records, hdr, (float *)nullptr, epoch); } while (0)
+    if (eci) { // (t0 = -1 is outside the SIMPLE decode's range: the general form keeps every event)
+        if (ev->xmap) SAE_SCATTER(true, false, 2);
+        else SAE_SCATTER(false, false, 2);
+    } else if (ev->xmap) SAE_SCATTER(true, false, 1);
+    else if (G.simple) SAE_SCATTER(false, true, 1);
+    else SAE_SCATTER(false, false, 1);
 #undef SAE_SCATTER
     SaeFastP q;
     q.H = H; q.W = W; q.twl = p.twl; q.thl = p.thl; q.tiles_x = p.tiles_x; q.T = p.T; q.n_lamda = n_lamda;
-    for (int l = 0; l < n_lamda; ++l) q.lam[l] = lam[l];
+    for (int l = 0; l < (eci ? 21 : n_lamda); ++l) q.lam[l] = lam[l];
     q.nowf = (float)now;
     q.data = (const uint2 *)ev->data;
     q.mem_in = mem_in; q.mem_out = mem_out; q.out_f32 = out_f32; q.out_u8 = out_u8; q.hdr = hdr;
     const CmP cmq = cm_params(p, w8);
-    hipLaunchKernelGGL(kf_sae_sub, dim3(p.pairs * kFW), dim3(kSubCells), 0, st, q, cmq, S);
+    if (eci) hipLaunchKernelGGL(kf_sae_sub<true>, dim3(p.pairs * kFW), dim3(kSubCells), 0, st, q, cmq, S);
+    else hipLaunchKernelGGL(kf_sae_sub<false>, dim3(p.pairs * kFW), dim3(kSubCells), 0, st, q, cmq, S);
     HIP_TRY(hipGetLastError());
     return FRLW_OK;
 }

@@ -457,10 +457,12 @@ def test_ev_samples_laid_out_in_one_frame_equal_their_own_encodes(er):
 
 
 @pytest.mark.parametrize("shape,n,maps", [((240, 304), 100_000, False), ((17, 33), 3_000, False), ((97, 131), 60_000, False),
-                                          ((512, 640), 12_000, True), ((240, 304), 1, False)])
+                                          ((512, 640), 12_000, True), ((240, 304), 1, False), ((256, 320), 90_000, True),
+                                          ((240, 304), 15_000, False)])
 def test_eci_single_launch_equals_general_path_and_oracle(er, orc, shape, n, maps, monkeypatch):
-    """Small Event Count Image calls take ONE launch (k_eci_scan: every workgroup counts its 2048 pixels over all events,
-    generate_eventcountimage.py:19-41) -- against the five-launch general path (forced by the tuning knob) and the oracle, bit for
+    """Small Event Count Image calls take TWO launches through the chunk-major partition (kf_scatter_cm + the counting form of
+    kf_sae_sub: 16 384 events and more on frames of the GEN1 class) or ONE (k_eci_scan: every workgroup counts its 2048 pixels
+    over all events, generate_eventcountimage.py:19-41) -- against the five-launch general path (forced by the tuning knob) and the oracle, bit for
     bit: hot pixels beyond the 20-add saturation, x >= W aliasing into the next row, down-scale maps, a single event; and an
     event outside the frame raises IndexError on both paths."""
     from frlw_evd_amd import _lib
