@@ -29,7 +29,8 @@ tw = (time.perf_counter() - t0) / 20 * 1e3
 print(f"engine fwd wall (sync each): {tw:.3f} ms")
 t2 = timeit(lambda: eng.detect(x), n=10)
 print(f"engine fwd+decode+nms (incl. host list): {t2:.3f} ms")
-with torch.no_grad():
-    x5 = x[..., None]
-    t3 = timeit(lambda: m.reference_outputs(x5), n=10)
-print(f"torch (MIOpen) fwd: {t3:.3f} ms  {B/t3*1e3:.0f} frames/s")
+if os.environ.get("MIOPEN", "0") == "1":  # the comparison leg stays out of the product's kernel profile unless asked for
+    with torch.no_grad():
+        x5 = x[..., None]
+        t3 = timeit(lambda: m.reference_outputs(x5), n=10)
+    print(f"torch (MIOpen) fwd: {t3:.3f} ms  {B/t3*1e3:.0f} frames/s")
