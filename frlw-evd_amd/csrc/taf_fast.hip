@@ -859,7 +859,10 @@ __global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(MAXB > kMax
     const uint32_t my_off = pre + inc - mine;
     if (tid < T) {
         loff[tid] = my_off;
-        dir[(long long)chunk * T + tid] = (mine << 16) | my_off; // the chunk's directory row (every chunk writes all of it)
+        // the directory is BIN-major, dir[bin][chunk] (every chunk writes its entry of all T bins: T scattered 4-byte stores
+        // per workgroup): a consumer reads its bin's column as ONE contiguous stretch -- chunk-major rows made every consumer's
+        // first step 512 loads from 512 lines (5 of the 30 us of a kf_split_whole workgroup)
+        dir[(long long)tid * (long long)gridDim.x + chunk] = (mine << 16) | my_off;
     }
     __syncthreads();
     // ---- phase C: stage the chunk bin-major in LDS
@@ -932,7 +935,8 @@ struct TileP {
 constexpr int kColMax = 4096; // chunks per sequence a consumer keeps in LDS (32 KB); longer sequences take the histogram path
 
 struct CmP { // kernel argument of the chunk-major consumers
-    const uint32_t *dir; // [chunks][TB]: count << 16 | offset of the bin's run inside the chunk's records
+    const uint32_t *dir; // [TB][n_chunks]: count << 16 | offset of the bin's run inside the chunk's records
+    int n_chunks;        // chunks of the call (all sequences)
     const uint32_t *rec; // chunk-major records (kf_scatter_cm)
     int TB;              // bins per sequence
     int chunk_ev;        // events per chunk = records a chunk's stretch of rec[] can hold
@@ -956,7 +960,7 @@ __device__ __forceinline__ uint32_t col_load(const CmP &m, const SeqTab &S, int 
     for (int cb = 0; cb < C; cb += NT) { // passes of NT chunks, one per thread (workgroup-uniform trip count: usually one)
         const int c = cb + tid;
         // (clamped index, masked value: no load sits under a lane condition)
-        const uint32_t v = m.dir[(long long)(c0 + (c < C ? c : C - 1)) * m.TB + b];
+        const uint32_t v = m.dir[(long long)b * m.n_chunks + (c0 + (c < C ? c : C - 1))];
         const uint32_t e = c < C ? v : 0u, cnt = e >> 16;
         const uint32_t inc = wave_incl_scan(cnt);
         if (lane == kWave - 1) wsum[wv] = inc;
@@ -2521,7 +2525,7 @@ __global__ __launch_bounds__(4 * kWave) void kf_ev_sub(EvTileP q, int all_tiles,
         uint32_t n = 0;
         for (int cb = 0; cb < C; cb += kWave) { // the column, 64 chunks per step (wave-uniform trip count)
             const int c = cb + lane;
-            const uint32_t v = cm.dir[(long long)(c0 + (c < C ? c : C - 1)) * cm.TB + b];
+            const uint32_t v = cm.dir[(long long)b * cm.n_chunks + (c0 + (c < C ? c : C - 1))];
             const uint32_t e = c < C ? v : 0u, cnt = e >> 16;
             const uint32_t inc = wave_incl_scan(cnt), run = n + inc - cnt;
             if (c < C) { colL[c] = run; colD[c] = out0 + (uint32_t)c * (uint32_t)cm.chunk_ev + (e & 0xffffu) - run; }
@@ -2628,7 +2632,7 @@ __global__ __launch_bounds__(kFaddWaves *kWave) void kf_ev_fadd(EvTileP q, CmP c
     uint32_t n = 0;
     for (int cb = 0; cb < C; cb += NT) { // (workgroup-uniform trip count; C <= kColEv)
         const int c = cb + tid;
-        const uint32_t v = cm.dir[(long long)(c0 + (c < C ? c : C - 1)) * cm.TB + b];
+        const uint32_t v = cm.dir[(long long)b * cm.n_chunks + (c0 + (c < C ? c : C - 1))];
         const uint32_t e = c < C ? v : 0u, cnt = e >> 16;
         const uint32_t inc = wave_incl_scan(cnt);
         if (lane == kWave - 1) s_wsum[wv] = inc;
@@ -2753,7 +2757,7 @@ __global__ __launch_bounds__(kSubCells) void kf_sae_sub(SaeFastP q, CmP cm, SeqT
     uint32_t n = 0;
     for (int cb = 0; cb < C; cb += NT) { // the sub-tile's column of the directory (workgroup-uniform trip count; C <= kColEv)
         const int c = cb + tid;
-        const uint32_t v = cm.dir[(long long)(c < C ? c : C - 1) * cm.TB + sg];
+        const uint32_t v = cm.dir[(long long)sg * cm.n_chunks + (c < C ? c : C - 1)];
         const uint32_t e = c < C ? v : 0u, cnt = e >> 16;
         const uint32_t inc = wave_incl_scan(cnt);
         if (lane == kWave - 1) s_wsum[wv] = inc;
@@ -3000,6 +3004,7 @@ inline CmP cm_params(const FastPlan &p, char *w8)
     cm.dir = (const uint32_t *)(w8 + p.off_counts);
     cm.rec = (const uint32_t *)(w8 + p.off_records);
     cm.TB = p.TB;
+    cm.n_chunks = p.chunks;
     cm.chunk_ev = p.chunk;
     cm.hot_start = (uint32_t *)(w8 + p.off_base);
     cm.hot_seg0 = (uint32_t *)(w8 + p.off_seg0);
