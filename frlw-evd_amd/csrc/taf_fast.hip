@@ -1651,18 +1651,26 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_waves_per_eu(8,
     const int ty = tile / q.tiles_x, tx = tile - ty * q.tiles_x;
     const int x0 = tx << q.twl, y0 = ty << q.thl, tw1 = (1 << q.twl) - 1;
     const long long plane = (long long)q.H * q.W;
-    const int cell = tid & (kSubCells - 1);
-    const int pol = cell & 1;
-    const int pt = sub * (kSubCells / 2) + (cell >> 1);
-    const int py = y0 + (pt >> q.twl), px = x0 + (pt & tw1);
-    const bool owner = tid < kSubCells, ok = owner && py < q.H && px < q.W;
-    float *srow = q.state + (((long long)s * plane + (long long)py * q.W + px) * 2 + pol) * K;
+    const bool owner = tid < kSubCells;
+    // (the row's address is worked out again wherever it is needed, from a thread id the compiler cannot recognise: kept alive
+    // across phase 1 its pieces were spilled -- 32 bytes of scratch per lane, which the write counter showed as 73 MB per encode)
+    auto row_of = [&](int t, bool &in_frame) -> float * {
+        asm volatile("" : "+v"(t));
+        const int c = t & (kSubCells - 1), p2 = sub * (kSubCells / 2) + (c >> 1);
+        const int yy = y0 + (p2 >> q.twl), xx = x0 + (p2 & tw1);
+        in_frame = t < kSubCells && yy < q.H && xx < q.W;
+        return q.state + (((long long)s * plane + (long long)yy * q.W + xx) * 2 + (c & 1)) * K;
+    };
     float st[kMaxK];
     // The state rows are needed behind phase 1 (and their registers should not be alive during it) -- but their trip to HBM should
     // overlap the window scan: one word of every row is requested HERE (a wavefront's rows are 2 KB in a row: all its lines come
     // in) and dropped behind phase 0; the real load then finds the lines in the caches.
     float row_touch = 0.0f;
-    if (ok) row_touch = srow[0];
+    {
+        bool in_frame;
+        const float *r = row_of(tid, in_frame);
+        if (in_frame) row_touch = r[0];
+    }
 
     for (int i = tid; i <= NW; i += kWalkThreads) wstart[i] = end;
     if (tid == 0) s_unsorted = 0;
@@ -1827,6 +1835,8 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_waves_per_eu(8,
         if (g0 == 0) { // the state rows: requested behind phase 1 (their registers are not alive during it), used behind the barrier
 #pragma unroll
             for (int kk = 0; kk < kMaxK; ++kk) st[kk] = 0.0f;
+            bool ok;
+            const float *srow = row_of(tid, ok);
             if (ok) {
                 if (K8) {
                     const float4 a = ((const float4 *)srow)[0], b = ((const float4 *)srow)[1];
@@ -1863,20 +1873,31 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_waves_per_eu(8,
 
     // ---- write-out: state, optional f32 view (2K, H, W), optional uint8 leaky transform (K, 2, H, W)
     uint8_t *ob = (uint8_t *)&s_area[0][0]; // [2K planes][128 pixels of the sub-tile] (the last phase 2 ended with a barrier)
-    if (ok) {
-        if (K8) {
-            ((float4 *)srow)[0] = make_float4(st[0], st[1], st[2], st[3]);
-            ((float4 *)srow)[1] = make_float4(st[4], st[5], st[6], st[7]);
-        } else {
+    // K = 8: a lane holds a whole 32-byte row; stored from here it would leave as two instructions of 16 bytes at a 32-byte stride
+    // -- half a sector each, twice the write requests (WRITE_SIZE showed 147 MB for 74).  The rows go through LDS instead and
+    // leave below from all 512 threads, 16 bytes each, consecutive threads writing consecutive pieces: whole lines.
+    float4 *rowst = (float4 *)&s_area[1][0]; // [256 rows][2] (behind the 2 KB of uint8 staging; the plane areas are dead)
+    static_assert(kWalkWaveWords * 4 >= 2 * kMaxK * (kSubCells / 2) && (kWalkWaves - 1) * kWalkWaveWords * 4 >= kSubCells * 32, "staging fits");
+    if (K8 && owner) {
+        rowst[2 * tid] = make_float4(st[0], st[1], st[2], st[3]);
+        rowst[2 * tid + 1] = make_float4(st[4], st[5], st[6], st[7]);
+    }
+    const int pol = tid & 1;
+    {
+        bool ok;
+        float *srow = row_of(tid, ok);
+        if (ok) {
+            if (!K8) {
 #pragma unroll
-            for (int k = 0; k < kMaxK; ++k)
-                if (k < K) srow[k] = st[k];
-        }
-        if (q.view_f32) {
-            float *vw = q.view_f32 + (long long)s * 2 * K * plane + (long long)py * q.W + px;
+                for (int k = 0; k < kMaxK; ++k)
+                    if (k < K) srow[k] = st[k];
+            }
+            if (q.view_f32) { // (the row's element index / (2 K) is the pixel, generate_taf.py:55)
+                float *vw = q.view_f32 + (long long)s * 2 * K * plane + ((srow - q.state) / (2 * K) - (long long)s * plane);
 #pragma unroll
-            for (int k = 0; k < kMaxK; ++k)
-                if (k < K) vw[(long long)(2 * k + pol) * plane] = st[k]; // generate_taf.py:55
+                for (int k = 0; k < kMaxK; ++k)
+                    if (k < K) vw[(long long)(2 * k + pol) * plane] = st[k];
+            }
         }
     }
     if (q.out_u8) {
@@ -1891,9 +1912,17 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_waves_per_eu(8,
                 }
             }
         }
-        WPROF(6);
-        __syncthreads();
-        WPROF(7);
+    }
+    WPROF(6);
+    if (K8 || q.out_u8) __syncthreads(); // (workgroup-uniform)
+    WPROF(7);
+    if (K8) { // thread t: half t & 1 of the row of cell t / 2
+        const int c2 = tid >> 1, pt2 = sub * (kSubCells / 2) + (c2 >> 1);
+        const int py2 = y0 + (pt2 >> q.twl), px2 = x0 + (pt2 & tw1);
+        if (py2 < q.H && px2 < q.W)
+            ((float4 *)(q.state + (((long long)s * plane + (long long)py2 * q.W + px2) * 2 + (c2 & 1)) * 8))[tid & 1] = rowst[tid];
+    }
+    if (q.out_u8) {
         // the (K, 2, H, W) volume leaves plane by plane in 16-pixel pieces: one 16-byte store where the row allows
         for (int c = tid; c < 2 * K * 8; c += kWalkThreads) {
             const int pl = c >> 3, part = c & 7;
