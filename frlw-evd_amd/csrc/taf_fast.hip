@@ -1133,7 +1133,10 @@ __global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     __shared__ uint32_t cE[kFW][kFW], cD[kFW][kFW]; // [wavefront]: per chunk, see step 4
     __shared__ uint32_t s_start, s_first;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (q.hdr->status != 0) return;
+    // (CM: the status is REQUESTED here and tested behind the directory column -- a test in front of it made the column's load
+    // wait for the header's round trip; the directory lies at addresses the plan fixes, reading it is safe whatever the status)
+    const int32_t status0 = q.hdr->status;
+    if (!CM && status0 != 0) return;
     const int blk = (int)blockIdx.x + q.first_block;
     if (!CM && blk >= q.pairs) { // the blocks behind the tiles: one segment of a skewed tile each (4b, counting)
         if (q.first_block && blk == q.pairs && tid == 0) q.sub[(long long)q.pairs * kFW] = q.base[q.pairs]; // (the last tile's block is not there to do it)
@@ -1155,6 +1158,7 @@ __global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         // they turned every "is this chunk of the list there at all" test below into divergent control flow, and 19 of the 32
         // records were spilled)
         n = col_load<kFT>(cm, S, s, g - s * q.T, colL, colD, &wtot[0][0]);
+        if (status0 != 0) return;
         if (n == 0u) {
             if (tid < kFW) { q.sub[(long long)g * kFW + tid] = 0u; q.sub_end[(long long)g * kFW + tid] = 0u; }
             return;
