@@ -754,6 +754,36 @@ __host__ __device__ inline size_t scatter_cm_lds_bytes(int T, int chunk)
 // kBigBpw: 128 VGPRs, ONE workgroup per CU, chunks up to 20 480 events (LDS: 80 KB of staging + the counters) -- for large
 // calls with tile bins, where a consumer gathers one run per chunk: 10 M events at 1280x720 leave 512 chunks with 43-record
 // runs instead of 1536 with 14-record ones.
+#ifndef FRLW_SCATTER_AHEAD
+#define FRLW_SCATTER_AHEAD 4
+#endif
+#if defined(FRLW_WALK_PROF) || defined(FRLW_SCAT_PROF) // developer timeline of kf_taf_walk / kf_scatter_cm (tools/enc_lab.cpp prints it): cycles between stamps, summed over workgroups
+constexpr int kProfWgs = 131072;
+__device__ unsigned long long g_walk_prof[kProfWgs * 9];
+#define XPROF(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pd_[i] += t_ - tp_; tp_ = t_; } while (0)
+#define XPROF_INIT() unsigned long long tp_ = __builtin_amdgcn_s_memtime(), pd_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define XPROF_END() do { if (threadIdx.x == 0 && blockIdx.x < kProfWgs) for (int i_ = 0; i_ < 9; ++i_) g_walk_prof[blockIdx.x * 9 + i_] += pd_[i_]; } while (0)
+#endif
+#ifdef FRLW_WALK_PROF
+#define WPROF(i) XPROF(i)
+#define WPROF_INIT() XPROF_INIT()
+#define WPROF_END() XPROF_END()
+#else
+#define WPROF(i) do { } while (0)
+#define WPROF_INIT() do { } while (0)
+#define WPROF_END() do { } while (0)
+#endif
+#ifdef FRLW_SCAT_PROF
+#define SPROF(i) XPROF(i)
+#define SPROF_INIT() XPROF_INIT()
+#define SPROF_END() XPROF_END()
+#define SPROF_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define SPROF(i) do { } while (0)
+#define SPROF_INIT() do { } while (0)
+#define SPROF_END() do { } while (0)
+#define SPROF_DRAIN() do { } while (0)
+#endif
 template <bool HAS_MAP, bool EV = false, bool SIMPLE = false, int MAXB = kMaxBpw, int SAE = 0>
 __global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(MAXB > kMaxBpw ? 4 : 8, MAXB > kMaxBpw ? 4 : 8))) void kf_scatter_cm(FastGeom G, SeqTab S, uint32_t *dir, uint32_t *records, FastHeader *hdr, float *tlut_w,
                                                      uint32_t epoch)
@@ -767,6 +797,7 @@ __global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(MAXB > kMax
     __shared__ unsigned long long wg_seen;
     __shared__ int serr;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    SPROF_INIT();
     const int chunk = (int)chunk_of_block(blockIdx.x, gridDim.x);
     const int s = seq_of_chunk(S, chunk);
     uint32_t *wcnt = wcnt_all + (size_t)wv * T;
@@ -791,11 +822,16 @@ __global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(MAXB > kMax
     const long long left = S.ev0[s + 1] - wave_begin;
     const uint32_t nloc = left < (long long)G.run ? (uint32_t)(left < 0 ? 0 : left) : (uint32_t)G.run;
     const long long t0 = S.t0[s];
+    // The chunk's events: kAhead batches per wavefront are requested here, batch j + kAhead when batch j is ranked (phase A).
+    // All MAXB at once (the form until round 5) fills the CU's memory queue -- 160 KB per CU, every CU of the part in the same
+    // burst -- and the wavefronts then stand at the ISSUE of their loads until HBM has served the queue: 8 of a workgroup's 26 us
+    // in front of the first decoded event (developer timeline, -DFRLW_SCAT_PROF).
+    constexpr int kAhead = MAXB > FRLW_SCATTER_AHEAD ? FRLW_SCATTER_AHEAD : MAXB;
     uint2 q[MAXB];
+    const uint2 *src = G.data + wave_begin;
     if (nloc > 0) { // wave-uniform; no load under a lane condition: lanes behind the run's end re-read its last event
-        const uint2 *src = G.data + wave_begin;
 #pragma unroll
-        for (int j = 0; j < MAXB; ++j) {
+        for (int j = 0; j < kAhead; ++j) {
             const uint32_t i = (uint32_t)(j * kWave + lane);
             q[j] = src[i < nloc ? i : nloc - 1u];
         }
@@ -812,7 +848,13 @@ __global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(MAXB > kMax
         }
         if (bad) atomicOr(&serr, ST_MULBAD); // (reaches the header with the other flags, at the end)
     }
-    __syncthreads();
+    // The barrier that publishes the zeroed counters must NOT wait for the event loads: __syncthreads() drains vmcnt, and the
+    // burst of a whole chunk (160 KB per CU, every CU of the part at once: HBM-bound, 8 of a workgroup's 26 us) would have to
+    // land before the first event is decoded.  A raw s_barrier behind the LDS writes only: the compiler's counted waits
+    // (loads return in order) then let batch j be ranked while batches j + 1 ... are still on their way.
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    SPROF(0);
+    SPROF(1);
     // ---- phase A: stream rank of every event inside (wavefront, bin), one returning LDS atomic each (lane order = stream order)
     uint32_t where[MAXB], word[MAXB];
     unsigned long long wseen = 0ull;
@@ -821,6 +863,13 @@ __global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(MAXB > kMax
     for (int j = 0; j < MAXB; ++j) {
         where[j] = 0xffffffffu;
         word[j] = 0u;
+        if (j + kAhead < MAXB) {
+            if (nloc > 0 && j + kAhead < G.bpw) { // wave-uniform
+                const uint32_t i2 = (uint32_t)((j + kAhead) * kWave + lane);
+                q[j + kAhead] = src[i2 < nloc ? i2 : nloc - 1u];
+            }
+            asm volatile("" ::: "memory"); // (the request stays HERE: hoisted to the top it is the burst again)
+        }
         if (j < G.bpw) {
             const uint32_t i = (uint32_t)(j * kWave + lane);
             if (i < nloc) {
@@ -837,7 +886,9 @@ __global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(MAXB > kMax
         }
     }
     if (err) atomicOr(&serr, err);
+    SPROF(2);
     __syncthreads();
+    SPROF(3);
     // ---- phase B: per bin, exclusive prefix of the 16 wavefront counts; chunk-local offsets of the bins
     uint32_t mine = 0; // records of bin `tid` in this chunk
     for (int b = tid; b < T; b += kFT) {
@@ -865,6 +916,7 @@ __global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(MAXB > kMax
         dir[(long long)tid * (long long)gridDim.x + chunk] = (mine << 16) | my_off;
     }
     __syncthreads();
+    SPROF(4);
     // ---- phase C: stage the chunk bin-major in LDS
 #pragma unroll
     for (int j = 0; j < MAXB; ++j) {
@@ -880,9 +932,14 @@ __global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(MAXB > kMax
     }
     if (lane == 0 && wseen) atomicOr(&wg_seen, wseen);
     __syncthreads();
+    SPROF(5);
     // ---- phase D: the staged chunk leaves as it is, one linear sweep into the chunk's own stretch of rec[]
     uint32_t *dst = records + (chunk_begin - S.ev0[0]);
     for (uint32_t qi = tid; qi < total; qi += kFT) dst[qi] = stage[qi];
+    SPROF(6);
+    SPROF_DRAIN();
+    SPROF(7);
+    SPROF_END();
     if (tid == 0) {
         if (epoch != 0u) {
             // bounded: ~2^22 polls of >= 128 cycles (a fraction of a second; the wait is normally over before it starts).  A part
@@ -1547,17 +1604,6 @@ __global__ __launch_bounds__(kFT) void kf_segcount_cm(TileP q, CmP cm, SeqTab S)
 //            (generate_taf.py:27-49), skipped for windows that are empty in the whole sequence (:40-41).
 // (ds_add_f32 would do the ordered sum in one instruction -- it applies same-address lanes in lane order with v_add_f32
 // rounding, checked by the self-test below -- but runs at 192 cycles per wave-instruction per CU: measured, not used.)
-#ifdef FRLW_WALK_PROF // developer timeline of kf_taf_walk (tools/enc_lab.cpp prints it): cycles between stamps, summed over workgroups
-constexpr int kProfWgs = 131072;
-__device__ unsigned long long g_walk_prof[kProfWgs * 9];
-#define WPROF(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pd_[i] += t_ - tp_; tp_ = t_; } while (0)
-#define WPROF_INIT() unsigned long long tp_ = __builtin_amdgcn_s_memtime(), pd_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}
-#define WPROF_END() do { if (threadIdx.x == 0 && blockIdx.x < kProfWgs) for (int i_ = 0; i_ < 9; ++i_) g_walk_prof[blockIdx.x * 9 + i_] += pd_[i_]; } while (0)
-#else
-#define WPROF(i) do { } while (0)
-#define WPROF_INIT() do { } while (0)
-#define WPROF_END() do { } while (0)
-#endif
 constexpr int kWalkWaves = 8;
 constexpr int kWalkThreads = kWalkWaves * kWave;
 constexpr int kWalkRpt = 4;                 // records per lane and pass
@@ -3094,7 +3140,7 @@ int lds_order_ok(char *w8, hipStream_t st)
 
 extern "C" {
 
-#ifdef FRLW_WALK_PROF
+#if defined(FRLW_WALK_PROF) || defined(FRLW_SCAT_PROF)
 int frlw_debug_walk_prof(unsigned long long *out16)
 {
     static unsigned long long host[kProfWgs * 9];
