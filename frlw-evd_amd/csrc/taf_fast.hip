@@ -909,7 +909,9 @@ __global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(MAXB > kMax
     for (int k = 0; k < kFW; ++k) { if (k < wv) pre += wtot[k]; total += wtot[k]; }
     const uint32_t my_off = pre + inc - mine;
     if (tid < T) {
-        loff[tid] = my_off;
+        // (the bin's slot in the staged chunk goes INTO the wavefronts' prefixes: phase C then reads one table per record, not two)
+#pragma unroll
+        for (int w = 0; w < kFW; ++w) wcnt_all[(size_t)w * T + tid] += my_off;
         // the directory is BIN-major, dir[bin][chunk] (every chunk writes its entry of all T bins: T scattered 4-byte stores
         // per workgroup): a consumer reads its bin's column as ONE contiguous stretch -- chunk-major rows made every consumer's
         // first step 512 loads from 512 lines (5 of the 30 us of a kf_split_whole workgroup)
@@ -922,7 +924,7 @@ __global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(MAXB > kMax
     for (int j = 0; j < MAXB; ++j) {
         if (j < G.bpw && where[j] != 0xffffffffu) {
             const uint32_t b = where[j] >> 16;
-            stage[loff[b] + wcnt[b] + (where[j] & 0xffffu)] = word[j];
+            stage[wcnt[b] + (where[j] & 0xffffu)] = word[j];
         }
     }
 #pragma unroll
@@ -1181,9 +1183,12 @@ __global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     constexpr int RPT = kSplitSeg / kFT; // 8 records per thread and chunk of 8192
     // scnt [sub-tile][batch] tickets, then exclusive prefixes | stage: one chunk of records, sub-tile-major.  CM, while the
     // list is gathered (before either is used): the column L | D | the position index
-    __shared__ __attribute__((aligned(16))) uint32_t pool[kFW * kWholeRow + kSplitSeg];
+    // CM: the column lies over the STAGING area (+ a tail of its own), not over the counters: the counters are zeroed in front of
+    // the gather and the tickets are taken as the gathered records arrive -- no barrier, no drained load queue in between
+    constexpr int kColWords = 2 * kColMax + 1 + kSplitWhole / 32 + 1;
+    constexpr int kPoolTail = CM && kColWords > kSplitSeg ? kColWords - kSplitSeg : 0;
+    __shared__ __attribute__((aligned(16))) uint32_t pool[kFW * kWholeRow + kSplitSeg + kPoolTail];
     uint32_t *scnt = pool, *stage = pool + kFW * kWholeRow;
-    static_assert(2 * kColMax + 1 + kSplitWhole / 32 + 1 <= kFW * kWholeRow + kSplitSeg, "the column fits the pool");
     __shared__ uint32_t wtot[kFW][kFW];        // segment counting (4b): [wavefront][sub-tile]
     __shared__ uint32_t vtot[kFW];             // records of every sub-tile
     __shared__ uint32_t vbeg[kFW][kFW];        // [wavefront]: every wavefront's own copy of the sub-tile starts
@@ -1208,9 +1213,10 @@ __global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     uint32_t beg, n;
     uint32_t m[kWholeChunks][RPT];
     if (CM) {
-        uint32_t *colL = pool, *colD = pool + kColMax + 1;
-        uint16_t *idx = (uint16_t *)(pool + 2 * kColMax + 1);
+        uint32_t *colL = stage, *colD = stage + kColMax + 1;
+        uint16_t *idx = (uint16_t *)(stage + 2 * kColMax + 1);
         const int s = g / q.T, C = S.chunk0[s + 1] - S.chunk0[s];
+        for (int i = tid; i < kFW * kWholeRow; i += kFT) scnt[i] = 0u; // (published by the barriers of col_load)
         // (readfirstlane: the workgroup-uniform values that come out of LDS are uniform for the COMPILER too -- as vector values
         // they turned every "is this chunk of the list there at all" test below into divergent control flow, and 19 of the 32
         // records were spilled)
@@ -1264,7 +1270,7 @@ __global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             }
         }
         beg = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_start);
-        __syncthreads(); // the column is dead: its space becomes scnt / stage
+        // (the column is dead once the last address is out; its space is written again in step 4, three barriers from here)
     } else {
         beg = q.base[g];
         const uint32_t end = q.base[g + 1];
@@ -1285,8 +1291,10 @@ __global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 m[c][u] = q.rec[beg + (i < n ? i : n - 1u)];
             }
     }
-    for (int i = tid; i < kFW * kWholeRow; i += kFT) scnt[i] = 0u;
-    __syncthreads();
+    if (!CM) {
+        for (int i = tid; i < kFW * kWholeRow; i += kFT) scnt[i] = 0u;
+        __syncthreads();
+    }
     // 2. tickets: batch (c, u, wv) of the stream, counter [sub-tile][batch]; packed four to a register (a ticket is < 64)
     uint32_t rk[kWholeChunks][RPT / 4];
 #pragma unroll
