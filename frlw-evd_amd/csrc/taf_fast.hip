@@ -889,17 +889,19 @@ __global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(MAXB > kMax
     SPROF(2);
     __syncthreads();
     SPROF(3);
-    // ---- phase B: per bin, exclusive prefix of the 16 wavefront counts; chunk-local offsets of the bins
+    // ---- phase B: per bin (thread = bin: T <= kFT), exclusive prefix of the 16 wavefront counts; chunk-local offsets of the bins.
+    // The prefixes stay in registers until the bin's slot in the staged chunk is known and go back to LDS ONCE, slot included:
+    // phase C then reads one table per record
     uint32_t mine = 0; // records of bin `tid` in this chunk
-    for (int b = tid; b < T; b += kFT) {
-        uint32_t run = 0;
+    uint32_t pv[kFW];
+    {
+        const int b = tid < T ? tid : 0;
 #pragma unroll
         for (int w = 0; w < kFW; ++w) {
-            const uint32_t v = wcnt_all[(size_t)w * T + b];
-            wcnt_all[(size_t)w * T + b] = run;
-            run += v;
+            pv[w] = mine;
+            mine += wcnt_all[(size_t)w * T + b];
         }
-        mine = run;
+        if (tid >= T) mine = 0u;
     }
     const uint32_t inc = wave_incl_scan(mine);
     if (lane == kWave - 1) wtot[wv] = inc;
@@ -909,9 +911,8 @@ __global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(MAXB > kMax
     for (int k = 0; k < kFW; ++k) { if (k < wv) pre += wtot[k]; total += wtot[k]; }
     const uint32_t my_off = pre + inc - mine;
     if (tid < T) {
-        // (the bin's slot in the staged chunk goes INTO the wavefronts' prefixes: phase C then reads one table per record, not two)
 #pragma unroll
-        for (int w = 0; w < kFW; ++w) wcnt_all[(size_t)w * T + tid] += my_off;
+        for (int w = 0; w < kFW; ++w) wcnt_all[(size_t)w * T + tid] = pv[w] + my_off;
         // the directory is BIN-major, dir[bin][chunk] (every chunk writes its entry of all T bins: T scattered 4-byte stores
         // per workgroup): a consumer reads its bin's column as ONE contiguous stretch -- chunk-major rows made every consumer's
         // first step 512 loads from 512 lines (5 of the 30 us of a kf_split_whole workgroup)
