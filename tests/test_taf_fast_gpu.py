@@ -474,6 +474,32 @@ def test_chunk_major_equals_histogram_partition(shape, n_seq, n, hot, monkeypatc
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("shape,n_seq,n,hot,bpw", [((720, 1280), 1, 700_000, True, 20), ((720, 1280), 2, 333_337, False, 12),
+                                                    ((240, 304), 3, 250_001, True, 20), ((97, 131), 2, 9_000, False, 20)])
+def test_big_chunks_equal_histogram_partition(shape, n_seq, n, hot, bpw, monkeypatch):
+    """The one-workgroup-per-CU scatter (chunks of up to 20 batches per wavefront: what a 10 M-event call takes by itself) forced
+    onto small and ragged calls with frlw_tuning_t::batches_per_wave -- last chunks of a few events, wavefronts without any,
+    sequences of different lengths -- against the histogram partition: state, view and uint8 volume bit for bit, with a state
+    carried over from a first call.  (Its event loads are requested four batches ahead of the ranks)"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from frlw_evd_amd import _lib, event_representation as er, synth
+    H, W = shape
+    K, win, n_win = 8, 10_000, 8
+    recs = [synth.to_dat8(synth.synth_events(1500 + j, n // (1 + 2 * (j == 1)), W, H, n_win * win, hotspot=hot)) for j in range(n_seq)]
+    offs = np.concatenate([[0], np.cumsum([len(r) for r in recs])])
+    dat = torch.from_numpy(np.ascontiguousarray(np.concatenate(recs)).view(np.uint8).reshape(-1, 8).copy()).cuda()
+    outs = []
+    for tuning in (_lib.FrlwTuning(chunk_major=1, direct_bins=0, batches_per_wave=bpw), _lib.FrlwTuning(chunk_major=0, direct_bins=0)):
+        monkeypatch.setattr(er, "TUNING", tuning)
+        st = torch.full((n_seq, H, W, 2, K), -6000.0, device="cuda")
+        for _ in range(2):
+            u8, view = er.encode_taf_batch(dat, offs, (H, W), st, 0, win, n_win, K, want_view=True)
+        outs.append((st, u8, view))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+
+
 def test_chunk_major_error_leaves_everything_untouched(monkeypatch):
     """The chunk-major scatter is also the validator (there is no histogram pass in front of it): an event behind the span sets
     the status, nothing is written, the deferred word carries it, and the next clean call on the workspace starts clean."""

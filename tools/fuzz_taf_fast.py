@@ -41,6 +41,8 @@ def main():
         # the others: the partition mode at random (library's choice / sub-tile bins forced where the frame allows / tile bins)
         cmaj = int(rng.integers(-1, 2))  # the partition: library's choice / histogram + scans / chunk-major
         er.TUNING = _lib.FrlwTuning(taf_tile_walk=1) if tile_walk else [_lib.FrlwTuning(chunk_major=cmaj), _lib.FrlwTuning(direct_bins=1, chunk_major=cmaj), _lib.FrlwTuning(direct_bins=0, chunk_major=cmaj)][int(rng.integers(0, 3))]
+        if not tile_walk and rng.random() < 0.15:  # the one-workgroup-per-CU scatter (big chunks), which only 6 M-event calls take by themselves
+            er.TUNING = _lib.FrlwTuning(chunk_major=1, direct_bins=0, batches_per_wave=int(rng.choice([9, 12, 20])))
         K = int(rng.choice([8, 8, 8, 5, 4, 1, 7]))
         n_win = int(rng.choice([1, 2, 3, 8, 8, 13, 64]))
         win = int(rng.choice([1_000, 10_000, 10_000, 7_777, 50_000]))
