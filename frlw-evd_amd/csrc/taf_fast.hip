@@ -1554,7 +1554,7 @@ __global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 // chunk-major partition: records of every sub-tile in every split segment (kf_split_whole<false> does this in its spare
 // workgroups; here the segments only exist once kf_split_whole<true> has run).  Most calls have none: the workgroups leave
 // after one load.
-__global__ __launch_bounds__(kFT) void kf_segcount_cm(TileP q, CmP cm, SeqTab S)
+__global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(8, 8))) void kf_segcount_cm(TileP q, CmP cm, SeqTab S) // (64 VGPRs: two workgroups per CU)
 {
     __shared__ ColLds cl;
     __shared__ uint32_t wtot[kFW][kFW];
@@ -2580,7 +2580,9 @@ __global__ __launch_bounds__(NW *kWave) void kf_ev_tile(EvTileP q)
 constexpr int kColEv = 511;       // chunks per sequence a wavefront's column holds
 constexpr int kEvListCap = 2048;  // records of a sub-tile's list kept in LDS per wavefront
 template <int BINS, bool CMD = false>
-__global__ __launch_bounds__(4 * kWave) void kf_ev_sub(EvTileP q, int all_tiles, CmP cm, SeqTab S)
+// (five wavefronts per SIMD where the registers allow it without spills -- the five-bin list walk, 102 -> 92 VGPRs: every
+// wavefront is a latency chain of its own, one more of them per SIMD hides more of it)
+__global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu((BINS <= 5 && !CMD) ? 5 : 1, 8))) void kf_ev_sub(EvTileP q, int all_tiles, CmP cm, SeqTab S)
 {
     __shared__ uint32_t s_cnt[4][kSubCells / 2];
     __shared__ uint16_t s_off[4][kSubCells];
@@ -3109,7 +3111,7 @@ inline void launch_split_cm(TileP &q, const FastPlan &p, const SeqTab &S, char *
     q.sub = (uint32_t *)(w8 + p.off_sub);
     q.sub_end = (uint32_t *)(w8 + p.off_sub_end);
     // (direct mode never comes here: its consumers gather their own lists)
-    const int seg_grid = p.max_segs < 256 ? p.max_segs : 256; // (they stride over the segments; most calls have none)
+    const int seg_grid = p.max_segs < 512 ? p.max_segs : 512; // (they stride over the segments; most calls have none; two workgroups per CU)
     hipLaunchKernelGGL(kf_split_whole<true>, dim3(p.pairs), dim3(kFT), 0, st, q, cm, S);
     hipLaunchKernelGGL(kf_segcount_cm, dim3(seg_grid), dim3(kFT), 0, st, q, cm, S);
     hipLaunchKernelGGL(kf_split_place<true>, dim3(seg_grid), dim3(kFT), 0, st, q, cm, S);
