@@ -552,7 +552,7 @@ int frlw_conv2d_dgrad(const float *dz, int B, int Ho, int Wo, int Cout, const fl
 int64_t frlw_conv2d_wgrad_scratch_floats(int B, int Ho, int Wo, int Cin, int Cout, int k)
 {
     const long long R = (long long)k * k * Cin;
-    static const long long target = dev_knob("FRLW_WGRAD_TARGET", 1280ll);
+    static const long long target = dev_knob("FRLW_WGRAD_TARGET", 1024ll); // four 128 x 128 workgroups per CU (wgrad_want_splits rounds DOWN to it)
     const long long sp = wgrad_want_splits(R, Cout, (long long)B * Ho * Wo, target);
     const long long groups = sp > 64 ? (sp + kWgradGroup - 1) / kWgradGroup : 0;
     return (sp + groups) * R * Cout;

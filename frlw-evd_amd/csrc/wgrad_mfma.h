@@ -254,8 +254,12 @@ inline long long wgrad_want_splits(long long R, int Cout, long long M, long long
     const long long bm = R > 64 ? 128 : 64, bn = wgrad_wide(R, Cout) ? 128 : (R > 64 && Cout <= 32 ? 32 : 64);
     const long long tiles = ((R + bm - 1) / bm) * ((Cout + bn - 1) / bn);
     const long long nk = (M + 15) / 16;
-    long long sp = (target + tiles - 1) / tiles;
-    if (sp > 256) sp = 256;                    // (more than 64 partial tiles per output tile: two-stage reduction)
+    // floor, not ceil: `target` workgroups are what the part holds at once (five 128 x 128 workgroups per CU); one split more and
+    // 36 tiles x 36 splits = 1296 workgroups leave a sixth workgroup on 16 CUs -- a second, nearly empty round of the whole
+    // kernel (the 256 -> 256 3 x 3 layers: 27.8 -> 27.4 ms per train step)
+    long long sp = target / tiles;
+    static const long long max_sp = dev_knob("FRLW_WGRAD_MAXSP", 256ll);
+    if (sp > max_sp) sp = max_sp;              // (more than 64 partial tiles per output tile: two-stage reduction)
     if (sp > nk / 4) sp = nk / 4;
     if (sp < 1) sp = 1;
     return sp;

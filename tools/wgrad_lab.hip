@@ -58,7 +58,7 @@ int main(int argc, char **argv)
         a.k = sh.k; a.stride = sh.s; a.pad = (sh.k - 1) / 2; a.R = sh.k * sh.k * sh.Cin; a.M = B * Ho * Wo;
         a.partial = scratch;
         a.prec = (int)dev_knob("FRLW_WGRAD_PREC", 1); // 1: three bf16 MFMAs per product
-        const int target = (int)dev_knob("FRLW_WGRAD_TARGET", 1280);
+        const int target = (int)dev_knob("FRLW_WGRAD_TARGET", 1024);
         auto run = [&]() { launch_wgrad(a, target, scratch_floats, st); };
         for (int i = 0; i < 2; ++i) run();
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
