@@ -159,8 +159,16 @@ class Timer:
         return wall / steps, dev_ms
 
 
-GRAPHED_NOTE = {"launch": "the K timed steps are ONE HIP graph replay (launch-bound call: ~20 us of Python per eager call); "
-                          "eager_ms_per_step = the same K steps as eager calls"}
+def graphed_row(row, units, per_graph, eager):
+    """A small single-stream encode: `value` / `ms_per_step` = K EAGER calls (what rounds 1-4 reported under these keys and what a
+    Python caller in a loop gets); `graph_value` / `graph_ms_per_step` = the same K steps replayed as ONE HIP graph (the kernels
+    without ~20 us of Python per call); roofline.device_ms is the graph replay's (kernel time, the roofline's denominator)."""
+    row["value"] = round(units / eager / 1e6, 2)
+    row["ms_per_step"] = round(eager * 1e3, 4)
+    row["graph_value"] = round(units / per_graph / 1e6, 2)
+    row["graph_ms_per_step"] = round(per_graph * 1e3, 4)
+    row["launch"] = "value, ms_per_step: K eager calls; graph_*: the K steps as ONE HIP graph replay; roofline: graph device time"
+    return row
 
 
 def run_graphed(timer, fn, steps, warmup):
@@ -204,22 +212,45 @@ def roofline(alg_bytes, dev_ms, kernel, copy_gbs, units):
             "units_per_launch": units, "device_ms": round(dev_ms, 4), "traffic": None}
 
 
-# The driver's parser keeps the FIRST 24 keys of `roofline` (strings included) and drops every other block of the line: these 24,
-# in this order, are what BENCH_rNN.json carries -- the 12 headline keys, then the detector half of BASELINE.json's metric
-# (core/model.py:40-61 is the forward it stands for), the train step, and the GEN1-shaped encoder rows.  Everything else
-# (strings, the remaining flat scalars) follows behind and lives in the nested blocks as well.
+# The driver reads back a bounded number of bytes and its parser keeps the FIRST 24 keys of `roofline`: the line rank 0 prints is
+# the COMPACT line (<= 6 000 bytes, tests/test_bench_line.py) -- the 12 top-level scalars, `config` (four short strings), `roofline`
+# = these 24 keys in this order + at most 30 further scalars (ROOFLINE_MORE), `cpu_baseline` = CPU_BASELINE_KEYS.  Every other
+# block (`also`, `gen1`, `detector`, `train`, `general_path`, `stripe_sharding`, `allreduce`, every descriptive string) goes to
+# the side file bench_detail.json next to this script (tools/refresh_r06.sh copies it into profiles/).
 ROOFLINE_FIRST_24 = (
     "bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "device_ms", "algorithmic_bytes", "traffic_x_algorithmic",
     "frac_of_copy", "copy_GBs_measured",
     "detector_frames_per_s", "detector_ms_per_batch", "detector_frac", "detector_1mpx_frac",
     "train_ms", "train_frac", "encode_plus_train_ms",
-    "gen1_taf_single_ms", "gen1_taf_single_frac", "gen1_taf_x64_frac", "gen1_ev_single_ms", "gen1_ev_x64_frac",
+    "gen1_taf_single_graph_ms", "gen1_taf_single_frac", "gen1_taf_x64_frac", "gen1_ev_single_graph_ms", "gen1_ev_x64_frac",
 )
+# (`*_graph_ms`: K steps replayed as ONE HIP graph; `*_eager_ms`: the same K steps as K eager calls -- round 4 and before reported
+#  the eager time under `gen1_*_single_ms`, round 5 the graph replay under the same name; the two now have a key each)
+ROOFLINE_MORE = (
+    "taf_mpx_hotspot_ms", "taf_mpx_hotspot_frac", "taf_mpx_hotspot_traffic_x", "general_path_ms",
+    "gen1_taf_single_eager_ms", "gen1_taf_single_traffic_x", "gen1_taf_x64_ms", "gen1_taf_x64_traffic_x",
+    "gen1_ev_single_eager_ms", "gen1_ev_single_default_call_ms", "gen1_ev_single_frac", "gen1_ev_single_traffic_x",
+    "gen1_ev_x64_ms", "gen1_ev_x64_traffic_x",
+    "sae_gen1_graph_ms", "sae_gen1_frac", "eci_gen1_graph_ms", "eci_gen1_frac",
+    "detector_TFLOPs", "detector_fwd_nms_ms", "detector_fwd_nms_typical_ms", "detector_1mpx_ms_per_batch", "detector_1mpx_fwd_nms_ms",
+    "train_TFLOPs", "train_eager_ms", "train_miopen_ms", "encode_ahead_plus_train_ms",
+    "allreduce_exposed_ms", "global64_ms", "stripe_ms",
+)
+CPU_BASELINE_KEYS = ("value", "unit", "cores", "kind", "cpu", "all_cores_value", "all_cores_threads", "sample")
+TOP_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data")
+CONFIG_KEYS = ("workload", "path", "parallelism", "detail")
+LINE_LIMIT = 6000
+DETAIL_FILE = "bench_detail.json"
+
+
+def _short(v, n):
+    return v if not isinstance(v, str) or len(v) <= n else v[:n - 1] + "~"
 
 
 def order_roofline(result):
-    """Re-key result['roofline'] so that ROOFLINE_FIRST_24 come first (None where a leg did not run: the position is what
-    counts), the remaining scalars after them; descriptive strings move to result['config'] (tests/test_bench_line.py)."""
+    """Re-key result['roofline'] (the DETAIL form): ROOFLINE_FIRST_24 first (None where a leg did not run: the position is what
+    counts), ROOFLINE_MORE behind them, then whatever else the legs wrote; descriptive strings move to result['config']."""
     roof = result["roofline"]
     if roof.get("traffic") and roof.get("algorithmic_bytes"):
         roof["traffic_x_algorithmic"] = round(roof["traffic"] / roof["algorithmic_bytes"], 3)
@@ -228,6 +259,9 @@ def order_roofline(result):
         if k in roof:
             cfg[k] = roof.pop(k)
     ordered = {k: roof.get(k) for k in ROOFLINE_FIRST_24}
+    for k in ROOFLINE_MORE:
+        if k in roof:
+            ordered[k] = roof[k]
     for k, v in roof.items():
         if k not in ordered:
             ordered[k] = v
@@ -235,11 +269,52 @@ def order_roofline(result):
     return result
 
 
+def compact_line(result):
+    """The ONE line rank 0 prints, from the detail form `order_roofline` left: scalars only inside `roofline` (the two strings
+    `bound`, `unit` and a short `kernel` aside), no prose, nothing nested."""
+    line = {k: result.get(k) for k in TOP_KEYS}
+    cfg = result.get("config", {})
+    line["config"] = {"workload": _short(cfg.get("workload", ""), 160), "path": _short(cfg.get("path", ""), 48),
+                      "parallelism": _short(cfg.get("parallelism", ""), 48), "detail": DETAIL_FILE}
+    roof = result["roofline"]
+    out = {}
+    for k in ROOFLINE_FIRST_24 + ROOFLINE_MORE:
+        v = roof.get(k)
+        if k in ROOFLINE_FIRST_24 or v is not None:
+            if isinstance(v, (dict, list)):
+                continue
+            out[k] = _short(v, 140) if k == "kernel" else _short(v, 16)
+    line["roofline"] = out
+    cb = result.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {k: _short(cb[k], 96 if k == "sample" else 48) for k in CPU_BASELINE_KEYS if k in cb}
+    return line
+
+
+def emit(result, out, write_detail=True):
+    """Detail -> bench_detail.json (and stderr), the compact line -> the real stdout.  The line is refused when it outgrows
+    LINE_LIMIT: a line the driver cannot parse is worth nothing (BENCH_r05.json)."""
+    order_roofline(result)
+    line = compact_line(result)
+    text = json.dumps(line)
+    if len(text) > LINE_LIMIT or "\n" in text or not text.isascii():
+        raise SystemExit(f"bench.py: the JSON line is {len(text)} bytes (limit {LINE_LIMIT}) or not one ASCII line")
+    if write_detail:
+        detail = dict(result, line=line)
+        try:
+            with open(os.path.join(ROOT, DETAIL_FILE), "w") as f:
+                json.dump(detail, f, indent=1)
+        except OSError as e:  # (a read-only checkout: the line still goes out)
+            print(f"bench.py: {DETAIL_FILE} not written: {e}", file=sys.stderr)
+        print("bench.py detail: " + json.dumps(result), file=sys.stderr, flush=True)
+    print(text, file=out, flush=True)
+    return line
+
+
 def fast_kernel_label(er=None):
     """The launch sequence `frlw_taf_encode_batch` runs on the headline workload (chunk-major partition with large chunks, DESIGN.md
     3.6; profiles/r05_bench_kernel_stats.csv shows exactly these names)."""
-    return ("frlw_taf_encode_batch = kf_scatter_cm + kf_split_whole<true> + kf_segcount_cm + kf_split_place<true> + kf_taf_walk "
-            "(dominant: kf_taf_walk)")
+    return "frlw_taf_encode_batch = kf_scatter_cm + kf_split_whole + kf_segcount_cm + kf_split_place + kf_taf_walk (dominant)"
 
 
 def attach_traffic(roof, tag):
@@ -492,19 +567,28 @@ def main():
         result["gen1"] = {k: row for k, row in zip(names, result["also"][:4])}
         # the driver's parser keeps SCALAR keys of `roofline` only: one flat key per number
         flat = result["roofline"]
+
+        def flat_row(prefix, row):
+            rf = row["roofline"]
+            if "graph_ms_per_step" in row:  # small single-stream encodes: the graph replay and the eager calls, a key each
+                flat[f"{prefix}_graph_ms"] = row["graph_ms_per_step"]
+                flat[f"{prefix}_eager_ms"] = row["ms_per_step"]
+            else:
+                flat[f"{prefix}_ms"] = row["ms_per_step"]
+            if "default_call_ms" in row:
+                flat[f"{prefix}_default_call_ms"] = row["default_call_ms"]
+            flat[f"{prefix}_frac"] = rf["frac"]
+            if rf.get("traffic"):
+                flat[f"{prefix}_traffic_x"] = round(rf["traffic"] / rf["algorithmic_bytes"], 3)
         for k, row in result["gen1"].items():
-            flat[f"gen1_{k}_mev_s"] = row["value"]
-            flat[f"gen1_{k}_ms"] = row["ms_per_step"]
-            flat[f"gen1_{k}_GBs"] = row["roofline"]["achieved"]
-            flat[f"gen1_{k}_frac"] = row["roofline"]["frac"]
-            flat[f"gen1_{k}_traffic"] = row["roofline"].get("traffic")
+            flat_row(f"gen1_{k}", row)
         for row in result["also"][4:]:
-            tag = row.get("tag")
-            if tag:
-                flat[f"{tag}_mev_s"] = row["value"]
-                flat[f"{tag}_ms"] = row["ms_per_step"]
-                flat[f"{tag}_frac"] = row["roofline"]["frac"]
-                flat[f"{tag}_traffic"] = row["roofline"].get("traffic")
+            if row.get("tag"):
+                flat_row(row["tag"], row)
+    if "general_path" in result:
+        result["roofline"]["general_path_ms"] = result["general_path"]["device_ms"]
+    if "stripe_sharding" in result:
+        result["roofline"]["stripe_ms"] = result["stripe_sharding"]["ms_per_step"]
     if not args.no_detector:
         result["detector"] = bench_detector(args, torch, world, rank, timer)
         d = result["detector"]  # the second half of BASELINE.json's metric, in the keys the driver keeps (scalars)
@@ -524,9 +608,13 @@ def main():
             if "x_f32_mfma_peak" in o["roofline"]:
                 flat[f"detector_{tagp}_x_f32_mfma_peak"] = o["roofline"]["x_f32_mfma_peak"]
             flat["detector_bf16x3_vs_f32_max_rel_diff"] = o["max_rel_diff_bf16x3_vs_f32"]
+        flat["detector_fwd_nms_ms"] = d.get("fwd_plus_decode_nms_ms")
+        flat["detector_fwd_nms_typical_ms"] = d.get("fwd_plus_decode_nms_typical_ms")
         if "shape_1mpx" in d:
             flat["detector_1mpx_frames_per_s"] = d["shape_1mpx"]["value"]
             flat["detector_1mpx_frac"] = d["shape_1mpx"]["roofline"]["frac"]
+            flat["detector_1mpx_ms_per_batch"] = d["shape_1mpx"]["ms_per_batch"]
+            flat["detector_1mpx_fwd_nms_ms"] = d["shape_1mpx"].get("fwd_plus_decode_nms_ms")
     if not args.no_train:
         try:
             result["train"] = bench_train(args, torch, world, rank, local_rank, timer)
@@ -550,13 +638,20 @@ def main():
                 flat["encode_plus_train_frames_per_s"] = t["encode_plus_train_step"]["value"]
                 flat["encode_ahead_plus_train_ms"] = t["encode_plus_train_step"]["encode_ahead"]["ms_per_step"]
                 flat["encode_ahead_plus_train_frames_per_s"] = t["encode_plus_train_step"]["encode_ahead"]["value"]
+            if "eager" in t:
+                flat["train_eager_ms"] = t["eager"]["ms_per_step"]
+            if "same_step_with_miopen_convs" in t:
+                flat["train_miopen_ms"] = t["same_step_with_miopen_convs"]["ms_per_step"]
+            if "allreduce" in t:
+                flat["allreduce_exposed_ms"] = t["allreduce"]["allreduce_exposed_ms"]
+            if "global64" in t:
+                flat["global64_ms"] = t["global64"]["ms_per_step"]
         except Exception as e:  # never lose the headline line to the extra leg
             result["train"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline_taf(dat_h, n, H, W, K, n_win, win_us)
-    order_roofline(result)
     if rank == 0:
-        print(json.dumps(result), file=out, flush=True)
+        emit(result, out)
     if dist.is_initialized():
         dist.destroy_process_group()
 
@@ -579,7 +674,8 @@ def bench_also(args, torch, synth, er, timer, rank, n_gpus, copy_gbs):
            "value": round(n_gpus * n2 / per / 1e6, 2), "unit": "Mevents/s", "ms_per_step": round(per * 1e3, 4),
            "roofline": roofline(taf_algorithmic_bytes(n2, H2, W2, K2), dev, "frlw_taf_encode_batch, one sequence, direct mode = kf_scatter_cm + kf_taf_walk<K8, direct> (two launches)" if n2 >= er.FAST_MIN_EVENTS else "frlw_taf_encode (k_taf_tile dominant)", copy_gbs,
                                 f"{n2} events")}
-    row.update(GRAPHED_NOTE, eager_ms_per_step=round(eager * 1e3, 4))
+    graphed_row(row, n_gpus * n2, per, eager)
+    row["path"] = "encode_taf_dat(fast=True, check=False): an OPT-IN for unchecked calls (fast='auto' takes it for checked calls only)"
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         row["cpu_baseline"] = cpu_baseline_taf(rec2, n2, H2, W2, K2, nw2, wu2, all_cores=False)
     out.append(row)
@@ -608,7 +704,10 @@ def bench_also(args, torch, synth, er, timer, rank, n_gpus, copy_gbs):
            "roofline": roofline(ev_algorithmic_bytes(1_000_000, H2, W2, 5), dev,
                                 "frlw_ev_encode_batch, one window, direct mode = kf_scatter_cm + kf_ev_fadd (two launches)", copy_gbs,
                                 "1000000 events")}
-    row.update(GRAPHED_NOTE, eager_ms_per_step=round(eager * 1e3, 4))
+    graphed_row(row, n_gpus * 1_000_000, per, eager)
+    row["path"] = "encode_ev_dat(fast=True, check=False): the two-launch form is an OPT-IN for unchecked calls (fast='auto' takes it for checked calls only)"
+    dflt, _d = timer.run(lambda: er.encode_ev_dat(dat4, (H2, W2), 250_000, 250_000, volume_bins=5), steps, 2)
+    row["default_call_ms"] = round(dflt * 1e3, 4)  # encode_ev_dat with its defaults: fast="auto", check=True (one host sync per call)
     pg, dg, _e = run_graphed(timer, lambda: er.encode_ev_dat(dat4, (H2, W2), 250_000, 250_000, volume_bins=5, check=False, fast=False), steps, 3)
     row["general_path"] = {"ms_per_step": round(pg * 1e3, 4), "device_ms": round(dg, 4), "kernel": "frlw_ev_encode (five launches)"}
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
@@ -646,7 +745,7 @@ def bench_also(args, torch, synth, er, timer, rank, n_gpus, copy_gbs):
            "value": round(n_gpus * 1_000_000 / per / 1e6, 2), "unit": "Mevents/s", "ms_per_step": round(per * 1e3, 4),
            "roofline": roofline(sae_algorithmic_bytes(1_000_000, H2, W2, len(LAM)), dev,
                                 "frlw_sae_encode = kf_scatter_cm<SAE> + kf_sae_sub (two launches)", copy_gbs, "1000000 events")}
-    row.update(GRAPHED_NOTE, eager_ms_per_step=round(eager * 1e3, 4))
+    graphed_row(row, n_gpus * 1_000_000, per, eager)
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         row["cpu_baseline"] = cpu_baseline_generic(
             lambda orc: orc.sae_stream_dat8(rec6, (H2, W2), (H2, W2), LAM, None, now6, win6), len(rec6), "sae_stream_dat8")
@@ -662,7 +761,7 @@ def bench_also(args, torch, synth, er, timer, rank, n_gpus, copy_gbs):
            "value": round(n_gpus * 100_000 / per / 1e6, 2), "unit": "Mevents/s", "ms_per_step": round(per * 1e3, 4),
            "roofline": roofline(eci_algorithmic_bytes(100_000, H2, W2), dev,
                                 "frlw_eci_encode = kf_scatter_cm<ECI> + kf_sae_sub<count> (two launches)", copy_gbs, "100000 events")}
-    row.update(GRAPHED_NOTE, eager_ms_per_step=round(eager7 * 1e3, 4))
+    graphed_row(row, n_gpus * 100_000, per, eager7)
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         row["cpu_baseline"] = cpu_baseline_generic(lambda orc: orc.eci_stream_dat8(rec7, (H2, W2), (H2, W2)), len(rec7),
                                                    "eci_stream_dat8", reps=40)

@@ -1,6 +1,9 @@
-"""The JSON line of bench.py: the driver's parser keeps the first 24 keys of `roofline` -- the detector half of BASELINE.json's
-metric (the forward of core/model.py:40-61), the train step and the GEN1-shaped rows must sit inside them."""
+"""The JSON line of bench.py.  The driver reads back a bounded number of bytes (BENCH_r05.json: a 20 kB line came back unparsed) and
+its parser keeps the first 24 keys of `roofline`: the line must stay <= 6 000 bytes at N = 1 and N = 8 with worst-case field widths,
+and the detector half of BASELINE.json's metric (the forward of core/model.py:40-61), the train step and the GEN1-shaped rows must sit
+inside those 24 keys.  Everything else lives in bench_detail.json."""
 import importlib.util
+import io
 import json
 import os
 
@@ -16,28 +19,100 @@ def _bench():
 
 WANTED = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic",
           "detector_frames_per_s", "detector_ms_per_batch", "detector_frac", "detector_1mpx_frac", "train_ms", "train_frac",
-          "encode_plus_train_ms", "gen1_taf_single_ms", "gen1_taf_single_frac", "gen1_taf_x64_frac", "gen1_ev_single_ms",
+          "encode_plus_train_ms", "gen1_taf_single_graph_ms", "gen1_taf_single_frac", "gen1_taf_x64_frac", "gen1_ev_single_graph_ms",
           "gen1_ev_x64_frac")
+BIG = 123456789012.123456  # wider than any number a leg can produce
+PROSE = "prose that belongs in bench_detail.json, not in the line; " * 8
+
+
+def _full_result(b, n_gpus):
+    """A detail-form result as main() assembles it with every leg run, every field at a worst-case width and the prose blocks of
+    the legs attached (they must not reach the line)."""
+    roof = b.roofline(212_710_400 * 64, 0.165, b.fast_kernel_label() + " " + PROSE, 5500.0, "10000000 events")
+    roof["traffic"] = 412_902_400 * 64
+    roof["traffic_source"] = "profiles/traffic_taf_mpx.json " + PROSE
+    for k in b.ROOFLINE_FIRST_24 + b.ROOFLINE_MORE:
+        if k not in roof or roof[k] is None:
+            roof[k] = BIG
+    roof["mfma"] = PROSE
+    roof["detector_dtype"] = PROSE
+    for i in range(40):
+        roof[f"some_other_scalar_{i}"] = BIG
+    result = {"metric": "TAF encode throughput (Mevents/s)", "value": BIG, "unit": "Mevents/s", "n_gpus": n_gpus, "steps": 100000,
+              "warmup": 100000, "ms_per_step": BIG, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+              "data": "synthetic",
+              "config": {"workload": "taf_mpx (BASELINE.json configs[2]) " + PROSE, "path": "fast (csrc/taf_fast.hip) " + PROSE,
+                         "events_per_step_per_gpu": 10_000_000, "parallelism": f"sequence-sharded x{n_gpus} (no collective) " + PROSE},
+              "roofline": roof,
+              "also": [{"workload": PROSE, "roofline": dict(roof), "launch": PROSE, "sample": PROSE}] * 7,
+              "gen1": {"taf_single": {"what": PROSE}}, "general_path": {"value": BIG, "device_ms": BIG},
+              "detector": {"roofline": {"mfma": PROSE, "flops_model": PROSE}, "shape_1mpx": {"workload": PROSE}, "cpu_baseline": {"sample": PROSE}},
+              "train": {"launch": PROSE, "convolutions": PROSE, "roofline": {"flops_model": PROSE},
+                        "allreduce": {"hooks": PROSE, "ddp": PROSE, "exposed_ms_by_hook": {"default": BIG, "rs_ag": BIG}},
+                        "global64": {"workload": PROSE, "allreduce": {"hooks": PROSE}}}}
+    if n_gpus > 1:
+        result["stripe_sharding"] = {"workload": PROSE, "value": BIG, "ms_per_step": BIG, "rows_of_rank0": [0, 90]}
+    else:
+        result["cpu_baseline"] = {"value": BIG, "unit": "Mevents/s", "cores": 1, "kind": "port", "sample": PROSE, "host_cpus": 256,
+                                  "host_physical_cores": 128, "threads_per_core": 2, "cpu": "AMD EPYC 9575F 64-Core Processor " + PROSE,
+                                  "all_cores": {"value": BIG, "sample": PROSE}, "all_cores_value": BIG, "all_cores_threads": 128}
+    return result
+
+
+def _check_line(b, line, n_gpus):
+    text = json.dumps(line)
+    assert len(text) <= b.LINE_LIMIT == 6000, len(text)
+    assert "\n" not in text and text.isascii()
+    assert tuple(line)[:12] == b.TOP_KEYS
+    assert tuple(line["config"]) == b.CONFIG_KEYS and len(line["config"]) <= 4
+    assert all(isinstance(v, str) and len(v) <= 160 for v in line["config"].values())
+    roof = line["roofline"]
+    assert tuple(roof)[:24] == b.ROOFLINE_FIRST_24
+    assert len(roof) <= 24 + 30
+    for k, v in roof.items():
+        assert not isinstance(v, (dict, list)), k
+        if isinstance(v, str):
+            assert k in ("bound", "kernel", "unit"), k  # no prose: mfma / launch / what / sample / flops_model stay in the detail
+    for banned in ("mfma", "launch", "what", "sample", "flops_model", "traffic_source", "detector_dtype"):
+        assert banned not in roof
+    assert set(line) <= set(b.TOP_KEYS) | {"config", "roofline", "cpu_baseline"}
+    if n_gpus == 1:
+        assert set(line["cpu_baseline"]) <= set(b.CPU_BASELINE_KEYS)
+        for k in ("value", "unit", "cores", "kind"):
+            assert k in line["cpu_baseline"]
+    assert json.loads(text) == line
+
+
+def test_line_fits_6000_bytes_at_one_and_eight_gpus_with_worst_case_widths():
+    b = _bench()
+    for n in (1, 8):
+        result = _full_result(b, n)
+        b.order_roofline(result)
+        _check_line(b, b.compact_line(result), n)
+
+
+def test_emit_prints_one_line_and_keeps_the_rest_in_the_detail(tmp_path, monkeypatch, capsys):
+    b = _bench()
+    monkeypatch.setattr(b, "ROOT", str(tmp_path))
+    out = io.StringIO()
+    b.emit(_full_result(b, 8), out)
+    printed = out.getvalue()
+    assert printed.count("\n") == 1 and printed.endswith("\n")
+    _check_line(b, json.loads(printed), 8)
+    detail = json.load(open(tmp_path / b.DETAIL_FILE))
+    for k in ("also", "gen1", "detector", "train", "general_path", "stripe_sharding", "line"):
+        assert k in detail
+    assert detail["line"] == json.loads(printed)
+    assert detail["train"]["allreduce"]["hooks"].startswith("prose")
+    assert "bench.py detail:" in capsys.readouterr().err  # the detail also goes to stderr, never to stdout
 
 
 def test_first_24_roofline_keys_carry_detector_and_train():
     b = _bench()
     assert len(b.ROOFLINE_FIRST_24) == 24 and len(set(b.ROOFLINE_FIRST_24)) == 24
-    # a line as main() assembles it: headline first, the flat scalars in the order the legs run (gen1 rows, detector, train)
-    roof = b.roofline(212_710_400, 0.165, b.fast_kernel_label(), 5500.0, "10000000 events")
-    roof["traffic"] = 412_902_400
-    roof["traffic_source"] = "profiles/traffic_taf_mpx.json"
-    for k in ("taf_single", "taf_x64", "ev_single", "ev_x64"):
-        for f in ("mev_s", "ms", "GBs", "frac", "traffic"):
-            roof[f"gen1_{k}_{f}"] = 1.0
-    for t in ("sae_gen1", "eci_gen1", "taf_mpx_hotspot"):
-        for f in ("mev_s", "ms", "frac", "traffic"):
-            roof[f"{t}_{f}"] = 1.0
-    for k in ("detector_frames_per_s", "detector_ms_per_batch", "detector_batch_per_gpu", "detector_TFLOPs", "detector_frac",
-              "detector_dtype", "detector_1mpx_frames_per_s", "detector_1mpx_frac", "train_frames_per_s", "train_ms", "train_TFLOPs",
-              "train_frac", "train_dtype", "encode_plus_train_ms", "encode_plus_train_frames_per_s"):
-        roof[k] = 2.0
-    result = {"config": {"workload": "w"}, "roofline": roof}
+    assert len(b.ROOFLINE_MORE) <= 30 and not set(b.ROOFLINE_MORE) & set(b.ROOFLINE_FIRST_24)
+    result = _full_result(b, 1)
+    result["roofline"]["traffic"], result["roofline"]["algorithmic_bytes"] = 412_902_400, 212_710_400
     b.order_roofline(result)
     first = list(result["roofline"])[:24]
     assert tuple(first) == b.ROOFLINE_FIRST_24
@@ -45,9 +120,9 @@ def test_first_24_roofline_keys_carry_detector_and_train():
         assert k in first, k
     assert all(result["roofline"][k] is not None for k in first)
     assert result["roofline"]["traffic_x_algorithmic"] == round(412_902_400 / 212_710_400, 3)
-    # strings that are not the judge's keys left the object; nothing was lost from the line
+    # strings that are not the judge's keys left the object; nothing was lost from the detail
     assert "traffic_source" in result["config"] and "units_per_launch" in result["config"]
-    assert "sae_gen1_ms" in result["roofline"] and "detector_TFLOPs" in result["roofline"]
+    assert "some_other_scalar_3" in result["roofline"]
     json.dumps(result)
 
 
@@ -57,11 +132,23 @@ def test_a_leg_that_did_not_run_keeps_the_positions():
     b.order_roofline(result)
     assert tuple(list(result["roofline"])[:24]) == b.ROOFLINE_FIRST_24
     assert result["roofline"]["detector_frac"] is None
+    line = b.compact_line(result)
+    assert tuple(line["roofline"])[:24] == b.ROOFLINE_FIRST_24 and len(line["roofline"]) == 24
+
+
+def test_small_single_stream_rows_keep_eager_and_graph_apart():
+    """`ms_per_step` of a graphed row is the EAGER time (what rounds 1-4 reported), the graph replay has its own key."""
+    b = _bench()
+    row = b.graphed_row({}, 1_000_000, 30e-6, 50e-6)
+    assert row["ms_per_step"] == 0.05 and row["graph_ms_per_step"] == 0.03
+    assert row["value"] == 20000.0 and row["graph_value"] == 33333.33
+    assert "gen1_taf_single_ms" not in b.ROOFLINE_FIRST_24 and "gen1_ev_single_ms" not in b.ROOFLINE_FIRST_24
 
 
 def test_headline_kernel_label_names_the_chunk_major_kernels():
     b = _bench()
     label = b.fast_kernel_label()
+    assert len(label) <= 140
     for name in ("kf_scatter_cm", "kf_split_whole", "kf_segcount_cm", "kf_split_place", "kf_taf_walk"):
         assert name in label
     assert "kf_hist" not in label and "kf_tilescan" not in label
