@@ -62,6 +62,7 @@ _EV = C.POINTER(FrlwEvents)
 SYMBOLS = {
     "frlw_version": (C.c_char_p, []),
     "frlw_encoder_workspace_bytes": (_SZ, [_I64, _I, _I]),
+    "frlw_encoder_path_counts": (_I, [C.POINTER(C.c_uint64)]),
     "frlw_encoder_status": (_I, [_P, _P, C.POINTER(C.c_int)]),
     "frlw_workspace_init": (_I, [_P, _SZ, _P]),
     "frlw_encoder_deferred_status": (_I, [_P, _P, C.POINTER(C.c_int)]),
@@ -102,7 +103,8 @@ SYMBOLS = {
     "frlw_det_add_pred": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I64]),
     "frlw_det_add_conv": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I64, _I, _I, _I, _I, _I, _I]),
     "frlw_det_add_decode_nms": (_I, [_P, _I, _I, _I, _I, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
-                                     C.c_float, C.c_float, _I, _I, _I]),
+                                     C.c_float, C.c_float, _I, _I, _I, _I]),
+    "frlw_det_nms_workspace_floats": (C.c_longlong, [_I]),
     "frlw_det_run": (_I, [_P, _I, C.POINTER(C.c_void_p), _I, _I, _I, _P]),
     "frlw_det_bfm_weight_count": (_I, [_I]),
     "frlw_det_add_bfm_stem": (_I, [_P, _I, _I, _I, _I, _P, _I, _I]),

@@ -336,7 +336,17 @@ __global__ __launch_bounds__(256) void k_spp_pool(float *buf, int H, int W, int 
     }
 }
 
-// ---- decode + NMS (yolo_head.py:258-303), one workgroup per image ---------------------------------
+// ---- decode + NMS (yolo_head.py:258-303) ----------------------------------------------------------
+// Three launches so that the quadratic part runs on the whole GPU (round 6; one workgroup per image did everything before:
+// 32 or 8 of 256 CUs, a third of the forward's time on top of it):
+//   k_decode_sort  one workgroup per image: decode, candidates obj > thr compacted in anchor order, sorted by score
+//                  (descending, ties by anchor index = a stable sort); the order and the sorted xyxy boxes go to the workspace
+//   k_nms_matrix   (image, 64-row block, 64-column word) wavefronts over the upper triangle: bit j of maskT[word][row i] =
+//                  "box i suppresses box j" = j > i and IoU(i, j) > thr -- every CU computes IoUs
+//   k_nms_sweep    one small workgroup per image walks the rows in score order on 64-bit masks (thread t owns word t of the
+//                  `removed` set; a chunk of 64 rows is resolved by the owner of its diagonal word, its kept rows are OR-ed
+//                  into the later words; the next chunk's masks are in flight meanwhile), then emits in score order.
+// Same comparison everywhere: inter / (area_i + area_j - inter) > thr on xyxy corners without + 1, f32, this operation order.
 struct DecodeArgs {
     const float *raw; // (B, A, 5 + nc): [reg 4, sigmoid(obj), sigmoid(cls)...]
     int A, nc, n_levels;
@@ -344,38 +354,47 @@ struct DecodeArgs {
     float obj_thr, iou_thr;
     float *decoded;   // optional (B, A, 5 + nc): boxes decoded, rest copied
     float *dets;      // (B, A, 6): [cx, cy, w, h, argmax cls, obj * max cls] in descending-score order
-    int *counts;      // (B): detections per image (0 = the reference's single all-zero row)
+    int *counts;      // (B, 1 + A): detections per image (0 = the reference's single all-zero row), then the score order
+    float *ws;        // (B, nms_ws_floats(A)): per image [n, pad x3 | sorted boxes float4 x A64 | maskT u64 [A64 / 64][A64]]
 };
 
 constexpr int NMS_MAX = 8192; // candidates per image the device NMS holds (1 Mpx detector shape: 6720 anchors)
-// LDS (dynamic, one workgroup per image): phase 1 = the sort keys, skey[n] f32 | sidx[n] i32; phase 2 = the sorted
-// boxes, x1 | y1 | x2 | y2 [n] f32 + suppressed flags [n] u8.  n = candidates rounded up to a power of two.
-__host__ __device__ inline size_t nms_lds_bytes(int cap) { return (size_t)cap * 17 + 64; }
+__host__ __device__ inline int nms_a64(int A) { return A < NMS_MAX ? (A + 63) / 64 * 64 : NMS_MAX; } // candidates <= min(A, NMS_MAX)
+__host__ __device__ inline long long nms_ws_floats(int A)
+{
+    const long long a64 = nms_a64(A);
+    return 4 + 4 * a64 + 2 * (a64 / 64) * a64;
+}
+// LDS of k_decode_sort (dynamic): the sort keys, skey[n] f32 | sidx[n] i32, n = candidates rounded up to a power of two.
+__host__ __device__ inline size_t nms_lds_bytes(int cap) { return (size_t)cap * 8 + 64; }
 
-__global__ __launch_bounds__(1024) void k_decode_nms(DecodeArgs a, int cap)
+__device__ __forceinline__ void nms_anchor_box(const DecodeArgs &a, int b, int i, float &cx, float &cy, float &w, float &h)
+{
+    int lvl = 0, off = i;
+    while (lvl + 1 < a.n_levels && off >= a.lvl_h[lvl] * a.lvl_w[lvl]) { off -= a.lvl_h[lvl] * a.lvl_w[lvl]; ++lvl; }
+    const float gx = (float)(off % a.lvl_w[lvl]), gy = (float)(off / a.lvl_w[lvl]), s = (float)a.lvl_stride[lvl];
+    const float *r = a.raw + ((long long)b * a.A + i) * (5 + a.nc);
+    cx = (r[0] + gx) * s;      // (xy + grid) * stride, yolo_head.py:271
+    cy = (r[1] + gy) * s;
+    w = (r[2] * r[2]) * s;     // square(wh) * stride, :272
+    h = (r[3] * r[3]) * s;
+}
+
+__global__ __launch_bounds__(1024) void k_decode_sort(DecodeArgs a, int cap)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char nms_lds[];
-    float *skey = (float *)nms_lds;        // phase 1
+    float *skey = (float *)nms_lds;
     int *sidx = (int *)(skey + cap);
-    float *sx1 = (float *)nms_lds, *sy1 = sx1 + cap, *sx2 = sy1 + cap, *sy2 = sx2 + cap; // phase 2
-    unsigned char *ssup = (unsigned char *)(sy2 + cap);
     __shared__ int scount;
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const int F = 5 + a.nc;
     int *count_out = a.counts + (long long)b * (1 + a.A);
-    int *order = count_out + 1; // scratch: anchor index of every candidate in score order
+    int *order = count_out + 1; // anchor index of every candidate in score order
+    float *wsb = a.ws + (long long)b * nms_ws_floats(a.A);
+    int *n_out = (int *)wsb;
+    float4 *boxes = (float4 *)(wsb + 4);
     if (tid == 0) scount = 0;
     __syncthreads();
-    auto anchor_box = [&](int i, float &cx, float &cy, float &w, float &h) {
-        int lvl = 0, off = i;
-        while (lvl + 1 < a.n_levels && off >= a.lvl_h[lvl] * a.lvl_w[lvl]) { off -= a.lvl_h[lvl] * a.lvl_w[lvl]; ++lvl; }
-        const float gx = (float)(off % a.lvl_w[lvl]), gy = (float)(off / a.lvl_w[lvl]), s = (float)a.lvl_stride[lvl];
-        const float *r = a.raw + ((long long)b * a.A + i) * F;
-        cx = (r[0] + gx) * s;      // (xy + grid) * stride, yolo_head.py:271
-        cy = (r[1] + gy) * s;
-        w = (r[2] * r[2]) * s;     // square(wh) * stride, :272
-        h = (r[3] * r[3]) * s;
-    };
     // ---- decode; candidates = obj > threshold, compacted in anchor order by a block-wide stable scan
     // (sort stability must not depend on thread timing): do it in chunks of nt anchors
     for (int base = 0; base < a.A; base += nt) {
@@ -388,7 +407,7 @@ __global__ __launch_bounds__(1024) void k_decode_nms(DecodeArgs a, int cap)
             cand = obj > a.obj_thr;    // :276
             if (a.decoded) {
                 float cx, cy, w, h;
-                anchor_box(i, cx, cy, w, h);
+                nms_anchor_box(a, b, i, cx, cy, w, h);
                 float *d = a.decoded + ((long long)b * a.A + i) * F;
                 d[0] = cx; d[1] = cy; d[2] = w; d[3] = h;
                 for (int c = 4; c < F; ++c) d[c] = r[c];
@@ -408,115 +427,154 @@ __global__ __launch_bounds__(1024) void k_decode_nms(DecodeArgs a, int cap)
         if (tid == 0) { int t = scount; for (int k = 0; k < (nt + 63) / 64; ++k) t += wcount[k]; scount = t; }
         __syncthreads();
     }
-    if (scount > cap) { if (tid == 0) *count_out = -1; return; } // more candidates than the LDS holds (A > 8192 only)
+    if (scount > cap) { if (tid == 0) { *count_out = -1; *n_out = -1; } return; } // more candidates than the LDS holds (A > 8192 only)
     const int n = scount;
+    if (tid == 0) *n_out = n;
     if (n == 0) { if (tid == 0) *count_out = 0; return; }
     // ---- sort candidates by score descending, ties by anchor index ascending (= a stable sort):
-    // bitonic network over the next power of two, keys (score, -index)
+    // bitonic network over the next power of two, keys (score, -index); one compare-exchange per thread and step
     int np2 = 1;
     while (np2 < n) np2 <<= 1;
     for (int i = n + tid; i < np2; i += nt) { skey[i] = -INFINITY; sidx[i] = 0x7fffffff; }
     __syncthreads();
     for (int size = 2; size <= np2; size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int i = tid; i < np2; i += nt) {
-                const int j = i ^ stride;
-                if (j > i) {
-                    const bool up = (i & size) == 0; // descending blocks first
-                    const float ki = skey[i], kj = skey[j];
-                    const int ii = sidx[i], ij = sidx[j];
-                    const bool i_first = ki > kj || (ki == kj && ii < ij); // i should precede j in the final order
-                    if (up ? !i_first : i_first) { skey[i] = kj; skey[j] = ki; sidx[i] = ij; sidx[j] = ii; }
-                }
+            for (int p = tid; p < (np2 >> 1); p += nt) {
+                const int i = ((p & ~(stride - 1)) << 1) | (p & (stride - 1)), j = i | stride;
+                const bool up = (i & size) == 0; // descending blocks first
+                const float ki = skey[i], kj = skey[j];
+                const int ii = sidx[i], ij = sidx[j];
+                const bool i_first = ki > kj || (ki == kj && ii < ij); // i should precede j in the final order
+                if (up ? !i_first : i_first) { skey[i] = kj; skey[j] = ki; sidx[i] = ij; sidx[j] = ii; }
             }
             __syncthreads();
         }
     }
-    // ---- the order leaves the LDS (global scratch), the sorted boxes take its place
-    for (int i = tid; i < n; i += nt) order[i] = sidx[i];
-    __syncthreads();
+    // ---- the order and the sorted corner boxes leave for the workspace (x1, y1, x2, y2 as :280 forms them)
     for (int i = tid; i < n; i += nt) {
+        const int anchor = sidx[i];
+        order[i] = anchor;
         float cx, cy, w, h;
-        anchor_box(order[i], cx, cy, w, h);
-        const float x1 = cx - w / 2, y1 = cy - h / 2, x2 = cx + w / 2, y2 = cy + h / 2; // :280
-        // (order[i] was written by this very thread; the barrier above ended every read of the sort keys, whose LDS
-        // words change meaning here)
-        sx1[i] = x1; sy1[i] = y1; sx2[i] = x2; sy2[i] = y2;
-        ssup[i] = 0;
+        nms_anchor_box(a, b, anchor, cx, cy, w, h);
+        boxes[i] = make_float4(cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2);
     }
-    __syncthreads();
-    // ---- greedy suppression in score order, IoU = inter / (area_i + area_j - inter) > thr, resolved 64
-    // boxes at a time: (a) the chunk's 64 x 64 "i suppresses j" bit matrix in parallel, (b) one thread walks
-    // the chunk's 64 rows sequentially on bitmasks, (c) the chunk's kept boxes suppress all later boxes in
-    // parallel.  Same result as the box-by-box loop, ~3 barriers per 64 boxes instead of one per box.
-    __shared__ unsigned long long rowmask[64];
-    __shared__ unsigned long long keptmask;
-    auto iou_gt = [&](int i, int j) {
-        const float xx1 = fmaxf(sx1[i], sx1[j]), yy1 = fmaxf(sy1[i], sy1[j]);
-        const float xx2 = fminf(sx2[i], sx2[j]), yy2 = fminf(sy2[i], sy2[j]);
+}
+
+// grid (words / 4, row blocks, B), 4 wavefronts per workgroup: wavefront = one 64 x 64 block of the suppression matrix.
+__global__ __launch_bounds__(256) void k_nms_matrix(DecodeArgs a)
+{
+    const int b = blockIdx.z, rb = blockIdx.y, lane = threadIdx.x & 63, cw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long a64 = nms_a64(a.A);
+    float *wsb = a.ws + (long long)b * nms_ws_floats(a.A);
+    const int n = *(const int *)wsb;
+    if (n <= 0 || cw < rb || rb * 64 >= n || cw * 64 >= n) return; // (wave-uniform; no barrier in this kernel)
+    const float4 *boxes = (const float4 *)(wsb + 4);
+    unsigned long long *maskT = (unsigned long long *)(wsb + 4 + 4 * a64);
+    const int gi = rb * 64 + lane, gj = cw * 64 + lane;
+    const float4 rbx = gi < n ? boxes[gi] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 cbx = gj < n ? boxes[gj] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float r_area = (rbx.z - rbx.x) * (rbx.w - rbx.y), c_area = (cbx.z - cbx.x) * (cbx.w - cbx.y);
+    const bool thr_nonneg = a.iou_thr >= 0.0f;
+    unsigned long long mine = 0ull;
+#pragma unroll 8
+    for (int i = 0; i < 64; ++i) {
+        const float x1 = __shfl(rbx.x, i), y1 = __shfl(rbx.y, i), x2 = __shfl(rbx.z, i), y2 = __shfl(rbx.w, i), ai = __shfl(r_area, i);
+        const float xx1 = fmaxf(x1, cbx.x), yy1 = fmaxf(y1, cbx.y);
+        const float xx2 = fminf(x2, cbx.z), yy2 = fminf(y2, cbx.w);
         const float iw = fmaxf(xx2 - xx1, 0.0f), ih = fmaxf(yy2 - yy1, 0.0f);
         const float inter = iw * ih;
-        const float ai = (sx2[i] - sx1[i]) * (sy2[i] - sy1[i]), aj = (sx2[j] - sx1[j]) * (sy2[j] - sy1[j]);
-        return inter / (ai + aj - inter) > a.iou_thr;
+        const bool pair = rb * 64 + i < gj && gj < n && rb * 64 + i < n;
+        unsigned long long bal = 0ull;
+        // no overlap anywhere in this row of the block: 0 / x is 0 or NaN, never > thr (thr >= 0) -- the division is skipped
+        if (!thr_nonneg || __ballot(pair && inter > 0.0f) != 0ull)
+            bal = __ballot(pair && inter / (ai + c_area - inter) > a.iou_thr);
+        if (lane == i) mine = bal;
+    }
+    maskT[(long long)cw * a64 + gi] = mine; // rows at or behind n: zero
+}
+
+constexpr int kSweepThreads = 128; // = NMS_MAX / 64 words
+__global__ __launch_bounds__(kSweepThreads) void k_nms_sweep(DecodeArgs a)
+{
+    __shared__ unsigned long long keptw[kSweepThreads];
+    __shared__ int wpre[kSweepThreads + 1];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int F = 5 + a.nc;
+    const long long a64 = nms_a64(a.A);
+    float *wsb = a.ws + (long long)b * nms_ws_floats(a.A);
+    const int n = *(const int *)wsb;
+    if (n <= 0) return; // (k_decode_sort has written the count: 0 or -1)
+    int *count_out = a.counts + (long long)b * (1 + a.A);
+    const int *order = count_out + 1;
+    const int nwn = (n + 63) >> 6;
+    const unsigned long long *col = (const unsigned long long *)(wsb + 4 + 4 * a64) + (long long)t * a64; // word t of every row
+    const bool active = t < nwn;
+    unsigned long long rem = 0ull;
+    ulonglong2 bufA[32], bufB[32];
+    auto load = [&](ulonglong2 (&m)[32], int c) {
+        if (active && t >= c) {
+            const ulonglong2 *src = (const ulonglong2 *)(col + (long long)c * 64);
+#pragma unroll
+            for (int k = 0; k < 32; ++k) m[k] = src[k];
+        }
     };
-    for (int c0 = 0; c0 < n; c0 += 64) {
-        const int nb = n - c0 < 64 ? n - c0 : 64;
-        if (tid < 64) rowmask[tid] = 0ull;
-        __syncthreads();
-        for (int p = tid; p < 64 * 64; p += nt) {
-            const int i = p >> 6, j = p & 63;
-            if (i < j && j < nb && iou_gt(c0 + i, c0 + j)) atomicOr(&rowmask[i], 1ull << j);
+    auto step = [&](ulonglong2 (&cur)[32], ulonglong2 (&nxt)[32], int c) {
+        if (c + 1 < nwn) load(nxt, c + 1); // the next chunk's masks fly while this one is resolved
+        const int nb = n - c * 64 < 64 ? n - c * 64 : 64;
+        if (t == c) { // the owner of the diagonal word: the chunk's 64 rows in score order
+            unsigned long long sup = rem, kept = 0ull;
+#pragma unroll
+            for (int i = 0; i < 64; ++i) {
+                const unsigned long long m = (i & 1) ? cur[i >> 1].y : cur[i >> 1].x;
+                const bool keep = i < nb && !((sup >> i) & 1ull);
+                kept |= keep ? 1ull << i : 0ull;
+                sup |= keep ? m : 0ull;
+            }
+            keptw[c] = kept;
         }
-        __syncthreads();
-        if (tid == 0) {
-            unsigned long long sup = 0ull, kept = 0ull;
-            for (int i = 0; i < nb; ++i) sup |= (unsigned long long)(ssup[c0 + i] != 0) << i;
-            for (int i = 0; i < nb; ++i)
-                if (!((sup >> i) & 1ull)) { kept |= 1ull << i; sup |= rowmask[i]; }
-            keptmask = kept;
-        }
-        __syncthreads();
-        const unsigned long long kept = keptmask;
-        if (tid < nb) ssup[c0 + tid] = ((kept >> tid) & 1ull) ? 0 : 1;
-        for (int j = c0 + 64 + tid; j < n; j += nt) {
-            if (ssup[j]) continue;
-            unsigned long long k = kept;
-            while (k) {
-                const int i = __ffsll((long long)k) - 1;
-                k &= k - 1ull;
-                if (iou_gt(c0 + i, j)) { ssup[j] = 1; break; }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // (LDS only: the prefetch above stays in flight)
+        const unsigned long long kept = keptw[c];
+        if (active && t > c) {
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                if ((kept >> (8 * g)) & 0xffull) { // wave-uniform
+#pragma unroll
+                    for (int i = 8 * g; i < 8 * g + 8; ++i) {
+                        const unsigned long long m = (i & 1) ? cur[i >> 1].y : cur[i >> 1].x;
+                        rem |= ((kept >> i) & 1ull) ? m : 0ull;
+                    }
+                }
             }
         }
-        __syncthreads();
+    };
+    load(bufA, 0);
+    for (int c = 0; c < nwn; c += 2) {
+        step(bufA, bufB, c);
+        if (c + 1 < nwn) step(bufB, bufA, c + 1);
     }
-    // ---- emit kept boxes in score order: exclusive scan of the kept flags gives the output row
-    __shared__ int wtot[16];
-    int run = 0;
-    for (int base = 0; base < n; base += nt) {
-        const int i = base + tid;
-        const bool keep = i < n && !ssup[i];
-        const unsigned long long bal = __ballot(keep);
-        const int lane = tid & 63, wv = tid >> 6;
-        if (lane == 0) wtot[wv] = __popcll(bal);
-        __syncthreads();
-        int pre = run;
-        for (int k = 0; k < wv; ++k) pre += wtot[k];
-        const int row = pre + __popcll(bal & ((1ull << lane) - 1ull));
-        if (keep) {
-            const int anchor = order[i];
-            const float *r = a.raw + ((long long)b * a.A + anchor) * F;
-            int best = 0;
-            float bv = r[5];
-            for (int c = 1; c < a.nc; ++c) if (r[5 + c] > bv) { bv = r[5 + c]; best = c; } // first max, like argmax
-            float *d = a.dets + ((long long)b * a.A + row) * 6;
-            anchor_box(anchor, d[0], d[1], d[2], d[3]);
-            d[4] = (float)best;
-            d[5] = r[4] * bv; // obj * max cls, yolo_head.py:301
-        }
-        for (int k = 0; k < (nt + 63) / 64; ++k) run += wtot[k];
-        __syncthreads();
+    __syncthreads();
+    // ---- emit kept boxes in score order: output row = kept boxes in front
+    if (t == 0) {
+        int run = 0;
+        for (int k = 0; k < nwn; ++k) { wpre[k] = run; run += __popcll(keptw[k]); }
+        wpre[nwn] = run;
+        *count_out = run;
     }
-    if (tid == 0) *count_out = run;
+    __syncthreads();
+    for (int i = t; i < n; i += kSweepThreads) {
+        const unsigned long long kw = keptw[i >> 6];
+        if (!((kw >> (i & 63)) & 1ull)) continue;
+        const int row = wpre[i >> 6] + __popcll(kw & ((1ull << (i & 63)) - 1ull));
+        const int anchor = order[i];
+        const float *r = a.raw + ((long long)b * a.A + anchor) * F;
+        int best = 0;
+        float bv = r[5];
+        for (int c = 1; c < a.nc; ++c) if (r[5 + c] > bv) { bv = r[5 + c]; best = c; } // first max, like argmax
+        float *d = a.dets + ((long long)b * a.A + row) * 6;
+        nms_anchor_box(a, b, anchor, d[0], d[1], d[2], d[3]);
+        d[4] = (float)best;
+        d[5] = r[4] * bv; // obj * max cls, yolo_head.py:301
+    }
 }
 
 // ---- plan ------------------------------------------------------------------------------------------
@@ -536,7 +594,7 @@ struct Op {
     int src, dst, res;      // buffer indices
     ConvArgs conv;          // pointers x / y / res filled at run time; w / bias are baked
     int C, H, W, cs_src, co_src, cs_dst, co_dst;
-    DecodeArgs dec; int decoded_buf, dets_buf, counts_buf;
+    DecodeArgs dec; int decoded_buf, dets_buf, counts_buf, nms_buf;
     const float *bfm_w;     // OP_BFM: packed weights (device)
     PredInferArgs pred;     // OP_PRED
     FocusStemArgs fstem;    // OP_FOCUS_STEM
@@ -855,13 +913,16 @@ int frlw_det_add_pred(frlw_detector_t *d, int src_buf, int src_cs, int src_co, i
     return FRLW_OK;
 }
 
+long long frlw_det_nms_workspace_floats(int A) { return A < 1 ? 0 : nms_ws_floats(A); }
+
 int frlw_det_add_decode_nms(frlw_detector_t *d, int raw_buf, int A, int nc, int n_levels, const int *lvl_h,
                             const int *lvl_w, const int *lvl_stride, float obj_thr, float iou_thr, int decoded_buf,
-                            int dets_buf, int counts_buf)
+                            int dets_buf, int counts_buf, int nms_buf)
 {
-    if (!d || n_levels < 1 || n_levels > 4 || nc < 1 || nc > 80 || A < 1) return FRLW_ERR_ARG;
+    if (!d || n_levels < 1 || n_levels > 4 || nc < 1 || nc > 80 || A < 1 || nms_buf < 0) return FRLW_ERR_ARG;
     Op op = {};
     op.type = OP_DECODE; op.src = raw_buf; op.decoded_buf = decoded_buf; op.dets_buf = dets_buf; op.counts_buf = counts_buf;
+    op.nms_buf = nms_buf;
     DecodeArgs &a = op.dec;
     a.A = A; a.nc = nc; a.n_levels = n_levels; a.obj_thr = obj_thr; a.iou_thr = iou_thr;
     for (int i = 0; i < n_levels; ++i) { a.lvl_h[i] = lvl_h[i]; a.lvl_w[i] = lvl_w[i]; a.lvl_stride[i] = lvl_stride[i]; }
@@ -972,13 +1033,17 @@ int frlw_det_run(const frlw_detector_t *d, int B, void *const *bufs, int n_bufs,
             DecodeArgs a = op.dec;
             a.raw = buf(op.src); a.decoded = buf(op.decoded_buf); a.dets = buf(op.dets_buf);
             a.counts = (int *)buf(op.counts_buf);
-            if (!a.raw || !a.dets || !a.counts) return FRLW_ERR_ARG;
+            a.ws = buf(op.nms_buf);
+            if (!a.raw || !a.dets || !a.counts || !a.ws) return FRLW_ERR_ARG;
             int cap = 1024; // LDS sized for the anchors of this network, up to NMS_MAX candidates
             while (cap < a.A && cap < NMS_MAX) cap <<= 1;
             const size_t lds = nms_lds_bytes(cap);
             if (lds > 64 * 1024)
-                (void)hipFuncSetAttribute((const void *)k_decode_nms, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(k_decode_nms, dim3(B), dim3(1024), lds, s, a, cap);
+                (void)hipFuncSetAttribute((const void *)k_decode_sort, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(k_decode_sort, dim3(B), dim3(1024), lds, s, a, cap);
+            const int words = nms_a64(a.A) / 64; // candidates never exceed min(A, NMS_MAX)
+            hipLaunchKernelGGL(k_nms_matrix, dim3((words + 3) / 4, words, B), dim3(256), 0, s, a);
+            hipLaunchKernelGGL(k_nms_sweep, dim3(B), dim3(kSweepThreads), 0, s, a);
             break;
         }
         default: return FRLW_ERR_ARG;

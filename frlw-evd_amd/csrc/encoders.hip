@@ -753,16 +753,30 @@ size_t frlw_encoder_workspace_bytes(int64_t n_events, int H, int W)
 {
     Plan p;
     if (!make_plan(n_events, H, W, nullptr, p)) return 0;
-    return p.bytes;
+    // frlw_sae_encode / frlw_eci_encode take the two-launch form of taf_fast.hip when the call is eligible: its chunk-major tables
+    // are a little larger than the general plan's (1 M events at 304x240: 372 against 347 KB on top of the same 8 n bytes of
+    // records), and a caller that allocates exactly what this query returns must get that path too
+    const size_t fast = sae_fast_workspace_bytes(n_events, H, W);
+    return fast > p.bytes ? fast : p.bytes;
+}
+
+int frlw_encoder_path_counts(uint64_t counts[4])
+{
+    if (!counts) return FRLW_ERR_ARG;
+    for (int i = 0; i < 4; ++i) counts[i] = (uint64_t)g_path_counts[i].load(std::memory_order_relaxed);
+    return FRLW_OK;
 }
 
 int frlw_encoder_status(const void *workspace, frlw_stream_t stream, int *status_out)
 {
     if (!workspace || !status_out) return FRLW_ERR_ARG;
     int32_t st = 0;
+    uint32_t stall = 0u;
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(hipMemcpyAsync(&st, workspace, sizeof(st), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&stall, (const char *)workspace + kStallOffset, sizeof(stall), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    if (stall) st |= ST_STALL; // (kept outside the range a late workgroup 0 resets: frlw_common.h kStallOffset)
     *status_out = (st & ST_INDEX) ? FRLW_ERR_INDEX : (st & ST_POLARITY) ? FRLW_ERR_POLARITY : (st & ST_SPAN) ? FRLW_ERR_SPAN : (st & ST_STALL) ? FRLW_ERR_HIP : FRLW_OK;
     return FRLW_OK;
 }
@@ -813,7 +827,9 @@ int frlw_eci_encode(const frlw_events_t *ev, int H, int W, float *out_f32, uint8
         tuning_valid(ev->tuning) && (ev->xmap == nullptr) == (ev->ymap == nullptr) &&
         tuning_knob(ev->tuning, &frlw_tuning_t::staged_scatter, -1) != 0) {
         const long long wgs = ((long long)H * W + kEciScanPix - 1) / kEciScanPix;
-        if (wgs * ev->n <= (8ll << 20) && (long long)H * W < (1ll << 31)) {
+        // W <= 65536: k_eci_scan forms the flat pixel x + W * y in 32 bits, and x, y reach 65535 through the coordinate maps -- a
+        // wider frame (which the general path places with 64-bit arithmetic) could wrap an out-of-frame event back into the frame
+        if (wgs * ev->n <= (8ll << 20) && (long long)H * W < (1ll << 31) && W <= 65536) {
             (void)hipGetLastError();
             if (ev->xmap)
                 hipLaunchKernelGGL(k_eci_scan<true>, dim3((unsigned)wgs), dim3(kEciScanThreads), 0, s, (const uint2 *)ev->data, (long long)ev->n,
@@ -822,9 +838,11 @@ int frlw_eci_encode(const frlw_events_t *ev, int H, int W, float *out_f32, uint8
                 hipLaunchKernelGGL(k_eci_scan<false>, dim3((unsigned)wgs), dim3(kEciScanThreads), 0, s, (const uint2 *)ev->data, (long long)ev->n,
                                    (const uint16_t *)nullptr, (const uint16_t *)nullptr, 0, 0, q, (WsHeader *)workspace);
             HIP_TRY(hipGetLastError());
+            g_path_counts[3].fetch_add(1ull, std::memory_order_relaxed);
             return FRLW_OK;
         }
     }
+    g_path_counts[3].fetch_add(1ull, std::memory_order_relaxed);
     Partitioned pt;
     int rc = partition_events(ev, H, W, KIND_ECI, 0, 1, 1, 0, workspace, workspace_bytes, s, pt);
     if (rc != FRLW_OK) return rc;
@@ -867,6 +885,7 @@ int frlw_sae_encode(const frlw_events_t *ev, int H, int W, const double *lamdas,
         const int rc2 = sae_fast_try(ev, H, W, lamf, n_lamda, mem_in, mem_out, now, window_us, out_f32, out_u8, workspace, workspace_bytes, s);
         if (rc2 <= 0) return rc2;
     }
+    g_path_counts[1].fetch_add(1ull, std::memory_order_relaxed);
     Partitioned pt;
     const int filt = window_us > 0;
     int rc = partition_events(ev, H, W, KIND_SAE, now - window_us, 1, 1, filt, workspace,

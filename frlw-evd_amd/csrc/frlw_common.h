@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <atomic>
 
 #include "frlw_evd.h"
 
@@ -73,6 +74,11 @@ static_assert(sizeof(WsHeader) <= kHeaderBytes, "header");
 // since frlw_workspace_init / the last frlw_encoder_deferred_status (unchecked callers read it once per batch or epoch
 // instead of synchronising after every call); the 24 bytes in front of it receive the one-time LDS self-test result.
 constexpr size_t kStickyOffset = kHeaderBytes - 8;
+// ... and `stall`, 8 bytes in front of `sticky`: the epoch of a fast-path call one of whose workgroups gave up its bounded wait
+// for the header reset (ST_STALL).  It lies OUTSIDE the range workgroup 0 resets, so a workgroup 0 that starts late cannot
+// wipe the verdict of its own call; workgroup 0 (and the captured form's reset kernel) clears it only when it belongs to an
+// EARLIER call.  frlw_encoder_status reports FRLW_ERR_HIP while it is set.
+constexpr size_t kStallOffset = kHeaderBytes - 16;
 constexpr size_t kSelftestOffset = kHeaderBytes - 64;
 static_assert(sizeof(WsHeader) <= kSelftestOffset, "header tail");
 __device__ __forceinline__ void fold_sticky_status(void *hdr, int status)
@@ -396,6 +402,11 @@ int hip_fail(hipError_t e, const char *what, int line);
 int sae_fast_try(const frlw_events_t *ev, int H, int W, const float *lam, int n_lamda, const float *mem_in, float *mem_out,
                  long long now, long long window_us, float *out_f32, uint8_t *out_u8, void *workspace, size_t workspace_bytes,
                  hipStream_t st);
+
+// Workspace bytes the two-launch form asks for (0: the call is not eligible) and the per-process launch counters behind
+// frlw_encoder_path_counts: [0] SAE two-launch, [1] SAE general, [2] ECI two-launch, [3] ECI single-launch scan / general.
+size_t sae_fast_workspace_bytes(long long n, int H, int W);
+extern std::atomic<unsigned long long> g_path_counts[4];
 
 // hist -> scans -> stable scatter: tile-major 8-byte records {window << (twl + 4) | cell, f32 bits}.
 int partition_events(const frlw_events_t *ev, int H, int W, int kind, long long t0, long long win,

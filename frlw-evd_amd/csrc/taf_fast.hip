@@ -812,6 +812,11 @@ __global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(MAXB > kMax
         // so launch_fast_cm put a reset kernel in front instead and nobody resets or waits here.
         uint32_t *h32 = (uint32_t *)hdr;
         for (int i = tid; i < (int)(offsetof(FastHeader, epoch) / 4); i += kFT) h32[i] = 0u;
+        if (tid == 0) { // an EARLIER call's stall verdict goes; this call's own (a workgroup that gave up before we started) stays
+            uint32_t *sw = (uint32_t *)((char *)hdr + kStallOffset);
+            const uint32_t was = __hip_atomic_load(sw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (was != 0u && was != epoch) atomicCAS(sw, was, 0u);
+        }
         __threadfence();
         __syncthreads();
         if (tid == 0) __hip_atomic_store(&hdr->epoch, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -836,6 +841,7 @@ __global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(MAXB > kMax
             q[j] = src[i < nloc ? i : nloc - 1u];
         }
     }
+    int pre_err = 0;
     // the per-call value table, spread over the grid while the event loads fly (generate_taf.py:215,:26 /
     // generate_eventvolume.py:141,:23): tlut[r] and the exhaustive check "float(r * (1 / den)) == float(r / den) for every r"
     if (tlut_w) {
@@ -846,7 +852,9 @@ __global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(MAXB > kMax
             bad |= (float)((double)r * rcp) != exact;
             tlut_w[r] = EV ? exact : exact - 1.0f;
         }
-        if (bad) atomicOr(&serr, ST_MULBAD); // (reaches the header with the other flags, at the end)
+        // kept in a register until phase A's flags are OR-ed in BEHIND the barrier below: `serr` is zeroed by thread 0 in front
+        // of that barrier, and an atomicOr from another wavefront here could land before the zero and be lost
+        if (bad) pre_err = ST_MULBAD;
     }
     // The barrier that publishes the zeroed counters must NOT wait for the event loads: __syncthreads() drains vmcnt, and the
     // burst of a whole chunk (160 KB per CU, every CU of the part at once: HBM-bound, 8 of a workgroup's 26 us) would have to
@@ -858,7 +866,7 @@ __global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(MAXB > kMax
     // ---- phase A: stream rank of every event inside (wavefront, bin), one returning LDS atomic each (lane order = stream order)
     uint32_t where[MAXB], word[MAXB];
     unsigned long long wseen = 0ull;
-    int err = 0;
+    int err = pre_err;
 #pragma unroll
     for (int j = 0; j < MAXB; ++j) {
         where[j] = 0xffffffffu;
@@ -952,7 +960,11 @@ __global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(MAXB > kMax
                 if (++polls > (1u << 22)) break;
                 __builtin_amdgcn_s_sleep(2);
             }
-            if (polls > (1u << 22)) { atomicOr(&hdr->status, ST_STALL); fold_sticky_status(hdr, ST_STALL); return; }
+            if (polls > (1u << 22)) { // (not hdr->status: a workgroup 0 that starts later would zero it; see kStallOffset)
+                atomicExch((uint32_t *)((char *)hdr + kStallOffset), epoch);
+                fold_sticky_status(hdr, ST_STALL);
+                return;
+            }
         }
         const unsigned long long m = wg_seen;
         const unsigned long long have = __hip_atomic_load(&hdr->wmask[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -3006,6 +3018,7 @@ __global__ __launch_bounds__(256) void kf_header_reset(FastHeader *hdr)
 {
     uint32_t *h32 = (uint32_t *)hdr;
     for (int i = threadIdx.x; i < (int)(offsetof(FastHeader, epoch) / 4); i += 256) h32[i] = 0u;
+    if (threadIdx.x == 0) *(uint32_t *)((char *)hdr + kStallOffset) = 0u; // (the captured form has no wait and no stall of its own)
 }
 
 // the chunk-major partition: ONE kernel (its first workgroup resets the header; a reset kernel in front of it inside a capture)
@@ -3511,6 +3524,36 @@ int frlw_ev_encode_batch(const frlw_events_t *ev, const int64_t *seq_offsets, co
 } // extern "C"
 
 namespace frlw {
+// The plan of the two-launch form for one call of n events on an H x W frame, or false when the call is not eligible (shared by
+// sae_fast_try and by frlw_encoder_workspace_bytes: the size query must cover what the call will ask for).
+static bool sae_fast_plan(long long n, int H, int W, long long t0v, FastPlan &p, SeqTab &S)
+{
+    // positions + 1 must fit the 20 bits above the 12-bit cell; tiny calls gain nothing
+    if (n < 16384 || n >= (1ll << 20) - 1) return false;
+    const int64_t offs[2] = {0, (int64_t)n};
+    const int64_t t0[1] = {(int64_t)t0v};
+    if (!fast_plan(n, 1, H, W, p, DIRECT_FORCE, 0, true) || !p.direct) return false; // frames of at most 64 tiles (the 304x240 class)
+    {   // at least ~64 chunks: the plan's largest-chunk rule (one GEN1 stream of 1 M events: 144 chunks) would leave a
+        // 100 000-event call with 15 scatter workgroups on 256 CUs
+        long long ce = ((n + 63) / 64 + 15) / 16 * 16;
+        if (ce < 1024) ce = 1024;
+        if (ce < p.chunk) { p.chunk = (int)ce; p.bpw = (p.chunk / kFW + kWave - 1) / kWave; }
+    }
+    if (!fast_layout(offs, t0, 1, p, S, 1u)) return false;
+    if (p.max_seq_chunks > kColEv || p.chunk > 65535 || p.big) return false;
+    if (scatter_cm_lds_bytes(p.TB, p.chunk) > 160 * 1024) return false;
+    return true;
+}
+
+size_t sae_fast_workspace_bytes(long long n, int H, int W)
+{
+    FastPlan p;
+    SeqTab S;
+    return sae_fast_plan(n, H, W, 0, p, S) ? p.bytes : 0;
+}
+
+std::atomic<unsigned long long> g_path_counts[4]; // [0] SAE two-launch, [1] SAE general, [2] ECI two-launch, [3] ECI general / scan
+
 // frlw_sae_encode's two-launch form (see kf_sae_sub).  Returns FRLW_OK when it has launched the encode, 1 when the call is not
 // eligible (nothing launched: the caller takes the general path), a negative FRLW_ERR_* on a HIP failure.
 int sae_fast_try(const frlw_events_t *ev, int H, int W, const float *lam, int n_lamda, const float *mem_in, float *mem_out,
@@ -3523,22 +3566,11 @@ int sae_fast_try(const frlw_events_t *ev, int H, int W, const float *lam, int n_
     if (!ev || ev->layout != FRLW_LAYOUT_DAT8 || !ev->data || !workspace || (!eci && window_us <= 0)) return 1;
     if ((ev->xmap == nullptr) != (ev->ymap == nullptr) || !tuning_valid(ev->tuning)) return 1;
     const long long n = ev->n;
-    // positions + 1 must fit the 20 bits above the 12-bit cell; tiny calls gain nothing; staged_scatter = 0 keeps the general path (tests)
-    if (n < 16384 || n >= (1ll << 20) - 1 || tuning_knob(ev->tuning, &frlw_tuning_t::staged_scatter, -1) == 0) return 1;
+    if (tuning_knob(ev->tuning, &frlw_tuning_t::staged_scatter, -1) == 0) return 1; // staged_scatter = 0 keeps the general path (tests)
     FastPlan p;
     SeqTab S;
-    const int64_t offs[2] = {0, (int64_t)n};
-    const int64_t t0[1] = {(int64_t)(now - window_us)};
-    if (!fast_plan(n, 1, H, W, p, DIRECT_FORCE, 0, true) || !p.direct) return 1; // frames of at most 64 tiles (the 304x240 class)
-    {   // at least ~64 chunks: the plan's largest-chunk rule (one GEN1 stream of 1 M events: 144 chunks) would leave a
-        // 100 000-event call with 15 scatter workgroups on 256 CUs
-        long long ce = ((n + 63) / 64 + 15) / 16 * 16;
-        if (ce < 1024) ce = 1024;
-        if (ce < p.chunk) { p.chunk = (int)ce; p.bpw = (p.chunk / kFW + kWave - 1) / kWave; }
-    }
-    if (!fast_layout(offs, t0, 1, p, S, 1u)) return 1;
-    if (p.max_seq_chunks > kColEv || p.chunk > 65535 || p.big || workspace_bytes < p.bytes) return 1;
-    if (scatter_cm_lds_bytes(p.TB, p.chunk) > 160 * 1024) return 1;
+    if (!sae_fast_plan(n, H, W, now - window_us, p, S)) return 1;
+    if (workspace_bytes < p.bytes) return 1; // (frlw_encoder_workspace_bytes covers p.bytes: only a caller that sized the workspace itself gets here)
     FastGeom G;
     G.data = (const uint2 *)ev->data;
     G.xmap = ev->xmap; G.ymap = ev->ymap; G.map_w = ev->map_w; G.map_h = ev->map_h;
@@ -3580,6 +3612,7 @@ int sae_fast_try(const frlw_events_t *ev, int H, int W, const float *lam, int n_
     if (eci) hipLaunchKernelGGL(kf_sae_sub<true>, dim3(p.pairs * kFW), dim3(kSubCells), 0, st, q, cmq, S);
     else hipLaunchKernelGGL(kf_sae_sub<false>, dim3(p.pairs * kFW), dim3(kSubCells), 0, st, q, cmq, S);
     HIP_TRY(hipGetLastError());
+    g_path_counts[eci ? 2 : 0].fetch_add(1ull, std::memory_order_relaxed);
     return FRLW_OK;
 }
 } // namespace frlw

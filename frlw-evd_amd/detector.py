@@ -336,12 +336,14 @@ class DetectorEngine:
         self.dec_buf = self._new_buf(1, A, F).buf
         self.dets_buf = self._new_buf(1, A, 6).buf
         self.counts_buf = self._new_buf(1, 1, 1 + A).buf  # per image: [count, scratch of A ints]
+        # per image: candidate count, sorted corner boxes, the "i suppresses j" bit matrix (k_nms_matrix / k_nms_sweep)
+        self.nms_buf = self._new_buf(1, 1, int(lib.frlw_det_nms_workspace_floats(A))).buf
         n = len(levels)
         arr = C.c_int * n
         _lib.check(lib.frlw_det_add_decode_nms(self.handle, raw.buf, A, nc, n, arr(*[v.h for v in levels]),
                                                arr(*[v.w for v in levels]), arr(*[int(s) for s in head.strides]),
                                                C.c_float(head.obj_threshold), C.c_float(head.nms_threshold),
-                                               self.dec_buf, self.dets_buf, self.counts_buf), "decode")
+                                               self.dec_buf, self.dets_buf, self.counts_buf, self.nms_buf), "decode")
         head.hw = [(v.h, v.w) for v in levels]
         # split-K scratch: 8 splits x (< 256 tiles of 64 x 64), independent of the batch size
         self.scratch_floats = 8 * 256 * 64 * 64

@@ -108,18 +108,27 @@ typedef struct frlw_events {
 /* frlw_taf_encode flags */
 #define FRLW_TAF_U8_FLIP_K 1 /* write out_u8 newest slot first (np.flip(axis=0), generate_taf.py:229) */
 
-/* Bytes of device workspace any encoder needs for `n_events` events on an H x W encode shape. */
+/* Bytes of device workspace any encoder needs for `n_events` events on an H x W encode shape: the larger of the general
+ * plan and of the two-launch form frlw_sae_encode / frlw_eci_encode take for eligible calls (a workspace of exactly this
+ * size gets the same path a larger one gets). */
 size_t frlw_encoder_workspace_bytes(int64_t n_events, int H, int W);
 
+/* Which form frlw_sae_encode / frlw_eci_encode launched, counted per process since it loaded the library (diagnostics and
+ * tests; the results are the same bits either way): counts[0] = Surface of Active Events through the two-launch form,
+ * [1] = through the general path, [2] = Event Count Image through the two-launch form, [3] = through the single-launch
+ * scan or the general path. */
+int frlw_encoder_path_counts(uint64_t counts[4]);
+
 /* Synchronise `stream` and fetch the data-dependent status of the last encoder call that used
- * `workspace`: FRLW_OK, FRLW_ERR_INDEX, FRLW_ERR_POLARITY or FRLW_ERR_SPAN. */
+ * `workspace`: FRLW_OK, FRLW_ERR_INDEX, FRLW_ERR_POLARITY, FRLW_ERR_SPAN, or FRLW_ERR_HIP when a workgroup of a
+ * fast-path launch gave up waiting for the launch's header reset (a bounded wait; the call's outputs are then incomplete). */
 int frlw_encoder_status(const void *workspace, frlw_stream_t stream, int *status_out);
 
 /* Callers that do not synchronise after every call (a training loop that encodes batch after batch) still must not
  * train on a stale state: every encoder call also ORs its data-dependent status into a word of the workspace header
  * that survives the next call.  frlw_workspace_init() zeroes the header once after the workspace is allocated;
  * frlw_encoder_deferred_status() synchronises `stream`, returns the accumulated status of all calls since (FRLW_OK or
- * the first of FRLW_ERR_INDEX / _POLARITY / _SPAN) and clears it.  The reference raises at the offending call
+ * the first of FRLW_ERR_INDEX / _POLARITY / _SPAN / _HIP) and clears it.  The reference raises at the offending call
  * (torch's IndexError in index_add_, generate_taf.py:24); this is the same information, one host sync per batch. */
 int frlw_workspace_init(void *workspace, size_t workspace_bytes, frlw_stream_t stream);
 int frlw_encoder_deferred_status(void *workspace, frlw_stream_t stream, int *status_out);
@@ -360,7 +369,12 @@ int frlw_det_add_conv(frlw_detector_t *d, int src_buf, int src_cs, int src_co, i
  *   dets_buf   : (B, A, 6) f32          counts_buf : (B, 1 + A) int32; [b][0] = detections of image b: 0 = nothing
  *                passed (the reference then returns one all-zero row), -1 = more than 8192 candidates (only reachable
  *                with A > 8192; not handled on device); [b][1..] = scratch (the candidates' anchors in score order)
+ *   nms_buf    : (B, frlw_det_nms_workspace_floats(A)) f32 of scratch: per image the candidate count, the sorted corner
+ *                boxes and the bit matrix "box i suppresses box j" (A = 6720: 5.8 MB per image).  Three launches: decode +
+ *                sort per image, the bit matrix over the whole GPU, one small workgroup per image walking it in score order.
  */
+long long frlw_det_nms_workspace_floats(int A);
+
 /* The three biased 1x1 prediction convolutions of one head level in eval mode (yolo_head.py:205-231) as ONE streaming
  * pass: rows 0..4 of w_dev (F = 5 + nc rows of C floats: reg x4, obj, cls x nc) read channels [src_co, src_co + C) of the
  * level's feature buffer, rows 5.. read [src_co + C, src_co + 2 C); sigmoid on outputs >= 4; the result lands at anchors
@@ -371,7 +385,7 @@ int frlw_det_add_pred(frlw_detector_t *d, int src_buf, int src_cs, int src_co, i
 
 int frlw_det_add_decode_nms(frlw_detector_t *d, int raw_buf, int A, int nc, int n_levels, const int *lvl_h,
                             const int *lvl_w, const int *lvl_stride, float obj_thr, float iou_thr,
-                            int decoded_buf, int dets_buf, int counts_buf);
+                            int decoded_buf, int dets_buf, int counts_buf, int nms_buf);
 
 /* Launch ops [first, last) (last < 0: to the end) for B images on `stream`; bufs: n_bufs device pointers. */
 int frlw_det_run(const frlw_detector_t *d, int B, void *const *bufs, int n_bufs, int first, int last,

@@ -47,6 +47,15 @@ def host(t):
     return t.cpu().numpy()
 
 
+def path_counts():
+    """frlw_encoder_path_counts: [SAE two-launch, SAE general, ECI two-launch, ECI scan / general] launches of this process."""
+    import ctypes as C
+    from frlw_evd_amd import _lib
+    c = (C.c_uint64 * 4)()
+    _lib.check(_lib.load().frlw_encoder_path_counts(c), "frlw_encoder_path_counts")
+    return np.array(list(c), dtype=np.int64)
+
+
 def assert_ulp(got, want, ulps, what):
     a = np.ascontiguousarray(got).view(np.int32).astype(np.int64)
     b = np.ascontiguousarray(want).view(np.int32).astype(np.int64)
@@ -481,10 +490,18 @@ def test_eci_single_launch_equals_general_path_and_oracle(er, orc, shape, n, map
     if maps:
         xm, ym = er.coordinate_maps((Hs, Ws), (H, W), "cuda")
     dat = torch.from_numpy(rec.view(np.uint8).reshape(-1, 8).copy()).cuda()
+    c0 = path_counts()
     out1, u1 = er.encode_eci_dat(dat, (H, W), want_u8=True, xmap=xm, ymap=ym)
+    c1 = path_counts()
     monkeypatch.setattr(er, "TUNING", _lib.FrlwTuning(staged_scatter=0))  # the general path
     out0, u0 = er.encode_eci_dat(dat, (H, W), want_u8=True, xmap=xm, ymap=ym)
     monkeypatch.setattr(er, "TUNING", None)
+    c2 = path_counts()
+    # WHICH form ran (the equality below holds on a silent fall-back too): the two-launch form for the GEN1-class calls of at
+    # least 16 384 events, the scan / general path below that and under the knob
+    two_launch = n >= 16384 and (H, W) in ((240, 304), (97, 131), (256, 320))
+    assert list(c1 - c0) == ([0, 0, 1, 0] if two_launch else [0, 0, 0, 1]), (c0, c1)
+    assert list(c2 - c1) == [0, 0, 0, 1], (c1, c2)
     assert torch.equal(out1, out0) and torch.equal(u1, u0)
     assert_bitexact(host(out1), orc.eci_stream_dat8(rec, (Hs, Ws), (H, W)), "single-launch eci vs oracle")
     if not maps and n > 100:
@@ -527,8 +544,11 @@ def test_sae_two_launch_form_equals_general_path(er, orc, shape, n, maps, shuffl
     res = []
     for tun in (None, _lib.FrlwTuning(staged_scatter=0)):
         monkeypatch.setattr(er, "TUNING", tun)
+        c0 = path_counts()
         o1, u1, m1 = er.encode_sae_dat(dat[:half], (H, W), LAMDAS, None, now - 1_000_000, win, want_u8=True, xmap=xm, ymap=ym)
         o2, u2, m2 = er.encode_sae_dat(dat[half:], (H, W), LAMDAS, m1, now, win, want_u8=True, xmap=xm, ymap=ym)
+        # WHICH form ran: both calls through the two-launch form by default, both through the general path under the knob
+        assert list(path_counts() - c0) == ([2, 0, 0, 0] if tun is None else [0, 2, 0, 0]), tun
         res.append((o1, u1, m1, o2, u2, m2))
     monkeypatch.setattr(er, "TUNING", None)
     for a, b in zip(res[0], res[1]):
@@ -536,3 +556,41 @@ def test_sae_two_launch_form_equals_general_path(er, orc, shape, n, maps, shuffl
     _, om1 = orc.sae_stream_dat8(rec[:half], (Hs, Ws), (H, W), LAMDAS, None, now - 1_000_000, win)
     _, om2 = orc.sae_stream_dat8(rec[half:], (Hs, Ws), (H, W), LAMDAS, om1, now, win)
     assert_bitexact(host(res[0][5]), om2, "memory after two calls")
+
+
+@pytest.mark.parametrize("kind,n", [("sae", 1_000_000), ("sae", 20_000), ("eci", 100_000)])
+def test_workspace_of_exactly_the_queried_size_gets_the_two_launch_form(er, kind, n):
+    """A C caller allocates exactly frlw_encoder_workspace_bytes() -- the only size query include/frlw_evd.h documents for
+    frlw_sae_encode / frlw_eci_encode -- and must get the same two-launch form a larger workspace gets (the
+    chunk-major tables are larger than the general plan's, and the query used to return the general plan's size)."""
+    import ctypes as C
+    from frlw_evd_amd import _lib
+    lib = _lib.load()
+    H, W = 240, 304
+    ev = synth.synth_events(7400 + n % 97, n, W, H, 5_000_000, t_offset=30_000_000)
+    dat = dat_dev(ev)
+    need = lib.frlw_encoder_workspace_bytes(n, H, W)
+    assert need > 0
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")  # exactly the queried size, no slack
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.frlw_workspace_init(C.c_void_p(ws.data_ptr()), ws.numel(), st), "init")
+    desc = _lib.FrlwEvents(dat.data_ptr(), n, _lib.LAYOUT_DAT8, 0, None, None, 0, 0, None)
+    status = C.c_int(0)
+    c0 = path_counts()
+    if kind == "sae":
+        lam = (C.c_double * len(LAMDAS))(*LAMDAS)
+        out = torch.empty((2 * len(LAMDAS), H, W), device="cuda")
+        mem = torch.empty((2, H, W), device="cuda")
+        _lib.check(lib.frlw_sae_encode(C.byref(desc), H, W, lam, len(LAMDAS), None, C.c_void_p(mem.data_ptr()), 35_000_000, 5_541_263,
+                                       C.c_void_p(out.data_ptr()), None, C.c_void_p(ws.data_ptr()), ws.numel(), st), "sae")
+        assert list(path_counts() - c0) == [1, 0, 0, 0]
+        want, _u, wmem = er.encode_sae_dat(dat, (H, W), LAMDAS, None, 35_000_000, 5_541_263)
+        assert torch.equal(mem, wmem)
+    else:
+        out = torch.empty((2, H, W), device="cuda")
+        _lib.check(lib.frlw_eci_encode(C.byref(desc), H, W, C.c_void_p(out.data_ptr()), None, C.c_void_p(ws.data_ptr()), ws.numel(), st), "eci")
+        assert list(path_counts() - c0) == [0, 0, 1, 0]
+        want, _u = er.encode_eci_dat(dat, (H, W))
+    _lib.check(lib.frlw_encoder_status(C.c_void_p(ws.data_ptr()), st, C.byref(status)), "status")
+    assert status.value == 0
+    assert torch.equal(out, want)
