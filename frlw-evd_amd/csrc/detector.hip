@@ -341,11 +341,12 @@ __global__ __launch_bounds__(256) void k_spp_pool(float *buf, int H, int W, int 
 // 32 or 8 of 256 CUs, a third of the forward's time on top of it):
 //   k_decode_sort  one workgroup per image: decode, candidates obj > thr compacted in anchor order, sorted by score
 //                  (descending, ties by anchor index = a stable sort); the order and the sorted xyxy boxes go to the workspace
-//   k_nms_matrix   (image, 64-row block, 64-column word) wavefronts over the upper triangle: bit j of maskT[word][row i] =
+//   k_nms_matrix   (image, 64-row block, 64-column word) wavefronts over the upper triangle: bit j of mask[row i][word] =
 //                  "box i suppresses box j" = j > i and IoU(i, j) > thr -- every CU computes IoUs
 //   k_nms_sweep    one small workgroup per image walks the rows in score order on 64-bit masks (thread t owns word t of the
 //                  `removed` set; a chunk of 64 rows is resolved by the owner of its diagonal word, its kept rows are OR-ed
-//                  into the later words; the next chunk's masks are in flight meanwhile), then emits in score order.
+//                  into the later words; the next chunk's masks are in flight meanwhile); the kept bits go to the workspace
+//   k_nms_emit     (image, 256 candidates) workgroups write the kept boxes in score order.
 // Same comparison everywhere: inter / (area_i + area_j - inter) > thr on xyxy corners without + 1, f32, this operation order.
 struct DecodeArgs {
     const float *raw; // (B, A, 5 + nc): [reg 4, sigmoid(obj), sigmoid(cls)...]
@@ -355,15 +356,16 @@ struct DecodeArgs {
     float *decoded;   // optional (B, A, 5 + nc): boxes decoded, rest copied
     float *dets;      // (B, A, 6): [cx, cy, w, h, argmax cls, obj * max cls] in descending-score order
     int *counts;      // (B, 1 + A): detections per image (0 = the reference's single all-zero row), then the score order
-    float *ws;        // (B, nms_ws_floats(A)): per image [n, pad x3 | sorted boxes float4 x A64 | maskT u64 [A64 / 64][A64]]
+    float *ws;        // (B, nms_ws_floats(A)): per image [n, pad x3 | kept bits u64 x 128 | sorted boxes float4 x A64 | mask u64 [A64][A64 / 64]]
 };
 
 constexpr int NMS_MAX = 8192; // candidates per image the device NMS holds (1 Mpx detector shape: 6720 anchors)
+constexpr int kNmsHdr = 4 + 2 * (NMS_MAX / 64); // floats in front of the boxes: n, pad x3, the kept bits of k_nms_sweep
 __host__ __device__ inline int nms_a64(int A) { return A < NMS_MAX ? (A + 63) / 64 * 64 : NMS_MAX; } // candidates <= min(A, NMS_MAX)
 __host__ __device__ inline long long nms_ws_floats(int A)
 {
     const long long a64 = nms_a64(A);
-    return 4 + 4 * a64 + 2 * (a64 / 64) * a64;
+    return kNmsHdr + 4 * a64 + 2 * (a64 / 64) * a64;
 }
 // LDS of k_decode_sort (dynamic): the sort keys, skey[n] f32 | sidx[n] i32, n = candidates rounded up to a power of two.
 __host__ __device__ inline size_t nms_lds_bytes(int cap) { return (size_t)cap * 8 + 64; }
@@ -392,7 +394,7 @@ __global__ __launch_bounds__(1024) void k_decode_sort(DecodeArgs a, int cap)
     int *order = count_out + 1; // anchor index of every candidate in score order
     float *wsb = a.ws + (long long)b * nms_ws_floats(a.A);
     int *n_out = (int *)wsb;
-    float4 *boxes = (float4 *)(wsb + 4);
+    float4 *boxes = (float4 *)(wsb + kNmsHdr);
     if (tid == 0) scount = 0;
     __syncthreads();
     // ---- decode; candidates = obj > threshold, compacted in anchor order by a block-wide stable scan
@@ -468,8 +470,8 @@ __global__ __launch_bounds__(256) void k_nms_matrix(DecodeArgs a)
     float *wsb = a.ws + (long long)b * nms_ws_floats(a.A);
     const int n = *(const int *)wsb;
     if (n <= 0 || cw < rb || rb * 64 >= n || cw * 64 >= n) return; // (wave-uniform; no barrier in this kernel)
-    const float4 *boxes = (const float4 *)(wsb + 4);
-    unsigned long long *maskT = (unsigned long long *)(wsb + 4 + 4 * a64);
+    const float4 *boxes = (const float4 *)(wsb + kNmsHdr);
+    unsigned long long *mask = (unsigned long long *)(wsb + kNmsHdr + 4 * a64);
     const int gi = rb * 64 + lane, gj = cw * 64 + lane;
     const float4 rbx = gi < n ? boxes[gi] : make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 cbx = gj < n ? boxes[gj] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -490,45 +492,49 @@ __global__ __launch_bounds__(256) void k_nms_matrix(DecodeArgs a)
             bal = __ballot(pair && inter / (ai + c_area - inter) > a.iou_thr);
         if (lane == i) mine = bal;
     }
-    maskT[(long long)cw * a64 + gi] = mine; // rows at or behind n: zero
+    mask[(long long)gi * (a64 / 64) + cw] = mine; // rows at or behind n: zero (one scattered 8-byte store per 64 x 64 IoUs)
 }
 
 constexpr int kSweepThreads = 128; // = NMS_MAX / 64 words
 __global__ __launch_bounds__(kSweepThreads) void k_nms_sweep(DecodeArgs a)
 {
     __shared__ unsigned long long keptw[kSweepThreads];
-    __shared__ int wpre[kSweepThreads + 1];
     const int b = blockIdx.x, t = threadIdx.x;
-    const int F = 5 + a.nc;
     const long long a64 = nms_a64(a.A);
+    const int nw = (int)(a64 / 64);
     float *wsb = a.ws + (long long)b * nms_ws_floats(a.A);
     const int n = *(const int *)wsb;
     if (n <= 0) return; // (k_decode_sort has written the count: 0 or -1)
-    int *count_out = a.counts + (long long)b * (1 + a.A);
-    const int *order = count_out + 1;
     const int nwn = (n + 63) >> 6;
-    const unsigned long long *col = (const unsigned long long *)(wsb + 4 + 4 * a64) + (long long)t * a64; // word t of every row
+    // row-major mask: the 64 lanes of a wavefront read 64 consecutive words of one row (thread t = word t)
+    const unsigned long long *col = (const unsigned long long *)(wsb + kNmsHdr + 4 * a64) + t;
     const bool active = t < nwn;
     unsigned long long rem = 0ull;
-    ulonglong2 bufA[32], bufB[32];
-    auto load = [&](ulonglong2 (&m)[32], int c) {
+    unsigned long long bufA[64], bufB[64];
+    auto load = [&](unsigned long long (&m)[64], int c) {
         if (active && t >= c) {
-            const ulonglong2 *src = (const ulonglong2 *)(col + (long long)c * 64);
+            const unsigned long long *src = col + (long long)c * 64 * nw;
 #pragma unroll
-            for (int k = 0; k < 32; ++k) m[k] = src[k];
+            for (int i = 0; i < 64; ++i) m[i] = src[(long long)i * nw];
         }
     };
-    auto step = [&](ulonglong2 (&cur)[32], ulonglong2 (&nxt)[32], int c) {
+    auto step = [&](unsigned long long (&cur)[64], unsigned long long (&nxt)[64], int c) {
         if (c + 1 < nwn) load(nxt, c + 1); // the next chunk's masks fly while this one is resolved
         const int nb = n - c * 64 < 64 ? n - c * 64 : 64;
         if (t == c) { // the owner of the diagonal word: the chunk's 64 rows in score order
             unsigned long long sup = rem, kept = 0ull;
+            unsigned long long any = 0ull;
 #pragma unroll
-            for (int i = 0; i < 64; ++i) {
-                const unsigned long long m = (i & 1) ? cur[i >> 1].y : cur[i >> 1].x;
-                const bool keep = i < nb && !((sup >> i) & 1ull);
-                kept |= keep ? 1ull << i : 0ull;
-                sup |= keep ? m : 0ull;
+            for (int i = 0; i < 64; ++i) any |= cur[i];
+            const unsigned long long valid = nb == 64 ? ~0ull : (1ull << nb) - 1ull;
+            if ((any & valid) == 0ull) kept = ~sup & valid; // nobody inside the chunk suppresses anybody
+            else {
+#pragma unroll
+                for (int i = 0; i < 64; ++i) {
+                    const bool keep = i < nb && !((sup >> i) & 1ull);
+                    kept |= keep ? 1ull << i : 0ull;
+                    sup |= keep ? cur[i] : 0ull;
+                }
             }
             keptw[c] = kept;
         }
@@ -539,10 +545,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_nms_sweep(DecodeArgs a)
             for (int g = 0; g < 8; ++g) {
                 if ((kept >> (8 * g)) & 0xffull) { // wave-uniform
 #pragma unroll
-                    for (int i = 8 * g; i < 8 * g + 8; ++i) {
-                        const unsigned long long m = (i & 1) ? cur[i >> 1].y : cur[i >> 1].x;
-                        rem |= ((kept >> i) & 1ull) ? m : 0ull;
-                    }
+                    for (int i = 8 * g; i < 8 * g + 8; ++i) rem |= ((kept >> i) & 1ull) ? cur[i] : 0ull;
                 }
             }
         }
@@ -553,28 +556,53 @@ __global__ __launch_bounds__(kSweepThreads) void k_nms_sweep(DecodeArgs a)
         if (c + 1 < nwn) step(bufB, bufA, c + 1);
     }
     __syncthreads();
-    // ---- emit kept boxes in score order: output row = kept boxes in front
-    if (t == 0) {
-        int run = 0;
-        for (int k = 0; k < nwn; ++k) { wpre[k] = run; run += __popcll(keptw[k]); }
-        wpre[nwn] = run;
-        *count_out = run;
+    unsigned long long *kept_out = (unsigned long long *)(wsb + 4);
+    if (t < nwn) kept_out[t] = keptw[t];
+}
+
+// kept boxes -> dets rows in score order: output row = kept boxes in front.  grid (ceil(A64 / 256), B)
+__global__ __launch_bounds__(256) void k_nms_emit(DecodeArgs a)
+{
+    __shared__ int wpre[NMS_MAX / 64 + 1];
+    const int b = blockIdx.y, t = threadIdx.x;
+    const int F = 5 + a.nc;
+    float *wsb = a.ws + (long long)b * nms_ws_floats(a.A);
+    const int n = *(const int *)wsb;
+    if (n <= 0 || (int)blockIdx.x * 256 >= n) return;
+    const unsigned long long *keptw = (const unsigned long long *)(wsb + 4);
+    int *count_out = a.counts + (long long)b * (1 + a.A);
+    const int *order = count_out + 1;
+    const int nwn = (n + 63) >> 6;
+    // kept boxes in front of every word: wavefront 0 scans the <= 128 popcounts (two per lane)
+    if (t < 64) {
+        const int c0 = 2 * t < nwn ? __popcll(keptw[2 * t]) : 0, c1 = 2 * t + 1 < nwn ? __popcll(keptw[2 * t + 1]) : 0;
+        int inc = c0 + c1;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(inc, off);
+            if (t >= off) inc += v;
+        }
+        const int ex = inc - c0 - c1;
+        if (2 * t < nwn) wpre[2 * t] = ex;
+        if (2 * t + 1 < nwn) wpre[2 * t + 1] = ex + c0;
+        if (t == 63) wpre[nwn] = inc; // all kept boxes
     }
     __syncthreads();
-    for (int i = t; i < n; i += kSweepThreads) {
-        const unsigned long long kw = keptw[i >> 6];
-        if (!((kw >> (i & 63)) & 1ull)) continue;
-        const int row = wpre[i >> 6] + __popcll(kw & ((1ull << (i & 63)) - 1ull));
-        const int anchor = order[i];
-        const float *r = a.raw + ((long long)b * a.A + anchor) * F;
-        int best = 0;
-        float bv = r[5];
-        for (int c = 1; c < a.nc; ++c) if (r[5 + c] > bv) { bv = r[5 + c]; best = c; } // first max, like argmax
-        float *d = a.dets + ((long long)b * a.A + row) * 6;
-        nms_anchor_box(a, b, anchor, d[0], d[1], d[2], d[3]);
-        d[4] = (float)best;
-        d[5] = r[4] * bv; // obj * max cls, yolo_head.py:301
-    }
+    if (blockIdx.x == 0 && t == 0) *count_out = wpre[nwn];
+    const int i = blockIdx.x * 256 + t;
+    if (i >= n) return;
+    const unsigned long long kw = keptw[i >> 6];
+    if (!((kw >> (i & 63)) & 1ull)) return;
+    const int row = wpre[i >> 6] + __popcll(kw & ((1ull << (i & 63)) - 1ull));
+    const int anchor = order[i];
+    const float *r = a.raw + ((long long)b * a.A + anchor) * F;
+    int best = 0;
+    float bv = r[5];
+    for (int c = 1; c < a.nc; ++c) if (r[5 + c] > bv) { bv = r[5 + c]; best = c; } // first max, like argmax
+    float *d = a.dets + ((long long)b * a.A + row) * 6;
+    nms_anchor_box(a, b, anchor, d[0], d[1], d[2], d[3]);
+    d[4] = (float)best;
+    d[5] = r[4] * bv; // obj * max cls, yolo_head.py:301
 }
 
 // ---- plan ------------------------------------------------------------------------------------------
@@ -1044,6 +1072,7 @@ int frlw_det_run(const frlw_detector_t *d, int B, void *const *bufs, int n_bufs,
             const int words = nms_a64(a.A) / 64; // candidates never exceed min(A, NMS_MAX)
             hipLaunchKernelGGL(k_nms_matrix, dim3((words + 3) / 4, words, B), dim3(256), 0, s, a);
             hipLaunchKernelGGL(k_nms_sweep, dim3(B), dim3(kSweepThreads), 0, s, a);
+            hipLaunchKernelGGL(k_nms_emit, dim3(words * 64 / 256 + 1, B), dim3(256), 0, s, a);
             break;
         }
         default: return FRLW_ERR_ARG;
