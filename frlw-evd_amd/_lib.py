@@ -41,7 +41,7 @@ class FrlwTuning(C.Structure):
                 ("tile_width_log2", C.c_int32), ("batches_per_wave", C.c_int32), ("hot_tile_records", C.c_int32),
                 ("staged_scatter", C.c_int32), ("quarter_below", C.c_int32), ("no_value_table", C.c_int32),
                 ("taf_tile_walk", C.c_int32), ("direct_bins", C.c_int32), ("chunk_major", C.c_int32),
-                ("ev_lds_float_atomics", C.c_int32)]
+                ("ev_lds_float_atomics", C.c_int32), ("walk_window_table", C.c_int32)]
 
     def __init__(self, **kw):
         super().__init__(*[int(kw.pop(name, -1)) for name, _ in self._fields_])

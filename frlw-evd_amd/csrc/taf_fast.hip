@@ -127,6 +127,7 @@ struct FastPlan {
     int chunks, slabs, pairs;
     size_t off_counts, off_slabtot, off_base, off_sub, off_seg0, off_segcnt, off_errs, off_tlut, off_records, off_records2, bytes;
     size_t off_sub_end, off_segdesc; // chunk-major partition: list ends, pair of every split segment
+    size_t off_wst, off_wst_flag;    // TileP::wst / wst_flag
     int max_seq_chunks;              // chunks of the longest sequence (the column a chunk-major consumer keeps in LDS)
     int max_segs;
 };
@@ -237,6 +238,8 @@ bool fast_layout(const int64_t *seq_offsets, const int64_t *t_start, int n_seq, 
     p.off_records2 = off; off = align_up(off + (size_t)(n > 0 ? n : 1) * 4, 256);
     p.off_sub_end = off; off = align_up(off + ((size_t)p.pairs * kFW + 1) * 4, 256);
     p.off_segdesc = off; off = align_up(off + (size_t)p.max_segs * 4, 256);
+    p.off_wst = off;     off = align_up(off + (size_t)p.pairs * kFW * (FRLW_MAX_WINDOWS + 1) * 4, 256);
+    p.off_wst_flag = off; off = align_up(off + (size_t)p.pairs * 4, 256);
     p.bytes = off;
     return true;
 }
@@ -1001,6 +1004,11 @@ struct TileP {
     float *state;    // (B, H, W, 2, K)
     float *view_f32; // (B, 2K, H, W) or NULL
     uint8_t *out_u8; // (B, K, 2, H, W) or NULL
+    // window starts, written by kf_split_whole<true> for the tiles it splits (TAF only; NULL otherwise): wst[sg * (n_windows + 1)
+    // + w] = list position of the first record of window w in sub-tile list sg, 0xffffffff: the window has none -- what the walk's
+    // own scan finds; wst_flag[pair] = 0: no table (the walk scans its list), 1: table valid, 2: a list of the tile is not
+    // window-sorted (the walk filters the whole list per window)
+    uint32_t *wst, *wst_flag;
 };
 
 // ---- the consumer side of the chunk-major partition: a bin's column of the directory ----------------------------------
@@ -1128,6 +1136,7 @@ __device__ __forceinline__ void fifo_step_half(float (&st)[4], bool upper, bool 
 }
 
 #define LDS_FENCE() asm volatile("" ::: "memory")
+#define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory") // workgroup barrier that publishes LDS only: loads / stores in flight stay in flight
 
 __device__ __forceinline__ int pair_of_segment(const uint32_t *seg0, int pairs, uint32_t seg)
 {
@@ -1187,6 +1196,7 @@ __device__ __forceinline__ void split_count_segment(const TileP &q, uint32_t seg
 constexpr int kWholeChunks = FRLW_WHOLE_SEGS;
 constexpr int kWholeBatches = kWholeChunks * kSplitSeg / kWave; // 512 batches of 64 records
 constexpr int kWholeRow = kWholeBatches + 1;                    // row stride of scnt: the 16 counters of one batch in 16 banks
+
 // CM (chunk-major partition): the tile's list is not contiguous -- it is gathered from the tile's column of the directory
 // (col_*), the 16 sub-tile lists go wherever the header's cursor says, and a skewed tile only books its space and its split
 // segments here (kf_segcount_cm / kf_split_place<true> do the work: the segments are not known before this kernel runs).
@@ -1207,6 +1217,9 @@ __global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     __shared__ uint32_t vbeg[kFW][kFW];        // [wavefront]: every wavefront's own copy of the sub-tile starts
     __shared__ uint32_t cE[kFW][kFW], cD[kFW][kFW]; // [wavefront]: per chunk, see step 4
     __shared__ uint32_t s_start, s_first;
+    __shared__ int s_unsorted;
+    __shared__ int s_fw[kWholeChunks][kFW], s_lw[kWholeChunks][kFW]; // (CM, TAF) first / last window of every sub-tile list inside every chunk, -1: no record
+    __shared__ uint32_t s_wst[CM ? kFW * (FRLW_MAX_WINDOWS + 1) : 1];  // (CM, TAF) the tile's rows of TileP::wst while they are made
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     // (CM: the status is REQUESTED here and tested behind the directory column -- a test in front of it made the column's load
     // wait for the header's round trip; the directory lies at addresses the plan fixes, reading it is safe whatever the status)
@@ -1237,12 +1250,19 @@ __global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         if (status0 != 0) return;
         if (n == 0u) {
             if (tid < kFW) { q.sub[(long long)g * kFW + tid] = 0u; q.sub_end[(long long)g * kFW + tid] = 0u; }
+            if (q.wst && tid == 0) q.wst_flag[g] = 0u; // (empty lists: the walk's scan finds nothing to read)
             return;
         }
         const bool hot = n > q.tile_max;
         if (tid == 0) {
             s_start = atomicAdd(&q.hdr->rec_cursor, n); // the tile's 16 lists: n records of rec2[] from here
             if (hot) s_first = atomicAdd(&q.hdr->seg_cursor, (n + kSplitSeg - 1) / kSplitSeg);
+            if (q.wst && hot) q.wst_flag[g] = 0u; // (the segment kernels place this tile: no table)
+            s_unsorted = 0;
+        }
+        if (q.wst && !hot) { // the tile's rows of the window table start at "no record" (published by the barriers below)
+            if (tid < kWholeChunks * kFW) { (&s_fw[0][0])[tid] = -1; (&s_lw[0][0])[tid] = -1; }
+            for (int i = tid; i < kFW * (q.n_windows + 1); i += kFT) s_wst[i] = 0xffffffffu;
         }
         if (hot) { // a skewed tile (or a call with few tiles): cut into segments of 8192 list positions, one workgroup each
             __syncthreads();
@@ -1366,6 +1386,7 @@ __global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     // Per chunk and sub-tile b (every wavefront keeps its own copy, no barrier for the tables):
     //   cE[b] = (records of sub-tiles < b in the chunk) - (prefix of b at the chunk's first batch)   -> slot = cE[b] + prefix + ticket
     //   cD[b] = (start of b's list) + (prefix of b at the chunk's first batch) - (records of sub-tiles < b)  -> address = cD[b] + slot
+    const bool wtab = CM && q.wst != nullptr; // (kernel-uniform)
 #pragma unroll
     for (int c = 0; c < kWholeChunks; ++c) {
         if ((uint32_t)(c * kSplitSeg) >= n) break; // workgroup-uniform
@@ -1397,6 +1418,12 @@ __global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             }
         }
         __syncthreads();
+        // (CM, TAF) the window starts kf_taf_walk needs, so that it does not have to scan its list for them.  The staged chunk is
+        // sub-tile-major and stable: neighbours of one sub-tile are neighbours of that sub-tile's LIST.  A record whose sub-tile or
+        // window differs from its staged predecessor's (and the chunk's first record) is a candidate for "first record of its
+        // window in its list": the minimum list position over the candidates IS that record (a candidate that is no true start --
+        // the first record of a sub-tile in a later chunk -- has an earlier record of its window in front of it, a candidate
+        // too), taken with one LDS atomicMin -- a handful per chunk; two LDS reads + four instructions per record otherwise.
 #pragma unroll
         for (int u = 0; u < RPT; ++u) {
             const uint32_t i = (uint32_t)(u * kFT + tid);
@@ -1405,7 +1432,59 @@ __global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 q.rec2[cD[wv][(r & (kCells - 1)) >> 8] + i] = r;
             }
         }
-        __syncthreads(); // the staging area is reused by the next chunk
+        if (wtab) { // (a pass of its own: a branch per record inside the sweep above kept its LDS reads from being issued together)
+            const uint32_t dmask = (((1u << q.wb) - 1u) << kCellBits) | (uint32_t)(kCells - 1) >> 8 << 8;
+            uint32_t cand = 0u; // bit u: record u * 1024 + tid of the chunk is a candidate
+#pragma unroll
+            for (int u0 = 0; u0 < RPT; u0 += 2) { // two records' reads issued together (clamped indices; the empty asm keeps the
+                uint32_t r[2], rp[2];               // compiler from putting each read under its own `i < nch` branch, one LDS round trip each;
+#pragma unroll                                      // four at a time spilled five of the later chunks' records)
+                for (int k = 0; k < 2; ++k) {
+                    const uint32_t i = (uint32_t)((u0 + k) * kFT + tid);
+                    r[k] = stage[i];                            // (i < 8192: inside the staging area whatever nch is; what lies
+                    rp[k] = stage[(i - 1u) & (kSplitSeg - 1)];  // behind the chunk's end, or in front of record 0, is masked below)
+                }
+#pragma unroll
+                for (int k = 0; k < 2; ++k) asm volatile("" : "+v"(r[k]), "+v"(rp[k]));
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const uint32_t i = (uint32_t)((u0 + k) * kFT + tid);
+                    cand |= (i < nch && (((r[k] ^ rp[k]) & dmask) != 0u || i == 0u || i == nch - 1u) ? 1u : 0u) << (u0 + k);
+                }
+            }
+            while (cand) { // rare: a handful of records per chunk
+                const int u = __builtin_ctz(cand);
+                cand &= cand - 1u;
+                const uint32_t i = (uint32_t)(u * kFT + tid);
+                const uint32_t r = stage[i], rp = stage[i > 0u ? i - 1u : 0u];
+                const int bsub = (int)((r & (kCells - 1)) >> 8), bp = (int)((rp & (kCells - 1)) >> 8);
+                const int wc = (int)__builtin_amdgcn_ubfe(r, kCellBits, q.wb), wpn = (int)__builtin_amdgcn_ubfe(rp, kCellBits, q.wb);
+                const bool same = i > 0u && bp == bsub; // the staged predecessor is the list predecessor
+                // (an LDS atomic: global ones sat in front of every chunk's barrier, which waits for the memory queue to drain)
+                if (!same || wc != wpn) atomicMin(&s_wst[bsub * (q.n_windows + 1) + wc], cD[wv][bsub] + i - vbeg[wv][bsub]);
+                if (same && wc < wpn) s_unsorted = 1;
+                if (!same) { s_fw[c][bsub] = wc; if (i > 0u) s_lw[c][bp] = wpn; } // first window of list bsub / last of list bp in this chunk
+                if (i == nch - 1u) s_lw[c][bsub] = wc;
+            }
+        }
+        // the staging area is reused by the next chunk; behind the LAST chunk only step 5 follows, which touches LDS alone: a raw
+        // barrier there (a __syncthreads() would make the workgroup wait for the drain of its last 32 KB of stores)
+        if (wtab && (uint32_t)((c + 1) * kSplitSeg) >= n) LDS_BARRIER();
+        else __syncthreads();
+    }
+    // 5. (CM, TAF) a window index that DEcreases between list neighbours marks the tile unsorted (the walk then filters the whole
+    // list per window, as it does after its own scan): inside a chunk the sweep saw it at the neighbour; across chunks it is the
+    // list's last window in one chunk against its first in the next one that has any.
+    if (wtab) {
+        if (tid < kFW) {
+            int prev = -1;
+            for (int c = 0; c < kWholeChunks; ++c)
+                if (s_fw[c][tid] >= 0) { if (s_fw[c][tid] < prev) s_unsorted = 1; prev = s_lw[c][tid]; }
+        }
+        uint32_t *const wr = q.wst + (long long)g * kFW * (q.n_windows + 1);
+        for (int i = tid; i < kFW * (q.n_windows + 1); i += kFT) wr[i] = s_wst[i];
+        LDS_BARRIER();
+        if (tid == 0) q.wst_flag[g] = s_unsorted ? 2u : 1u;
     }
 }
 
@@ -1662,10 +1741,12 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_waves_per_eu(8,
     const unsigned long long wmask = q.hdr->wmask[s];
     const uint32_t mul_bad0 = q.hdr->mul_bad;
     uint32_t beg = 0u, end = 0u;
+    uint32_t wtab = 0u; // 1 / 2: kf_split_whole<true> has left this tile's window starts / found its list unsorted (TileP::wst_flag)
     if (!CMD) {
         // (sub[] of the NEXT pair is only written if that pair went through a split kernel: take the tile's own end)
         beg = q.sub[sg];
         end = q.sub_end ? q.sub_end[sg] : ((sub == kFW - 1 && !q.direct) ? q.base[g + 1] : q.sub[sg + 1]);
+        if (q.wst) wtab = q.wst_flag[g];
     }
     if (status0 != 0) return; // data-dependent error: nothing is written (the caller re-runs the general path)
     WPROF_INIT();
@@ -1743,18 +1824,39 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_waves_per_eu(8,
         if (in_frame) row_touch = r[0];
     }
 
-    for (int i = tid; i <= NW; i += kWalkThreads) wstart[i] = end;
-    if (tid == 0) s_unsorted = 0;
+    // The window starts: read from the table kf_split_whole<true> left (wtab != 0: no scan, no barrier -- the planes and counters
+    // a wavefront zeroes are its own), or found by a scan of the list (phase 0: every other partition form).
+    uint32_t first_w = 0u;
+    unsigned long long nonempty = 0ull;
+    bool general;
+    const bool use_mul = mul_bad0 == 0u; // checked for every r of the domain by the partition kernel
+    const double rcp = q.rcp;
+    const uint32_t wfield = (1u << q.wb) - 1u;
+    const int rshift = kCellBits + q.wb;
     {   // planes and counters start at zero (CMD: the column is dead since the barrier behind the gather)
         uint2 *z = (uint2 *)&s_area[wv][0];
         static_assert(kWalkWaveWords % (2 * kWave) == 0, "whole 8-byte sweeps");
 #pragma unroll
         for (int i = 0; i < kWalkWaveWords / 2 / kWave; ++i) z[i * kWave + lane] = make_uint2(0u, 0u);
     }
-    const bool use_mul = mul_bad0 == 0u; // checked for every r of the domain by the partition kernel
-    const double rcp = q.rcp;
-    const uint32_t wfield = (1u << q.wb) - 1u;
-    const int rshift = kCellBits + q.wb;
+    if (!CMD && wtab != 0u) { // workgroup-uniform
+        // lane = window: records of the list in front of window `lane` (window-sorted list); entry NW = all of them
+        const uint32_t *wrow = q.wst + (long long)sg * (NW + 1);
+        const uint32_t fw0 = wrow[lane < NW ? lane : NW];
+        // the list's lines are requested while the table row is on its way (one word per 128-byte line and thread: 16 384 records
+        // per round); phase 1's loads, which wait for the row, then find them in the caches
+        uint32_t list_touch = 0u;
+        for (uint32_t i = beg + 32u * (uint32_t)tid; i < end; i += 32u * kWalkThreads) list_touch |= list[i];
+        asm volatile("" ::"v"(list_touch));
+        first_w = fw0 != 0xffffffffu ? beg + fw0 : end; // what the scan leaves in wstart[]
+        nonempty = __ballot(lane < NW && fw0 != 0xffffffffu);
+        general = wtab == 2u;
+        asm volatile("" ::"v"(row_touch));
+        WPROF(0);
+        WPROF(1);
+    } else {
+    for (int i = tid; i <= NW; i += kWalkThreads) wstart[i] = end;
+    if (tid == 0) s_unsorted = 0;
     __syncthreads();
     WPROF(0);
     // ---- phase 0: first record of every window; a window index that decreases = not window-sorted.  A thread looks at four
@@ -1796,14 +1898,15 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_waves_per_eu(8,
     __syncthreads();
     asm volatile("" ::"v"(row_touch)); // (the touch has landed; nothing else wants the value)
     WPROF(1);
-    const bool general = s_unsorted != 0;
-    if (general && tid == 0) atomicAdd(&q.hdr->filtered_tiles, 1u);
+    general = s_unsorted != 0;
     // wstart[w'] = first record of window w', or `end` for a window without records: window w's stretch starts at the minimum over
     // w' >= w (a window without records starts where the next one does) -- every wavefront finds that window for itself in a
     // ballot over the lanes (lane = window), instead of one thread walking the table between two barriers (12 % of the
     // workgroup's life)
-    const uint32_t first_w = wstart[lane < NW ? lane : NW];
-    const unsigned long long nonempty = __ballot(lane < NW && first_w != end); // (lane = window; window-sorted list: their starts ascend)
+    first_w = wstart[lane < NW ? lane : NW];
+    nonempty = __ballot(lane < NW && first_w != end); // (lane = window; window-sorted list: their starts ascend)
+    }
+    if (general && tid == 0) atomicAdd(&q.hdr->filtered_tiles, 1u);
     WPROF(2);
 
     float *rplane = (float *)&s_area[wv][0];                      // [kWalkSlots][256]
@@ -3230,6 +3333,8 @@ size_t frlw_taf_batch_workspace_bytes(int64_t n_events, int n_seq, int H, int W,
         off = align_up(off + (size_t)(n_events > 0 ? n_events : 1) * 4, 256);
         off = align_up(off + ((size_t)p.pairs * kFW + 1) * 4, 256);
         off = align_up(off + (2 * (size_t)(n_events / kSplitSeg) + 1) * 4, 256);
+        off = align_up(off + (size_t)p.pairs * kFW * (FRLW_MAX_WINDOWS + 1) * 4, 256);
+        off = align_up(off + (size_t)p.pairs * 4, 256);
         if (off > need) need = off;
     }
     return need;
@@ -3332,9 +3437,14 @@ int taf_batch_run(int phases, const frlw_events_t *ev, const int64_t *seq_offset
     q.state = state; q.view_f32 = view_f32; q.out_u8 = out_u8;
     q.direct = p.direct;
     q.sub_end = nullptr;
+    q.wst = nullptr; q.wst_flag = nullptr;
     if (cm && p.direct) {
         q.rec2 = (uint32_t *)(w8 + p.off_records2); // (kf_taf_walk<.., true> books and fills its own list)
     } else if (cm) {
+        if (tuning_knob(ev->tuning, &frlw_tuning_t::walk_window_table, 1) != 0) { // kf_split_whole<true> leaves the walk its window starts
+            q.wst = (uint32_t *)(w8 + p.off_wst);
+            q.wst_flag = (uint32_t *)(w8 + p.off_wst_flag);
+        }
         launch_split_cm(q, p, S, w8, st);
     } else if (p.direct) { // kf_scatter's bins were the sub-tiles: its output IS the sub-tile-major list, base[] its sub[]
         q.rec2 = (uint32_t *)(w8 + p.off_records);

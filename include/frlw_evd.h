@@ -84,6 +84,9 @@ typedef struct frlw_tuning {
     int32_t ev_lds_float_atomics; /* frlw_ev_encode_batch, direct mode of the chunk-major partition: 1 = one wavefront per sub-tile
                                * sums its list with LDS float atomics in stream order (kf_ev_fadd: short latency chain, 3 x the
                                * cycles per record -- the default up to 3 M events per call), 0 = the ticket-sort kernel */
+    int32_t walk_window_table; /* frlw_taf_encode_batch, chunk-major partition with tile bins: 1 = the split kernel leaves every
+                               * sub-tile list's window starts in a table and the walk reads them (the default), 0 = the walk
+                               * finds them with a scan of its list, as it does for every other partition form */
 } frlw_tuning_t;
 
 typedef struct frlw_events {

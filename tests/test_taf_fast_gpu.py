@@ -575,3 +575,50 @@ def test_captured_encode_replays_against_the_oracle(er, orc, shape, n_seq, n):
             assert_u8_budget(host(u8[j]), ou8, 1e-5, f"uint8 of sequence {j}")
     with torch.cuda.stream(side):
         er.raise_deferred()
+
+
+@pytest.mark.parametrize("shape,n_seq,n,K,n_win,win,hot", [((720, 1280), 1, 3_000_000, 8, 8, 10_000, False),
+                                                           ((240, 304), 12, 700_000, 8, 8, 10_000, True),    # tiles of three chunks, tiles over the segment limit
+                                                           ((240, 304), 9, 300_000, 4, 64, 1_000, False),    # 64 windows
+                                                           ((240, 304), 9, 200_000, 5, 1, 40_000, False),    # ONE window (no window bits in the record)
+                                                           ((97, 131), 40, 30_000, 3, 5, 7_001, True)])
+def test_walk_window_table_equals_the_walks_own_scan(shape, n_seq, n, K, n_win, win, hot, monkeypatch):
+    """frlw_tuning_t::walk_window_table 1 (the default: kf_split_whole<true> leaves every sub-tile list's window starts in a table,
+    kf_taf_walk reads them) against 0 (the walk scans its list), forced onto tile bins + the chunk-major partition: sequences
+    with windows without any event (at the front, in the middle, at the end), an unsorted sequence (the tile is flagged and the
+    walk filters per window), a sequence whose time runs backwards twice, an empty sequence, tiles that span several staging
+    chunks and tiles the segment kernels place (no table: the walk scans) -- state, view and uint8 volume bit for bit, with a
+    state carried over from a first call."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from frlw_evd_amd import _lib, event_representation as er, synth
+    H, W = shape
+    span = n_win * win
+    recs = [synth.to_dat8(synth.synth_events(1700 + j, n // (1 + 3 * (j == 1)), W, H, span, hotspot=hot and j % 3 == 0)) for j in range(n_seq)]
+    if n_seq >= 5:
+        if n_win >= 3:
+            r = recs[2]
+            recs[2] = r[((r["t"] // win) != 1) & ((r["t"] // win) != 0)]        # no event in windows 0 and 1
+            r = recs[3]
+            recs[3] = r[(r["t"] // win) < n_win - 2]                             # none in the last two
+        recs[4] = recs[4][np.random.default_rng(11).permutation(len(recs[4]))]   # unsorted
+        recs[0] = np.concatenate([recs[0]] * 3)                                  # time runs backwards twice
+        recs[-1] = recs[-1][:0]                                                  # empty
+    offs = np.concatenate([[0], np.cumsum([len(r) for r in recs])])
+    dat = torch.from_numpy(np.ascontiguousarray(np.concatenate(recs)).view(np.uint8).reshape(-1, 8).copy()).cuda()
+    outs = []
+    for wt in (1, 0):
+        monkeypatch.setattr(er, "TUNING", _lib.FrlwTuning(chunk_major=1, direct_bins=0, walk_window_table=wt))
+        st = torch.full((n_seq, H, W, 2, K), -6000.0, device="cuda")
+        for _ in range(2):
+            u8, view = er.encode_taf_batch(dat, offs, (H, W), st, 0, win, n_win, K, want_view=True)
+        outs.append((st, u8, view))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    # ... and against the histogram partition (no table anywhere)
+    monkeypatch.setattr(er, "TUNING", _lib.FrlwTuning(chunk_major=0, direct_bins=0))
+    st = torch.full((n_seq, H, W, 2, K), -6000.0, device="cuda")
+    for _ in range(2):
+        u8, view = er.encode_taf_batch(dat, offs, (H, W), st, 0, win, n_win, K, want_view=True)
+    for a, b in zip(outs[0], (st, u8, view)):
+        assert torch.equal(a, b)
