@@ -485,6 +485,11 @@ def main():
     torch.cuda.set_device(local_rank)
     n_gpus = world
     _lib.load()
+    # every rank runs the lane-order self-test of the fast paths on its own GPU; the job takes them only if ALL ranks passed
+    # (dist.agree_fast_path: a mixed world would have one rank on the general path and everybody else waiting for it)
+    fast_ok = fd.agree_fast_path()
+    if not fast_ok:  # (never seen on gfx950; the batched rows have no general-path form)
+        args.no_also = True
     timer = Timer(torch, fd, er)
     copy_gbs = copy_bandwidth(torch)
 
@@ -493,7 +498,7 @@ def main():
     dat_h = synth.to_dat8(ev)
     dat = torch.from_numpy(dat_h.view(np.uint8).reshape(-1, 8)).cuda()
     state = torch.full((H, W, 2, K), -6000.0, device="cuda")
-    use_fast = n >= er.FAST_MIN_EVENTS
+    use_fast = n >= er.FAST_MIN_EVENTS and fast_ok
 
     def step(fast=use_fast):
         return er.encode_taf_dat(dat, (H, W), state, 0, win_us, n_win, K, want_view=False, want_u8=True, flip_k=True,

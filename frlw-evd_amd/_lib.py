@@ -72,6 +72,7 @@ SYMBOLS = {
     "frlw_taf_encode": (_I, [_EV, _I, _I, _I, _I64, _I64, _I, _P, _P, _P, _I, _P, _SZ, _P]),
     "frlw_selftest_mfma_f32_rate": (_I, [_I, _I, _P, _P, _P]),
     "frlw_selftest_lds_atomic_order": (_I, [_I, _I, _P, _P]),
+    "frlw_fast_path_verdict": (_I, [_P, _SZ, _P, C.POINTER(C.c_int)]),
     "frlw_taf_batch_workspace_bytes": (_SZ, [_I64, _I, _I, _I, _I64]),
     "frlw_taf_encode_batch": (_I, [_EV, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _I, _I, _I, _I, _I64, _I, _P, _P, _P, _I,
                                   _P, _SZ, _P]),

@@ -3295,6 +3295,16 @@ int frlw_debug_force_lds_order(int value)
 }
 #endif
 
+int frlw_fast_path_verdict(void *workspace, size_t workspace_bytes, frlw_stream_t stream, int *ok_out)
+{
+    if (!workspace || workspace_bytes < kHeaderBytes || !ok_out) return FRLW_ERR_ARG;
+    (void)hipGetLastError();
+    const int rc = lds_order_ok((char *)workspace, (hipStream_t)stream); // runs the self-test on the first call per device, cached afterwards
+    if (rc != FRLW_OK && rc != FRLW_ERR_UNSUPPORTED) return rc;
+    *ok_out = rc == FRLW_OK ? 1 : 0;
+    return FRLW_OK;
+}
+
 int frlw_selftest_lds_atomic_order(int n_addr, int iters, unsigned long long *out_dev, frlw_stream_t stream)
 {
     if (!out_dev || n_addr < 1 || n_addr > 512 || iters < 1) return FRLW_ERR_ARG;

@@ -78,6 +78,26 @@ def sum_over_ranks(values):
     return [float(v) for v in t]
 
 
+def agree_fast_path(group=None, local_ok=None):
+    """One verdict for the whole job on the encoders' fast paths: the MINIMUM over the ranks of each rank's LDS lane-order
+    self-test (``event_representation.fast_path_ok``: once per process and device, 0.7 ms -- eight times on an 8-GPU node).  A
+    rank whose device fails the test would quietly take the general path -- same bits, several times the encode time -- and
+    every other rank would wait for it at the next collective; after this call either every rank runs the fast kernels or none
+    does (``event_representation.FAST_PATH_ENABLED``).  Returns the job's verdict.  ``local_ok``: this rank's own verdict when the
+    caller has it already (tests on CPU).  Call it once, after ``init_from_env`` and before the first encode."""
+    from . import event_representation as er
+    if local_ok is None:
+        local_ok = er.fast_path_ok() if torch.cuda.is_available() else True
+    ok = bool(local_ok)
+    if dist.is_initialized():
+        dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+        ok = bool(int(t.item()))
+    er.FAST_PATH_ENABLED = ok
+    return ok
+
+
 def job_throughput(units_this_rank, seconds_this_rank):
     """Whole-job rate: units all ranks processed / the slowest rank's time."""
     total = sum_over_ranks([units_this_rank])[0]

@@ -29,6 +29,10 @@ from . import _lib
 _WORKSPACES = {}
 TUNING = None  # a _lib.FrlwTuning to attach to every encoder call (experiments / tests forcing a path); None = defaults
 FAST_MIN_EVENTS = 1_000_000  # single streams shorter than this take the general TAF path (encode_taf_dat, fast="auto")
+# False: every encoder takes the general path (the batched entry points raise NotImplementedError like on a device that failed the
+# lane-order self-test).  Set by dist.agree_fast_path() when ANY rank of the job failed it: results do not depend on the path,
+# step times do, and ranks that wait for each other in a collective should not run different kernels.
+FAST_PATH_ENABLED = True
 
 
 def _stream():
@@ -77,6 +81,17 @@ def raise_deferred(what="encoder calls since the last check"):
 
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def fast_path_ok(device=None):
+    """The library's verdict on the LDS lane-order property for ``device`` (default: the current one): True = the fast paths run
+    there.  Runs the one-time self-test if no fast-path call has yet (0.7 ms, one host synchronisation per process and device)."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    with torch.cuda.device(device):
+        ws = _workspace(1, 8, 8, device)
+        ok = C.c_int(0)
+        _lib.check(_lib.load().frlw_fast_path_verdict(_ptr(ws), ws.numel(), _stream(), C.byref(ok)), "frlw_fast_path_verdict")
+    return bool(ok.value)
 
 
 def _events_f64(events):
@@ -269,6 +284,8 @@ def encode_taf_batch(dat, seq_offsets, shape, state, t_start, window_us=10000, n
     B = len(offs) - 1
     if B < 1 or B > _lib.MAX_SEQUENCES:
         raise ValueError(f"1..{_lib.MAX_SEQUENCES} sequences per call")
+    if not FAST_PATH_ENABLED:
+        raise NotImplementedError("the fast path is switched off for this job (dist.agree_fast_path: a rank failed the self-test)")
     t0 = [int(t_start)] * B if not hasattr(t_start, "__len__") else [int(t) for t in t_start]
     assert state.dtype == torch.float32 and state.is_contiguous() and tuple(state.shape) == (B, H, W, 2, K)
     d, desc = _events_dat(dat, xmap, ymap)
@@ -373,6 +390,7 @@ def encode_taf_dat(dat, shape, state, t_start, window_us=10000, n_windows=8, vol
     n = dat.numel() * dat.element_size() // 8
     if fast == "auto":
         fast = bool(check) and n >= FAST_MIN_EVENTS
+    fast = fast and FAST_PATH_ENABLED
     if fast:
         if check:
             # The fall-back below takes a ValueError / IndexError of the fast call to mean "THIS call wrote nothing".  The status
@@ -464,6 +482,7 @@ def encode_ev_dat(dat, shape, t_end, window_us, volume_bins=5, want_f32=True, wa
     n = dat.numel() * dat.element_size() // 8
     if fast == "auto":
         fast = bool(check) and n >= FAST_MIN_EVENTS
+    fast = fast and FAST_PATH_ENABLED
     if fast:
         if check:  # (an earlier unchecked call's error must not be mistaken for this call's: encode_taf_dat explains)
             pending = _WORKSPACES.get(("batch", dat.device.index, torch.cuda.current_stream().cuda_stream))
@@ -500,6 +519,8 @@ def encode_ev_batch(dat, seq_offsets, shape, t_end, window_us, volume_bins=5, wa
     B = len(offs) - 1
     if B < 1 or B > _lib.MAX_SEQUENCES:
         raise ValueError(f"1..{_lib.MAX_SEQUENCES} sequences per call")
+    if not FAST_PATH_ENABLED:
+        raise NotImplementedError("the fast path is switched off for this job (dist.agree_fast_path: a rank failed the self-test)")
     te = [int(t_end)] * B if not hasattr(t_end, "__len__") else [int(t) for t in t_end]
     d, desc = _events_dat(dat, xmap, ymap)
     ws = _batch_workspace(offs[-1] - offs[0], B, H, W, window_us, d.device)

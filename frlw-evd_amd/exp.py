@@ -163,7 +163,8 @@ class basicExp:
             net = net.cuda()
         ids = [self.settings.local_rank] if torch.cuda.is_available() else None
         # core/exp.py:391; bucket view + static graph: the gradient all-reduce reuses its buckets (dist.ddp_kwargs)
-        from .dist import ddp_kwargs
+        from .dist import agree_fast_path, ddp_kwargs
+        agree_fast_path()  # the encoders' fast paths run on every rank or on none (one all-reduce)
         self.model = DistributedDataParallel(net, device_ids=ids, broadcast_buffers=False, **ddp_kwargs())
 
     # ---- optimisation -----------------------------------------------------------------------------------

@@ -248,6 +248,15 @@ int frlw_ev_encode_batch(const frlw_events_t *ev, const int64_t *seq_offsets, co
                          int bins, int64_t window_us, float *out_f32, uint8_t *out_u8, void *workspace,
                          size_t workspace_bytes, frlw_stream_t stream);
 
+/* The verdict of the one-time LDS lane-order self-test of the fast paths (frlw_taf_encode_batch, frlw_ev_encode_batch, the
+ * two-launch forms of frlw_sae_encode / frlw_eci_encode) for the CURRENT device: *ok_out = 1 when the property held, 0 when
+ * it did not (those entry points then answer FRLW_ERR_UNSUPPORTED and callers take the general path -- same bits, different
+ * step time).  The test runs once per process and device (0.7 ms, one host synchronisation), on the first fast-path call or
+ * here, whichever comes first: a job of N ranks runs it N times, once on each GPU.  Ranks that must keep the same step time
+ * agree on the MINIMUM of their verdicts before the first encode (frlw_evd_amd.dist.agree_fast_path: one all-reduce).
+ * `workspace`: any initialised encoder workspace (>= 1 KB). */
+int frlw_fast_path_verdict(void *workspace, size_t workspace_bytes, frlw_stream_t stream, int *ok_out);
+
 /* Self-test of the gfx950 properties frlw_taf_encode_batch relies on, for the lanes of one LDS atomic instruction that
  * hit the same address: a returning integer add serves them in ascending lane order, and ds_add_f32 applies them in that
  * order with v_add_f32 rounding (= the reference's sequential f32 sum).  256 workgroups x `iters` batches of random

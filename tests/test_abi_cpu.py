@@ -24,7 +24,7 @@ def test_product_library_has_no_developer_hooks():
 
 def test_tuning_struct_carries_its_size():
     t = _lib.FrlwTuning(direct_bins=1)
-    assert t.struct_size == 11 * 4 and t.direct_bins == 1 and t.tile_width_log2 == -1 and t.ev_lds_float_atomics == -1
+    assert t.struct_size == 12 * 4 and t.direct_bins == 1 and t.tile_width_log2 == -1 and t.ev_lds_float_atomics == -1 and t.walk_window_table == -1
 
 
 def test_library_exports_every_declared_symbol():

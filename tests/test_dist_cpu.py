@@ -48,6 +48,42 @@ def test_two_process_gloo(tmp_path):
     assert r0[5] == r1[5] == sum(s * s for s in range(11))           # nothing lost, nothing twice
 
 
+def _agree_worker(rank, world, port, out_dir, failing_rank):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    fd.init_from_env(backend="gloo")
+    from frlw_evd_amd import event_representation as er
+    assert er.FAST_PATH_ENABLED is True
+    verdict = fd.agree_fast_path(local_ok=rank != failing_rank)
+    np.save(os.path.join(out_dir, f"a{rank}.npy"), np.array([int(verdict), int(er.FAST_PATH_ENABLED)]))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("failing_rank", [-1, 1])
+def test_ranks_agree_on_the_fast_path(tmp_path, failing_rank):
+    """The LDS lane-order self-test runs per process and device; one rank on the general path beside fast ranks changes step
+    times (everybody waits for it at the next collective), not results.  dist.agree_fast_path takes the MINIMUM of the ranks'
+    verdicts: all ranks pass -> everybody keeps the fast paths; rank 1 fails -> NOBODY takes them (module switch on every rank)."""
+    world = 2
+    mp.spawn(_agree_worker, args=(world, _free_port(), str(tmp_path), failing_rank), nprocs=world, join=True)
+    want = 1 if failing_rank < 0 else 0
+    for r in range(world):
+        assert np.load(tmp_path / f"a{r}.npy").tolist() == [want, want]
+
+
+def test_fast_path_switch_sends_every_encoder_to_the_general_path(monkeypatch):
+    """With the job-wide switch off the batched entry points refuse like a device that failed the self-test (before any device
+    work: this runs without a GPU) and the single-stream wrappers stop asking for the fast path."""
+    from frlw_evd_amd import event_representation as er
+    monkeypatch.setattr(er, "FAST_PATH_ENABLED", False)
+    st = torch.zeros((1, 8, 8, 2, 8))
+    with pytest.raises(NotImplementedError):
+        er.encode_taf_batch(torch.zeros((4, 8), dtype=torch.uint8), [0, 4], (8, 8), st, 0)
+    with pytest.raises(NotImplementedError):
+        er.encode_ev_batch(torch.zeros((4, 8), dtype=torch.uint8), [0, 4], (8, 8), 10, 10)
+    assert fd.agree_fast_path(local_ok=True) is True and er.FAST_PATH_ENABLED is True  # one rank: its own verdict
+    monkeypatch.setattr(er, "FAST_PATH_ENABLED", True)
+
+
 def test_single_process_helpers():
     assert fd.shard_round_robin(range(5), 0, 1) == [0, 1, 2, 3, 4]
     assert fd.shard_range(10, 0, 1) == (0, 10)
