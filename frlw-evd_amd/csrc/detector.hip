@@ -25,6 +25,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <utility>
 #include <vector>
 
 #include "frlw_evd.h"
@@ -81,6 +82,9 @@ inline bool launch_focus(const float *x, int B, int C, int H, int W, float *y, h
     return true;
 }
 
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_ic(F &&f, std::integer_sequence<int, Is...>) { (f(ConvIC<Is>{}), ...); } // f(ConvIC<0>{}), f(ConvIC<1>{}), ...
+
 // Focus + stem convolution in one kernel (network_blocks.py:205-217 followed by the 3x3 BaseConv of darknet.py:292):
 // the space-to-depth image is never written.  A persistent workgroup keeps the whole weight operand (9 * 4 C0 rows of 32
 // output channels) in LDS and walks 8 x 16 output tiles: the 10 x 18 halo patch of the Focus image is built in LDS straight
@@ -100,24 +104,41 @@ template <int C0, int P> constexpr int focus_stem_w_floats()
     return P == 1 ? (9 * 4 * C0 + 15) / 16 * 16 * 32 + (9 * C0 + 7) / 4 * 4 : 9 * 4 * C0 * 32;
 }
 
-template <int C0, int P = 0>
-__global__ __launch_bounds__(256) void k_focus_stem(FocusStemArgs a)
+// DB: TWO patch areas (C0 = 10: 46 + 2 x 32 KB, one workgroup per CU).  The values of tile t + 1 go from their registers into
+// the other area in front of the MFMAs of tile t -- LDS stores are fire-and-forget: their 8-way bank conflicts (pixel stride 44
+// floats, the stride that keeps the fragment reads conflict-free) are served while the matrix pipe works -- and one raw barrier
+// per tile, which leaves the loads of tile t + 2 and the output stores in flight, replaces the two __syncthreads() around a fill
+// that nothing overlapped (173 us at 55 % MFMA busy with two workgroups per CU taking turns).
+// ... and the weight operand does not go through LDS at all there: lane (h, n) keeps its 9 x C0 / 2 x 4 = 180 values of column
+// n in registers for the life of the (persistent) workgroup -- one wavefront per SIMD owns the whole 512-entry register file --
+// so a k-step costs no ds_read_b32 (one per MFMA before), only the float4 of patch values every fourth step.
+template <int C0, int P = 0, bool DB = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, DB ? 1 : 8))) void k_focus_stem(FocusStemArgs a)
 {
     constexpr int CF = 4 * C0, PS = CF + 4, TH = 8, TW = 16, PH = TH + 2, PW = TW + 2, KT = 9 * CF;
     constexpr int QT = CF / 4, NQ = 9 * QT, NS = (NQ + 3) / 4; // P = 1: quads per tap, quads, bf16 k-steps of 16 k = 4 quads
     static_assert(C0 % 2 == 0, "quads are paired");
     extern __shared__ __attribute__((aligned(16))) float fs_lds[];
-    float *Ws = fs_lds, *patch = fs_lds + focus_stem_w_floats<C0, P>();
+    float *Ws = fs_lds, *patch = fs_lds + (DB ? 0 : focus_stem_w_floats<C0, P>());
     int *qoff = (int *)(fs_lds + NS * 16 * 32); // P = 1: float offset of quad g inside the patch, relative to the tap-(0, 0) pixel
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (P == 1) {
         for (int i = tid; i < NS * 4 * 32; i += 256) ((uint4 *)Ws)[i] = ((const uint4 *)a.w)[i];
         for (int g = tid; g < NQ; g += 256) { const int tap = g / QT; qoff[g] = ((tap / 3) * PW + tap % 3) * PS + 4 * (g - tap * QT); }
-    } else {
+    } else if (!DB) {
         for (int i = tid; i < KT * 8; i += 256) ((float4 *)Ws)[i] = ((const float4 *)a.w)[i];
     }
     const int Ho = a.H / 2, Wo = a.W / 2;
     const int fh = lane >> 5, m = lane & 31, n = lane & 31;
+    float wreg[DB ? 9 : 1][DB ? C0 / 2 : 1][4];
+    if (DB) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int j = 0; j < C0 / 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) wreg[t][j][e] = a.w[(t * CF + 4 * fh + 8 * j + e) * 32 + n];
+    }
     const int pp0 = (2 * wv + (m >> 4)) * PW + (m & 15);
     const float bias = n < a.Cout ? a.bias[n] : 0.0f;
     // This thread's share of a patch fill: items i = tid + 256 u -> (c, input row iy, column pair jx).  Everything but the
@@ -145,23 +166,36 @@ __global__ __launch_bounds__(256) void k_focus_stem(FocusStemArgs a)
             if (it_yx[u] >= 0 && (unsigned)y < (unsigned)a.H && (unsigned)xc < (unsigned)a.W) pv[u] = *(const float2 *)(base + it_src[u]);
         }
     };
+    auto fill = [&](float *dst) {
+#pragma unroll
+        for (int u = 0; u < NI; ++u)
+            if (it_yx[u] >= 0) { dst[it_dst[u]] = pv[u].x; dst[it_dst[u] + 2 * C0] = pv[u].y; } // px = 0: q = py; px = 1: q = py + 2
+    };
+    constexpr int kPatchFloats = PH * PW * PS;
     if ((int)blockIdx.x < a.n_tiles) fetch(blockIdx.x);
+    if (DB) { // the first tile's patch, and the second tile's values on their way
+        if ((int)blockIdx.x < a.n_tiles) fill(patch);
+        if ((int)(blockIdx.x + gridDim.x) < a.n_tiles) fetch(blockIdx.x + gridDim.x);
+        __syncthreads(); // (also: the weights are in LDS)
+    }
+    int cur = 0;
     for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
         const int b = tile / (a.tiles_x * a.tiles_y), tr = tile - b * (a.tiles_x * a.tiles_y);
         const int fy0 = (tr / a.tiles_x) * TH, fx0 = (tr % a.tiles_x) * TW;
-        __syncthreads(); // the previous tile's reads of the patch are done (first pass: the weights are in LDS)
-#pragma unroll
-        for (int u = 0; u < NI; ++u)
-            if (it_yx[u] >= 0) { patch[it_dst[u]] = pv[u].x; patch[it_dst[u] + 2 * C0] = pv[u].y; } // px = 0: q = py; px = 1: q = py + 2
-        __syncthreads();
-        if (tile + (int)gridDim.x < a.n_tiles) fetch(tile + gridDim.x);
+        if (!DB) {
+            __syncthreads(); // the previous tile's reads of the patch are done (first pass: the weights are in LDS)
+            fill(patch);
+            __syncthreads();
+            if (tile + (int)gridDim.x < a.n_tiles) fetch(tile + gridDim.x);
+        }
+        const float *const pcur = patch + (DB ? cur * kPatchFloats : 0);
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
         if constexpr (P == 1) {
             // k = tap * CF + channel is cut into quads g = k / 4; bf16 k-step st takes quads 4 st + h and 4 st + 2 + h of lane half h
             // (the pairing of conv_mfma.h: conv_split_kmem), the weights' split image has the matching records
-            const float *pbase = patch + pp0 * PS;
+            const float *pbase = pcur + pp0 * PS;
             const uint4 *wrec = (const uint4 *)Ws + 2 * fh * 32 + n;
 #pragma unroll
             for (int st = 0; st < NS; ++st) {
@@ -176,10 +210,39 @@ __global__ __launch_bounds__(256) void k_focus_stem(FocusStemArgs a)
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bl), acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bh), acc, 0, 0, 0);
             }
+        } else if constexpr (DB) {
+            // The float4 of patch values of group g + 1 (four k-steps) is requested BEFORE the MFMAs of group g, into the other of
+            // two register sets, as asm with a counted wait: left to the compiler every group read its float4 into the same four
+            // registers right in front of its MFMAs -- an LDS round trip exposed per 256 cycles of matrix work.
+            // (Measured and dropped: fill, fetch and the previous tile's epilogue dealt out BETWEEN the groups -- 164 -> 177 us: the
+            // lane-conditional stores and loads bring ~60 branches into a loop that is otherwise 180 MFMAs and 45 reads.)
+            constexpr int G = 9 * (C0 / 2);
+            if (tile + (int)gridDim.x < a.n_tiles) fill(patch + (cur ^ 1) * kPatchFloats); // tile t + 1: nobody reads that area since the last barrier
+            if (tile + 2 * (int)gridDim.x < a.n_tiles) fetch(tile + 2 * gridDim.x);
+            const uint32_t abase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const float *)(pcur + pp0 * PS + fh * 4);
+            f32x4 fa[2];
+            auto rd = [&fa, abase](auto gc) {
+                constexpr int g = decltype(gc)::value, t = g / (C0 / 2), j = g % (C0 / 2);
+                constexpr int off = (((t / 3) * PW + (t % 3)) * PS + 8 * j) * 4;
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[g & 1]) : "v"(abase), "n"(off));
+            };
+            auto grp = [&](auto gc) {
+                constexpr int g = decltype(gc)::value, t = g / (C0 / 2), j = g % (C0 / 2);
+                if constexpr (g + 1 < G) rd(ConvIC<(g + 1 < G ? g + 1 : g)>{});
+                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(g + 1 < G ? 1 : 0) : "memory");
+                asm volatile("" : "+v"(fa[g & 1]));
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][0], wreg[t][j][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][1], wreg[t][j][1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][2], wreg[t][j][2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][3], wreg[t][j][3], acc, 0, 0, 0);
+            };
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (this wavefront's own patch stores of a moment ago: counted out of the waits below)
+            rd(ConvIC<0>{});
+            static_for_ic(grp, std::make_integer_sequence<int, G>{});
         } else
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            const float *prow = patch + (pp0 + (t / 3) * PW + (t % 3)) * PS + fh * 4;
+            const float *prow = pcur + (pp0 + (t / 3) * PW + (t % 3)) * PS + fh * 4;
             const float *wrow = Ws + (t * CF + 4 * fh) * 32 + n;
 #pragma unroll
             for (int j = 0; j < C0 / 2; ++j) {
@@ -199,6 +262,10 @@ __global__ __launch_bounds__(256) void k_focus_stem(FocusStemArgs a)
                 if (oy < Ho && ox < Wo)
                     a.y[(((long long)b * Ho + oy) * Wo + ox) * a.y_cs + a.y_co + n] = act_apply(acc[r] + bias, ACT_SILU);
             }
+        }
+        if (DB) { // everybody is done reading this tile's patch and has written its share of the next one (LDS only: the loads of
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // tile t + 2 and the output stores stay in flight)
+            cur ^= 1;
         }
     }
 }
@@ -1005,14 +1072,15 @@ int frlw_det_run(const frlw_detector_t *d, int B, void *const *bufs, int n_bufs,
             a.n_tiles = B * a.tiles_x * a.tiles_y;
             const int cf = 4 * op.C;
             const int wfl = a.prec == 1 ? (op.C == 10 ? focus_stem_w_floats<10, 1>() : focus_stem_w_floats<16, 1>()) : 9 * cf * 32;
-            const size_t lds = ((size_t)wfl + (size_t)180 * (cf + 4)) * sizeof(float);
-            const int per_cu = lds <= 80 * 1024 ? 2 : 1;
+            const bool db = op.C == 10 && a.prec != 1; // two patch areas, weights in registers: one workgroup per CU (k_focus_stem<.., DB>)
+            const size_t lds = ((size_t)(db ? 0 : wfl) + (size_t)(db ? 2 : 1) * 180 * (cf + 4)) * sizeof(float);
+            const int per_cu = db ? 1 : (lds <= 80 * 1024 ? 2 : 1);
             const int grid = a.n_tiles < 256 * per_cu ? a.n_tiles : 256 * per_cu;
             auto go = [&](auto kern) {
                 (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
             };
-            if (op.C == 10) { if (a.prec == 1) go(k_focus_stem<10, 1>); else go(k_focus_stem<10, 0>); }
+            if (op.C == 10) { if (a.prec == 1) go(k_focus_stem<10, 1>); else go(k_focus_stem<10, 0, true>); }
             else { if (a.prec == 1) go(k_focus_stem<16, 1>); else go(k_focus_stem<16, 0>); }
             break;
         }
