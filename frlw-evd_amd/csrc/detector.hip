@@ -703,9 +703,9 @@ struct Op {
 // (B, A, 5 + nc) head tensor.  HBM-bound: 2 C * 4 bytes per anchor.
 
 template <int NG>
-__global__ __launch_bounds__(256) void k_pred_infer(PredInferArgs a)
+__device__ __forceinline__ void pred_infer_body(const PredInferArgs &a, int block, int n_blocks)
 {
-    const int lane = threadIdx.x & 63, wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
+    const int lane = threadIdx.x & 63, wave = block * 4 + (threadIdx.x >> 6), n_waves = n_blocks * 4;
     const int c4n = a.C / 4;
     const bool has = lane < c4n;
     float4 w[NG * 8];
@@ -754,6 +754,17 @@ __global__ __launch_bounds__(256) void k_pred_infer(PredInferArgs a)
             }
         }
     }
+}
+
+// the head levels' prediction ops as ONE launch (consecutive OP_PRED ops of a plan: frlw_det_run merges them): workgroups
+// [first[l], first[l + 1]) serve level l
+struct PredInferMulti { PredInferArgs lv[4]; int first[5]; int n; };
+template <int NG>
+__global__ __launch_bounds__(256) void k_pred_infer(PredInferMulti a)
+{
+    int l = 0;
+    while (l + 1 < a.n && (int)blockIdx.x >= a.first[l + 1]) ++l;
+    pred_infer_body<NG>(a.lv[l], (int)blockIdx.x - a.first[l], a.first[l + 1] - a.first[l]);
 }
 
 int grid_1d(long long n) { long long g = (n + 255) / 256; if (g > 4096) g = 4096; if (g < 1) g = 1; return (int)g; }
@@ -1114,15 +1125,24 @@ int frlw_det_run(const frlw_detector_t *d, int B, void *const *bufs, int n_bufs,
                 return FRLW_ERR_UNSUPPORTED;
             break;
         }
-        case OP_PRED: {
-            PredInferArgs a = op.pred;
-            a.x = buf(op.src); a.out = buf(op.dst);
-            if (!a.x || !a.out) return FRLW_ERR_ARG;
-            a.M = (long long)B * a.hw;
-            long long wg = (a.M + 31) / 32; // >= 8 rows per wavefront
-            if (wg > 2048) wg = 2048;
-            if (a.F <= 8) hipLaunchKernelGGL(k_pred_infer<1>, dim3((int)wg), dim3(256), 0, s, a);
-            else hipLaunchKernelGGL(k_pred_infer<2>, dim3((int)wg), dim3(256), 0, s, a);
+        case OP_PRED: { // this op and the OP_PRED ops that directly follow it on the same lane (the head levels): one launch
+            PredInferMulti pm = {};
+            const int i = oi;
+            int j = i;
+            for (; j < last && j - i < 4 && d->ops[j].type == OP_PRED && d->ops[j].lane == op.lane && d->ops[j].pred.F == op.pred.F; ++j) {
+                PredInferArgs a = d->ops[j].pred;
+                a.x = buf(d->ops[j].src); a.out = buf(d->ops[j].dst);
+                if (!a.x || !a.out) return FRLW_ERR_ARG;
+                a.M = (long long)B * a.hw;
+                long long wg = (a.M + 31) / 32; // >= 8 rows per wavefront
+                if (wg > 2048) wg = 2048;
+                pm.lv[j - i] = a;
+                pm.first[j - i + 1] = pm.first[j - i] + (int)wg;
+            }
+            pm.n = j - i;
+            if (op.pred.F <= 8) hipLaunchKernelGGL(k_pred_infer<1>, dim3(pm.first[pm.n]), dim3(256), 0, s, pm);
+            else hipLaunchKernelGGL(k_pred_infer<2>, dim3(pm.first[pm.n]), dim3(256), 0, s, pm);
+            oi = j - 1; // (the loop's ++oi steps behind the last merged op)
             break;
         }
         case OP_DECODE: {

@@ -281,6 +281,7 @@ class DetectorEngine:
         lanes = os.environ.get("FRLW_DET_LANES", "0") != "0"  # head levels on side streams: measured no gain (5.17 vs 5.08 ms), off
         if lanes:
             _lib.check(lib.frlw_det_add_fork(self.handle), "fork")
+        preds = []  # the levels' prediction ops are added behind the last tower: consecutive OP_PRED ops run as ONE launch
         for k, v in enumerate(levels):
             _lib.check(lib.frlw_det_set_lane(self.handle, k if (lanes and k <= 2) else 0), "lane")
             hs = self._new_buf(v.h, v.w, 256)
@@ -314,23 +315,25 @@ class DetectorEngine:
                              head.cls_preds[k].bias.detach()], 0).float().cpu()
             w_rows = torch.cat([head.reg_preds[k].weight.detach(), head.obj_preds[k].weight.detach(),
                                 head.cls_preds[k].weight.detach()], 0).float().cpu().reshape(F, 256).contiguous()
+            preds.append((k, v, both, w_rows, b_p, off))
+            off += v.h * v.w
+        _lib.check(lib.frlw_det_set_lane(self.handle, 0), "lane")
+        if lanes:
+            _lib.check(lib.frlw_det_add_join(self.handle), "join")
+        for k, v, both, w_rows, b_p, off_k in preds:
             rc = lib.frlw_det_add_pred(self.handle, both.buf, both.cs, both.co, 256, v.h * v.w, self._dev(w_rows), self._dev(b_p),
-                                       F, raw.buf, off, A * F)
+                                       F, raw.buf, off_k, A * F)
             if rc == _lib.FRLW_ERR_UNSUPPORTED:  # very many classes: the block-matrix convolution [[W_reg, 0], [W_obj, 0], [0, W_cls]]
                 w_p = torch.zeros((F, 512, 1, 1), dtype=torch.float32)
                 w_p[0:4, 0:256] = head.reg_preds[k].weight.detach().float().cpu()
                 w_p[4:5, 0:256] = head.obj_preds[k].weight.detach().float().cpu()
                 w_p[5:F, 256:512] = head.cls_preds[k].weight.detach().float().cpu()
-                dst = View(raw.buf, F, off * F, F, v.h, v.w)
+                dst = View(raw.buf, F, off_k * F, F, v.h, v.w)
                 self._conv_raw(w_p, b_p, both, dst, 1, 1, ACT_SIGMOID, dst_bs=A * F, sig_from=4)
             else:
                 _lib.check(rc, "frlw_det_add_pred")
                 self.flops_per_image += 2 * v.h * v.w * F * 256
                 self.ops_meta.append(("pred", v.h * v.w, F, 512, 2 * v.h * v.w * F * 256))
-            off += v.h * v.w
-        _lib.check(lib.frlw_det_set_lane(self.handle, 0), "lane")
-        if lanes:
-            _lib.check(lib.frlw_det_add_join(self.handle), "join")
         self.n_forward_ops = lib.frlw_det_num_ops(self.handle)
         # ---- decode + NMS (yolo_head.py:258-303)
         self.dec_buf = self._new_buf(1, A, F).buf
