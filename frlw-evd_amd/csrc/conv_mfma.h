@@ -45,6 +45,9 @@ struct ConvArgs {
     int prec;          // 0: float32 MFMA on the [K][Npad] float32 operand; 1: three bf16 MFMAs per product on the split operand (below)
     double *stats;     // train forward (act NONE, no bias): per slab of BM output rows and channel {sum, sum of squares} of the
     int stats_rows;    // outputs -- [stats_rows][Cout][2]; set by launch_conv (0 / NULL: the launch does not produce them)
+    float *y2;         // optional second destination: the output nearest-upsampled x2 (nn.Upsample(scale_factor=2), yolo_pafpn.py:29) --
+    int y2_cs, y2_co;  // pixel (oy, ox) also lands at (2 oy + {0, 1}, 2 ox + {0, 1}) of a (2 Ho, 2 Wo) NHWC view with this pixel
+    long long y2_bs;   // stride / channel offset / image stride: the FPN's upsample costs four more stores in the epilogue, not a launch
 };
 
 // ---- float32 products from three bf16 MFMAs (prec = 1) ---------------------------------------------------------------------
@@ -656,6 +659,15 @@ __global__ __launch_bounds__(64 * WROWS * WCOLS) void k_conv_mfma(ConvArgs a)
                                 o[0] += rr.x; o[1] += rr.y; o[2] += rr.z; o[3] += rr.w;
                             }
                             *(float4 *)(a.y + (long long)b * a.y_bs + (long long)pix * a.y_cs + a.y_co + n) = make_float4(o[0], o[1], o[2], o[3]);
+                            if (a.y2) { // (workgroup-uniform)
+                                const int oy = pix / a.Wo, ox = pix - oy * a.Wo;
+                                float *u = a.y2 + (long long)b * a.y2_bs + ((long long)(2 * oy) * (2 * a.Wo) + 2 * ox) * a.y2_cs + a.y2_co + n;
+                                const float4 v = make_float4(o[0], o[1], o[2], o[3]);
+                                *(float4 *)u = v;
+                                *(float4 *)(u + a.y2_cs) = v;
+                                *(float4 *)(u + (long long)2 * a.Wo * a.y2_cs) = v;
+                                *(float4 *)(u + (long long)(2 * a.Wo + 1) * a.y2_cs) = v;
+                            }
                         }
                         pix += 8;
                         while (pix >= howo) { pix -= howo; ++b; }
@@ -686,6 +698,11 @@ __global__ __launch_bounds__(64 * WROWS * WCOLS) void k_conv_mfma(ConvArgs a)
                     long long yo = (long long)pix * a.y_cs;
                     if (a.y_rp) { const int oy = pix / a.Wo; yo = (long long)oy * a.y_rp + (long long)(pix - oy * a.Wo) * a.y_cs; }
                     a.y[(long long)b * a.y_bs + yo + a.y_co + n] = v;
+                    if (a.y2) {
+                        const int oy = pix / a.Wo, ox = pix - oy * a.Wo;
+                        float *u = a.y2 + (long long)b * a.y2_bs + ((long long)(2 * oy) * (2 * a.Wo) + 2 * ox) * a.y2_cs + a.y2_co + n;
+                        u[0] = v; u[a.y2_cs] = v; u[(long long)2 * a.Wo * a.y2_cs] = v; u[(long long)(2 * a.Wo + 1) * a.y2_cs] = v;
+                    }
                 }
             }
         }
@@ -1008,6 +1025,7 @@ inline bool launch_conv(ConvArgs &c, float *scratch, long long scratch_floats, h
         h.M = (nb - b0) * howo;
         h.x = c.x + (long long)b0 * c.x_bs;
         h.y = c.y + (long long)b0 * c.y_bs;
+        if (c.y2) h.y2 = c.y2 + (long long)b0 * c.y2_bs;
         if (c.res) h.res = c.res + (long long)b0 * c.r_bs;
         return launch_conv(h, scratch, scratch_floats, s);
     }
@@ -1060,7 +1078,7 @@ inline bool launch_conv(ConvArgs &c, float *scratch, long long scratch_floats, h
         const long long wgs = (long long)((c.M + 63) / 64) * ((c.Npad + bn - 1) / bn);
         const int nk = (c.K + kSplitBK - 1) / kSplitBK;
         // small feature maps leave most CUs idle: split the contraction over blockIdx.z
-        if (wgs < split_below && nk >= 64 && scratch) { // (contractions shorter than 1024 gained nothing from splitting: measured)
+        if (wgs < split_below && nk >= 64 && scratch && !c.y2) { // (contractions shorter than 1024 gained nothing from splitting: measured; the upsampled copy is written by the convolution's own epilogue)
             int sp = (int)((split_target + wgs - 1) / wgs);
             if (sp > 8) sp = 8;
             if (sp > nk / 8) sp = nk / 8;

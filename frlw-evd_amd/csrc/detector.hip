@@ -690,6 +690,7 @@ struct Op {
     ConvArgs conv;          // pointers x / y / res filled at run time; w / bias are baked
     int C, H, W, cs_src, co_src, cs_dst, co_dst;
     DecodeArgs dec; int decoded_buf, dets_buf, counts_buf, nms_buf;
+    int ups_buf;            // OP_CONV: > 0 = the buffer that also receives the output upsampled x2 (ConvArgs::y2); 0 (the network input's index): none
     const float *bfm_w;     // OP_BFM: packed weights (device)
     PredInferArgs pred;     // OP_PRED
     FocusStemArgs fstem;    // OP_FOCUS_STEM
@@ -963,6 +964,18 @@ int frlw_det_add_upsample(frlw_detector_t *d, int src_buf, int cs_src, int co_sr
                           int dst_buf, int cs_dst, int co_dst)
 {
     if (!d) return FRLW_ERR_ARG;
+    if (!d->ops.empty()) {
+        // the slice was written by the convolution added just before (the FPN's lateral / reduce 1x1, yolo_pafpn.py:92-100): its
+        // epilogue stores the upsampled copy as well -- four more 16-byte stores per output row instead of a launch
+        Op &pv = d->ops.back();
+        const ConvArgs &pc = pv.conv;
+        if (pv.type == OP_CONV && pv.lane == d->cur_lane && pv.dst == src_buf && pc.y_cs == cs_src && pc.y_co == co_src && pc.Cout == C &&
+            pc.Ho == H && pc.Wo == W && pc.y_rp == 0 && pv.ups_buf == 0 && dst_buf > 0 && ((cs_dst | co_dst | C) & 3) == 0) {
+            pv.ups_buf = dst_buf;
+            pv.conv.y2_cs = cs_dst; pv.conv.y2_co = co_dst; pv.conv.y2_bs = (long long)4 * H * W * cs_dst;
+            return FRLW_OK;
+        }
+    }
     Op op = {};
     op.type = OP_UPSAMPLE; op.src = src_buf; op.dst = dst_buf; op.C = C; op.H = H; op.W = W;
     op.cs_src = cs_src; op.co_src = co_src; op.cs_dst = cs_dst; op.co_dst = co_dst;
@@ -1118,7 +1131,8 @@ int frlw_det_run(const frlw_detector_t *d, int B, void *const *bufs, int n_bufs,
         case OP_CONV: {
             ConvArgs c = op.conv;
             c.x = buf(op.src); c.y = buf(op.dst); c.res = buf(op.res);
-            if (!c.x || !c.y) return FRLW_ERR_ARG;
+            c.y2 = op.ups_buf > 0 ? buf(op.ups_buf) : nullptr;
+            if (!c.x || !c.y || (op.ups_buf > 0 && !c.y2)) return FRLW_ERR_ARG;
             c.M = B * c.Ho * c.Wo;
             if (!launch_conv(c, d->scratch_buf >= 0 ? buf(d->scratch_buf) + (long long)op.lane * d->scratch_floats : nullptr,
                              d->scratch_buf >= 0 ? d->scratch_floats : 0, s))

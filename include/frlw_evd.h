@@ -349,7 +349,9 @@ int frlw_det_bfm_weight_count(int C);
 int frlw_det_add_bfm_stem(frlw_detector_t *d, int src_buf, int C, int H, int W, const float *weights, int n_weights,
                           int dst_buf);
 
-/* nn.Upsample(scale_factor=2, mode="nearest") of a channel slice (yolo_pafpn.py:29). */
+/* nn.Upsample(scale_factor=2, mode="nearest") of a channel slice (yolo_pafpn.py:29).  When the slice is the output of the
+ * convolution added just before (same lane; the FPN's lateral / reduce 1x1 convolutions), no launch is added: that
+ * convolution's epilogue stores the upsampled copy too. */
 int frlw_det_add_upsample(frlw_detector_t *d, int src_buf, int cs_src, int co_src, int C, int H, int W,
                           int dst_buf, int cs_dst, int co_dst);
 

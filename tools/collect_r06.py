@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""Copy the summaries tools/refresh_r05.sh left under gpurun_out/refresh_r05/ into profiles/ (prefix r05_) and rebuild
+"""Copy the summaries tools/refresh_r06.sh left under gpurun_out/refresh_r06/ into profiles/ (prefix r06_) and rebuild
 profiles/traffic_*.json from the PMC summaries: FETCH_SIZE (KiB) x 1024 x 2 (gfx950 reports half of a coalesced read,
 MI355X_MICROARCH.md; checked against kf_hist, whose read is exactly 8 B per event), WRITE_SIZE (KiB) x 1024.  The traffic
 files are tagged with the hash of the kernel sources: bench.py reports `roofline.traffic` only while that hash matches."""
 import hashlib, json, os, re, shutil
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-O = os.path.join(ROOT, "gpurun_out", "refresh_r05")
+O = os.path.join(ROOT, "gpurun_out", "refresh_r06")
 P = os.path.join(ROOT, "profiles")
 
 
@@ -34,9 +34,9 @@ def traffic(cfg, tag, alg, prefixes):
     json.dump({"workload": tag, "hbm_bytes_per_encode": tot, "algorithmic_bytes": alg, "ratio": round(tot / alg, 3),
                "kernel_source_sha": sha(),
                "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over `build/enc_lab <lib> --cfg " + cfg +
-                         "` (tools/refresh_r05.sh: the same kernels on a stream of the same shape), per-dispatch averages, KiB x 1024, "
+                         "` (tools/refresh_r06.sh: the same kernels on a stream of the same shape), per-dispatch averages, KiB x 1024, "
                          "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of a coalesced read)",
-               "per_kernel": out, "source": f"profiles/r05_{cfg}_pmc_summary.txt"},
+               "per_kernel": out, "source": f"profiles/r06_{cfg}_pmc_summary.txt"},
               open(os.path.join(P, f"traffic_{tag}.json"), "w"), indent=1)
     print(tag, "traffic MB", round(tot / 1e6, 1), "ratio", round(tot / alg, 3),
           {k: (round(v["fetch_bytes_corrected"] / 1e6, 1), round(v["write_bytes"] / 1e6, 1)) for k, v in out.items()})
@@ -44,7 +44,7 @@ def traffic(cfg, tag, alg, prefixes):
 
 for f in os.listdir(O):
     if f.endswith(".csv") or f.endswith(".txt") or f.endswith(".json"):
-        shutil.copy(os.path.join(O, f), os.path.join(P, "r05_" + f))
+        shutil.copy(os.path.join(O, f), os.path.join(P, "r06_" + f))
 taf = lambda n, H, W, K=8: 8 * n + 2 * 4 * 2 * K * H * W + 2 * K * H * W
 ev = lambda n, H, W, b=5: 8 * n + 4 * 2 * b * H * W
 traffic("mpx", "taf_mpx", taf(10_000_000, 720, 1280), ("kf_",))
@@ -55,6 +55,7 @@ traffic("evb1", "ev_gen1", ev(1_000_000, 240, 304), ("kf_",))
 traffic("evb64", "ev_gen1_x64", 64 * ev(1_000_000, 240, 304), ("kf_",))
 traffic("sae", "sae_gen1", 8 * 1_000_000 + 2 * 4 * 2 * 240 * 304 + 4 * 6 * 240 * 304, ("kf_",))
 traffic("eci", "eci_gen1", 8 * 100_000 + 4 * 2 * 240 * 304, ("kf_",))
-d = json.load(open(os.path.join(P, "r05_bench.json")))
+d = json.load(open(os.path.join(P, "r06_bench_detail.json")))
 print("TAF", d["value"], d["ms_per_step"], d["roofline"]["frac"], [(a["value"], a["ms_per_step"], a["roofline"]["frac"]) for a in d["also"]])
 print("det", d["detector"]["value"], d["detector"]["roofline"]["frac"], "train", d["train"]["ms_per_step"], d["train"].get("same_step_with_miopen_convs"))
+print("line bytes", len(open(os.path.join(P, "r06_bench.json")).read()))

@@ -1,12 +1,12 @@
 #!/bin/bash
-# All profile passes of round 5 in one gpurun call; summaries land under gpurun_out/refresh_r05/ (then
-# tools/collect_r05.py copies them into profiles/).      gpurun --timeout 2400 -- 'bash tools/refresh_r05.sh'
+# All profile passes of round 6 in one gpurun call; summaries land under gpurun_out/refresh_r06/ (then
+# tools/collect_r06.py copies them into profiles/).      gpurun --timeout 2400 -- 'bash tools/refresh_r06.sh'
 set -u
-R=${GRAFT_REPO_ROOT:-$(pwd)}; K=$R/gpurun_out/refresh_r05; rm -rf $K; mkdir -p $K
+R=${GRAFT_REPO_ROOT:-$(pwd)}; K=$R/gpurun_out/refresh_r06; rm -rf $K; mkdir -p $K
 LIB=$R/frlw-evd_amd/csrc/libfrlw_evd.so
 cd /tmp && export TMPDIR=/tmp
 stats() { # tag program args...   (the program itself behind `--`: no shell, no env wrapper)
-  local tag=$1; shift; local O=/tmp/frlw_r05_$tag; rm -rf $O; mkdir -p $O
+  local tag=$1; shift; local O=/tmp/frlw_r06_$tag; rm -rf $O; mkdir -p $O
   rocprofv3 --kernel-trace --stats --output-format csv -d $O -o t -- "$@" > $O/run.log 2>&1; echo "$tag rc=$?"
   cp "$(find $O -name '*kernel_stats.csv' | head -1)" $K/${tag}_kernel_stats.csv
 }
@@ -28,7 +28,7 @@ pmc() { # out-dir tag counters -- program args...
   rocprofv3 --kernel-trace --pmc "${ctrs[@]}" --output-format csv -d $O/$tag -o p -- "$@" > $O/$tag/run.log 2>&1; echo "pmc $O $tag rc=$?"
 }
 for W in mpx mpx_hot gen1 gen1x64 evb1 evb64; do
-  O=/tmp/frlw_r05_pmcsum_$W; rm -rf $O
+  O=/tmp/frlw_r06_pmcsum_$W; rm -rf $O
   if [ $W = mpx ] || [ $W = gen1 ]; then
     pmc $O sq1 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES -- $R/build/enc_lab $LIB --cfg $W --reps 3
     pmc $O sq2 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS -- $R/build/enc_lab $LIB --cfg $W --reps 3
@@ -38,11 +38,16 @@ for W in mpx mpx_hot gen1 gen1x64 evb1 evb64; do
   python3 $R/tools/pmc_summary.py $O > $K/${W}_pmc_summary.txt
 done
 for W in sae eci; do
-  O=/tmp/frlw_r05_pmcsum_$W; rm -rf $O
+  O=/tmp/frlw_r06_pmcsum_$W; rm -rf $O
   pmc $O fetch FETCH_SIZE -- python3 $R/tools/run_small_encoders.py $W 3
   pmc $O write WRITE_SIZE -- python3 $R/tools/run_small_encoders.py $W 3
   python3 $R/tools/pmc_summary.py $O > $K/${W}_pmc_summary.txt
 done
-cd $R && python3 bench.py > $K/bench.json 2> $K/bench.err; echo "bench rc=$?"
-python3 bench.py --hotspot --no-detector --no-train --no-also > $K/bench_hotspot.json 2>> $K/bench.err; echo "bench hot rc=$?"
+# the NMS launches by candidate count, the window-table A/B (same box), the big 3x3 layer's MFMA-busy share and clock
+python3 $R/tools/time_nms.py 2>&1 | grep -v amdgpu.ids > $K/nms_by_candidates.txt
+python3 $R/tools/time_wtab.py 2>&1 | grep -v amdgpu.ids > $K/wtab_ab.txt
+HOT=1 python3 $R/tools/time_wtab.py 2>&1 | grep -v amdgpu.ids > $K/wtab_ab_hot.txt
+(cd $R && bash tools/pmc_clock_bin.sh build/conv_lab 32 20 2 > $K/conv_big_clock.txt 2>&1); cd /tmp
+cd $R && python3 bench.py > $K/bench.json 2> $K/bench.err; echo "bench rc=$?"; cp bench_detail.json $K/bench_detail.json
+python3 bench.py --hotspot --no-detector --no-train --no-also --no-cpu-baseline > $K/bench_hotspot.json 2>> $K/bench.err; echo "bench hot rc=$?"
 ls -la $K
