@@ -520,3 +520,40 @@ def test_engine_follows_the_weights(gpu):
             e3 = m.engine()
         assert e3 is not e2
         assert rel_err(e3.raw_outputs(x[..., 0, 0]), m.reference_outputs(x[..., 0])) <= TOL
+
+
+@pytest.mark.parametrize("n_cand", [1, 2, 63, 64, 65, 127, 128, 129, 640, 1000, 1679, 1680])
+def test_device_nms_at_chunk_boundaries_vs_the_torch_restatement(gpu, n_cand):
+    """The device NMS works on 64-box chunks (k_nms_matrix: 64 x 64 blocks of the suppression matrix; k_nms_sweep: one chunk's
+    diagonal block, then its kept rows OR-ed into the later words): candidate counts on and around the chunk boundaries, boxes
+    large enough that suppression chains run ACROSS chunks (a box suppressed by a kept box of an earlier chunk must not
+    suppress anybody itself), tied scores, and an image with no candidate beside it -- same survivors, same order, same six
+    columns as the box-by-box restatement of yolo_head.py:258-303 (itself pinned to the reference's decode_outputs)."""
+    m = build_yolox(10, 2)
+    m.load_state_dict(recipe_state_dict(m, seed=3))
+    m.eval().to(gpu)
+    eng = m.engine()
+    eng.build((10, 256, 320))
+    A, F = eng.A, eng.F
+    rng = np.random.default_rng(100 + n_cand)
+    raw = np.zeros((3, A, F), np.float32)
+    raw[..., 0:2] = rng.uniform(-0.5, 0.5, (3, A, 2))
+    raw[..., 2:4] = rng.uniform(0.8, 2.6, (3, A, 2))           # boxes of 5 .. 200 px: dense overlaps on every level
+    raw[..., 5:] = rng.uniform(0, 1, (3, A, F - 5))
+    raw[..., 4] = 0.05
+    for b, n in ((0, n_cand), (2, max(1, n_cand // 2))):        # image 1: nothing passes
+        pick = rng.choice(A, size=n, replace=False)
+        raw[b, pick, 4] = rng.choice(np.array([0.31, 0.5, 0.5, 0.77, 0.9], np.float32), size=n)  # many ties
+    raw_t = torch.from_numpy(raw)
+    counts, dets = _device_postprocess(m, raw_t, gpu)
+    m.head.hw = [(32, 40), (16, 20), (8, 10)]
+    want = m.head.decode_outputs(raw_t.to(gpu))
+    assert counts[1] == 0 and want[1].shape == (1, 6) and float(want[1].abs().sum()) == 0.0
+    for b in (0, 2):
+        w = want[b].cpu()
+        assert counts[b] == w.shape[0], (b, counts[b], w.shape)
+        got = dets[b, :counts[b]]
+        assert torch.equal(got[:, 4], w[:, 4])                       # class ids
+        assert float((got - w).abs().max()) <= 1e-4
+    if n_cand >= 640:
+        assert counts[0] < n_cand                                     # something WAS suppressed
