@@ -1096,7 +1096,14 @@ int frlw_det_run(const frlw_detector_t *d, int B, void *const *bufs, int n_bufs,
             a.n_tiles = B * a.tiles_x * a.tiles_y;
             const int cf = 4 * op.C;
             const int wfl = a.prec == 1 ? (op.C == 10 ? focus_stem_w_floats<10, 1>() : focus_stem_w_floats<16, 1>()) : 9 * cf * 32;
-            const bool db = op.C == 10 && a.prec != 1; // two patch areas, weights in registers: one workgroup per CU (k_focus_stem<.., DB>)
+            // k_focus_stem<.., DB> (two patch areas, weights in registers, pipelined fragment reads: one workgroup per CU) measured the
+            // same as the plain form (160.8 against 162.1 us, profiles/r05_ / r06_det_kernel_stats.csv): developer builds only
+#ifdef FRLW_DEV_BUILD
+            static const long long db_knob = dev_knob("FRLW_FOCUS_STEM_DB", 0ll);
+            const bool db = db_knob != 0 && op.C == 10 && a.prec != 1;
+#else
+            const bool db = false;
+#endif
             const size_t lds = ((size_t)(db ? 0 : wfl) + (size_t)(db ? 2 : 1) * 180 * (cf + 4)) * sizeof(float);
             const int per_cu = db ? 1 : (lds <= 80 * 1024 ? 2 : 1);
             const int grid = a.n_tiles < 256 * per_cu ? a.n_tiles : 256 * per_cu;
@@ -1104,7 +1111,13 @@ int frlw_det_run(const frlw_detector_t *d, int B, void *const *bufs, int n_bufs,
                 (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
             };
-            if (op.C == 10) { if (a.prec == 1) go(k_focus_stem<10, 1>); else go(k_focus_stem<10, 0, true>); }
+            if (op.C == 10) {
+                if (a.prec == 1) go(k_focus_stem<10, 1>);
+#ifdef FRLW_DEV_BUILD
+                else if (db) go(k_focus_stem<10, 0, true>);
+#endif
+                else go(k_focus_stem<10, 0>);
+            }
             else { if (a.prec == 1) go(k_focus_stem<16, 1>); else go(k_focus_stem<16, 0>); }
             break;
         }

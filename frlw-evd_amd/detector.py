@@ -251,16 +251,20 @@ class DetectorEngine:
         # ---- neck (yolo_pafpn.py:77-113)
         fpn_out0 = cat_n4.slice(c4, c4)
         self._baseconv(neck.lateral_conv0, d5, fpn_out0)
+        n_ops = lib.frlw_det_num_ops(self.handle)
         _lib.check(lib.frlw_det_add_upsample(self.handle, fpn_out0.buf, fpn_out0.cs, fpn_out0.co, c4, h5, w5,
                                              cat_p4.buf, cat_p4.cs, 0), "upsample")
-        self.ops_meta.append(("upsample", h4 * w4, c4, 0, 0))
+        if lib.frlw_det_num_ops(self.handle) > n_ops:  # (no launch of its own when the producing convolution's epilogue writes it)
+            self.ops_meta.append(("upsample", h4 * w4, c4, 0, 0))
         f_out0 = self._new_buf(h4, w4, c4)
         self._csp(neck.C3_p4, cat_p4, f_out0)
         fpn_out1 = cat_n3.slice(c3, c3)
         self._baseconv(neck.reduce_conv1, f_out0, fpn_out1)
+        n_ops = lib.frlw_det_num_ops(self.handle)
         _lib.check(lib.frlw_det_add_upsample(self.handle, fpn_out1.buf, fpn_out1.cs, fpn_out1.co, c3, h4, w4,
                                              cat_p3.buf, cat_p3.cs, 0), "upsample")
-        self.ops_meta.append(("upsample", h3 * w3, c3, 0, 0))
+        if lib.frlw_det_num_ops(self.handle) > n_ops:
+            self.ops_meta.append(("upsample", h3 * w3, c3, 0, 0))
         pan_out2 = self._new_buf(h3, w3, c3)
         self._csp(neck.C3_p3, cat_p3, pan_out2)
         self._baseconv(neck.bu_conv2, pan_out2, cat_n3.slice(0, c3))
@@ -333,7 +337,12 @@ class DetectorEngine:
             else:
                 _lib.check(rc, "frlw_det_add_pred")
                 self.flops_per_image += 2 * v.h * v.w * F * 256
-                self.ops_meta.append(("pred", v.h * v.w, F, 512, 2 * v.h * v.w * F * 256))
+                # (consecutive prediction ops are ONE launch: one row of the per-launch table for all of them)
+                if self.ops_meta and self.ops_meta[-1][0] == "pred" and k > preds[0][0]:
+                    last = self.ops_meta[-1]
+                    self.ops_meta[-1] = ("pred", last[1] + v.h * v.w, F, 512, last[4] + 2 * v.h * v.w * F * 256)
+                else:
+                    self.ops_meta.append(("pred", v.h * v.w, F, 512, 2 * v.h * v.w * F * 256))
         self.n_forward_ops = lib.frlw_det_num_ops(self.handle)
         # ---- decode + NMS (yolo_head.py:258-303)
         self.dec_buf = self._new_buf(1, A, F).buf

@@ -622,3 +622,30 @@ def test_walk_window_table_equals_the_walks_own_scan(shape, n_seq, n, K, n_win, 
         u8, view = er.encode_taf_batch(dat, offs, (H, W), st, 0, win, n_win, K, want_view=True)
     for a, b in zip(outs[0], (st, u8, view)):
         assert torch.equal(a, b)
+
+
+def test_stall_verdict_survives_the_header_reset_and_is_cleared_by_the_next_call(er):
+    """a workgroup that gives up its bounded wait for the header reset used to OR ST_STALL into hdr->status, which
+    a workgroup 0 that starts later zeroes.  The verdict now lives in a word outside the reset range (8 bytes in front of the
+    sticky word, keyed by the call's epoch): frlw_encoder_status reports FRLW_ERR_HIP while it is set, and workgroup 0 of a LATER
+    call clears an EARLIER call's verdict (a stall cannot be provoked from outside: the word is planted by hand here)."""
+    import ctypes as C
+    from frlw_evd_amd import _lib
+    lib = _lib.load()
+    H, W, K = 240, 304, 8
+    rec = synth.to_dat8(synth.synth_events(1900, 300_000, W, H, 80_000))
+    dat = to_dev(rec)
+    st = torch.full((1, H, W, 2, K), -6000.0, device="cuda")
+    er.encode_taf_batch(dat, [0, len(rec)], (H, W), st, 0, 10_000, 8, K)  # allocates / initialises the batch workspace
+    ws = er._WORKSPACES[("batch", dat.device.index, torch.cuda.current_stream().cuda_stream)]
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    status = C.c_int(0)
+    ws[1024 - 16:1024 - 12].view(torch.int32).fill_(0x7fffff01)  # "the call with epoch 0x7fffff01 stalled"
+    _lib.check(lib.frlw_encoder_status(C.c_void_p(ws.data_ptr()), stream, C.byref(status)), "status")
+    assert status.value == _lib.FRLW_ERR_HIP
+    st2 = torch.full((1, H, W, 2, K), -6000.0, device="cuda")
+    er.encode_taf_batch(dat, [0, len(rec)], (H, W), st2, 0, 10_000, 8, K)  # a later call: its workgroup 0 drops the old verdict
+    _lib.check(lib.frlw_encoder_status(C.c_void_p(ws.data_ptr()), stream, C.byref(status)), "status")
+    assert status.value == 0
+    assert int(ws[1024 - 16:1024 - 12].view(torch.int32).item()) == 0
+    assert torch.equal(st, st2)
