@@ -47,6 +47,7 @@ done
 python3 $R/tools/time_nms.py 2>&1 | grep -v amdgpu.ids > $K/nms_by_candidates.txt
 python3 $R/tools/time_wtab.py 2>&1 | grep -v amdgpu.ids > $K/wtab_ab.txt
 HOT=1 python3 $R/tools/time_wtab.py 2>&1 | grep -v amdgpu.ids > $K/wtab_ab_hot.txt
+CFG=gen1x64 python3 $R/tools/time_wtab.py 2>&1 | grep -v amdgpu.ids > $K/wtab_ab_gen1x64.txt
 (cd $R && bash tools/pmc_clock_bin.sh build/conv_lab 32 20 2 > $K/conv_big_clock.txt 2>&1); cd /tmp
 cd $R && python3 bench.py > $K/bench.json 2> $K/bench.err; echo "bench rc=$?"; cp bench_detail.json $K/bench_detail.json
 python3 bench.py --hotspot --no-detector --no-train --no-also --no-cpu-baseline > $K/bench_hotspot.json 2>> $K/bench.err; echo "bench hot rc=$?"

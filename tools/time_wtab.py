@@ -5,20 +5,27 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from frlw_evd_amd import _lib, synth, event_representation as er
-H, W, K, nw, win, n = 720, 1280, 8, 8, 10_000, 10_000_000
 hot = os.environ.get("HOT") == "1"
-ev = synth.synth_events(1003, n, W, H, nw * win, hotspot=hot)
-dat = torch.from_numpy(synth.to_dat8(ev).view(np.uint8).reshape(-1, 8)).cuda()
-state = torch.full((H, W, 2, K), -6000.0, device="cuda")
+if os.environ.get("CFG") == "gen1x64":  # 64 GEN1-shaped streams of 1 M events in one call (tile bins, 8192-event chunks)
+    H, W, K, nw, win, n, B = 240, 304, 8, 8, 10_000, 1_000_000, 64
+else:
+    H, W, K, nw, win, n, B = 720, 1280, 8, 8, 10_000, 10_000_000, 1
+recs = [synth.to_dat8(synth.synth_events(1003 + j, n, W, H, nw * win, hotspot=hot)) for j in range(B)]
+offs = np.concatenate([[0], np.cumsum([len(r) for r in recs])])
+dat = torch.from_numpy(np.concatenate(recs).view(np.uint8).reshape(-1, 8)).cuda()
+del recs
+state = torch.full((B, H, W, 2, K), -6000.0, device="cuda")
+def enc():
+    er.encode_taf_batch(dat, offs, (H, W), state, 0, win, nw, K, check=False)
 def run(knob, steps):
     er.TUNING = _lib.FrlwTuning(walk_window_table=knob)
     for _ in range(3):
-        er.encode_taf_dat(dat, (H, W), state, 0, win, nw, K, check=False, fast=True)
+        enc()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(steps):
-        er.encode_taf_dat(dat, (H, W), state, 0, win, nw, K, check=False, fast=True)
+        enc()
     e1.record(); torch.cuda.synchronize()
     er.raise_deferred()
     return e0.elapsed_time(e1) / steps * 1e3
