@@ -127,9 +127,9 @@ SYMBOLS = {
     "frlw_baseconv_weight_cache_floats": (_I64, [_I, _I, _I, _I]),
     "frlw_baseconv_train_scratch_bytes": (_I64, [_I, _I, _I, _I, _I, _I, _I]),
     "frlw_baseconv_train_fwd": (_I, [_P, _P, _P, _P, C.c_float, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P,
-                                    C.c_float, _P, _P, _P, _I64, _I, _P]),
+                                    C.c_float, _P, _P, _P, _I64, _P, _I, _P]),
     "frlw_baseconv_train_bwd": (_I, [_P, _I64, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P,
-                                    _P, _I64, _I, _P]),
+                                    _P, _I64, _P, _I, _P]),
     "frlw_spp_train_fwd": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
     "frlw_spp_train_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
     "frlw_pred_bwd_scratch_floats": (_I64, [_I64, _I, _I]),

@@ -45,6 +45,8 @@ struct ConvArgs {
     int prec;          // 0: float32 MFMA on the [K][Npad] float32 operand; 1: three bf16 MFMAs per product on the split operand (below)
     double *stats;     // train forward (act NONE, no bias): per slab of BM output rows and channel {sum, sum of squares} of the
     int stats_rows;    // outputs -- [stats_rows][Cout][2]; set by launch_conv (0 / NULL: the launch does not produce them)
+    int *sk_counters;  // split-K reduced INSIDE the kernel (k_conv_mfma<.., SK = true>): one arrival counter per output tile, zero
+                       // between launches (the last-arriving split of a tile sums all splits, finishes the tile and resets it); NULL: k_splitk_reduce
     float *y2;         // optional second destination: the output nearest-upsampled x2 (nn.Upsample(scale_factor=2), yolo_pafpn.py:29) --
     int y2_cs, y2_co;  // pixel (oy, ox) also lands at (2 oy + {0, 1}, 2 ox + {0, 1}) of a (2 Ho, 2 Wo) NHWC view with this pixel
     long long y2_bs;   // stride / channel offset / image stride: the FPN's upsample costs four more stores in the epilogue, not a launch
@@ -127,8 +129,25 @@ __device__ __forceinline__ float4 conv_load16(__amdgpu_buffer_rsrc_t r, uint32_t
 // BM x BN output tile, 4 wavefronts arranged WROWS x WCOLS, each owning TM x TN MFMA tiles of 32 x 32.
 // UT ("uniform taps"): Cin % BK == 0, so a k-tile lies inside one filter tap and the tap changes for the whole
 // workgroup at once: the gather offsets are recomputed only then, a k-tile costs one add per load.
+template <int BM, int BN, int WROWS, int WCOLS, int BK, bool UT, int D, int P, bool SK>
+__device__ __forceinline__ void conv_mfma_body(const ConvArgs &a);
+
 template <int BM, int BN, int WROWS, int WCOLS, int BK, bool UT, int D = 2, int P = 0>
 __global__ __launch_bounds__(64 * WROWS * WCOLS) void k_conv_mfma(ConvArgs a)
+{
+    conv_mfma_body<BM, BN, WROWS, WCOLS, BK, UT, D, P, false>(a);
+}
+
+// the 64 x 64 tile with the split-K reduction inside the kernel (see the epilogue): its last-arriving workgroup keeps 16 partial
+// rows in registers, and the launches that use it want five workgroups per CU -- five wavefronts per SIMD, at most 96 registers
+template <int BK>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_conv_mfma_sk(ConvArgs a)
+{
+    conv_mfma_body<64, 64, 2, 2, BK, true, 2, 0, true>(a);
+}
+
+template <int BM, int BN, int WROWS, int WCOLS, int BK, bool UT, int D, int P, bool SK>
+__device__ __forceinline__ void conv_mfma_body(const ConvArgs &a)
 {
     constexpr int NT = 64 * WROWS * WCOLS; // four wavefronts (eight for the 128 x 256 tile)
     constexpr int TM = BM / (32 * WROWS), TN = BN / (32 * WCOLS);
@@ -581,10 +600,81 @@ __global__ __launch_bounds__(64 * WROWS * WCOLS) void k_conv_mfma(ConvArgs a)
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const int m = m0 + wr * TM * 32 + 32 * i + er + 8 * t;
-                    if (m < a.M && n < a.Npad) *(float4 *)(dst + (long long)m * a.Npad + n) = *(const float4 *)&epw[(er + 8 * t) * EPLD + ec];
+                    if (m < a.M && n < a.Npad) {
+                        const f32x4 v = *(const f32x4 *)&epw[(er + 8 * t) * EPLD + ec];
+                        float *ptr = dst + (long long)m * a.Npad + n;
+                        // SK: write-through (sc1) stores -- the reader is another workgroup, possibly on another XCD, whose L2
+                        // is not coherent with this one's (MI355X_MICROARCH.md: inter-workgroup visibility)
+                        if (SK) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(ptr), "v"(v) : "memory");
+                        else *(f32x4 *)ptr = v;
+                    }
                 }
             }
-        return;
+        if constexpr (!SK) return;
+        else {
+            // ---- the split that arrives LAST at the tile's counter sums all splits (in split order, like k_splitk_reduce: the
+            // same bits), applies bias / activation / residual and writes the tile; the others are done.  Protocol: every
+            // wavefront drains its sc1 stores, workgroup barrier, ONE agent-scope atomic add; the add that returns splits - 1
+            // has seen every other workgroup's add, hence (their drain + barrier in front of it) all their stores in memory;
+            // its workgroup reads them with sc1 loads (L1 bypassed; no line of the partial buffer has been read in this launch,
+            // so no L2 holds an old copy).  The counter goes back to 0 for the next launch.
+            static_assert(TM == 1 && TN == 1, "the in-kernel reduction is written for one 32 x 32 tile per wavefront");
+            __shared__ int s_last;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                int *cp = a.sk_counters + blockIdx.y * gridDim.x + blockIdx.x;
+                const int old = __hip_atomic_fetch_add(cp, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int last = old == a.splits - 1;
+                if (last) __hip_atomic_store(cp, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_last = last;
+            }
+            __syncthreads();
+            if (!s_last) return;
+            const int howo2 = a.Ho * a.Wo;
+            const long long zstride = (long long)a.M * a.Npad;
+            const int n = n0 + wc * 32 + ec;
+            float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.bias && n < a.Cout) bias4 = *(const float4 *)(a.bias + n);
+#pragma unroll
+            for (int tp = 0; tp < 2; ++tp) { // two of the thread's four rows at a time: 16 loads in flight (the registers of 32 would cost the main loop a wavefront per SIMD)
+                f32x4 part[2][8];
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    const int m = m0 + wr * 32 + er + 8 * (2 * tp + tt);
+                    const float *src = a.partial + (long long)(m < a.M ? m : 0) * a.Npad + (n < a.Npad ? n : 0);
+#pragma unroll
+                    for (int z = 0; z < 8; ++z)
+                        if (z < a.splits) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(part[tt][z]) : "v"(src + z * zstride) : "memory");
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    const int m = m0 + wr * 32 + er + 8 * (2 * tp + tt);
+#pragma unroll
+                    for (int z = 0; z < 8; ++z) asm volatile("" : "+v"(part[tt][z]));
+                    float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                    for (int z = 0; z < 8; ++z)
+                        if (z < a.splits) { v[0] += part[tt][z][0]; v[1] += part[tt][z][1]; v[2] += part[tt][z][2]; v[3] += part[tt][z][3]; }
+                    if (m < a.M && n < a.Cout) {
+                        const float bb[4] = {bias4.x, bias4.y, bias4.z, bias4.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int act = (a.act == ACT_SIGMOID && n + e < a.sig_from) ? ACT_NONE : a.act;
+                            v[e] = act_apply(v[e] + bb[e], act);
+                        }
+                        const int b = m / howo2, pix = m - b * howo2;
+                        if (a.res) {
+                            const float4 rr = *(const float4 *)(a.res + (long long)b * a.r_bs + (long long)pix * a.r_cs + a.r_co + n);
+                            v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+                        }
+                        *(float4 *)(a.y + (long long)b * a.y_bs + (long long)pix * a.y_cs + a.y_co + n) = make_float4(v[0], v[1], v[2], v[3]);
+                    }
+                }
+            }
+            return;
+        }
     }
     const int howo = a.Ho * a.Wo;
     if (((a.Cout | a.y_cs | a.y_co | a.r_cs | a.r_co) & 3) == 0 && (a.y_bs & 3) == 0 && (a.r_bs & 3) == 0 && a.y_rp == 0) {
@@ -1007,7 +1097,7 @@ inline void launch_conv_tile_p1(const ConvArgs &c, dim3 grid, hipStream_t s)
 
 // Tile choice and split-K for one convolution; `scratch` (scratch_floats floats, may be NULL) holds split-K partials.
 // Returns false (nothing launched) when a single image's view exceeds the 32-bit buffer offsets.
-inline bool launch_conv(ConvArgs &c, float *scratch, long long scratch_floats, hipStream_t s)
+inline bool launch_conv(ConvArgs &c, float *scratch, long long scratch_floats, hipStream_t s, int *sk_counters = nullptr)
 {
     const int howo = c.Ho * c.Wo, nb = c.M / howo;
     const int n_groups = c.group_n ? (c.Npad + c.group_n - 1) / c.group_n : 1;
@@ -1019,7 +1109,7 @@ inline bool launch_conv(ConvArgs &c, float *scratch, long long scratch_floats, h
         c.stats_rows = 0;
         const int b0 = nb / 2;
         h.M = b0 * howo;
-        if (!launch_conv(h, scratch, scratch_floats, s)) return false;
+        if (!launch_conv(h, scratch, scratch_floats, s, sk_counters)) return false;
         h = c;
         h.stats = nullptr;
         h.M = (nb - b0) * howo;
@@ -1027,13 +1117,14 @@ inline bool launch_conv(ConvArgs &c, float *scratch, long long scratch_floats, h
         h.y = c.y + (long long)b0 * c.y_bs;
         if (c.y2) h.y2 = c.y2 + (long long)b0 * c.y2_bs;
         if (c.res) h.res = c.res + (long long)b0 * c.r_bs;
-        return launch_conv(h, scratch, scratch_floats, s);
+        return launch_conv(h, scratch, scratch_floats, s, sk_counters);
     }
     if (x_bytes > kMaxViewBytes || (long long)c.K * c.Npad * 4 > kMaxViewBytes) return false;
     c.x_bytes = (uint32_t)x_bytes;
     c.w_bytes = (uint32_t)((long long)(c.prec == 1 ? (c.K + 15) / 16 * 16 : c.K) * c.Npad * 4);
     c.splits = 1;
     c.partial = nullptr;
+    c.sk_counters = nullptr;
     double *const stats_req = c.stats; // wanted by the caller; granted per tile below (never with split-K or the scalar epilogue)
     c.stats = nullptr;
     c.stats_rows = 0;
@@ -1096,6 +1187,14 @@ inline bool launch_conv(ConvArgs &c, float *scratch, long long scratch_floats, h
         }
 #endif
         grant_stats(64);
+        const bool vec = ((c.Cout | c.Npad | c.y_cs | c.y_co | c.r_cs | c.r_co | c.y_rp) & 3) == 0 && (c.y_bs & 3) == 0 && (c.r_bs & 3) == 0;
+        // the reduction inside the kernel (SK): float32 operand, uniform taps, vector rows, a counter per tile -- else k_splitk_reduce
+        if (c.splits > 1 && sk_counters && vec && c.prec == 0 && c.Cin % CONV_BK_SMALL == 0 && c.y_rp == 0 &&
+            (long long)((c.M + 63) / 64) * ((c.Npad + 63) / 64) <= 1024) {
+            c.sk_counters = sk_counters;
+            hipLaunchKernelGGL((k_conv_mfma_sk<CONV_BK_SMALL>), dim3((c.M + 63) / 64, (c.Npad + 63) / 64, c.splits), dim3(256), 0, s, c);
+            return true;
+        }
 #ifdef FRLW_DEV_BUILD // lab variants, all measured without a net gain: two-wavefront workgroups, deeper rings
         if (w2n128) launch_conv_tile_p1<64, 128, 2, 1>(c, dim3((c.M + 63) / 64, (c.Npad + 127) / 128, c.splits), s);
         else if (w2n64) launch_conv_tile_p1<64, 64, 2, 1>(c, dim3((c.M + 63) / 64, (c.Npad + 63) / 64, c.splits), s);
@@ -1105,7 +1204,6 @@ inline bool launch_conv(ConvArgs &c, float *scratch, long long scratch_floats, h
 #endif
         launch_conv_tile<64, 64, 2, 2, CONV_BK_SMALL>(c, dim3((c.M + 63) / 64, (c.Npad + 63) / 64, c.splits), s);
         if (c.splits > 1) {
-            const bool vec = ((c.Cout | c.Npad | c.y_cs | c.y_co | c.r_cs | c.r_co | c.y_rp) & 3) == 0 && (c.y_bs & 3) == 0 && (c.r_bs & 3) == 0;
             if (vec) hipLaunchKernelGGL(k_splitk_reduce<true>, dim3(conv_grid_1d((long long)c.M * c.Cout / 4)), dim3(256), 0, s, c);
             else hipLaunchKernelGGL(k_splitk_reduce<false>, dim3(conv_grid_1d((long long)c.M * c.Cout)), dim3(256), 0, s, c);
         }

@@ -1147,9 +1147,15 @@ int frlw_det_run(const frlw_detector_t *d, int B, void *const *bufs, int n_bufs,
             c.y2 = op.ups_buf > 0 ? buf(op.ups_buf) : nullptr;
             if (!c.x || !c.y || (op.ups_buf > 0 && !c.y2)) return FRLW_ERR_ARG;
             c.M = B * c.Ho * c.Wo;
-            if (!launch_conv(c, d->scratch_buf >= 0 ? buf(d->scratch_buf) + (long long)op.lane * d->scratch_floats : nullptr,
-                             d->scratch_buf >= 0 ? d->scratch_floats : 0, s))
-                return FRLW_ERR_UNSUPPORTED;
+            {
+                // a lane's scratch region: split-K partial sums, and in its last 1024 words the tiles' arrival counters of the
+                // in-kernel reduction (zero when the caller hands the buffer over, reset by the kernel: frlw_det_set_scratch)
+                float *sc = d->scratch_buf >= 0 ? buf(d->scratch_buf) + (long long)op.lane * d->scratch_floats : nullptr;
+                const long long cap = d->scratch_buf >= 0 ? d->scratch_floats - 1024 : 0;
+                static const long long sk_knob = dev_knob("FRLW_CONV_SK_INKERNEL", 1ll);
+                int *counters = (sc && cap > 0 && sk_knob) ? (int *)(sc + cap) : nullptr;
+                if (!launch_conv(c, sc, cap > 0 ? cap : 0, s, counters)) return FRLW_ERR_UNSUPPORTED;
+            }
             break;
         }
         case OP_PRED: { // this op and the OP_PRED ops that directly follow it on the same lane (the head levels): one launch

@@ -484,7 +484,7 @@ int frlw_conv_weight_layouts_batch(const frlw_weight_layout_item_t *items, int n
 
 static int conv_common(const float *x, int B, int H, int W, int Cin, const float *w_gemm, int Cout, int k, int stride,
                        int tstride, int Ho, int Wo, float *y, float *scratch, int64_t scratch_floats, int precision, hipStream_t s,
-                       double *stats = nullptr, int *stats_rows = nullptr)
+                       double *stats = nullptr, int *stats_rows = nullptr, int *sk_counters = nullptr)
 {
     if (precision != 0 && precision != 1) return FRLW_ERR_ARG;
     (void)hipGetLastError(); // other libraries in the process (torch's BLAS look-ups) leave stale errors behind
@@ -498,7 +498,7 @@ static int conv_common(const float *x, int B, int H, int W, int Cin, const float
     c.tstride = tstride;
     c.prec = precision;
     c.stats = stats;
-    if (!launch_conv(c, scratch, scratch ? scratch_floats : 0, s)) return FRLW_ERR_UNSUPPORTED;
+    if (!launch_conv(c, scratch, scratch ? scratch_floats : 0, s, sk_counters)) return FRLW_ERR_UNSUPPORTED;
     if (stats_rows) *stats_rows = c.stats ? c.stats_rows : 0;
     if (hipGetLastError() != hipSuccess) return FRLW_ERR_HIP;
     return FRLW_OK;
@@ -513,8 +513,9 @@ int frlw_conv2d_fwd(const float *x, int B, int H, int W, int Cin, const float *w
     return conv_common(x, B, H, W, Cin, w_fwd, Cout, k, stride, 0, Ho, Wo, z, scratch, scratch_floats, precision, (hipStream_t)stream);
 }
 
-int frlw_conv2d_dgrad(const float *dz, int B, int Ho, int Wo, int Cout, const float *w_dgrad, int Cin, int k, int stride,
-                      int H, int W, float *dx, float *scratch, int64_t scratch_floats, int precision, frlw_stream_t stream)
+static int conv2d_dgrad_impl(const float *dz, int B, int Ho, int Wo, int Cout, const float *w_dgrad, int Cin, int k, int stride,
+                             int H, int W, float *dx, float *scratch, int64_t scratch_floats, int precision, frlw_stream_t stream,
+                             int *sk_counters)
 {
     if (precision != 0 && precision != 1) return FRLW_ERR_ARG;
     // dx[iy][ix][ci] = sum dz[(iy + pad - ky) / s][(ix + pad - kx) / s][co] * w[co][ci][ky][kx]: a stride-1 convolution of
@@ -540,13 +541,19 @@ int frlw_conv2d_dgrad(const float *dz, int B, int Ho, int Wo, int Cout, const fl
             c.res = nullptr; c.act = ACT_NONE;
             c.prec = precision;
             c.M = B * Ho * Wo; c.K = kh * kwc * Cout;
-            if (!launch_conv(c, scratch, scratch ? scratch_floats : 0, (hipStream_t)stream)) return FRLW_ERR_UNSUPPORTED;
+            if (!launch_conv(c, scratch, scratch ? scratch_floats : 0, (hipStream_t)stream, sk_counters)) return FRLW_ERR_UNSUPPORTED;
         }
         if (hipGetLastError() != hipSuccess) return FRLW_ERR_HIP;
         return FRLW_OK;
     }
     return conv_common(dz, B, Ho, Wo, Cout, w_dgrad, Cin, k, 1, stride == 2 ? 2 : 0, H, W, dx, scratch, scratch_floats,
-                       precision, (hipStream_t)stream);
+                       precision, (hipStream_t)stream, nullptr, nullptr, sk_counters);
+}
+
+int frlw_conv2d_dgrad(const float *dz, int B, int Ho, int Wo, int Cout, const float *w_dgrad, int Cin, int k, int stride,
+                      int H, int W, float *dx, float *scratch, int64_t scratch_floats, int precision, frlw_stream_t stream)
+{
+    return conv2d_dgrad_impl(dz, B, Ho, Wo, Cout, w_dgrad, Cin, k, stride, H, W, dx, scratch, scratch_floats, precision, stream, nullptr);
 }
 
 int64_t frlw_conv2d_wgrad_scratch_floats(int B, int Ho, int Wo, int Cin, int Cout, int k)
@@ -718,7 +725,7 @@ int frlw_baseconv_train_fwd(const float *x, const float *w, const float *gamma, 
                             int W, int Cin, int Cout, int k, int stride, float *z, float *y, float *mean, float *var,
                             float *invstd, float *running_mean, float *running_var, float momentum,
                             int64_t *num_batches_tracked, float *w_cache, void *scratch, int64_t scratch_bytes,
-                            int precision, frlw_stream_t stream)
+                            int *splitk_counters, int precision, frlw_stream_t stream)
 {
     if (!x || (!w && !w_cache) || !gamma || !beta || !z || !y || !mean || !var || !invstd || !scratch) return FRLW_ERR_ARG;
     if (scratch_bytes < frlw_baseconv_train_scratch_bytes(B, H, W, Cin, Cout, k, stride)) return FRLW_ERR_WORKSPACE;
@@ -738,7 +745,7 @@ int frlw_baseconv_train_fwd(const float *x, const float *w, const float *gamma, 
     if (stride != 1 && stride != 2) return FRLW_ERR_UNSUPPORTED;
     int stat_rows = 0; // > 0: the convolution's epilogue left the column sums of its output slabs in t.red
     if ((rc = conv_common(x, B, H, W, Cin, w_fwd, Cout, k, stride, 0, Ho, Wo, z, t.splitk, t.splitk_floats, precision, (hipStream_t)stream,
-                          t.red, &stat_rows)) != FRLW_OK) return rc;
+                          t.red, &stat_rows, splitk_counters)) != FRLW_OK) return rc;
     if ((rc = bn_stats_impl(z, M, Cout, eps, mean, var, invstd, t.red, running_mean, running_mean ? running_var : nullptr,
                             momentum, (long long *)num_batches_tracked, stream, stat_rows)) != FRLW_OK) return rc;
     return frlw_bn_silu_fwd(z, M, Cout, gamma, beta, mean, invstd, y, stream);
@@ -748,7 +755,8 @@ int frlw_baseconv_train_fwd(const float *x, const float *w, const float *gamma, 
 int frlw_baseconv_train_bwd(const float *dy, int64_t dy_row_stride, const float *x, const float *z, const float *w, const float *gamma,
                             const float *beta, const float *mean, const float *invstd, int B, int H, int W, int Cin,
                             int Cout, int k, int stride, float *dz, float *dx, float *dw, float *dgamma, float *dbeta,
-                            const float *w_cache, void *scratch, int64_t scratch_bytes, int precision, frlw_stream_t stream)
+                            const float *w_cache, void *scratch, int64_t scratch_bytes, int *splitk_counters, int precision,
+                            frlw_stream_t stream)
 {
     if (!dy || !x || !z || !w || !gamma || !beta || !mean || !invstd || !dz || !dw || !dgamma || !dbeta || !scratch)
         return FRLW_ERR_ARG;
@@ -763,7 +771,7 @@ int frlw_baseconv_train_bwd(const float *dy, int64_t dy_row_stride, const float 
         const float *w_dg = t.w_dg;
         if (w_cache) w_dg = w_cache + frlw_conv_operand_floats(k * k * Cin, Cout, precision); // laid out by the forward of this step
         else if ((rc = frlw_conv_weight_layouts(w, Cout, Cin, k, frlw_conv2d_dgrad_parity(k, stride, H, W), nullptr, t.w_dg, precision, stream)) != FRLW_OK) return rc;
-        if ((rc = frlw_conv2d_dgrad(dz, B, Ho, Wo, Cout, w_dg, Cin, k, stride, H, W, dx, t.splitk, t.splitk_floats, precision, stream)) != FRLW_OK) return rc;
+        if ((rc = conv2d_dgrad_impl(dz, B, Ho, Wo, Cout, w_dg, Cin, k, stride, H, W, dx, t.splitk, t.splitk_floats, precision, stream, splitk_counters)) != FRLW_OK) return rc;
     }
     return frlw_conv2d_wgrad(x, B, H, W, Cin, dz, Ho, Wo, Cout, k, stride, dw, t.wgrad, t.wgrad_floats, precision, stream);
 }

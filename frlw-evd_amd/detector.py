@@ -358,7 +358,7 @@ class DetectorEngine:
                                                self.dec_buf, self.dets_buf, self.counts_buf, self.nms_buf), "decode")
         head.hw = [(v.h, v.w) for v in levels]
         # split-K scratch: 8 splits x (< 256 tiles of 64 x 64), independent of the batch size
-        self.scratch_floats = 8 * 256 * 64 * 64
+        self.scratch_floats = 8 * 256 * 64 * 64 + 1024
         self._shapes.append(0)
         self.scratch_buf = len(self._shapes) - 1
         _lib.check(lib.frlw_det_set_scratch(self.handle, self.scratch_buf, self.scratch_floats), "scratch")
@@ -370,7 +370,8 @@ class DetectorEngine:
         if bufs is None:
             bufs = [None] + [torch.empty(B * n, dtype=torch.float32, device=self.device) for n in self._shapes[1:]]
             bufs[self.counts_buf] = torch.zeros(B * (1 + self.A), dtype=torch.int32, device=self.device)
-            bufs[self.scratch_buf] = torch.empty(3 * self.scratch_floats, dtype=torch.float32, device=self.device)
+            # (zeros: the last 1024 words of every lane's region are the arrival counters of the in-kernel split-K reduction)
+            bufs[self.scratch_buf] = torch.zeros(3 * self.scratch_floats, dtype=torch.float32, device=self.device)
             self._bufs[B] = bufs
         return bufs
 

@@ -135,6 +135,17 @@ def _scratch(dev, key, numel, dtype):
     return t
 
 
+def _sk_counters(dev):
+    """The arrival counters of the in-kernel split-K reduction (frlw_evd.h: frlw_baseconv_train_fwd): 1024 ints per device,
+    zero when created, kept at zero by the kernels themselves; one buffer for all layers (launches of a stream are ordered)."""
+    k = (dev.index, "splitk_counters", torch.int32)
+    t = _SCRATCH.get(k)
+    if t is None:
+        t = torch.zeros(1024, dtype=torch.int32, device=dev)
+        _SCRATCH[k] = t
+    return t
+
+
 def _stream(dev):
     return torch.cuda.current_stream(dev).cuda_stream
 
@@ -195,7 +206,8 @@ class _BaseConvTrain(torch.autograd.Function):
                                                run_mean.data_ptr() if run_mean is not None else None,
                                                run_var.data_ptr() if run_var is not None else None, C.c_float(momentum),
                                                tracked.data_ptr() if tracked is not None else None,
-                                               wc.data_ptr(), sc.data_ptr(), sc.numel(), prec, _stream(dev)), "baseconv_train_fwd")
+                                               wc.data_ptr(), sc.data_ptr(), sc.numel(), _sk_counters(dev).data_ptr(), prec,
+                                               _stream(dev)), "baseconv_train_fwd")
         ctx.wcache = wc
         # the data-gradient half of the cache depends on the parity class of (k, stride, H, W): a second forward of the same
         # layer on an input of another parity (shared layer, multi-scale graph) re-lays it -- remember what THIS forward wrote
@@ -230,7 +242,7 @@ class _BaseConvTrain(torch.autograd.Function):
                                                stride, dz.data_ptr(), dx.data_ptr() if dx is not None else None,
                                                dw.data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(),
                                                ctx.wcache.data_ptr() if fresh else None, sc.data_ptr(),
-                                               sc.numel(), ctx.wparity[1], _stream(dev)), "baseconv_train_bwd")
+                                               sc.numel(), _sk_counters(dev).data_ptr(), ctx.wparity[1], _stream(dev)), "baseconv_train_bwd")
         return dx, dw, dgb[0], dgb[1], None, None, None, None, None, None
 
 

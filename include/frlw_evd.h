@@ -323,7 +323,10 @@ int frlw_det_add_fork(frlw_detector_t *d);
 int frlw_det_add_join(frlw_detector_t *d);
 
 /* Optional scratch buffer (index into bufs; n_floats floats PER LANE, 3 lanes) for split-K partial sums of the
- * convolutions whose output grid would leave most CUs idle (8x10 feature maps). */
+ * convolutions whose output grid would leave most CUs idle (8x10 feature maps).  The buffer must be ZERO when it is first
+ * handed to frlw_det_run and is left alone by the caller afterwards: the last 1024 words of every lane's region are the
+ * arrival counters of the in-kernel reduction (k_conv_mfma_sk: the split that arrives last at a tile's counter sums all
+ * splits and resets it). */
 int frlw_det_set_scratch(frlw_detector_t *d, int buf, int64_t n_floats);
 
 /* Focus space-to-depth (network_blocks.py:205-217): NCHW (B, C, H, W) -> NHWC (B, H/2, W/2, 4C). */
@@ -555,18 +558,25 @@ int frlw_bn_silu_bwd(const float *dy, int64_t dy_row_stride, const float *z, int
  * forward then lays the weight out for itself AND for the data gradient in one launch, and the backward of the same
  * step (weights unchanged in between) reuses it instead of laying the weight out again.  w == NULL with a w_cache in
  * the forward: the cache holds both operands of the current weights already (frlw_conv_weight_layouts_batch: forward
- * operand first, the data-gradient operand frlw_conv_operand_floats(k*k*Cin, Cout, precision) floats behind it) and no layout kernel is launched. */
+ * operand first, the data-gradient operand frlw_conv_operand_floats(k*k*Cin, Cout, precision) floats behind it) and no layout kernel is launched.
+ * splitk_counters (may be NULL): 1024 ints owned by the caller, ZERO when first handed over and left alone by the caller
+ * afterwards -- one buffer for all layers and calls of a stream.  With it, a convolution that splits its contraction over
+ * blockIdx.z (thin layers: few output tiles, long contractions) sums the splits INSIDE the kernel -- the split that arrives
+ * last at its tile's counter adds all of them in split order, the same bits as the separate reduction launch, and sets the
+ * counter back to zero -- instead of launching k_splitk_reduce behind it (NULL).  frlw_det_run does the same with the last
+ * 1024 words of every lane's scratch region (frlw_det_set_scratch: the caller hands the buffer over zeroed). */
 int64_t frlw_baseconv_weight_cache_floats(int Cin, int Cout, int k, int precision);
 int64_t frlw_baseconv_train_scratch_bytes(int B, int H, int W, int Cin, int Cout, int k, int stride);
 int frlw_baseconv_train_fwd(const float *x, const float *w, const float *gamma, const float *beta, float eps, int B, int H,
                             int W, int Cin, int Cout, int k, int stride, float *z, float *y, float *mean, float *var,
                             float *invstd, float *running_mean, float *running_var, float momentum,
                             int64_t *num_batches_tracked, float *w_cache, void *scratch, int64_t scratch_bytes,
-                            int precision, frlw_stream_t stream);
+                            int *splitk_counters, int precision, frlw_stream_t stream);
 int frlw_baseconv_train_bwd(const float *dy, int64_t dy_row_stride, const float *x, const float *z, const float *w, const float *gamma,
                             const float *beta, const float *mean, const float *invstd, int B, int H, int W, int Cin,
                             int Cout, int k, int stride, float *dz, float *dx, float *dw, float *dgamma, float *dbeta,
-                            const float *w_cache, void *scratch, int64_t scratch_bytes, int precision, frlw_stream_t stream);
+                            const float *w_cache, void *scratch, int64_t scratch_bytes, int *splitk_counters, int precision,
+                            frlw_stream_t stream);
 
 /* Measurement aid: a bare loop of v_mfma_f32_32x32x2_f32 (the instruction of every convolution here) on `blocks`
  * workgroups of four wavefronts, iters x 32 MFMAs (= iters x 131072 FLOP) per wavefront, operands = the 256 floats of
