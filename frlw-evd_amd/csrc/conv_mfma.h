@@ -1169,10 +1169,16 @@ inline bool launch_conv(ConvArgs &c, float *scratch, long long scratch_floats, h
         const long long wgs = (long long)((c.M + 63) / 64) * ((c.Npad + bn - 1) / bn);
         const int nk = (c.K + kSplitBK - 1) / kSplitBK;
         // small feature maps leave most CUs idle: split the contraction over blockIdx.z
-        if (wgs < split_below && nk >= 64 && scratch && !c.y2) { // (contractions shorter than 1024 gained nothing from splitting: measured; the upsampled copy is written by the convolution's own epilogue)
+        // (contractions shorter than 1024 gained nothing from splitting while the reduction was a launch of its own; with the
+        // reduction inside the kernel -- sk_counters -- those of 512 and more do: detector forward 3.833 -> 3.782 ms, same box.
+        // The upsampled copy of ConvArgs::y2 is written by the convolution's own epilogue: no split there.)
+        static const long long split_min_nk = dev_knob("FRLW_CONV_SPLIT_MIN_NK", 0ll);
+        const long long min_nk = split_min_nk ? split_min_nk : (sk_counters ? 32 : 64);
+        if (wgs < split_below && nk >= min_nk && scratch && !c.y2) {
             int sp = (int)((split_target + wgs - 1) / wgs);
             if (sp > 8) sp = 8;
-            if (sp > nk / 8) sp = nk / 8;
+            static const long long split_min_per = dev_knob("FRLW_CONV_SPLIT_MIN_PER", 8ll); // k-tiles a split keeps at least
+            if (sp > nk / split_min_per) sp = (int)(nk / split_min_per);
             if (sp > 1 && (long long)sp * c.M * c.Npad <= scratch_floats) { c.splits = sp; c.partial = scratch; }
         }
         // (a deeper ring, D = 4, for launches that leave a workgroup alone on its CU was measured: no gain -- such
