@@ -2786,16 +2786,37 @@ __global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu((BINS
         if (end > beg) { const uint32_t v = list[i < end ? i : end - 1u]; nx[u] = i < end ? v : 0xffffffffu; }
     }
     LDS_FENCE();
-    for (uint32_t p0 = beg; p0 < end; p0 += 256) {
+    // A pass whose records all lie in ONE slice of the window (same floor(t*)) takes ev_pass's cheap form -- two weights per
+    // record, pairs added in stream order -- a pass that straddles a slice boundary the general one (every bin tried for every
+    // record).  A time-sorted list of ~1 700 records crosses the five boundaries in five of its seven 256-record passes; so a
+    // pass is CUT at the first record of the next slice (the rest of its 256 records is fetched again by the next pass): twelve
+    // cheap passes instead of two cheap and five general ones.  The cut uses an approximate slice index (float(r * bins) / window:
+    // monotone in r); ev_pass still classifies exactly, so a record the approximation puts on the wrong side of a boundary only
+    // costs that pass the general form.  Cuts in front of record 64 are not made (an unsorted list would otherwise crawl).
+    const float inv_win = 1.0f / (float)q.win;
+    const uint32_t ubins = (uint32_t)q.bins;
+    for (uint32_t p0 = beg; p0 < end;) {
         uint32_t pm[4];
+        uint32_t take = 256u;
+        {
+            const uint32_t k0 = (uint32_t)((float)(((uint32_t)__builtin_amdgcn_readfirstlane((int)nx[0]) >> kCellBits) * ubins) * inv_win);
+#pragma unroll
+            for (int u = 3; u >= 0; --u) { // (descending: the lowest u with a differing record wins)
+                pm[u] = nx[u];
+                const unsigned long long d = __ballot(pm[u] != 0xffffffffu && (uint32_t)((float)((pm[u] >> kCellBits) * ubins) * inv_win) != k0);
+                if (d) take = (uint32_t)(u * kWave) + (uint32_t)__builtin_ctzll(d);
+            }
+            if (take < (uint32_t)kWave) take = 256u;
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            pm[u] = nx[u];
-            const uint32_t i = p0 + 256u + (uint32_t)(u * kWave + lane);
+            if ((uint32_t)(u * kWave + lane) >= take) pm[u] = 0xffffffffu;
+            const uint32_t i = p0 + take + (uint32_t)(u * kWave + lane);
             const uint32_t v = list[i < end ? i : end - 1u];
             nx[u] = i < end ? v : 0xffffffffu;
         }
         ev_pass<BINS>(P, pm, lane, q, use_mul, rcp, binsf, acc);
+        p0 += take;
     }
     ev_store<BINS>(q, s, tile, sub, lane, acc);
 }
