@@ -422,7 +422,7 @@ class DetectorEngine:
         out = []
         for b, n in enumerate(counts):
             if n < 0:
-                # more than 8192 candidates (what k_decode_nms holds in LDS): only possible for inputs beyond the
+                # more than 8192 candidates (what k_decode_sort holds in LDS): only possible for inputs beyond the
                 # 1 Mpx detector shape (6720 anchors).  Such an image takes the box-by-box procedure on the decoded
                 # rows the kernel left in HBM (ROCm tensors, torch ops; same arithmetic and visiting order)
                 out.append(self._nms_large(bufs[self.dec_buf].view(B, self.A, self.F)[b]))
