@@ -89,3 +89,22 @@ def test_product_path_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.replace("test infrastructure", ""), f"{f} mentions the oracle"
+
+
+def test_round6_queries_are_host_only():
+    """The size query of the NMS workspace and the argument checks of the round-6 entry points run without a GPU."""
+    import ctypes as C
+    lib = _lib.load()
+    # per image: 4 + 256 header floats, 4 floats per (padded) anchor, 2 floats per (row, 64-column word) of the bit matrix
+    assert lib.frlw_det_nms_workspace_floats(1680) == 260 + 4 * 1728 + 2 * 27 * 1728
+    assert lib.frlw_det_nms_workspace_floats(6720) == 260 + 4 * 6720 + 2 * 105 * 6720
+    assert lib.frlw_det_nms_workspace_floats(100_000) == 260 + 4 * 8192 + 2 * 128 * 8192   # capped at the 8192 candidates the device NMS holds
+    assert lib.frlw_det_nms_workspace_floats(0) == 0
+    counts = (C.c_uint64 * 4)()
+    assert lib.frlw_encoder_path_counts(counts) == 0 and list(counts) == [0, 0, 0, 0]
+    assert lib.frlw_encoder_path_counts(None) == _lib.FRLW_ERR_ARG
+    ok = C.c_int(7)
+    assert lib.frlw_fast_path_verdict(None, 0, None, C.byref(ok)) == _lib.FRLW_ERR_ARG and ok.value == 7
+    # the two-launch forms of the single-stream encoders are covered by the documented size query
+    small = lib.frlw_encoder_workspace_bytes(1_000_000, 240, 304)
+    assert small >= 8 * 1_000_000 + 372_000   # records + the chunk-major tables (576 bins x 145 chunks and the rest)
