@@ -18,7 +18,7 @@ def test_in_kernel_reduction_equals_the_two_launch_form_bit_for_bit(tmp_path):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from frlw_evd_amd import _build
-    dev_lib = _build.build_dev()  # (rebuilds only when a source is newer)
+    dev_lib = _build.DEV_LIB if os.path.exists(_build.DEV_LIB) else _build.build_dev()  # (__graft_entry__.build() keeps it current)
     outs = []
     for knob in ("0", "1"):
         out = str(tmp_path / f"sk{knob}.pt")
