@@ -141,7 +141,13 @@ __global__ __launch_bounds__(64 * WROWS * WCOLS) void k_conv_mfma(ConvArgs a)
 // the 64 x 64 tile with the split-K reduction inside the kernel (see the epilogue): its last-arriving workgroup keeps 16 partial
 // rows in registers, and the launches that use it want five workgroups per CU -- five wavefronts per SIMD, at most 96 registers
 template <int BK>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_conv_mfma_sk(ConvArgs a)
+#ifndef SK_OCC
+#define SK_OCC 5
+#endif
+#ifndef SK_ROWS
+#define SK_ROWS 2
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SK_OCC, 8))) void k_conv_mfma_sk(ConvArgs a)
 {
     conv_mfma_body<64, 64, 2, 2, BK, true, 2, 0, true>(a);
 }
@@ -637,11 +643,11 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &a)
             float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
             if (a.bias && n < a.Cout) bias4 = *(const float4 *)(a.bias + n);
 #pragma unroll
-            for (int tp = 0; tp < 2; ++tp) { // two of the thread's four rows at a time: 16 loads in flight (the registers of 32 would cost the main loop a wavefront per SIMD)
-                f32x4 part[2][8];
+            for (int tp = 0; tp < 4 / SK_ROWS; ++tp) { // two of the thread's four rows at a time: 16 loads in flight (the registers of 32 would cost the main loop a wavefront per SIMD)
+                f32x4 part[SK_ROWS][8];
 #pragma unroll
-                for (int tt = 0; tt < 2; ++tt) {
-                    const int m = m0 + wr * 32 + er + 8 * (2 * tp + tt);
+                for (int tt = 0; tt < SK_ROWS; ++tt) {
+                    const int m = m0 + wr * 32 + er + 8 * (SK_ROWS * tp + tt);
                     const float *src = a.partial + (long long)(m < a.M ? m : 0) * a.Npad + (n < a.Npad ? n : 0);
 #pragma unroll
                     for (int z = 0; z < 8; ++z)
@@ -649,8 +655,8 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &a)
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-                for (int tt = 0; tt < 2; ++tt) {
-                    const int m = m0 + wr * 32 + er + 8 * (2 * tp + tt);
+                for (int tt = 0; tt < SK_ROWS; ++tt) {
+                    const int m = m0 + wr * 32 + er + 8 * (SK_ROWS * tp + tt);
 #pragma unroll
                     for (int z = 0; z < 8; ++z) asm volatile("" : "+v"(part[tt][z]));
                     float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
