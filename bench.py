@@ -960,29 +960,43 @@ def _train_variant(torch, timer, world, rank, local_rank, per_gpu_batch, ddp, ho
     return per, dev_ms, tr, state, one, (x, lab)
 
 
-def _allreduce_rows(torch, timer, world, rank, local_rank, per_gpu_batch, per_default, steps):
-    """How much of the gradient exchange is exposed (not hidden behind the backward), per communication hook: the DDP
-    step minus the same step on the bare module (same kernels, no gradient hooks, no collective)."""
+def _allreduce_rows(torch, timer, world, rank, local_rank, per_gpu_batch, per_main, main_is_two_graph, steps):
+    """How much of the gradient exchange is exposed (not hidden behind the backward), per form of the step: the step under
+    DDP with each communication hook minus the same eagerly launched step on the bare module (same kernels, no gradient
+    hooks, no collective); the two-graph step (``per_main`` when the main row ran it) minus the one-graph step of a lone rank."""
     per_ns, _, tr_ns, *_ = _train_variant(torch, timer, world, rank, local_rank, per_gpu_batch, False, None, steps, 2)
     grad_bytes = int(sum(p.numel() for p in tr_ns.model.parameters()) * 4)
     del tr_ns
+    if main_is_two_graph:
+        per_default, _, tr_d, *_ = _train_variant(torch, timer, world, rank, local_rank, per_gpu_batch, True, None, steps, 3)
+        del tr_d
+        per_ng, _, tr_ng, *_ = _train_variant(torch, timer, world, rank, local_rank, per_gpu_batch, False, None, steps, graph=True)
+        del tr_ng
+    else:
+        per_default, per_ng = per_main, None
     per_rs, _, tr_rs, *_ = _train_variant(torch, timer, world, rank, local_rank, per_gpu_batch, True, "rs_ag", steps, 3)
     del tr_rs
     per_t, _, tr_t, *_ = _train_variant(torch, timer, world, rank, local_rank, per_gpu_batch, True, "timed", steps, 3)
     hook = tr_t.comm_hook.summary() if tr_t.comm_hook is not None else {}
     del tr_t
     torch.cuda.empty_cache()
+    exposed = {"default": round(max(0.0, (per_default - per_ns) * 1e3), 3), "rs_ag": round(max(0.0, (per_rs - per_ns) * 1e3), 3)}
+    by_hook = {"default": round(per_default * 1e3, 3), "rs_ag": round(per_rs * 1e3, 3), "timed": round(per_t * 1e3, 3)}
+    if main_is_two_graph:
+        exposed["two_graph"] = round(max(0.0, (per_main - per_ng) * 1e3), 3)
+        by_hook["two_graph"] = round(per_main * 1e3, 3)
     out = {"gradient_bytes": grad_bytes, "step_ms_without_collective": round(per_ns * 1e3, 3),
-           "allreduce_exposed_ms": round(max(0.0, (per_default - per_ns) * 1e3), 3),
-           "exposed_ms_by_hook": {"default": round(max(0.0, (per_default - per_ns) * 1e3), 3),
-                                  "rs_ag": round(max(0.0, (per_rs - per_ns) * 1e3), 3)},
-           "step_ms_by_hook": {"default": round(per_default * 1e3, 3), "rs_ag": round(per_rs * 1e3, 3),
-                               "timed": round(per_t * 1e3, 3)},
+           "graph_step_ms_without_collective": None if per_ng is None else round(per_ng * 1e3, 3),
+           "allreduce_exposed_ms": exposed["two_graph" if main_is_two_graph else "default"],
+           "exposed_ms_by_hook": exposed, "step_ms_by_hook": by_hook,
            "bucket_bytes": hook.get("bucket_bytes"), "mean_bucket_ms": round(hook.get("mean_bucket_ms", 0.0), 3),
            "buckets_per_step": (hook["buckets"] // (steps + 3)) if hook.get("buckets") else None,
            "collective_ms_per_step": round(hook.get("total_ms", 0.0) / max(steps + 3, 1), 3),
-           "hooks": "default = DDP's bucketed RCCL all-reduce; rs_ag = reduce-scatter + all-gather per bucket "
-                    "(frlw_evd_amd.dist); timed = default + HIP events around each bucket's collective",
+           "hooks": "two_graph = Trainer(ddp=True, graph=True): forward + backward as one HIP graph, ONE all-reduce of the flat "
+                    "gradient buffer launched eagerly, Adam as a second graph (nothing of the exchange is hidden: the whole of it "
+                    "is exposed, the ~1 200 launches of the step are not); default = DistributedDataParallel's bucketed RCCL "
+                    "all-reduce behind eager launches; rs_ag = reduce-scatter + all-gather per bucket (frlw_evd_amd.dist); "
+                    "timed = default + HIP events around each bucket's collective",
            "ddp": "gradient_as_bucket_view, static_graph, 25 MB buckets (frlw_evd_amd.dist.ddp_kwargs)"}
     return out
 
@@ -996,9 +1010,21 @@ def bench_train(args, torch, world, rank, local_rank, timer):
     from frlw_evd_amd import e2e
     B = args.train_batch
     steps = 10
-    use_graph = world == 1  # one rank: forward + SimOTA + losses + backward + Adam replayed as ONE HIP graph; DDP ranks: eager
-    per, dev_ms, tr, state, one, (x, lab) = _train_variant(torch, timer, world, rank, local_rank, B, world > 1, None, steps,
-                                                           graph=use_graph)
+    # one rank: forward + SimOTA + losses + backward + Adam replayed as ONE HIP graph; DDP ranks: two graphs around one
+    # eagerly launched all-reduce of the flat gradient buffer (Trainer(ddp=True, graph=True)); FRLW_BENCH_DDP_EAGER=1 (or a
+    # capture that fails) keeps the DistributedDataParallel step with eager launches
+    use_graph = world == 1 or os.environ.get("FRLW_BENCH_DDP_EAGER") != "1"
+    capture_error = None
+    try:
+        per, dev_ms, tr, state, one, (x, lab) = _train_variant(torch, timer, world, rank, local_rank, B, world > 1, None, steps,
+                                                               graph=use_graph)
+    except Exception as e:  # noqa: BLE001 -- (no collective runs inside the capture: a failure there is the same on every rank)
+        if world == 1 or not use_graph:
+            raise
+        capture_error = f"{type(e).__name__}: {e}"[:300]
+        use_graph = False
+        torch.cuda.empty_cache()
+        per, dev_ms, tr, state, one, (x, lab) = _train_variant(torch, timer, world, rank, local_rank, B, True, None, steps)
     loss = state["loss"]
     from frlw_evd_amd.detector import DetectorEngine
     from frlw_evd_amd.yolox import train_ops as _tops
@@ -1014,16 +1040,23 @@ def bench_train(args, torch, world, rank, local_rank, timer):
     out = {"metric": "YOLOX train step (frames/s)", "value": round(world * B / per, 1), "unit": "frames/s",
            "ms_per_step": round(per * 1e3, 3), "per_gpu_batch": B, "global_batch": B * world, "steps": steps,
            "loss": round(loss, 4), "parallelism": f"ddp{world}" if world > 1 else "single", "scaling": "weak",
-           "launch": "one HIP graph per step (Trainer(graph=True): ~1 200 kernel nodes, the loss read back after every replay "
-                     "like core/exp.py:303)" if use_graph else "eager launches (DDP ranks)",
+           "launch": ("one HIP graph per step (Trainer(graph=True): ~1 200 kernel nodes, the loss read back after every replay "
+                      "like core/exp.py:303)" if world == 1 else
+                      "two HIP graphs per step around one eagerly launched RCCL all-reduce of the flat gradient buffer "
+                      "(Trainer(ddp=True, graph=True))") if use_graph else "eager launches (DistributedDataParallel ranks)",
            "convolutions": "csrc/train_ops.hip (MFMA fwd / dgrad / wgrad, BatchNorm + SiLU fwd / bwd), SimOTA + losses csrc/simota.hip",
            "dtype": "f32" if precision == "f32" else "f32 storage and accumulation, products from 3 bf16 MFMAs (bf16x3)",
            "roofline": mfma_roofline(tflops, precision, "k_conv_mfma (fwd + dgrad) + k_wgrad_mfma", flops_per_step=flops,
                                      flops_model="(3 x conv MACs x 2 of the 16-channel forward - the stem's data gradient, which "
                                      "is never computed: the network input needs none) x batch = forward + data gradient + weight gradient",
                                      stem_fraction_of_forward=round(stem_fl / probe.flops_per_image, 4), device_ms_per_step=round(dev_ms, 3))}
+    if capture_error:
+        out["graph_capture_error"] = capture_error
     if world > 1:
-        out["allreduce"] = _allreduce_rows(torch, timer, world, rank, local_rank, B, per, steps)
+        out["allreduce"] = _allreduce_rows(torch, timer, world, rank, local_rank, B, per, use_graph, steps)
+        if use_graph:  # the DistributedDataParallel step with eager launches beside it (what rounds 1-5 ran on N > 1 ranks)
+            e_ms = out["allreduce"]["step_ms_by_hook"]["default"]
+            out["eager"] = {"value": round(world * B / (e_ms * 1e-3), 1), "ms_per_step": e_ms, "graph_speedup": round(e_ms / (per * 1e3), 3)}
     # BASELINE.json configs[4]: the same step fed by the TAF encode of its batch (B GEN1-shaped streams of 8 x 125 000
     # events -> frlw_taf_encode_batch -> uint8 -> nearest 256x320 -> /255), everything on this GPU
     src = e2e.SyntheticTafSource(B, seed=1005 + 1000 * rank)
@@ -1097,13 +1130,14 @@ def bench_train(args, torch, world, rank, local_rank, timer):
             g64 = {"value": out["value"], "ms_per_step": out["ms_per_step"], "device_ms_per_step": round(dev_ms, 3),
                    "note": "N = 1: the same step as the weak row"}
         else:
-            per_g, dev_g, tr_g, *_ = _train_variant(torch, timer, world, rank, local_rank, b, world > 1, None, steps)
+            per_g, dev_g, tr_g, *_ = _train_variant(torch, timer, world, rank, local_rank, b, world > 1, None, steps,
+                                                    graph=use_graph)
             del tr_g
             g64 = {"value": round(G / per_g, 1), "ms_per_step": round(per_g * 1e3, 3), "device_ms_per_step": round(dev_g, 3)}
             tf = flops_img * b / (dev_g * 1e-3) / 1e12
             g64["roofline"] = mfma_roofline(tf, precision, "k_conv_mfma + k_wgrad_mfma")
             if world > 1:
-                g64["allreduce"] = _allreduce_rows(torch, timer, world, rank, local_rank, b, per_g, steps)
+                g64["allreduce"] = _allreduce_rows(torch, timer, world, rank, local_rank, b, per_g, use_graph, steps)
         out["global64"] = dict({"workload": f"global batch {G} over {world} GPU(s) = {b} per GPU (settings.py:41), DDP "
                                             "(core/exp.py:391)", "unit": "frames/s", "per_gpu_batch": b, "global_batch": G,
                                 "scaling": "strong"}, **g64)

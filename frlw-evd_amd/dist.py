@@ -119,6 +119,31 @@ def ddp_kwargs(bucket_cap_mb=None):
     return {"gradient_as_bucket_view": True, "static_graph": True, "bucket_cap_mb": cap}
 
 
+def broadcast_module_state(module, src=0, group=None, buffers=False):
+    """Every rank takes rank ``src``'s parameters, in place -- what ``DistributedDataParallel.__init__`` does before the first
+    step (core/exp.py:391 relies on it: the ranks build their models independently).  Buffers (the BatchNorm statistics) stay
+    per rank unless asked for, as under ``broadcast_buffers=False``.  One broadcast per dtype: the float32 parameters travel
+    as one flat message.  Returns the number of collectives issued."""
+    if not dist.is_initialized():
+        return 0
+    tensors = [p.data for p in module.parameters()]
+    if buffers:
+        tensors += list(module.buffers())
+    by_dtype = {}
+    for t in tensors:
+        if t.numel():
+            by_dtype.setdefault((t.dtype, t.device), []).append(t)
+    n = 0
+    with torch.no_grad():
+        for group_tensors in by_dtype.values():
+            flat = torch.cat([t.reshape(-1) for t in group_tensors])
+            dist.broadcast(flat, src, group=group)
+            for t, v in zip(group_tensors, flat.split([t.numel() for t in group_tensors])):
+                t.copy_(v.view_as(t))
+            n += 1
+    return n
+
+
 def reduce_scatter_allgather_hook(group, bucket):
     """DDP communication hook: average a gradient bucket with a reduce-scatter followed by an all-gather instead of one
     all-reduce.  On the fully connected xGMI mesh of an 8-GPU MI355X node each phase sends 1/world of the bucket to every

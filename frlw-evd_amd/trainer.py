@@ -17,6 +17,10 @@ One rank without DDP can replay the whole step -- forward, SimOTA + losses, back
 data-dependent on the host -- as ONE HIP graph (``Trainer(..., graph=True)`` or ``capture()``): the step is launch-bound
 in its loss and gradient-accumulation stretches and ends in the reference's ``loss.cpu()``, which drains the queue
 (15-20 % of the step idle in an eager trace, tools/train_gaps.sh); the replay leaves no gaps.
+
+Several ranks: ``Trainer(ddp=True, graph=True)`` replays the step as TWO graphs around one eagerly launched all-reduce of a
+flat gradient buffer -- forward + backward + gather | all-reduce | Adam -- without the DistributedDataParallel wrapper (its
+reducer cannot be captured); ``ddp=True`` alone keeps the wrapper and eager launches.
 """
 from __future__ import annotations
 
@@ -69,10 +73,23 @@ class Trainer:
         self.lr0, self.per_gpu_batch = init_lr(global_batch, nodes)
         self._graph = None          # (HIP graph, static images, static labels, static loss) once captured
         self._pinned = False
-        self._want_graph = bool(graph) and not ddp  # (DDP: eager -- capture of RCCL collectives is not validated here)
+        # ddp + graph on a GPU: the step is TWO HIP graphs around ONE eager all-reduce of a flat gradient buffer (see capture):
+        # no DistributedDataParallel wrapper (its reducer cannot be captured), the same averaged gradient
+        # (ddp="flat" asks for the wrapper-free exchange whatever the launch form: eager on a CPU, or without graph=True)
+        self._flat_ddp = ddp == "flat" or (bool(ddp) and bool(graph) and next(model.parameters()).is_cuda)
+        self._flat = None           # the flat gradient buffer of that form (every p.grad is a view of it after the capture)
+        self._world = 1
+        self._want_graph = bool(graph) and (not ddp or self._flat_ddp) and next(model.parameters()).is_cuda
         self.model = model
         self.comm_hook = None
-        if ddp:
+        if self._flat_ddp:
+            import torch.distributed as tdist
+            from .dist import broadcast_module_state
+            if not tdist.is_initialized():
+                raise RuntimeError("Trainer(ddp=True, graph=True) needs an initialised process group (dist.init_from_env)")
+            self._world = tdist.get_world_size()
+            broadcast_module_state(model)  # rank 0's parameters: what DistributedDataParallel's constructor does (buffers stay per rank)
+        elif ddp:
             from torch.nn.parallel import DistributedDataParallel
             ids = [local_rank] if (local_rank is not None and next(model.parameters()).is_cuda) else None
             from .dist import ddp_kwargs, install_comm_hook
@@ -115,8 +132,18 @@ class Trainer:
         self.optimizer.zero_grad()
         loss = self._forward(imgs, targets)
         self.scaler.scale(loss).backward()
+        if self._flat_ddp:  # (a batch the captured graphs were not made for, e.g. the short last batch of an epoch)
+            self._average_gradients()
         self.optimizer.step()  # NOT scaler.step: the 65536x scale reaches Adam (reference behaviour)
         return loss
+
+    def _average_gradients(self):
+        """The gradient exchange of the two-graph form, launched eagerly: divide by the world size, SUM over the ranks."""
+        import torch.distributed as tdist
+        grads = [p.grad for g in self.optimizer.param_groups for p in g["params"] if p.grad is not None]
+        flat = torch.cat([g.reshape(-1) for g in grads]).div_(self._world)
+        tdist.all_reduce(flat)
+        torch._foreach_copy_(grads, [v.view_as(g) for g, v in zip(grads, flat.split([g.numel() for g in grads]))])
 
     def capture(self, imgs, targets, warmup=3):
         """Capture one whole step for batches shaped like (imgs, targets) into a HIP graph.  The ``warmup`` steps torch's capture
@@ -127,7 +154,7 @@ class Trainer:
         steps that trained: 0.  The gradients are allocated inside the graph's memory pool, so ``zero_grad`` is part of the
         replay (set_to_none before capture)."""
         if not self._want_graph:
-            raise RuntimeError("graph capture needs Trainer(graph=True), one rank without DDP, parameters on the GPU")
+            raise RuntimeError("graph capture needs Trainer(graph=True) and parameters on the GPU")
         self.model.train()
         x, lab = imgs.clone(), targets.clone()
         snap_model = {k: v.detach().clone() for k, v in self.model.state_dict().items()}
@@ -146,12 +173,34 @@ class Trainer:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        self.optimizer.zero_grad(set_to_none=True)
-        with torch.cuda.graph(graph):
-            loss = self._forward(x, lab)
-            self.scaler.scale(loss).backward()
-            self.optimizer.step()
-        self._graph = (graph, x, lab, loss)
+        if self._flat_ddp:
+            # Several ranks: graph A = forward + loss + backward + the gradients gathered into ONE flat buffer and divided by
+            # the world size (DDP's default: divide, then SUM); the all-reduce of that buffer is launched eagerly between the
+            # replays (one large message: xGMI rings are per-link bound); graph B = Adam on views of the buffer.  The warm-up
+            # steps above ran WITHOUT any collective on every rank alike (they do not train), so no rank waits for another
+            # inside the capture.
+            params = [p for g in self.optimizer.param_groups for p in g["params"] if p.grad is not None]
+            sizes = [p.numel() for p in params]
+            self._flat = torch.empty(sum(sizes), dtype=params[0].dtype, device=params[0].device)
+            self.optimizer.zero_grad(set_to_none=True)
+            with torch.cuda.graph(graph):
+                loss = self._forward(x, lab)
+                self.scaler.scale(loss).backward()
+                torch.cat([p.grad.reshape(-1) for p in params], out=self._flat)
+                self._flat.div_(self._world)
+            for p, v in zip(params, self._flat.split(sizes)):
+                p.grad = v.view_as(p)
+            graph_b = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph_b):
+                self.optimizer.step()
+            self._graph = (graph, x, lab, loss, graph_b)
+        else:
+            self.optimizer.zero_grad(set_to_none=True)
+            with torch.cuda.graph(graph):
+                loss = self._forward(x, lab)
+                self.scaler.scale(loss).backward()
+                self.optimizer.step()
+            self._graph = (graph, x, lab, loss)
         # undo the warm-up: everything the steps above moved goes back to its snapshot, in place
         with torch.no_grad():
             for k, v in self.model.state_dict().items():
@@ -200,12 +249,16 @@ class Trainer:
         if self._want_graph and self._graph is None:
             self.capture(imgs, targets, warmup=3)
         if self._graph is not None and imgs.shape == self._graph[1].shape and targets.shape == self._graph[2].shape:
-            graph, x, lab, loss = self._graph
+            graph, x, lab, loss = self._graph[:4]
             if imgs.data_ptr() != x.data_ptr():  # (a producer that writes straight into input_buffers() skips this copy)
                 x.copy_(imgs, non_blocking=True)
             if targets.data_ptr() != lab.data_ptr():
                 lab.copy_(targets, non_blocking=True)
             graph.replay()
+            if self._flat_ddp:  # the one collective of the step, between the two graphs
+                import torch.distributed as tdist
+                tdist.all_reduce(self._flat)
+                self._graph[4].replay()
             # the replay moved the parameters without telling autograd: bump their version counters so that every cache
             # keyed on them (weight layouts, the folded inference engine) sees the change
             torch.autograd.graph.increment_version([p for g in self.optimizer.param_groups for p in g["params"]])

@@ -7,6 +7,7 @@ with a group of one -- and writes what it observed to the JSON file named on the
   * ``reduce_scatter_tensor`` / ``all_gather_into_tensor`` directly;
   * a DDP-wrapped ``Trainer.train_step`` (core/exp.py:391) with every communication hook: default, timed, rs_ag --
     losses and parameters after two steps must equal the bare (non-DDP) trainer's bit for bit at world 1;
+  * the same step as two HIP graphs around one all-reduce of the flat gradient buffer (``Trainer(ddp=True, graph=True)``);
   * ``encode_taf_stripe`` with its own collective (the MAX-reduce of the window-mask bits);
   * ``destroy_process_group``.
 """
@@ -55,11 +56,11 @@ def main(out_path):
         lab[:, 1] = torch.tensor([1, 100.0, 90.0 - seed, 30.0, 50.0])
         return x.cuda(), lab.cuda()
 
-    def trainer(ddp, hook):
+    def trainer(ddp, hook, graph=False):
         m = build_yolox(16, 2)
         m.load_state_dict(recipe_state_dict(m, seed=41))
         return Trainer(m.cuda(), global_batch=2, nodes=1, iters_per_epoch=4, max_epoch=10, warmup_epochs=0,
-                       local_rank=0, ddp=ddp, comm_hook=hook)
+                       local_rank=0, ddp=ddp, comm_hook=hook, graph=graph)
 
     batches = [inputs(s) for s in range(2)]
 
@@ -83,6 +84,18 @@ def main(out_path):
             entry["total_ms"] = s.get("total_ms", 0.0)
         res["hooks"][hook] = entry
         del tr
+
+    # the DDP step as two HIP graphs around ONE all-reduce of the flat gradient buffer (Trainer(ddp=True, graph=True)): the
+    # collective runs on RCCL between the replays; a third batch of another shape takes the eager form of the same exchange
+    tr = trainer(True, None, graph=True)
+    losses, params = run(tr)
+    odd = inputs(7, B=1)
+    bare = trainer(False, None)
+    run(bare)
+    res["graph2"] = {"losses": losses, "losses_equal": losses == base_losses, "params_equal": bool(torch.equal(params, base_params)),
+                     "two_graphs": tr._graph is not None and len(tr._graph) == 5, "wrapped": hasattr(tr.model, "module"),
+                     "odd_batch_loss_equal": tr.train_step(*odd, 2)[0] == bare.train_step(*odd, 2)[0]}
+    del tr, bare
 
     # ---- row-stripe encode: the window-mask reduce on RCCL (MAX over the mask bits)
     H, W, K, win, n_win = 240, 304, 8, 10_000, 8

@@ -91,6 +91,60 @@ def test_two_ddp_ranks_native_train_ops(tmp_path, hook):
     assert np.abs(g0 - want).max() <= 1e-3 * np.abs(want).max()
 
 
+def _trainer_worker(rank, world, port, out_dir, graph):
+    two_gpus = torch.cuda.device_count() >= world
+    dev = rank if two_gpus else 0
+    backend = "nccl" if two_gpus else "gloo"
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(dev), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), FRLW_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    from frlw_evd_amd import dist as fd
+    from frlw_evd_amd.trainer import Trainer
+    fd.init_from_env(backend)
+    torch.cuda.set_device(dev)
+    m = _build()
+    if rank == 1:  # the ranks build their models independently: rank 0's state must win
+        with torch.no_grad():
+            for p in m.parameters():
+                p.add_(0.01)
+    tr = Trainer(m, global_batch=2 * world, nodes=world, iters_per_epoch=4, max_epoch=10, warmup_epochs=0, local_rank=dev,
+                 ddp=True, graph=graph)
+    losses = []
+    for i in range(3):
+        x, lab = _inputs(rank + 10 * i)
+        losses.append(tr.train_step(x.cuda(), lab.cuda(), i)[0])
+    x, lab = _inputs(rank + 40, B=1)  # another shape: the eager form of the same step
+    losses.append(tr.train_step(x.cuda(), lab.cuda(), 3)[0])
+    torch.cuda.synchronize()
+    mod = tr.model.module if hasattr(tr.model, "module") else tr.model
+    if graph:
+        assert not hasattr(tr.model, "module") and tr._graph is not None and len(tr._graph) == 5
+    tag = "g" if graph else "e"
+    np.save(os.path.join(out_dir, f"p{tag}{rank}.npy"), torch.cat([p.detach().flatten().cpu() for p in mod.parameters()]).numpy())
+    np.save(os.path.join(out_dir, f"l{tag}{rank}.npy"), np.array(losses))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_graph_ddp_step_equals_the_eager_ddp_step(tmp_path):
+    """Trainer(ddp=True, graph=True) -- two HIP graphs around ONE all-reduce of a flat gradient buffer, no
+    DistributedDataParallel wrapper -- against the DistributedDataParallel trainer on the same two ranks and batches:
+    rank 0's initial state reaches rank 1, the ranks stay identical, and both forms land on the same parameters
+    (two addends commute: divide-then-SUM gives the same bits whatever the message layout)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    world = 2
+    for graph in (False, True):
+        mp.spawn(_trainer_worker, args=(world, _free_port(), str(tmp_path), graph), nprocs=world, join=True)
+    pe = [np.load(tmp_path / f"pe{r}.npy") for r in range(world)]
+    pg = [np.load(tmp_path / f"pg{r}.npy") for r in range(world)]
+    assert np.array_equal(pe[0], pe[1]) and np.array_equal(pg[0], pg[1])
+    for r in range(world):
+        le, lg = np.load(tmp_path / f"le{r}.npy"), np.load(tmp_path / f"lg{r}.npy")
+        assert np.allclose(le, lg, rtol=1e-6, atol=0), (r, le, lg)
+    assert np.abs(pe[0] - pg[0]).max() <= 1e-6 * np.abs(pe[0]).max()
+    fresh = torch.cat([p.detach().flatten().cpu() for p in _build().parameters()]).numpy()
+    assert np.abs(pg[0] - fresh).max() > 0  # it trained
+
+
 def _stripe_worker(rank, world, port, out_dir):
     two_gpus = torch.cuda.device_count() >= world
     dev = rank if two_gpus else 0

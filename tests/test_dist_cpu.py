@@ -103,9 +103,12 @@ def _ddp_worker(rank, world, port, out_dir, hook="default"):
     from test_detector_cpu import detector_input, train_labels
     m = build_yolox(10, 2)
     m.load_state_dict(recipe_state_dict(m, seed=1004 + rank))  # different init: DDP broadcasts rank 0's weights
-    tr = Trainer(m, global_batch=4, nodes=world, iters_per_epoch=10, ddp=True)   # per-GPU batch = 4 / 2
+    tr = Trainer(m, global_batch=4, nodes=world, iters_per_epoch=10, ddp="flat" if hook == "flat" else True)   # per-GPU batch = 4 / 2
     assert tr.per_gpu_batch == 2
-    assert tr.model.gradient_as_bucket_view and tr.model.static_graph  # dist.ddp_kwargs
+    if hook == "flat":  # no wrapper: rank 0's state broadcast by hand, one all-reduce of the flat gradient per step
+        assert tr.model is m and tr._flat_ddp and tr._world == world
+    else:
+        assert tr.model.gradient_as_bucket_view and tr.model.static_graph  # dist.ddp_kwargs
     x, lab = detector_input(1005, 4, H=128, W=160), train_labels()
     lab[..., 1:] *= 0.5  # boxes for the 128 x 160 input
     lo, hi = fd.shard_range(4, rank, world)
@@ -134,6 +137,12 @@ def test_ddp_train_step_two_ranks(tmp_path):
     h0, h1 = (np.load(tmp_path / f"d{i}_rs_ag.npy") for i in range(world))
     assert h0[2] == h1[2] and h0[3] == h1[3]
     assert np.allclose(h0, d0, rtol=1e-6, atol=0) and np.allclose(h1, d1, rtol=1e-6, atol=0)
+    # the wrapper-free exchange of the two-graph DDP step (Trainer(ddp="flat"): broadcast_module_state + one all-reduce of the
+    # flat gradient buffer; the GPU captures the halves around it as HIP graphs): the same trajectory again
+    mp.spawn(_ddp_worker, args=(world, _free_port(), str(tmp_path), "flat"), nprocs=world, join=True)
+    f0, f1 = (np.load(tmp_path / f"d{i}_flat.npy") for i in range(world))
+    assert f0[2] == f1[2] and f0[3] == f1[3] and f0[4] != f1[4]
+    assert np.allclose(f0, d0, rtol=1e-6, atol=0) and np.allclose(f1, d1, rtol=1e-6, atol=0)
 
 
 # ---- bench.py --gpus N is its own launcher (the flag used to be dead) --------------------------------

@@ -47,6 +47,8 @@ def test_every_collective_on_rccl_world_1(tmp_path):
         assert h["losses_equal"], (hook, h["losses"], res["losses_bare"])   # world 1: sum / 1 -- bit for bit
         assert h["params_equal"], hook
     assert res["hooks"]["timed"]["buckets"] >= 1 and res["hooks"]["timed"]["total_ms"] > 0
+    g2 = res["graph2"]  # two HIP graphs around one RCCL all-reduce, no DistributedDataParallel wrapper
+    assert g2["two_graphs"] and not g2["wrapped"] and g2["losses_equal"] and g2["params_equal"] and g2["odd_batch_loss_equal"], g2
     assert res["stripe_equals_whole"] and res["mask_reduce_identity"]
     assert res["destroyed"]
     assert any("rccl" in lib.lower() for lib in res["libs"]), res["libs"]       # the collectives ran in librccl
