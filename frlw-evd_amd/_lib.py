@@ -50,6 +50,16 @@ class FrlwTuning(C.Structure):
             raise TypeError(f"unknown tuning fields {sorted(kw)}")
 
 
+class FrlwBaseconvFuse(C.Structure):
+    """frlw_baseconv_fuse_t: what the blocks around a training-mode BaseConv fold into its launches (residual added to y, y
+    written into a channel slice, another consumer's gradient added to dx)."""
+    _fields_ = [("struct_size", C.c_int32), ("reserved", C.c_int32), ("residual", C.c_void_p), ("residual_row_stride", C.c_int64),
+                ("y_row_stride", C.c_int64), ("dx_add", C.c_void_p), ("dx_add_row_stride", C.c_int64)]
+
+    def __init__(self, residual=None, residual_row_stride=0, y_row_stride=0, dx_add=None, dx_add_row_stride=0):
+        super().__init__(C.sizeof(type(self)), 0, residual, int(residual_row_stride), int(y_row_stride), dx_add, int(dx_add_row_stride))
+
+
 class FrlwEvents(C.Structure):
     _fields_ = [("data", C.c_void_p), ("n", C.c_int64), ("layout", C.c_int32),
                 ("row_stride", C.c_int32), ("xmap", C.c_void_p), ("ymap", C.c_void_p),
@@ -127,9 +137,9 @@ SYMBOLS = {
     "frlw_baseconv_weight_cache_floats": (_I64, [_I, _I, _I, _I]),
     "frlw_baseconv_train_scratch_bytes": (_I64, [_I, _I, _I, _I, _I, _I, _I]),
     "frlw_baseconv_train_fwd": (_I, [_P, _P, _P, _P, C.c_float, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P,
-                                    C.c_float, _P, _P, _P, _I64, _P, _I, _P]),
+                                    C.c_float, _P, _P, _P, _I64, _P, _P, _I, _P]),
     "frlw_baseconv_train_bwd": (_I, [_P, _I64, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P,
-                                    _P, _I64, _P, _I, _P]),
+                                    _P, _I64, _P, _P, _I, _P]),
     "frlw_spp_train_fwd": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
     "frlw_spp_train_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
     "frlw_pred_bwd_scratch_floats": (_I64, [_I64, _I, _I]),

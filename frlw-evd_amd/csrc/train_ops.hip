@@ -356,9 +356,11 @@ __global__ __launch_bounds__(256) void k_bn_stats_final(const double *partial, i
 __device__ __forceinline__ float sigmoid_fast(float u) { return __frcp_rn(1.0f + __expf(-u)); }
 __device__ __forceinline__ float silu_f(float u) { return u * sigmoid_fast(u); }
 
-// y = silu(gamma * (z - mean) * invstd + beta)
+// y = silu(gamma * (z - mean) * invstd + beta) [+ res]
+// FUSE: the rows of y and res may be channel slices of wider NHWC tensors (y_rs / res_rs floats between two rows), res may be NULL
+template <bool FUSE>
 __global__ void k_bn_silu_fwd(const float *z, long long n4, int C, const float *gamma, const float *beta, const float *mean,
-                              const float *invstd, float *y)
+                              const float *invstd, float *y, long long y_rs, const float *res, long long res_rs)
 {
     const int C4 = C >> 2;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
@@ -369,7 +371,16 @@ __global__ void k_bn_silu_fwd(const float *z, long long n4, int C, const float *
         o.y = silu_f(gamma[c + 1] * ((v.y - mean[c + 1]) * invstd[c + 1]) + beta[c + 1]);
         o.z = silu_f(gamma[c + 2] * ((v.z - mean[c + 2]) * invstd[c + 2]) + beta[c + 2]);
         o.w = silu_f(gamma[c + 3] * ((v.w - mean[c + 3]) * invstd[c + 3]) + beta[c + 3]);
-        ((float4 *)y)[i] = o;
+        if (FUSE) {
+            const long long r = i / C4;
+            if (res) {
+                const float4 rr = *(const float4 *)(res + r * res_rs + c);
+                o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
+            }
+            *(float4 *)(y + r * y_rs + c) = o;
+        } else {
+            ((float4 *)y)[i] = o;
+        }
     }
 }
 
@@ -484,7 +495,8 @@ int frlw_conv_weight_layouts_batch(const frlw_weight_layout_item_t *items, int n
 
 static int conv_common(const float *x, int B, int H, int W, int Cin, const float *w_gemm, int Cout, int k, int stride,
                        int tstride, int Ho, int Wo, float *y, float *scratch, int64_t scratch_floats, int precision, hipStream_t s,
-                       double *stats = nullptr, int *stats_rows = nullptr, int *sk_counters = nullptr)
+                       double *stats = nullptr, int *stats_rows = nullptr, int *sk_counters = nullptr, const float *res = nullptr,
+                       long long res_rs = 0)
 {
     if (precision != 0 && precision != 1) return FRLW_ERR_ARG;
     (void)hipGetLastError(); // other libraries in the process (torch's BLAS look-ups) leave stale errors behind
@@ -493,7 +505,8 @@ static int conv_common(const float *x, int B, int H, int W, int Cin, const float
     c.x = x; c.H = H; c.W = W; c.Cin = Cin; c.x_cs = Cin; c.x_co = 0; c.x_bs = (long long)H * W * Cin;
     c.w = w_gemm; c.bias = nullptr; c.Cout = Cout; c.Npad = npad32(Cout); c.k = k; c.stride = stride; c.pad = (k - 1) / 2;
     c.y = y; c.Ho = Ho; c.Wo = Wo; c.y_cs = Cout; c.y_co = 0; c.y_bs = (long long)Ho * Wo * Cout;
-    c.res = nullptr; c.act = ACT_NONE; c.sig_from = 0;
+    c.res = res; c.r_cs = (int)(res_rs > 0 ? res_rs : Cout); c.r_co = 0; c.r_bs = (long long)Ho * Wo * c.r_cs;
+    c.act = ACT_NONE; c.sig_from = 0;
     c.M = B * Ho * Wo; c.K = k * k * Cin;
     c.tstride = tstride;
     c.prec = precision;
@@ -515,9 +528,12 @@ int frlw_conv2d_fwd(const float *x, int B, int H, int W, int Cin, const float *w
 
 static int conv2d_dgrad_impl(const float *dz, int B, int Ho, int Wo, int Cout, const float *w_dgrad, int Cin, int k, int stride,
                              int H, int W, float *dx, float *scratch, int64_t scratch_floats, int precision, frlw_stream_t stream,
-                             int *sk_counters)
+                             int *sk_counters, const float *dx_add = nullptr, int64_t dx_add_rs = 0)
 {
     if (precision != 0 && precision != 1) return FRLW_ERR_ARG;
+    // dx_add: dx = data gradient + dx_add in the epilogue (the gradient a second consumer of x has produced already; rows of
+    // dx_add_rs floats).  Stride-1 layers only: the parity classes of a stride-2 layer write interleaved rows.
+    if (dx_add && (stride != 1 || (dx_add_rs > 0 && (dx_add_rs < Cin || (dx_add_rs & 3))) || ((uintptr_t)dx_add & 15))) return FRLW_ERR_UNSUPPORTED;
     // dx[iy][ix][ci] = sum dz[(iy + pad - ky) / s][(ix + pad - kx) / s][co] * w[co][ci][ky][kx]: a stride-1 convolution of
     // dz (transposed gather for s = 2) with the flipped operand and padding k - 1 - pad = pad (odd k)
     if (stride != 1 && stride != 2) return FRLW_ERR_UNSUPPORTED;
@@ -547,7 +563,7 @@ static int conv2d_dgrad_impl(const float *dz, int B, int Ho, int Wo, int Cout, c
         return FRLW_OK;
     }
     return conv_common(dz, B, Ho, Wo, Cout, w_dgrad, Cin, k, 1, stride == 2 ? 2 : 0, H, W, dx, scratch, scratch_floats,
-                       precision, (hipStream_t)stream, nullptr, nullptr, sk_counters);
+                       precision, (hipStream_t)stream, nullptr, nullptr, sk_counters, dx_add, dx_add_rs);
 }
 
 int frlw_conv2d_dgrad(const float *dz, int B, int Ho, int Wo, int Cout, const float *w_dgrad, int Cin, int k, int stride,
@@ -646,16 +662,29 @@ static int bn_stats_impl(const float *z, int64_t M, int C, float eps, float *mea
     return FRLW_OK;
 }
 
-int frlw_bn_silu_fwd(const float *z, int64_t M, int C, const float *gamma, const float *beta, const float *mean,
-                     const float *invstd, float *y, frlw_stream_t stream)
+static int bn_silu_fwd_impl(const float *z, int64_t M, int C, const float *gamma, const float *beta, const float *mean,
+                            const float *invstd, float *y, int64_t y_rs, const float *res, int64_t res_rs, frlw_stream_t stream)
 {
     (void)hipGetLastError(); // other libraries in the process (torch's BLAS look-ups) leave stale errors behind
     if (!z || !y || !gamma || !beta || !mean || !invstd || M < 1 || C < 4 || (C & 3)) return FRLW_ERR_ARG;
+    if (y_rs <= 0) y_rs = C;
+    if (res_rs <= 0) res_rs = C;
+    if (y_rs < C || (y_rs & 3) || ((uintptr_t)y & 15) || (res && (res_rs < C || (res_rs & 3) || ((uintptr_t)res & 15)))) return FRLW_ERR_ARG;
     const long long n4 = (long long)M * C / 4;
-    hipLaunchKernelGGL(k_bn_silu_fwd, dim3(conv_grid_1d(n4)), dim3(256), 0, (hipStream_t)stream, z, n4, C, gamma, beta, mean,
-                       invstd, y);
+    if (res || y_rs != C)
+        hipLaunchKernelGGL(k_bn_silu_fwd<true>, dim3(conv_grid_1d(n4)), dim3(256), 0, (hipStream_t)stream, z, n4, C, gamma, beta, mean,
+                           invstd, y, (long long)y_rs, res, (long long)res_rs);
+    else
+        hipLaunchKernelGGL(k_bn_silu_fwd<false>, dim3(conv_grid_1d(n4)), dim3(256), 0, (hipStream_t)stream, z, n4, C, gamma, beta, mean,
+                           invstd, y, (long long)C, (const float *)nullptr, (long long)C);
     TRY_HIP(hipGetLastError());
     return FRLW_OK;
+}
+
+int frlw_bn_silu_fwd(const float *z, int64_t M, int C, const float *gamma, const float *beta, const float *mean,
+                     const float *invstd, float *y, frlw_stream_t stream)
+{
+    return bn_silu_fwd_impl(z, M, C, gamma, beta, mean, invstd, y, 0, nullptr, 0, stream);
 }
 
 int frlw_bn_silu_bwd(const float *dy, int64_t dy_row_stride, const float *z, int64_t M, int C, const float *gamma, const float *beta,
@@ -725,9 +754,10 @@ int frlw_baseconv_train_fwd(const float *x, const float *w, const float *gamma, 
                             int W, int Cin, int Cout, int k, int stride, float *z, float *y, float *mean, float *var,
                             float *invstd, float *running_mean, float *running_var, float momentum,
                             int64_t *num_batches_tracked, float *w_cache, void *scratch, int64_t scratch_bytes,
-                            int *splitk_counters, int precision, frlw_stream_t stream)
+                            int *splitk_counters, const frlw_baseconv_fuse_t *fuse, int precision, frlw_stream_t stream)
 {
     if (!x || (!w && !w_cache) || !gamma || !beta || !z || !y || !mean || !var || !invstd || !scratch) return FRLW_ERR_ARG;
+    if (fuse && fuse->struct_size != (int32_t)sizeof(frlw_baseconv_fuse_t)) return FRLW_ERR_ARG;
     if (scratch_bytes < frlw_baseconv_train_scratch_bytes(B, H, W, Cin, Cout, k, stride)) return FRLW_ERR_WORKSPACE;
     const int pad = (k - 1) / 2;
     const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
@@ -748,18 +778,21 @@ int frlw_baseconv_train_fwd(const float *x, const float *w, const float *gamma, 
                           t.red, &stat_rows, splitk_counters)) != FRLW_OK) return rc;
     if ((rc = bn_stats_impl(z, M, Cout, eps, mean, var, invstd, t.red, running_mean, running_mean ? running_var : nullptr,
                             momentum, (long long *)num_batches_tracked, stream, stat_rows)) != FRLW_OK) return rc;
-    return frlw_bn_silu_fwd(z, M, Cout, gamma, beta, mean, invstd, y, stream);
+    return bn_silu_fwd_impl(z, M, Cout, gamma, beta, mean, invstd, y, fuse ? fuse->y_row_stride : 0, fuse ? fuse->residual : nullptr,
+                            fuse ? fuse->residual_row_stride : 0, stream);
 }
 
 /* Gradients of the block: dx (NULL: not needed), dw (Cout, Cin, k, k), dgamma, dbeta.  dz: (B, Ho, Wo, Cout) work buffer. */
 int frlw_baseconv_train_bwd(const float *dy, int64_t dy_row_stride, const float *x, const float *z, const float *w, const float *gamma,
                             const float *beta, const float *mean, const float *invstd, int B, int H, int W, int Cin,
                             int Cout, int k, int stride, float *dz, float *dx, float *dw, float *dgamma, float *dbeta,
-                            const float *w_cache, void *scratch, int64_t scratch_bytes, int *splitk_counters, int precision,
-                            frlw_stream_t stream)
+                            const float *w_cache, void *scratch, int64_t scratch_bytes, int *splitk_counters,
+                            const frlw_baseconv_fuse_t *fuse, int precision, frlw_stream_t stream)
 {
     if (!dy || !x || !z || !w || !gamma || !beta || !mean || !invstd || !dz || !dw || !dgamma || !dbeta || !scratch)
         return FRLW_ERR_ARG;
+    if (fuse && fuse->struct_size != (int32_t)sizeof(frlw_baseconv_fuse_t)) return FRLW_ERR_ARG;
+    if (fuse && fuse->dx_add && (!dx || stride != 1)) return FRLW_ERR_UNSUPPORTED;
     if (scratch_bytes < frlw_baseconv_train_scratch_bytes(B, H, W, Cin, Cout, k, stride)) return FRLW_ERR_WORKSPACE;
     const int pad = (k - 1) / 2;
     const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
@@ -771,7 +804,8 @@ int frlw_baseconv_train_bwd(const float *dy, int64_t dy_row_stride, const float 
         const float *w_dg = t.w_dg;
         if (w_cache) w_dg = w_cache + frlw_conv_operand_floats(k * k * Cin, Cout, precision); // laid out by the forward of this step
         else if ((rc = frlw_conv_weight_layouts(w, Cout, Cin, k, frlw_conv2d_dgrad_parity(k, stride, H, W), nullptr, t.w_dg, precision, stream)) != FRLW_OK) return rc;
-        if ((rc = conv2d_dgrad_impl(dz, B, Ho, Wo, Cout, w_dg, Cin, k, stride, H, W, dx, t.splitk, t.splitk_floats, precision, stream, splitk_counters)) != FRLW_OK) return rc;
+        if ((rc = conv2d_dgrad_impl(dz, B, Ho, Wo, Cout, w_dg, Cin, k, stride, H, W, dx, t.splitk, t.splitk_floats, precision, stream, splitk_counters,
+                                    fuse ? fuse->dx_add : nullptr, fuse ? fuse->dx_add_row_stride : 0)) != FRLW_OK) return rc;
     }
     return frlw_conv2d_wgrad(x, B, H, W, Cin, dz, Ho, Wo, Cout, k, stride, dw, t.wgrad, t.wgrad_floats, precision, stream);
 }

@@ -37,13 +37,15 @@ class BaseConv(nn.Module):
         self.bn = nn.BatchNorm2d(out_channels)
         self.act = get_activation(act, inplace=True)
 
-    def forward(self, x):
+    def forward(self, x, into=None):
         if self.training and x.is_cuda:
             # train step on the GPU: forward, data / weight gradients and BatchNorm + SiLU run in the gfx950 kernels of
             # csrc/train_ops.hip (FRLW_NATIVE_TRAIN=0: torch autograd / MIOpen, for A/B timing)
             from . import train_ops
             if train_ops.eligible(x, self.conv, self.bn, self.act):
-                return train_ops.base_conv_train(x, self.conv, self.bn)
+                return train_ops.base_conv_train(x, self.conv, self.bn, into=into)
+        if into is not None:  # (callers ask train_ops.csp_join_eligible first)
+            raise RuntimeError("BaseConv: a destination slice needs the native training path")
         return self.act(self.bn(self.conv(x)))
 
 
@@ -59,8 +61,14 @@ class Bottleneck(nn.Module):
         self.conv2 = BaseConv(hidden, out_channels, 3, stride=1, act=act)
         self.use_add = shortcut and in_channels == out_channels
 
-    def forward(self, x):
-        y = self.conv2(self.conv1(x))
+    def forward(self, x, into=None):
+        if self.use_add and self.training and x.is_cuda:
+            from . import train_ops
+            if train_ops.bottleneck_eligible(x, self.conv1, self.conv2):  # shortcut and its gradient inside the blocks' launches
+                return train_ops.bottleneck_train(x, self.conv1, self.conv2, into=into)
+        if into is not None and self.use_add:
+            raise RuntimeError("Bottleneck: a destination slice needs the native training path")
+        y = self.conv2(self.conv1(x), into=into) if into is not None else self.conv2(self.conv1(x))
         return y + x if self.use_add else y
 
 
@@ -96,6 +104,21 @@ class CSPLayer(nn.Module):
         self.m = nn.Sequential(*[Bottleneck(hidden, hidden, shortcut, 1.0, depthwise, act=act) for _ in range(n)])
 
     def forward(self, x):
+        if self.training and x.is_cuda:
+            from . import train_ops
+            if train_ops.csp_join_eligible(x, self):
+                # conv1 | conv2 as one autograd node (dx of the two branches summed in an epilogue); conv2 and the last Bottleneck
+                # write their activations straight into the two halves of the buffer conv3 reads: no concatenation launch
+                hidden = self.conv1.conv.out_channels
+                buf = torch.empty((x.shape[0], 2 * hidden, x.shape[2], x.shape[3]), dtype=torch.float32, device=x.device,
+                                  memory_format=torch.channels_last)
+                x_1, x_2 = train_ops.pair_train(x, self.conv1, self.conv2, into_b=buf[:, hidden:])
+                for i, blk in enumerate(self.m):
+                    x_1 = blk(x_1, into=buf[:, :hidden] if i == len(self.m) - 1 else None)
+                return self.conv3(train_ops.join_slices(buf, x_1, x_2))
+            if train_ops.pair_eligible(x, self.conv1, self.conv2):  # one autograd node: dx of the two branches summed in an epilogue
+                x_1, x_2 = train_ops.pair_train(x, self.conv1, self.conv2)
+                return self.conv3(torch.cat((self.m(x_1), x_2), dim=1))
         return self.conv3(torch.cat((self.m(self.conv1(x)), self.conv2(x)), dim=1))
 
 

@@ -177,78 +177,200 @@ def native_enabled():
     return os.environ.get("FRLW_NATIVE_TRAIN", "1") != "0"
 
 
+class _Rec:
+    """What one BaseConv forward leaves for its backward beside the saved tensors (x, z, w, gamma, beta, stats)."""
+    __slots__ = ("geom", "wcache", "wparity", "wversion", "weight_ref")
+
+
+def _fwd_one(x, weight, gamma, beta, stride, eps, run_mean, run_var, momentum, tracked, residual=None, out=None):
+    """One frlw_baseconv_train_fwd call: (y, tensors to save, _Rec).  ``x``: float32 NHWC storage.  ``residual``: added to y in
+    the pass that writes it; ``out``: a (B, Cout, Ho, Wo) channel slice of a wider channels_last tensor y is written into."""
+    lib = _lib.load()
+    dev = x.device
+    B, Cin, H, W = x.shape
+    Cout, _, k, _ = weight.shape
+    pad = (k - 1) // 2
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    w = weight.detach().float().contiguous()
+    g = gamma.detach().float().contiguous()
+    b = beta.detach().float().contiguous()
+    z = torch.empty((B, Cout, Ho, Wo), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
+    fuse = None
+    if residual is not None or out is not None:
+        res, res_rs = (None, 0) if residual is None else _rows_in_place(residual)
+        y_rs = 0
+        if out is not None:
+            assert out.shape == z.shape and out.dtype == torch.float32 and out.stride()[1] == 1 and out.data_ptr() % 16 == 0
+            y_rs = out.stride()[3]
+        fuse = _lib.FrlwBaseconvFuse(residual=None if res is None else res.data_ptr(), residual_row_stride=res_rs, y_row_stride=y_rs)
+    y = out if out is not None else torch.empty_like(z)
+    stats = torch.empty((3, Cout), dtype=torch.float32, device=dev)  # mean, biased variance, invstd
+    sc = _scratch(dev, "block", lib.frlw_baseconv_train_scratch_bytes(B, H, W, Cin, Cout, k, stride), torch.uint8)
+    wc = _weight_cache(lib, weight, Cin, Cout, k)  # both GEMM operands of this weight, laid out once per step
+    parity = int(lib.frlw_conv2d_dgrad_parity(k, stride, H, W))
+    prec = layer_precision(Cout, k, stride)
+    # laid out already by layout_all_weights() for exactly this weight version, parity class, precision and buffer?
+    ready = _WREADY.get(id(weight)) == (weight._version, (parity, prec), wc.data_ptr()) and w.data_ptr() == weight.data_ptr()
+    _lib.check(lib.frlw_baseconv_train_fwd(x.data_ptr(), None if ready else w.data_ptr(), g.data_ptr(), b.data_ptr(), C.c_float(eps), B, H, W,
+                                           Cin, Cout, k, stride, z.data_ptr(), y.data_ptr(), stats[0].data_ptr(),
+                                           stats[1].data_ptr(), stats[2].data_ptr(),
+                                           run_mean.data_ptr() if run_mean is not None else None,
+                                           run_var.data_ptr() if run_var is not None else None, C.c_float(momentum),
+                                           tracked.data_ptr() if tracked is not None else None,
+                                           wc.data_ptr(), sc.data_ptr(), sc.numel(), _sk_counters(dev).data_ptr(),
+                                           C.byref(fuse) if fuse is not None else None, prec, _stream(dev)), "baseconv_train_fwd")
+    rec = _Rec()
+    rec.wcache = wc
+    # the data-gradient half of the cache depends on the parity class of (k, stride, H, W): a second forward of the same
+    # layer on an input of another parity (shared layer, multi-scale graph) re-lays it -- remember what THIS forward wrote
+    rec.wparity = (parity, prec)
+    _WCACHE_GEOM[id(weight)] = (weight._version, parity, prec)
+    rec.wversion = weight._version
+    rec.weight_ref = weight
+    rec.geom = (B, Cin, H, W, Cout, k, stride)
+    return y, (x, z, w, g, b, stats), rec
+
+
+def _bwd_one(rec, saved, dy, need_dx, dx_add=None):
+    """One frlw_baseconv_train_bwd call: (dx or None, dw, dgamma, dbeta).  ``dx_add``: the gradient another consumer of the same
+    input has produced already, added to dx in the data gradient's epilogue (stride-1 layers)."""
+    lib = _lib.load()
+    x, z, w, g, b, stats = saved
+    B, Cin, H, W, Cout, k, stride = rec.geom
+    dev = dy.device
+    dy, dy_rs = _rows_in_place(dy.float())
+    dz = torch.empty_like(z)
+    dx = (torch.empty((B, Cin, H, W), dtype=torch.float32, device=dev, memory_format=torch.channels_last) if need_dx else None)
+    dw = torch.empty((Cout, Cin, k, k), dtype=torch.float32, device=dev)
+    dgb = torch.empty((2, Cout), dtype=torch.float32, device=dev)
+    fuse = None
+    if dx_add is not None and dx is not None:
+        add, add_rs = _rows_in_place(dx_add.float())
+        fuse = _lib.FrlwBaseconvFuse(dx_add=add.data_ptr(), dx_add_row_stride=add_rs)
+    sc = _scratch(dev, "block", lib.frlw_baseconv_train_scratch_bytes(B, H, W, Cin, Cout, k, stride), torch.uint8)
+    # the operand cache belongs to the forward of THIS graph only while the weight (and the cache) are untouched
+    # since: a second forward of the same layer before this backward would have overwritten it with the same
+    # weights' layout (fine), an in-place weight update in between would not (then lay out again)
+    fresh = (rec.weight_ref._version == rec.wversion and _WCACHE.get(id(rec.weight_ref), (None, None))[1] is rec.wcache
+             and _WCACHE_GEOM.get(id(rec.weight_ref)) == (rec.wversion, *rec.wparity))
+    _lib.check(lib.frlw_baseconv_train_bwd(dy.data_ptr(), dy_rs, x.data_ptr(), z.data_ptr(), w.data_ptr(), g.data_ptr(),
+                                           b.data_ptr(), stats[0].data_ptr(), stats[2].data_ptr(), B, H, W, Cin, Cout, k,
+                                           stride, dz.data_ptr(), dx.data_ptr() if dx is not None else None,
+                                           dw.data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(),
+                                           rec.wcache.data_ptr() if fresh else None, sc.data_ptr(),
+                                           sc.numel(), _sk_counters(dev).data_ptr(), C.byref(fuse) if fuse is not None else None,
+                                           rec.wparity[1], _stream(dev)), "baseconv_train_bwd")
+    return dx, dw, dgb[0], dgb[1]
+
+
+class _Into:
+    """A destination slice handed to an autograd Function without autograd seeing it as an input: the (B, C, H, W) channel slice
+    of a wider channels_last buffer a block writes its activation into (the concatenation buffer of a CSPLayer)."""
+    __slots__ = ("t",)
+
+    def __init__(self, t):
+        # an ALIAS of the slice (same storage, offset, shape, strides), not a view: the tensor a Function returns must not be an
+        # autograd view of a buffer that other Functions write other slices of (autograd's view + in-place logic would take over)
+        self.t = torch.empty(0, dtype=t.dtype, device=t.device).set_(t.untyped_storage(), t.storage_offset(), t.shape, t.stride())
+
+
 class _BaseConvTrain(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, stride, eps, run_mean, run_var, momentum, tracked=None):
+    def forward(ctx, x, weight, gamma, beta, stride, eps, run_mean, run_var, momentum, tracked=None, into=None):
         ctx.set_materialize_grads(False)
-        lib = _lib.load()
-        dev = x.device
-        x = _nhwc(x.float())
-        B, Cin, H, W = x.shape
-        Cout, _, k, _ = weight.shape
-        pad = (k - 1) // 2
-        Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
-        w = weight.detach().float().contiguous()
-        g = gamma.detach().float().contiguous()
-        b = beta.detach().float().contiguous()
-        z = torch.empty((B, Cout, Ho, Wo), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
-        y = torch.empty_like(z)
-        stats = torch.empty((3, Cout), dtype=torch.float32, device=dev)  # mean, biased variance, invstd
-        sc = _scratch(dev, "block", lib.frlw_baseconv_train_scratch_bytes(B, H, W, Cin, Cout, k, stride), torch.uint8)
-        wc = _weight_cache(lib, weight, Cin, Cout, k)  # both GEMM operands of this weight, laid out once per step
-        parity = int(lib.frlw_conv2d_dgrad_parity(k, stride, H, W))
-        prec = layer_precision(Cout, k, stride)
-        # laid out already by layout_all_weights() for exactly this weight version, parity class, precision and buffer?
-        ready = _WREADY.get(id(weight)) == (weight._version, (parity, prec), wc.data_ptr()) and w.data_ptr() == weight.data_ptr()
-        _lib.check(lib.frlw_baseconv_train_fwd(x.data_ptr(), None if ready else w.data_ptr(), g.data_ptr(), b.data_ptr(), C.c_float(eps), B, H, W,
-                                               Cin, Cout, k, stride, z.data_ptr(), y.data_ptr(), stats[0].data_ptr(),
-                                               stats[1].data_ptr(), stats[2].data_ptr(),
-                                               run_mean.data_ptr() if run_mean is not None else None,
-                                               run_var.data_ptr() if run_var is not None else None, C.c_float(momentum),
-                                               tracked.data_ptr() if tracked is not None else None,
-                                               wc.data_ptr(), sc.data_ptr(), sc.numel(), _sk_counters(dev).data_ptr(), prec,
-                                               _stream(dev)), "baseconv_train_fwd")
-        ctx.wcache = wc
-        # the data-gradient half of the cache depends on the parity class of (k, stride, H, W): a second forward of the same
-        # layer on an input of another parity (shared layer, multi-scale graph) re-lays it -- remember what THIS forward wrote
-        ctx.wparity = (parity, prec)
-        _WCACHE_GEOM[id(weight)] = (weight._version, parity, prec)
-        ctx.wversion = weight._version
-        ctx.weight_ref = weight
-        ctx.save_for_backward(x, z, w, g, b, stats)
-        ctx.geom = (B, Cin, H, W, Cout, k, stride)
+        y, saved, ctx.rec = _fwd_one(_nhwc(x.float()), weight, gamma, beta, stride, eps, run_mean, run_var, momentum, tracked,
+                                     out=into.t if into is not None else None)
+        ctx.save_for_backward(*saved)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        lib = _lib.load()
-        x, z, w, g, b, stats = ctx.saved_tensors
-        B, Cin, H, W, Cout, k, stride = ctx.geom
-        dev = dy.device
-        dy, dy_rs = _rows_in_place(dy.float())
-        dz = torch.empty_like(z)
-        dx = (torch.empty((B, Cin, H, W), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
-              if ctx.needs_input_grad[0] else None)
-        dw = torch.empty((Cout, Cin, k, k), dtype=torch.float32, device=dev)
-        dgb = torch.empty((2, Cout), dtype=torch.float32, device=dev)
-        sc = _scratch(dev, "block", lib.frlw_baseconv_train_scratch_bytes(B, H, W, Cin, Cout, k, stride), torch.uint8)
-        # the operand cache belongs to the forward of THIS graph only while the weight (and the cache) are untouched
-        # since: a second forward of the same layer before this backward would have overwritten it with the same
-        # weights' layout (fine), an in-place weight update in between would not (then lay out again)
-        fresh = (ctx.weight_ref._version == ctx.wversion and _WCACHE.get(id(ctx.weight_ref), (None, None))[1] is ctx.wcache
-                 and _WCACHE_GEOM.get(id(ctx.weight_ref)) == (ctx.wversion, *ctx.wparity))
-        _lib.check(lib.frlw_baseconv_train_bwd(dy.data_ptr(), dy_rs, x.data_ptr(), z.data_ptr(), w.data_ptr(), g.data_ptr(),
-                                               b.data_ptr(), stats[0].data_ptr(), stats[2].data_ptr(), B, H, W, Cin, Cout, k,
-                                               stride, dz.data_ptr(), dx.data_ptr() if dx is not None else None,
-                                               dw.data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(),
-                                               ctx.wcache.data_ptr() if fresh else None, sc.data_ptr(),
-                                               sc.numel(), _sk_counters(dev).data_ptr(), ctx.wparity[1], _stream(dev)), "baseconv_train_bwd")
-        return dx, dw, dgb[0], dgb[1], None, None, None, None, None, None
+        dx, dw, dg, db = _bwd_one(ctx.rec, ctx.saved_tensors, dy, ctx.needs_input_grad[0])
+        return dx, dw, dg, db, None, None, None, None, None, None, None
 
 
-def base_conv_train(x, conv, bn):
-    """silu(bn(conv(x))) with batch statistics; the running statistics are updated in the same launch sequence like
-    nn.BatchNorm2d.forward does (momentum, unbiased variance, num_batches_tracked)."""
+class _JoinSlices(torch.autograd.Function):
+    """The concatenation that never ran: ``parts`` are channel slices of ``whole`` (in order, together all of it), written there by
+    the blocks that produced them; forward hands out the buffer, backward hands every producer its slice of the gradient (read
+    in place by the blocks' backward kernels, like the slices torch.cat's backward makes)."""
+
+    @staticmethod
+    def forward(ctx, whole, *parts):
+        w = whole.t
+        lo = 0
+        for p in parts:
+            assert p.data_ptr() == w.data_ptr() + 4 * lo and p.stride() == w.stride() and p.shape[0] == w.shape[0] and p.shape[2:] == w.shape[2:]
+            lo += p.shape[1]
+        assert lo == w.shape[1]
+        ctx.widths = [p.shape[1] for p in parts]
+        return w
+
+    @staticmethod
+    def backward(ctx, g):
+        out, lo = [], 0
+        for wd in ctx.widths:
+            out.append(g[:, lo:lo + wd] if g is not None else None)
+            lo += wd
+        return (None, *out)
+
+
+def join_slices(whole, *parts):
+    return _JoinSlices.apply(_Into(whole), *parts)
+
+
+class _BottleneckTrain(torch.autograd.Function):
+    """conv2(conv1(x)) + x of a Bottleneck with shortcut (network_blocks.py:89-111) as one autograd node: the shortcut is added
+    by the pass that writes conv2's activation, and its gradient by the epilogue of conv1's data gradient -- the two
+    elementwise launches autograd would make (forward add, gradient accumulation) are gone; same additions, same bits."""
+
+    @staticmethod
+    def forward(ctx, x, w1, g1, b1, w2, g2, b2, cfg1, cfg2, into=None):
+        ctx.set_materialize_grads(False)
+        x = _nhwc(x.float())
+        h, s1, ctx.rec1 = _fwd_one(x, w1, g1, b1, 1, *cfg1)
+        y, s2, ctx.rec2 = _fwd_one(h, w2, g2, b2, 1, *cfg2, residual=x, out=into.t if into is not None else None)
+        ctx.save_for_backward(*s1, *s2)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if dy is None:
+            return (None,) * 10
+        t = ctx.saved_tensors
+        dh, dw2, dg2, db2 = _bwd_one(ctx.rec2, t[6:], dy, True)
+        dx, dw1, dg1, db1 = _bwd_one(ctx.rec1, t[:6], dh, True, dx_add=dy)
+        return dx, dw1, dg1, db1, dw2, dg2, db2, None, None, None
+
+
+class _PairTrain(torch.autograd.Function):
+    """Two BaseConvs reading the same x (conv1 | conv2 of a CSPLayer, network_blocks.py:191-193; the first cls / reg convolution
+    of a head level, yolo_head.py:160-164) as one autograd node: the second data gradient adds the first in its epilogue
+    instead of autograd launching the accumulation."""
+
+    @staticmethod
+    def forward(ctx, x, wa, ga, ba, wb, gb, bb, stride, cfga, cfgb, into_b=None):
+        ctx.set_materialize_grads(False)
+        x = _nhwc(x.float())
+        ya, sa, ctx.reca = _fwd_one(x, wa, ga, ba, stride, *cfga)
+        yb, sb, ctx.recb = _fwd_one(x, wb, gb, bb, stride, *cfgb, out=into_b.t if into_b is not None else None)
+        ctx.save_for_backward(*sa, *sb)
+        return ya, yb
+
+    @staticmethod
+    def backward(ctx, dya, dyb):
+        t = ctx.saved_tensors
+        need = ctx.needs_input_grad[0]
+        dx, ga, gb = None, (None, None, None), (None, None, None)
+        if dyb is not None:
+            dx, *gb = _bwd_one(ctx.recb, t[6:], dyb, need)
+        if dya is not None:
+            dx, *ga = _bwd_one(ctx.reca, t[:6], dya, need, dx_add=dx)
+        return (dx, *ga, *gb, None, None, None, None)
+
+
+def _bn_cfg(bn):
+    """(eps, running_mean, running_var, momentum, num_batches_tracked on the device or None) of one forward, like
+    nn.BatchNorm2d.forward; a cumulative-average module (momentum None) bumps its counter on the host here."""
     track = bn.track_running_stats and bn.running_mean is not None
     momentum = 0.0
     tracked = None
@@ -261,13 +383,77 @@ def base_conv_train(x, conv, bn):
             tracked = bn.num_batches_tracked if bn.num_batches_tracked.is_cuda else None
             if tracked is None:
                 bn.num_batches_tracked += 1
-    y = _BaseConvTrain.apply(x, conv.weight, bn.weight, bn.bias, conv.stride[0], bn.eps,
-                             bn.running_mean if track else None, bn.running_var if track else None, float(momentum), tracked)
+    return (bn.eps, bn.running_mean if track else None, bn.running_var if track else None, float(momentum), tracked), track
+
+
+def _bn_done(bn, track):
     if track:
         # the kernels wrote the running statistics through raw pointers: tell autograd's version counters, which is what the
         # eval engine's weight signature (yolox/model.py) watches -- also when only a submodule is in training mode
         _bump_versions(bn.running_mean, bn.running_var)
+
+
+def base_conv_train(x, conv, bn, into=None):
+    """silu(bn(conv(x))) with batch statistics; the running statistics are updated in the same launch sequence like
+    nn.BatchNorm2d.forward does (momentum, unbiased variance, num_batches_tracked).  ``into``: the channel slice of a wider
+    channels_last buffer the activation is written into (and returned as)."""
+    cfg, track = _bn_cfg(bn)
+    y = _BaseConvTrain.apply(x, conv.weight, bn.weight, bn.bias, conv.stride[0], *cfg, _Into(into) if into is not None else None)
+    _bn_done(bn, track)
     return y
+
+
+def fuse_enabled():
+    """FRLW_TRAIN_FUSE=0: every BaseConv its own autograd node again (A/B timing; the results are the same bits)."""
+    return os.environ.get("FRLW_TRAIN_FUSE", "1") != "0"
+
+
+def bottleneck_train(x, c1, c2, into=None):
+    """``c2(c1(x)) + x`` for two BaseConv modules (Bottleneck with shortcut) as one autograd node."""
+    cfg1, t1 = _bn_cfg(c1.bn)
+    cfg2, t2 = _bn_cfg(c2.bn)
+    y = _BottleneckTrain.apply(x, c1.conv.weight, c1.bn.weight, c1.bn.bias, c2.conv.weight, c2.bn.weight, c2.bn.bias, cfg1, cfg2,
+                               _Into(into) if into is not None else None)
+    _bn_done(c1.bn, t1)
+    _bn_done(c2.bn, t2)
+    return y
+
+
+def pair_train(x, ca, cb, into_b=None):
+    """``(ca(x), cb(x))`` for two stride-1 BaseConv modules reading the same input, as one autograd node."""
+    cfga, ta = _bn_cfg(ca.bn)
+    cfgb, tb = _bn_cfg(cb.bn)
+    ya, yb = _PairTrain.apply(x, ca.conv.weight, ca.bn.weight, ca.bn.bias, cb.conv.weight, cb.bn.weight, cb.bn.bias,
+                              ca.conv.stride[0], cfga, cfgb, _Into(into_b) if into_b is not None else None)
+    _bn_done(ca.bn, ta)
+    _bn_done(cb.bn, tb)
+    return ya, yb
+
+
+def pair_eligible(x, ca, cb):
+    return (fuse_enabled() and ca.training and cb.training and eligible(x, ca.conv, ca.bn, ca.act) and eligible(x, cb.conv, cb.bn, cb.act)
+            and ca.conv.stride[0] == 1 and cb.conv.stride[0] == 1 and ca.conv.in_channels == cb.conv.in_channels)
+
+
+def csp_join_eligible(x, csp):
+    """The CSPLayer's concatenation as destination slices: conv2 and the last Bottleneck write straight into the buffer conv3
+    reads (no torch.cat launch).  Every BaseConv on the way must take the native path."""
+    hidden = csp.conv1.conv.out_channels
+    if not (pair_eligible(x, csp.conv1, csp.conv2) and len(csp.m) >= 1 and hidden % 4 == 0 and csp.conv2.conv.out_channels == hidden):
+        return False
+    for blk in csp.m:
+        c1, c2 = getattr(blk, "conv1", None), getattr(blk, "conv2", None)
+        if c1 is None or c2 is None or not (blk.training and c1.training and c2.training and eligible(x, c1.conv, c1.bn, c1.act)
+                                            and eligible(x, c2.conv, c2.bn, c2.act) and c2.conv.out_channels == hidden
+                                            and c1.conv.stride[0] == 1 and c2.conv.stride[0] == 1):
+            return False
+    return True
+
+
+def bottleneck_eligible(x, c1, c2):
+    return (fuse_enabled() and c1.training and c2.training and eligible(x, c1.conv, c1.bn, c1.act) and eligible(x, c2.conv, c2.bn, c2.act)
+            and c1.conv.stride[0] == 1 and c2.conv.stride[0] == 1 and c2.conv.in_channels == c1.conv.out_channels
+            and c2.conv.out_channels == c1.conv.in_channels)
 
 
 class _PredLevel(torch.autograd.Function):

@@ -90,11 +90,17 @@ class YOLOXHead(nn.Module):
     def train_outputs(self, xin):
         """Per level ``cat[reg, obj, cls]`` without sigmoid (yolo_head.py:186, training branch)."""
         outs = []
+        from . import train_ops
         for k, x in enumerate(xin):
             x = self.stems[k](x)
-            cls_feat = self.cls_convs[k](x)
-            reg_feat = self.reg_convs[k](x)
-            from . import train_ops
+            if x.is_cuda and len(self.cls_convs[k]) == 2 and len(self.reg_convs[k]) == 2 \
+                    and train_ops.pair_eligible(x, self.cls_convs[k][0], self.reg_convs[k][0]):
+                # the two towers read the same x: their first convolutions as one autograd node (dx summed in an epilogue)
+                c0, r0 = train_ops.pair_train(x, self.cls_convs[k][0], self.reg_convs[k][0])
+                cls_feat, reg_feat = self.cls_convs[k][1](c0), self.reg_convs[k][1](r0)
+            else:
+                cls_feat = self.cls_convs[k](x)
+                reg_feat = self.reg_convs[k](x)
             if train_ops.pred_eligible(reg_feat, cls_feat, self.reg_preds[k], self.obj_preds[k], self.cls_preds[k]):
                 outs.append(train_ops.pred_level(reg_feat, cls_feat, self.reg_preds[k], self.obj_preds[k], self.cls_preds[k]))
                 continue

@@ -564,19 +564,37 @@ int frlw_bn_silu_bwd(const float *dy, int64_t dy_row_stride, const float *z, int
  * blockIdx.z (thin layers: few output tiles, long contractions) sums the splits INSIDE the kernel -- the split that arrives
  * last at its tile's counter adds all of them in split order, the same bits as the separate reduction launch, and sets the
  * counter back to zero -- instead of launching k_splitk_reduce behind it (NULL).  frlw_det_run does the same with the last
- * 1024 words of every lane's scratch region (frlw_det_set_scratch: the caller hands the buffer over zeroed). */
+ * 1024 words of every lane's scratch region (frlw_det_set_scratch: the caller hands the buffer over zeroed).
+ * fuse (may be NULL): what the blocks AROUND this BaseConv would otherwise do in launches of their own (round 6) --
+ *   residual: y = silu(bn(conv(x))) + residual -- the Bottleneck shortcut (network_blocks.py:109-111) in the pass that writes y;
+ *   y_row_stride: y is a channel slice of a wider NHWC tensor (the concatenation buffer of a CSPLayer, network_blocks.py:191-193):
+ *     the block writes its output where the concatenation would have copied it;
+ *   dx_add: dx = data gradient + dx_add in the convolution's epilogue -- the gradient another consumer of the same x has
+ *     produced already (the shortcut's dy, the sibling 1x1 branch of a CSPLayer): autograd's accumulation launch is gone.
+ *     Stride-1 layers only (FRLW_ERR_UNSUPPORTED otherwise).
+ *   Row strides in floats, multiples of 4, 0 = dense; pointers 16-byte aligned.  The sums are the same IEEE additions the separate
+ *   launches made (a + b = b + a): results are bit-identical to the unfused sequence. */
+typedef struct frlw_baseconv_fuse {
+    int32_t struct_size;         /* sizeof(frlw_baseconv_fuse_t) */
+    int32_t reserved;
+    const float *residual;       /* forward; (B, Ho, Wo, Cout) rows */
+    int64_t residual_row_stride;
+    int64_t y_row_stride;        /* forward */
+    const float *dx_add;         /* backward; (B, H, W, Cin) rows */
+    int64_t dx_add_row_stride;
+} frlw_baseconv_fuse_t;
 int64_t frlw_baseconv_weight_cache_floats(int Cin, int Cout, int k, int precision);
 int64_t frlw_baseconv_train_scratch_bytes(int B, int H, int W, int Cin, int Cout, int k, int stride);
 int frlw_baseconv_train_fwd(const float *x, const float *w, const float *gamma, const float *beta, float eps, int B, int H,
                             int W, int Cin, int Cout, int k, int stride, float *z, float *y, float *mean, float *var,
                             float *invstd, float *running_mean, float *running_var, float momentum,
                             int64_t *num_batches_tracked, float *w_cache, void *scratch, int64_t scratch_bytes,
-                            int *splitk_counters, int precision, frlw_stream_t stream);
+                            int *splitk_counters, const frlw_baseconv_fuse_t *fuse, int precision, frlw_stream_t stream);
 int frlw_baseconv_train_bwd(const float *dy, int64_t dy_row_stride, const float *x, const float *z, const float *w, const float *gamma,
                             const float *beta, const float *mean, const float *invstd, int B, int H, int W, int Cin,
                             int Cout, int k, int stride, float *dz, float *dx, float *dw, float *dgamma, float *dbeta,
-                            const float *w_cache, void *scratch, int64_t scratch_bytes, int *splitk_counters, int precision,
-                            frlw_stream_t stream);
+                            const float *w_cache, void *scratch, int64_t scratch_bytes, int *splitk_counters,
+                            const frlw_baseconv_fuse_t *fuse, int precision, frlw_stream_t stream);
 
 /* Measurement aid: a bare loop of v_mfma_f32_32x32x2_f32 (the instruction of every convolution here) on `blocks`
  * workgroups of four wavefronts, iters x 32 MFMAs (= iters x 131072 FLOP) per wavefront, operands = the 256 floats of

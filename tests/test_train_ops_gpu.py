@@ -133,3 +133,91 @@ def test_spp_pools_vs_torch(B, C, H, W):
     ya.backward(g)
     yb.backward(g)
     assert rel(xa.grad.double(), xb.grad.double()) < 1e-5
+
+
+def _grads_of(module, x, dy_wide, lo):
+    """Forward + backward of ``module`` on a fresh leaf copy of x; the upstream gradient arrives as a channel slice of a wider
+    channels_last tensor (what the backward of a concatenation hands out)."""
+    xl = x.clone().requires_grad_(True)
+    y = module(xl)
+    y.backward(dy_wide[:, lo:lo + y.shape[1]])
+    torch.cuda.synchronize()
+    grads = {n: p.grad.clone() for n, p in module.named_parameters()}
+    bufs = {n: b.clone() for n, b in module.named_buffers()}
+    return y.detach().clone(), xl.grad.clone(), grads, bufs
+
+
+@pytest.mark.parametrize("block", ["bottleneck", "csp", "csp_noshortcut"])
+def test_fused_blocks_equal_the_unfused_sequence(block, monkeypatch):
+    """Bottleneck with shortcut as ONE autograd node (shortcut added by the pass that writes conv2's activation, its gradient by
+    the epilogue of conv1's data gradient) and conv1 | conv2 of a CSPLayer as one node (dx of the branches summed in an epilogue)
+    against every BaseConv as its own node with torch's add / gradient accumulation in between (FRLW_TRAIN_FUSE=0): the same IEEE
+    additions, so outputs, input gradient, every parameter gradient and the running statistics must be EQUAL."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import copy
+    from frlw_evd_amd.yolox.network_blocks import Bottleneck, CSPLayer
+    torch.manual_seed(5)
+    C = 64
+    if block == "bottleneck":
+        m = Bottleneck(C, C, shortcut=True, expansion=1.0)
+    else:
+        m = CSPLayer(C, C, n=2, shortcut=block == "csp")
+    for p in m.parameters():
+        if p.dim() == 1:
+            torch.nn.init.uniform_(p, 0.5, 1.5)
+    m = m.cuda().train()
+    ref = copy.deepcopy(m)
+    x = torch.randn(3, C, 16, 20, device="cuda").contiguous(memory_format=torch.channels_last)
+    dy_wide = torch.randn(3, C + 32, 16, 20, device="cuda").contiguous(memory_format=torch.channels_last)
+    monkeypatch.setenv("FRLW_TRAIN_FUSE", "1")
+    y1, dx1, g1, b1 = _grads_of(m, x, dy_wide, 16)
+    monkeypatch.setenv("FRLW_TRAIN_FUSE", "0")
+    y0, dx0, g0, b0 = _grads_of(ref, x, dy_wide, 16)
+    assert torch.equal(y1, y0) and torch.equal(dx1, dx0)
+    for n in g0:
+        assert torch.equal(g1[n], g0[n]), n
+    for n in b0:
+        assert torch.equal(b1[n], b0[n]), n
+    # and both agree with torch autograd of the same module in float64
+    monkeypatch.setenv("FRLW_NATIVE_TRAIN", "0")
+    x64 = x.double().clone().requires_grad_(True)
+    fresh = Bottleneck(C, C, shortcut=True, expansion=1.0) if block == "bottleneck" else CSPLayer(C, C, n=2, shortcut=block == "csp")
+    fresh = fresh.cuda().double().train()
+    fresh.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in m.state_dict().items()}, strict=True)
+    y64 = fresh(x64)
+    y64.backward(dy_wide[:, 16:16 + C].double())
+    assert rel(y1.double(), y64.detach()) < TOL and rel(dx1.double(), x64.grad) < TOL
+    for n, p in fresh.named_parameters():
+        assert rel(g1[n].double(), p.grad) < TOL, n
+
+
+def test_fused_train_step_equals_unfused(monkeypatch):
+    """The whole detector: loss and every parameter gradient of one step with the fused blocks (Bottleneck nodes, CSP / head pairs)
+    equal the unfused step's bit for bit."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from frlw_evd_amd.yolox import build_yolox
+    from frlw_evd_amd.yolox.model import recipe_state_dict
+    rng = np.random.default_rng(3)
+    x = torch.from_numpy(rng.integers(0, 256, size=(2, 16, 128, 160, 1, 1)).astype(np.float32) / np.float32(255)).cuda()
+    lab = torch.zeros(2, 80, 5, dtype=torch.float64)
+    lab[:, 0] = torch.tensor([0, 60.0, 50.0, 40.0, 30.0])
+    lab[:, 1] = torch.tensor([1, 100.0, 90.0, 30.0, 50.0])
+    lab = lab.cuda()
+    out = {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("FRLW_TRAIN_FUSE", fuse)
+        m = build_yolox(16, 2)
+        m.load_state_dict(recipe_state_dict(m, seed=12))
+        m = m.cuda().train()
+        loss = m(x, lab, None, None)
+        loss.backward()
+        torch.cuda.synchronize()
+        out[fuse] = (float(loss.detach()), {n: p.grad.clone() for n, p in m.named_parameters()},
+                     {n: b.clone() for n, b in m.named_buffers()})
+    assert out["1"][0] == out["0"][0]
+    for n, g in out["0"][1].items():
+        assert torch.equal(out["1"][1][n], g), n
+    for n, b in out["0"][2].items():
+        assert torch.equal(out["1"][2][n], b), n
