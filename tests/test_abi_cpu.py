@@ -108,3 +108,25 @@ def test_round6_queries_are_host_only():
     # the two-launch forms of the single-stream encoders are covered by the documented size query
     small = lib.frlw_encoder_workspace_bytes(1_000_000, 240, 304)
     assert small >= 8 * 1_000_000 + 372_000   # records + the chunk-major tables (576 bins x 145 chunks and the rest)
+
+
+def test_baseconv_fuse_struct_is_checked_on_the_host():
+    """frlw_baseconv_fuse_t carries its size; a wrong one is refused before anything is launched (the next check, the scratch
+    size, answers for a well-formed struct: no GPU needed for either)."""
+    import ctypes as C
+    lib = _lib.load()
+    assert C.sizeof(_lib.FrlwBaseconvFuse) == 48
+    p = C.c_void_p(0x1000)  # never dereferenced: both answers come from host-side argument checks
+    good = _lib.FrlwBaseconvFuse(residual=0x2000, y_row_stride=64)
+    bad = _lib.FrlwBaseconvFuse()
+    bad.struct_size = 40
+
+    def fwd(fuse):
+        return lib.frlw_baseconv_train_fwd(p, p, p, p, C.c_float(1e-5), 1, 8, 8, 16, 16, 1, 1, p, p, p, p, p, None, None, C.c_float(0.1),
+                                           None, None, p, 0, None, C.byref(fuse), 0, None)
+
+    def bwd(fuse):
+        return lib.frlw_baseconv_train_bwd(p, 0, p, p, p, p, p, p, p, 1, 8, 8, 16, 16, 1, 1, p, p, p, p, p, None, p, 0, None,
+                                           C.byref(fuse), 0, None)
+    assert fwd(bad) == _lib.FRLW_ERR_ARG and bwd(bad) == _lib.FRLW_ERR_ARG
+    assert fwd(good) == _lib.FRLW_ERR_WORKSPACE and bwd(good) == _lib.FRLW_ERR_WORKSPACE
