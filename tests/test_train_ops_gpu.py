@@ -171,6 +171,19 @@ def test_fused_blocks_equal_the_unfused_sequence(block, monkeypatch):
     x = torch.randn(3, C, 16, 20, device="cuda").contiguous(memory_format=torch.channels_last)
     dy_wide = torch.randn(3, C + 32, 16, 20, device="cuda").contiguous(memory_format=torch.channels_last)
     monkeypatch.setenv("FRLW_TRAIN_FUSE", "1")
+    probe = m(x.clone().requires_grad_(True))  # (a forward of its own: which autograd nodes does the fused module build?)
+    names, todo = set(), [probe.grad_fn]
+    while todo:
+        fn = todo.pop()
+        if fn is not None and fn not in names:
+            names.add(fn)
+            todo += [f for f, _ in fn.next_functions]
+    names = {type(f).__name__ for f in names}
+    want = {"bottleneck": {"_BottleneckTrainBackward"}, "csp": {"_BottleneckTrainBackward", "_PairTrainBackward", "_JoinSlicesBackward"},
+            "csp_noshortcut": {"_PairTrainBackward", "_JoinSlicesBackward"}}[block]
+    assert want <= names and not any("Cat" in n or "Add" in n for n in names), names
+    del probe
+    m.load_state_dict(ref.state_dict())  # undo the running-statistics update of the probe
     y1, dx1, g1, b1 = _grads_of(m, x, dy_wide, 16)
     monkeypatch.setenv("FRLW_TRAIN_FUSE", "0")
     y0, dx0, g0, b0 = _grads_of(ref, x, dy_wide, 16)
