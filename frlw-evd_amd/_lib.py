@@ -54,10 +54,18 @@ class FrlwBaseconvFuse(C.Structure):
     """frlw_baseconv_fuse_t: what the blocks around a training-mode BaseConv fold into its launches (residual added to y, y
     written into a channel slice, another consumer's gradient added to dx)."""
     _fields_ = [("struct_size", C.c_int32), ("reserved", C.c_int32), ("residual", C.c_void_p), ("residual_row_stride", C.c_int64),
-                ("y_row_stride", C.c_int64), ("dx_add", C.c_void_p), ("dx_add_row_stride", C.c_int64)]
+                ("y_row_stride", C.c_int64), ("dx_add", C.c_void_p), ("dx_add_row_stride", C.c_int64),
+                ("split", C.c_int32), ("reserved2", C.c_int32), ("w2", C.c_void_p), ("gamma2", C.c_void_p), ("beta2", C.c_void_p),
+                ("running_mean2", C.c_void_p), ("running_var2", C.c_void_p), ("num_batches_tracked2", C.c_void_p),
+                ("y2", C.c_void_p), ("y2_row_stride", C.c_int64), ("dy2", C.c_void_p), ("dy2_row_stride", C.c_int64)]
 
-    def __init__(self, residual=None, residual_row_stride=0, y_row_stride=0, dx_add=None, dx_add_row_stride=0):
-        super().__init__(C.sizeof(type(self)), 0, residual, int(residual_row_stride), int(y_row_stride), dx_add, int(dx_add_row_stride))
+    def __init__(self, **kw):
+        super().__init__()
+        self.struct_size = C.sizeof(type(self))
+        for k, v in kw.items():
+            if k not in dict(self._fields_) or k == "struct_size":
+                raise TypeError(f"unknown field {k}")
+            setattr(self, k, v if (v is None or dict(self._fields_)[k] is C.c_void_p) else int(v))
 
 
 class FrlwEvents(C.Structure):

@@ -42,15 +42,22 @@ namespace {
 // (0,0) (0,1) (1,0) (1,1) with 1, 2, 2, 4 taps -- row blocks starting at 0, 1, 3, 5 times Cout; inside a class the rows
 // are (t_ky, t_kx, co) where tap t reads dz[o' + t] and stands for kernel index 1 (parity 0) or 2, 0 (parity 1, t = 0, 1).
 // element (row, col) of the forward (which = 0) or data-gradient (which = 1) operand; zero in the padding (rows past K too)
-__device__ __forceinline__ float weight_operand_value(const float *w, int Cout, int Cin, int k, int which, int parity, long long row, int col)
+// (WPair: two BaseConvs stacked along the output channels -- channels >= split come from the second block's weight)
+struct WPair { const float *w, *w2; int split; };
+__device__ __forceinline__ const float *wpair_of(const WPair &p, int co, int Cin, int kk)
+{
+    return (p.split > 0 && co >= p.split) ? p.w2 - (long long)p.split * Cin * kk : p.w; // indexed with the stacked co below
+}
+__device__ __forceinline__ float weight_operand_value(const WPair wp, int Cout, int Cin, int k, int which, int parity, long long row, int col)
 {
     const int kk = k * k;
     if (which == 0) {
         const int ci = (int)(row % Cin), tap = (int)(row / Cin);
-        return (col < Cout && tap < kk) ? w[((long long)col * Cin + ci) * kk + tap] : 0.0f;
+        return (col < Cout && tap < kk) ? wpair_of(wp, col, Cin, kk)[((long long)col * Cin + ci) * kk + tap] : 0.0f;
     }
     const int co = (int)(row % Cout), tapf = (int)(row / Cout); // tapf = flipped tap index
     if (tapf >= kk || col >= Cin) return 0.0f;
+    const float *w = wpair_of(wp, co, Cin, kk);
     int tap = kk - 1 - tapf;
     if (parity) {
         const int cls = tapf < 1 ? 0 : (tapf < 3 ? 1 : (tapf < 5 ? 2 : 3));
@@ -66,7 +73,7 @@ __device__ __forceinline__ float weight_operand_value(const float *w, int Cout, 
 __host__ __device__ inline long long operand_rows(long long K, int prec) { return prec == 1 ? (K + 15) / 16 * 16 : K; }
 
 // float32 operands: one thread per element i of [forward | data gradient]
-__device__ __forceinline__ void weight_layout_elem(const float *w, int Cout, int Cin, int k, float *fwd, int np_f, float *dgr, int np_d,
+__device__ __forceinline__ void weight_layout_elem(const WPair w, int Cout, int Cin, int k, float *fwd, int np_f, float *dgr, int np_d,
                                                    int parity, long long nf, long long i)
 {
     if (i < nf) fwd[i] = weight_operand_value(w, Cout, Cin, k, 0, 0, i / np_f, (int)(i % np_f));
@@ -75,7 +82,7 @@ __device__ __forceinline__ void weight_layout_elem(const float *w, int Cout, int
 
 // split operands (conv_mfma.h, prec = 1): one thread per PAIR of 16-byte records (hi and lo of the same eight values) =
 // float-equivalents i .. i + 7 of [forward | data gradient], each operand ceil16(K) rows; i % 8 == 0
-__device__ __forceinline__ void weight_layout_record(const float *w, int Cout, int Cin, int k, float *fwd, int np_f, float *dgr, int np_d,
+__device__ __forceinline__ void weight_layout_record(const WPair w, int Cout, int Cin, int k, float *fwd, int np_f, float *dgr, int np_d,
                                                      int parity, long long nf, long long i)
 {
     const int which = i < nf ? 0 : 1;
@@ -97,7 +104,7 @@ __device__ __forceinline__ void weight_layout_record(const float *w, int Cout, i
     out[np] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
 }
 
-__global__ void k_weight_layouts(const float *w, int Cout, int Cin, int k, float *fwd, int np_f, float *dgr, int np_d, int parity, int prec)
+__global__ void k_weight_layouts(const WPair w, int Cout, int Cin, int k, float *fwd, int np_f, float *dgr, int np_d, int parity, int prec)
 {
     const int kk = k * k;
     const long long nf = fwd ? operand_rows((long long)kk * Cin, prec) * np_f : 0, nd = dgr ? operand_rows((long long)kk * Cout, prec) * np_d : 0;
@@ -127,7 +134,7 @@ __global__ __launch_bounds__(256) void k_weight_layouts_batch(const frlw_weight_
         if (cur.precision == 1 && base + kTile <= next) { // a whole tile of one split entry: one record pair per thread
             const int np_f = (cur.Cout + 31) / 32 * 32, np_d = (cur.Cin + 31) / 32 * 32;
             const long long nf = cur.w_fwd ? operand_rows((long long)cur.k * cur.k * cur.Cin, 1) * np_f : 0;
-            weight_layout_record(cur.w, cur.Cout, cur.Cin, cur.k, cur.w_fwd, np_f, cur.w_dgrad, np_d, (cur.dgrad_parity && cur.k == 3) ? 1 : 0, nf,
+            weight_layout_record(WPair{cur.w, cur.w2, cur.split}, cur.Cout, cur.Cin, cur.k, cur.w_fwd, np_f, cur.w_dgrad, np_d, (cur.dgrad_parity && cur.k == 3) ? 1 : 0, nf,
                                  base - cur.first + 8 * threadIdx.x);
             continue;
         }
@@ -145,9 +152,9 @@ __global__ __launch_bounds__(256) void k_weight_layouts_batch(const frlw_weight_
             const long long nf = it.w_fwd ? operand_rows((long long)it.k * it.k * it.Cin, it.precision) * np_f : 0;
             const int parity = (it.dgrad_parity && it.k == 3) ? 1 : 0;
             if (it.precision == 1) { // every eighth thread-slot lays a record pair (entries start at multiples of 32 elements)
-                if ((i & 7) == 0) weight_layout_record(it.w, it.Cout, it.Cin, it.k, it.w_fwd, np_f, it.w_dgrad, np_d, parity, nf, i - it.first);
+                if ((i & 7) == 0) weight_layout_record(WPair{it.w, it.w2, it.split}, it.Cout, it.Cin, it.k, it.w_fwd, np_f, it.w_dgrad, np_d, parity, nf, i - it.first);
             } else {
-                weight_layout_elem(it.w, it.Cout, it.Cin, it.k, it.w_fwd, np_f, it.w_dgrad, np_d, parity, nf, i - it.first);
+                weight_layout_elem(WPair{it.w, it.w2, it.split}, it.Cout, it.Cin, it.k, it.w_fwd, np_f, it.w_dgrad, np_d, parity, nf, i - it.first);
             }
         }
     }
@@ -328,13 +335,16 @@ __device__ __forceinline__ void bn_sum_partials(const double *partial, int n_wg,
 
 // mean, biased variance, invstd = 1 / sqrt(var + eps) in float32 (what BatchNorm2d normalises with)
 // (+ the running statistics of nn.BatchNorm2d when given: momentum update with the unbiased variance)
+// (pair: two BaseConvs stacked along the channels -- channels >= split update the second block's running statistics)
+struct RunStats2 { float *run_mean2, *run_var2; long long *tracked2; int split; };
 __global__ __launch_bounds__(256) void k_bn_stats_final(const double *partial, int n_wg, int C, long long M, float eps,
                                                         float *mean, float *var, float *invstd, float *run_mean,
-                                                        float *run_var, float momentum, long long *batches_tracked)
+                                                        float *run_var, float momentum, long long *batches_tracked, RunStats2 pr)
 {
     double s, ss;
     int c;
     if (batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *batches_tracked += 1; // nn.BatchNorm2d.num_batches_tracked
+    if (pr.tracked2 && blockIdx.x == 0 && threadIdx.x == 0) *pr.tracked2 += 1;
     bn_sum_partials(partial, n_wg, C, s, ss, c);
     if (c < 0) return;
     const double mu = s / (double)M;
@@ -345,8 +355,10 @@ __global__ __launch_bounds__(256) void k_bn_stats_final(const double *partial, i
     invstd[c] = (float)(1.0 / sqrt(v + (double)eps));
     if (run_mean) {
         const float unbiased = (float)v * ((float)M / (float)(M > 1 ? M - 1 : 1));
-        run_mean[c] = run_mean[c] * (1.0f - momentum) + momentum * (float)mu;
-        run_var[c] = run_var[c] * (1.0f - momentum) + momentum * unbiased;
+        float *rm = run_mean + c, *rv = run_var + c;
+        if (pr.split > 0 && c >= pr.split) { rm = pr.run_mean2 + (c - pr.split); rv = pr.run_var2 + (c - pr.split); }
+        *rm = *rm * (1.0f - momentum) + momentum * (float)mu;
+        *rv = *rv * (1.0f - momentum) + momentum * unbiased;
     }
 }
 
@@ -356,16 +368,33 @@ __global__ __launch_bounds__(256) void k_bn_stats_final(const double *partial, i
 __device__ __forceinline__ float sigmoid_fast(float u) { return __frcp_rn(1.0f + __expf(-u)); }
 __device__ __forceinline__ float silu_f(float u) { return u * sigmoid_fast(u); }
 
+// Two BaseConvs stacked along the channels (frlw_baseconv_fuse_t::split): channels [0, split) use the first block's gamma / beta
+// and rows, channels [split, C) the second block's.  split == 0: one block.  (split % 4 == 0: a float4 never straddles.)
+struct Aff2 { const float *g, *b, *g2, *b2; int split; };
+__device__ __forceinline__ void aff_of(const Aff2 &a, int c, const float *&g, const float *&b)
+{
+    const bool second = a.split > 0 && c >= a.split;
+    g = second ? a.g2 - a.split : a.g;
+    b = second ? a.b2 - a.split : a.b;
+}
+struct Rows2 { const float *p; long long rs; const float *p2; long long rs2; int split; };
+__device__ __forceinline__ const float *row_of(const Rows2 &d, long long r, int c)
+{
+    return (d.split > 0 && c >= d.split) ? d.p2 + r * d.rs2 + (c - d.split) : d.p + r * d.rs + c;
+}
+
 // y = silu(gamma * (z - mean) * invstd + beta) [+ res]
 // FUSE: the rows of y and res may be channel slices of wider NHWC tensors (y_rs / res_rs floats between two rows), res may be NULL
 template <bool FUSE>
-__global__ void k_bn_silu_fwd(const float *z, long long n4, int C, const float *gamma, const float *beta, const float *mean,
-                              const float *invstd, float *y, long long y_rs, const float *res, long long res_rs)
+__global__ void k_bn_silu_fwd(const float *z, long long n4, int C, const Aff2 ab, const float *mean,
+                              const float *invstd, float *y, long long y_rs, const float *res, long long res_rs, float *y2, long long y2_rs)
 {
     const int C4 = C >> 2;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C4) * 4;
         const float4 v = ((const float4 *)z)[i];
+        const float *gamma = ab.g, *beta = ab.b;
+        if (FUSE) aff_of(ab, c, gamma, beta);
         float4 o;
         o.x = silu_f(gamma[c + 0] * ((v.x - mean[c + 0]) * invstd[c + 0]) + beta[c + 0]);
         o.y = silu_f(gamma[c + 1] * ((v.y - mean[c + 1]) * invstd[c + 1]) + beta[c + 1]);
@@ -377,7 +406,8 @@ __global__ void k_bn_silu_fwd(const float *z, long long n4, int C, const float *
                 const float4 rr = *(const float4 *)(res + r * res_rs + c);
                 o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
             }
-            *(float4 *)(y + r * y_rs + c) = o;
+            if (ab.split > 0 && c >= ab.split) *(float4 *)(y2 + r * y2_rs + (c - ab.split)) = o;
+            else *(float4 *)(y + r * y_rs + c) = o;
         } else {
             ((float4 *)y)[i] = o;
         }
@@ -393,12 +423,15 @@ __device__ __forceinline__ float dsilu_times(float dy, float u)
 
 // partial[wg][c] = {sum du, sum du * zhat} in float64
 // (dy_rs: floats between two rows of dy -- C when dense, more when dy is a channel slice of a wider NHWC gradient)
-__global__ __launch_bounds__(256) void k_bn_silu_bwd_partial(const float *dy, long long dy_rs, const float *z, long long M, int C,
-                                                             const float *gamma, const float *beta, const float *mean,
+template <bool PAIR>
+__global__ __launch_bounds__(256) void k_bn_silu_bwd_partial(const Rows2 dyr, const float *z, long long M, int C,
+                                                             const Aff2 ab, const float *mean,
                                                              const float *invstd, double *partial)
 {
     bn_reduce_rows<true>(M, C, partial, [=](long long r, int c, float (&o)[8]) {
-        const float4 zv = *(const float4 *)(z + r * C + c), gv = *(const float4 *)(dy + r * dy_rs + c);
+        const float *gamma = ab.g, *beta = ab.b;
+        if (PAIR) aff_of(ab, c, gamma, beta);
+        const float4 zv = *(const float4 *)(z + r * C + c), gv = *(const float4 *)(PAIR ? row_of(dyr, r, c) : dyr.p + r * dyr.rs + c);
         const float zz[4] = {zv.x, zv.y, zv.z, zv.w}, gg[4] = {gv.x, gv.y, gv.z, gv.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -425,14 +458,20 @@ __global__ __launch_bounds__(256) void k_bn_silu_bwd_final(const double *partial
 }
 
 // dz = gamma * invstd * (du - mean(du) - zhat * mean(du * zhat))
-__global__ void k_bn_silu_bwd_apply(const float *dy, long long dy_rs, const float *z, long long n4, int C, const float *gamma,
-                                    const float *beta, const float *mean, const float *invstd, const float *sums, float *dz)
+template <bool PAIR>
+__global__ void k_bn_silu_bwd_apply(const Rows2 dyr, const float *z, long long n4, int C, const Aff2 ab,
+                                    const float *mean, const float *invstd, const float *sums, float *dz)
 {
     const int C4 = C >> 2;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C4) * 4;
         const float4 zv = ((const float4 *)z)[i];
-        const float4 gv = dy_rs == C ? ((const float4 *)dy)[i] : *(const float4 *)(dy + (i / C4) * dy_rs + c);
+        const float *gamma = ab.g, *beta = ab.b;
+        if (PAIR) aff_of(ab, c, gamma, beta);
+        const float *dy = dyr.p;
+        const long long dy_rs = dyr.rs;
+        const float4 gv = PAIR ? *(const float4 *)row_of(dyr, i / C4, c)
+                               : (dy_rs == C ? ((const float4 *)dy)[i] : *(const float4 *)(dy + (i / C4) * dy_rs + c));
         const float zz[4] = {zv.x, zv.y, zv.z, zv.w}, gg[4] = {gv.x, gv.y, gv.z, gv.w};
         float o[4];
 #pragma unroll
@@ -469,18 +508,25 @@ int64_t frlw_conv_operand_floats(int K, int N, int precision)
     return operand_rows(K, precision) * (int64_t)npad32(N);
 }
 
-int frlw_conv_weight_layouts(const float *w, int Cout, int Cin, int k, int dgrad_parity, float *w_fwd, float *w_dgrad,
-                             int precision, frlw_stream_t stream)
+static int weight_layouts_impl(const float *w, const float *w2, int split, int Cout, int Cin, int k, int dgrad_parity, float *w_fwd,
+                               float *w_dgrad, int precision, frlw_stream_t stream)
 {
     (void)hipGetLastError(); // other libraries in the process (torch's BLAS look-ups) leave stale errors behind
     if (!w || Cout < 1 || Cin < 1 || k < 1 || (!w_fwd && !w_dgrad)) return FRLW_ERR_ARG;
+    if (split > 0 && (!w2 || split >= Cout)) return FRLW_ERR_ARG;
     if (!precision_ok(precision, Cout, dgrad_parity && w_dgrad)) return FRLW_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     const long long total = (w_fwd ? frlw_conv_operand_floats(k * k * Cin, Cout, precision) : 0) + (w_dgrad ? frlw_conv_operand_floats(k * k * Cout, Cin, precision) : 0);
-    hipLaunchKernelGGL(k_weight_layouts, dim3(conv_grid_1d(precision == 1 ? total / 8 : total)), dim3(256), 0, s, w, Cout, Cin, k, w_fwd, npad32(Cout),
+    hipLaunchKernelGGL(k_weight_layouts, dim3(conv_grid_1d(precision == 1 ? total / 8 : total)), dim3(256), 0, s, WPair{w, w2, split > 0 ? split : 0}, Cout, Cin, k, w_fwd, npad32(Cout),
                        w_dgrad, npad32(Cin), (dgrad_parity && k == 3) ? 1 : 0, precision);
     TRY_HIP(hipGetLastError());
     return FRLW_OK;
+}
+
+int frlw_conv_weight_layouts(const float *w, int Cout, int Cin, int k, int dgrad_parity, float *w_fwd, float *w_dgrad,
+                             int precision, frlw_stream_t stream)
+{
+    return weight_layouts_impl(w, nullptr, 0, Cout, Cin, k, dgrad_parity, w_fwd, w_dgrad, precision, stream);
 }
 
 int frlw_conv_weight_layouts_batch(const frlw_weight_layout_item_t *items, int n, int64_t total, frlw_stream_t stream)
@@ -638,7 +684,7 @@ int64_t frlw_bn_scratch_doubles(int64_t M, int C)
 
 static int bn_stats_impl(const float *z, int64_t M, int C, float eps, float *mean, float *var, float *invstd,
                          double *scratch, float *run_mean, float *run_var, float momentum, long long *batches_tracked,
-                         frlw_stream_t stream, int have_partials = 0);
+                         frlw_stream_t stream, int have_partials = 0, RunStats2 pr = RunStats2{nullptr, nullptr, nullptr, 0});
 
 int frlw_bn_stats(const float *z, int64_t M, int C, float eps, float *mean, float *var, float *invstd, double *scratch,
                   frlw_stream_t stream)
@@ -648,7 +694,7 @@ int frlw_bn_stats(const float *z, int64_t M, int C, float eps, float *mean, floa
 
 static int bn_stats_impl(const float *z, int64_t M, int C, float eps, float *mean, float *var, float *invstd,
                          double *scratch, float *run_mean, float *run_var, float momentum, long long *batches_tracked,
-                         frlw_stream_t stream, int have_partials)
+                         frlw_stream_t stream, int have_partials, RunStats2 pr)
 {
     (void)hipGetLastError(); // other libraries in the process (torch's BLAS look-ups) leave stale errors behind
     if (!z || !mean || !var || !invstd || !scratch || M < 1 || C < 4 || (C & 3)) return FRLW_ERR_ARG;
@@ -657,26 +703,34 @@ static int bn_stats_impl(const float *z, int64_t M, int C, float eps, float *mea
     if (have_partials > 0) n_wg = have_partials; // the convolution's epilogue has written `have_partials` slabs into scratch
     else hipLaunchKernelGGL(k_bn_stats_partial, dim3(n_wg), dim3(256), 0, s, z, (long long)M, C, scratch);
     hipLaunchKernelGGL(k_bn_stats_final, dim3((C + kFinCh - 1) / kFinCh), dim3(256), 0, s, scratch, n_wg, C, (long long)M, eps, mean,
-                       var, invstd, run_mean, run_var, momentum, batches_tracked);
+                       var, invstd, run_mean, run_var, momentum, batches_tracked, pr);
     TRY_HIP(hipGetLastError());
     return FRLW_OK;
 }
 
+// split > 0: channels [split, C) are a second block's -- gamma2 / beta2, rows of y2 (y2_rs floats apart; the first block's y rows
+// are then `split` wide by default)
 static int bn_silu_fwd_impl(const float *z, int64_t M, int C, const float *gamma, const float *beta, const float *mean,
-                            const float *invstd, float *y, int64_t y_rs, const float *res, int64_t res_rs, frlw_stream_t stream)
+                            const float *invstd, float *y, int64_t y_rs, const float *res, int64_t res_rs, frlw_stream_t stream,
+                            int split = 0, const float *gamma2 = nullptr, const float *beta2 = nullptr, float *y2 = nullptr, int64_t y2_rs = 0)
 {
     (void)hipGetLastError(); // other libraries in the process (torch's BLAS look-ups) leave stale errors behind
     if (!z || !y || !gamma || !beta || !mean || !invstd || M < 1 || C < 4 || (C & 3)) return FRLW_ERR_ARG;
-    if (y_rs <= 0) y_rs = C;
+    const int c1 = split > 0 ? split : C; // channels of the (first) block
+    if (split > 0 && ((split & 3) || split >= C || !gamma2 || !beta2 || !y2 || res)) return FRLW_ERR_ARG;
+    if (y_rs <= 0) y_rs = c1;
     if (res_rs <= 0) res_rs = C;
-    if (y_rs < C || (y_rs & 3) || ((uintptr_t)y & 15) || (res && (res_rs < C || (res_rs & 3) || ((uintptr_t)res & 15)))) return FRLW_ERR_ARG;
+    if (y2_rs <= 0) y2_rs = C - c1;
+    if (y_rs < c1 || (y_rs & 3) || ((uintptr_t)y & 15) || (res && (res_rs < C || (res_rs & 3) || ((uintptr_t)res & 15)))) return FRLW_ERR_ARG;
+    if (split > 0 && (y2_rs < C - c1 || (y2_rs & 3) || ((uintptr_t)y2 & 15))) return FRLW_ERR_ARG;
     const long long n4 = (long long)M * C / 4;
-    if (res || y_rs != C)
-        hipLaunchKernelGGL(k_bn_silu_fwd<true>, dim3(conv_grid_1d(n4)), dim3(256), 0, (hipStream_t)stream, z, n4, C, gamma, beta, mean,
-                           invstd, y, (long long)y_rs, res, (long long)res_rs);
+    const Aff2 ab = {gamma, beta, gamma2, beta2, split > 0 ? split : 0};
+    if (res || y_rs != C || split > 0)
+        hipLaunchKernelGGL(k_bn_silu_fwd<true>, dim3(conv_grid_1d(n4)), dim3(256), 0, (hipStream_t)stream, z, n4, C, ab, mean,
+                           invstd, y, (long long)y_rs, res, (long long)res_rs, y2, (long long)y2_rs);
     else
-        hipLaunchKernelGGL(k_bn_silu_fwd<false>, dim3(conv_grid_1d(n4)), dim3(256), 0, (hipStream_t)stream, z, n4, C, gamma, beta, mean,
-                           invstd, y, (long long)C, (const float *)nullptr, (long long)C);
+        hipLaunchKernelGGL(k_bn_silu_fwd<false>, dim3(conv_grid_1d(n4)), dim3(256), 0, (hipStream_t)stream, z, n4, C, ab, mean,
+                           invstd, y, (long long)C, (const float *)nullptr, (long long)C, (float *)nullptr, (long long)0);
     TRY_HIP(hipGetLastError());
     return FRLW_OK;
 }
@@ -687,25 +741,44 @@ int frlw_bn_silu_fwd(const float *z, int64_t M, int C, const float *gamma, const
     return bn_silu_fwd_impl(z, M, C, gamma, beta, mean, invstd, y, 0, nullptr, 0, stream);
 }
 
+// split > 0: channels [split, C) are a second block's -- gamma2 / beta2, gradient rows dy2 (dy2_rs floats apart; dy's rows are
+// then `split` wide by default); z, dz, mean, invstd, dgamma, dbeta stay stacked (C wide)
+static int bn_silu_bwd_impl(const float *dy, int64_t dy_row_stride, const float *z, int64_t M, int C, const float *gamma, const float *beta,
+                            const float *mean, const float *invstd, float *dz, float *dgamma, float *dbeta, double *scratch,
+                            float *sums, frlw_stream_t stream, int split = 0, const float *gamma2 = nullptr, const float *beta2 = nullptr,
+                            const float *dy2 = nullptr, int64_t dy2_row_stride = 0)
+{
+    (void)hipGetLastError(); // other libraries in the process (torch's BLAS look-ups) leave stale errors behind
+    if (!dy || !z || !dz || !dgamma || !dbeta || !scratch || !sums || M < 1 || C < 4 || (C & 3)) return FRLW_ERR_ARG;
+    const int c1 = split > 0 ? split : C;
+    if (split > 0 && ((split & 3) || split >= C || !gamma2 || !beta2 || !dy2)) return FRLW_ERR_ARG;
+    const long long dy_rs = dy_row_stride > 0 ? dy_row_stride : c1;
+    const long long dy2_rs = dy2_row_stride > 0 ? dy2_row_stride : C - c1;
+    if (dy_rs < c1 || (dy_rs & 3) || ((uintptr_t)dy & 15)) return FRLW_ERR_ARG;
+    if (split > 0 && (dy2_rs < C - c1 || (dy2_rs & 3) || ((uintptr_t)dy2 & 15))) return FRLW_ERR_ARG;
+    const int n_wg = (int)((M + bn_rows_per_wg(M) - 1) / bn_rows_per_wg(M));
+    hipStream_t s = (hipStream_t)stream;
+    const Aff2 ab = {gamma, beta, gamma2, beta2, split > 0 ? split : 0};
+    const Rows2 dyr = {dy, dy_rs, dy2, dy2_rs, split > 0 ? split : 0};
+    const long long n4 = (long long)M * C / 4;
+    if (split > 0) {
+        hipLaunchKernelGGL(k_bn_silu_bwd_partial<true>, dim3(n_wg), dim3(256), 0, s, dyr, z, (long long)M, C, ab, mean, invstd, scratch);
+        hipLaunchKernelGGL(k_bn_silu_bwd_final, dim3((C + kFinCh - 1) / kFinCh), dim3(256), 0, s, scratch, n_wg, C, (long long)M, dgamma, dbeta, sums);
+        hipLaunchKernelGGL(k_bn_silu_bwd_apply<true>, dim3(conv_grid_1d(n4)), dim3(256), 0, s, dyr, z, n4, C, ab, mean, invstd, sums, dz);
+    } else {
+        hipLaunchKernelGGL(k_bn_silu_bwd_partial<false>, dim3(n_wg), dim3(256), 0, s, dyr, z, (long long)M, C, ab, mean, invstd, scratch);
+        hipLaunchKernelGGL(k_bn_silu_bwd_final, dim3((C + kFinCh - 1) / kFinCh), dim3(256), 0, s, scratch, n_wg, C, (long long)M, dgamma, dbeta, sums);
+        hipLaunchKernelGGL(k_bn_silu_bwd_apply<false>, dim3(conv_grid_1d(n4)), dim3(256), 0, s, dyr, z, n4, C, ab, mean, invstd, sums, dz);
+    }
+    TRY_HIP(hipGetLastError());
+    return FRLW_OK;
+}
+
 int frlw_bn_silu_bwd(const float *dy, int64_t dy_row_stride, const float *z, int64_t M, int C, const float *gamma, const float *beta,
                      const float *mean, const float *invstd, float *dz, float *dgamma, float *dbeta, double *scratch,
                      float *sums, frlw_stream_t stream)
 {
-    (void)hipGetLastError(); // other libraries in the process (torch's BLAS look-ups) leave stale errors behind
-    if (!dy || !z || !dz || !dgamma || !dbeta || !scratch || !sums || M < 1 || C < 4 || (C & 3)) return FRLW_ERR_ARG;
-    const long long dy_rs = dy_row_stride > 0 ? dy_row_stride : C;
-    if (dy_rs < C || (dy_rs & 3) || ((uintptr_t)dy & 15)) return FRLW_ERR_ARG;
-    const int n_wg = (int)((M + bn_rows_per_wg(M) - 1) / bn_rows_per_wg(M));
-    hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_bn_silu_bwd_partial, dim3(n_wg), dim3(256), 0, s, dy, dy_rs, z, (long long)M, C, gamma, beta, mean, invstd,
-                       scratch);
-    hipLaunchKernelGGL(k_bn_silu_bwd_final, dim3((C + kFinCh - 1) / kFinCh), dim3(256), 0, s, scratch, n_wg, C, (long long)M, dgamma,
-                       dbeta, sums);
-    const long long n4 = (long long)M * C / 4;
-    hipLaunchKernelGGL(k_bn_silu_bwd_apply, dim3(conv_grid_1d(n4)), dim3(256), 0, s, dy, dy_rs, z, n4, C, gamma, beta, mean, invstd,
-                       sums, dz);
-    TRY_HIP(hipGetLastError());
-    return FRLW_OK;
+    return bn_silu_bwd_impl(dy, dy_row_stride, z, M, C, gamma, beta, mean, invstd, dz, dgamma, dbeta, scratch, sums, stream);
 }
 
 /* ---- one call per BaseConv and direction (the per-operator entry points above stay for tests / other callers) ---- */
@@ -758,28 +831,38 @@ int frlw_baseconv_train_fwd(const float *x, const float *w, const float *gamma, 
 {
     if (!x || (!w && !w_cache) || !gamma || !beta || !z || !y || !mean || !var || !invstd || !scratch) return FRLW_ERR_ARG;
     if (fuse && fuse->struct_size != (int32_t)sizeof(frlw_baseconv_fuse_t)) return FRLW_ERR_ARG;
+    const int split = fuse ? fuse->split : 0; // > 0: two blocks stacked along the output channels (frlw_evd.h)
+    if (split < 0 || (split > 0 && ((split & 3) || split >= Cout || !fuse->gamma2 || !fuse->beta2 || !fuse->y2 || fuse->residual || (w && !fuse->w2))))
+        return FRLW_ERR_ARG;
     if (scratch_bytes < frlw_baseconv_train_scratch_bytes(B, H, W, Cin, Cout, k, stride)) return FRLW_ERR_WORKSPACE;
     const int pad = (k - 1) / 2;
     const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
     const int64_t M = (int64_t)B * Ho * Wo;
     TrainScratch t = carve(scratch, B, Ho, Wo, Cin, Cout, k);
     int rc;
+    const float *w2 = split > 0 ? fuse->w2 : nullptr;
     const float *w_fwd = t.w_fwd;
     if (w_cache && !w) { // the caller has laid both operands out already (frlw_conv_weight_layouts_batch)
         w_fwd = w_cache;
     } else if (w_cache) { // both operands in ONE launch, kept by the caller: the backward of this step finds its operand ready
         float *w_dg = w_cache + frlw_conv_operand_floats(k * k * Cin, Cout, precision);
-        if ((rc = frlw_conv_weight_layouts(w, Cout, Cin, k, frlw_conv2d_dgrad_parity(k, stride, H, W), w_cache, w_dg, precision, stream)) != FRLW_OK) return rc;
+        if ((rc = weight_layouts_impl(w, w2, split, Cout, Cin, k, frlw_conv2d_dgrad_parity(k, stride, H, W), w_cache, w_dg, precision, stream)) != FRLW_OK) return rc;
         w_fwd = w_cache;
-    } else if ((rc = frlw_conv_weight_layouts(w, Cout, Cin, k, 0, t.w_fwd, nullptr, precision, stream)) != FRLW_OK) return rc;
+    } else if ((rc = weight_layouts_impl(w, w2, split, Cout, Cin, k, 0, t.w_fwd, nullptr, precision, stream)) != FRLW_OK) return rc;
     if (stride != 1 && stride != 2) return FRLW_ERR_UNSUPPORTED;
     int stat_rows = 0; // > 0: the convolution's epilogue left the column sums of its output slabs in t.red
     if ((rc = conv_common(x, B, H, W, Cin, w_fwd, Cout, k, stride, 0, Ho, Wo, z, t.splitk, t.splitk_floats, precision, (hipStream_t)stream,
                           t.red, &stat_rows, splitk_counters)) != FRLW_OK) return rc;
+    RunStats2 pr = {nullptr, nullptr, nullptr, 0};
+    if (split > 0 && running_mean) {
+        if (!fuse->running_mean2 || !fuse->running_var2) return FRLW_ERR_ARG;
+        pr = RunStats2{fuse->running_mean2, fuse->running_var2, (long long *)fuse->num_batches_tracked2, split};
+    }
     if ((rc = bn_stats_impl(z, M, Cout, eps, mean, var, invstd, t.red, running_mean, running_mean ? running_var : nullptr,
-                            momentum, (long long *)num_batches_tracked, stream, stat_rows)) != FRLW_OK) return rc;
+                            momentum, (long long *)num_batches_tracked, stream, stat_rows, pr)) != FRLW_OK) return rc;
     return bn_silu_fwd_impl(z, M, Cout, gamma, beta, mean, invstd, y, fuse ? fuse->y_row_stride : 0, fuse ? fuse->residual : nullptr,
-                            fuse ? fuse->residual_row_stride : 0, stream);
+                            fuse ? fuse->residual_row_stride : 0, stream, split, split > 0 ? fuse->gamma2 : nullptr,
+                            split > 0 ? fuse->beta2 : nullptr, split > 0 ? fuse->y2 : nullptr, split > 0 ? fuse->y2_row_stride : 0);
 }
 
 /* Gradients of the block: dx (NULL: not needed), dw (Cout, Cin, k, k), dgamma, dbeta.  dz: (B, Ho, Wo, Cout) work buffer. */
@@ -793,17 +876,22 @@ int frlw_baseconv_train_bwd(const float *dy, int64_t dy_row_stride, const float 
         return FRLW_ERR_ARG;
     if (fuse && fuse->struct_size != (int32_t)sizeof(frlw_baseconv_fuse_t)) return FRLW_ERR_ARG;
     if (fuse && fuse->dx_add && (!dx || stride != 1)) return FRLW_ERR_UNSUPPORTED;
+    const int split = fuse ? fuse->split : 0;
+    if (split < 0 || (split > 0 && ((split & 3) || split >= Cout || !fuse->gamma2 || !fuse->beta2 || !fuse->dy2 || (!w_cache && !fuse->w2))))
+        return FRLW_ERR_ARG;
     if (scratch_bytes < frlw_baseconv_train_scratch_bytes(B, H, W, Cin, Cout, k, stride)) return FRLW_ERR_WORKSPACE;
     const int pad = (k - 1) / 2;
     const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
     const int64_t M = (int64_t)B * Ho * Wo;
     TrainScratch t = carve(scratch, B, Ho, Wo, Cin, Cout, k);
     int rc;
-    if ((rc = frlw_bn_silu_bwd(dy, dy_row_stride, z, M, Cout, gamma, beta, mean, invstd, dz, dgamma, dbeta, t.red, t.sums, stream)) != FRLW_OK) return rc;
+    if ((rc = bn_silu_bwd_impl(dy, dy_row_stride, z, M, Cout, gamma, beta, mean, invstd, dz, dgamma, dbeta, t.red, t.sums, stream, split,
+                               split > 0 ? fuse->gamma2 : nullptr, split > 0 ? fuse->beta2 : nullptr, split > 0 ? fuse->dy2 : nullptr,
+                               split > 0 ? fuse->dy2_row_stride : 0)) != FRLW_OK) return rc;
     if (dx) {
         const float *w_dg = t.w_dg;
         if (w_cache) w_dg = w_cache + frlw_conv_operand_floats(k * k * Cin, Cout, precision); // laid out by the forward of this step
-        else if ((rc = frlw_conv_weight_layouts(w, Cout, Cin, k, frlw_conv2d_dgrad_parity(k, stride, H, W), nullptr, t.w_dg, precision, stream)) != FRLW_OK) return rc;
+        else if ((rc = weight_layouts_impl(w, split > 0 ? fuse->w2 : nullptr, split, Cout, Cin, k, frlw_conv2d_dgrad_parity(k, stride, H, W), nullptr, t.w_dg, precision, stream)) != FRLW_OK) return rc;
         if ((rc = conv2d_dgrad_impl(dz, B, Ho, Wo, Cout, w_dg, Cin, k, stride, H, W, dx, t.splitk, t.splitk_floats, precision, stream, splitk_counters,
                                     fuse ? fuse->dx_add : nullptr, fuse ? fuse->dx_add_row_stride : 0)) != FRLW_OK) return rc;
     }

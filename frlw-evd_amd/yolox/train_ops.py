@@ -55,13 +55,30 @@ def _weight_cache(lib, weight, Cin, Cout, k):
     return hit[1]
 
 
+_PAIRS = {}  # id(first weight of a stacked pair) -> weakref of the second weight (set by the pair's forward; see _PairStackTrain)
+
+
+def _pair_second(w):
+    """The second weight of the stacked pair whose first weight is ``w`` (None: ``w`` is an ordinary weight)."""
+    ref = _PAIRS.get(id(w))
+    w2 = ref() if ref is not None else None
+    if ref is not None and w2 is None:
+        _PAIRS.pop(id(w), None)
+    return w2
+
+
+def _ver(w, w2=None):
+    return w._version if w2 is None else (w._version, w2._version)
+
+
 _WREADY = {}  # id(weight parameter) -> (version, parity, cache data_ptr) the batched layout below has laid the cache out for
 _PLANS = {}  # id(model) -> (weakref, item table on the device, total elements, [(weight, parity, cache, weight pointer)])
 
 
 def _layout_plan(model):
     """One table entry per natively trained BaseConv weight of `model` whose operand cache exists (= that has run one
-    forward): frlw_weight_layout_item_t {w, w_fwd, w_dgrad, Cout, Cin, k, parity, precision, reserved, first}."""
+    forward): frlw_weight_layout_item_t {w, w_fwd, w_dgrad, Cout, Cin, k, parity, precision, reserved, first, w2, split, reserved2};
+    the first weight of a stacked pair stands for both (Cout = the pair's channels, w2 / split = the second weight)."""
     import struct
     import weakref
     lib = _lib.load()
@@ -75,12 +92,23 @@ def _layout_plan(model):
         if hit is None or geom is None or hit[0]() is not w or not w.is_cuda or not w.is_contiguous() or w.dtype != torch.float32:
             continue
         Cout, Cin, k, _ = w.shape
+        w2 = _pair_second(w)
+        split = 0
+        if w2 is not None:
+            if not (w2.is_cuda and w2.is_contiguous() and w2.dtype == torch.float32 and isinstance(geom[0], tuple)):
+                continue
+            split, Cout = Cout, Cout + w2.shape[0]
+        elif isinstance(geom[0], tuple):
+            continue  # the cache was last laid out for a pair that is gone
         cache = hit[1]
         prec = geom[2]
         n_f, n_d = lib.frlw_conv_operand_floats(k * k * Cin, Cout, prec), lib.frlw_conv_operand_floats(k * k * Cout, Cin, prec)
-        blob += struct.pack("<QQQiiiiiiq", w.data_ptr(), cache.data_ptr(), cache.data_ptr() + 4 * n_f, Cout, Cin, k, geom[1], prec, 0, first)
+        if cache.numel() < n_f + n_d:
+            continue
+        blob += struct.pack("<QQQiiiiiiqQii", w.data_ptr(), cache.data_ptr(), cache.data_ptr() + 4 * n_f, Cout, Cin, k, geom[1], prec, 0, first,
+                            w2.data_ptr() if w2 is not None else 0, split, 0)
         first += n_f + n_d
-        rows.append((w, (geom[1], prec), cache, w.data_ptr()))
+        rows.append((w, (geom[1], prec), cache, w.data_ptr(), w2, w2.data_ptr() if w2 is not None else 0))
     if not rows:
         return None
     import numpy as np
@@ -97,9 +125,10 @@ def layout_all_weights(model):
     plan = _PLANS.get(id(model))
     stale = plan is None or plan[0]() is not model
     if not stale:
-        for w, parity, cache, ptr in plan[3]:  # parity = (parity class, precision) the entry was written for
+        for w, parity, cache, ptr, w2, ptr2 in plan[3]:  # parity = (parity class, precision) the entry was written for
             hit, geom = _WCACHE.get(id(w)), _WCACHE_GEOM.get(id(w))
-            if hit is None or hit[1] is not cache or geom is None or geom[1:] != parity or w.data_ptr() != ptr:
+            if (hit is None or hit[1] is not cache or geom is None or geom[1:] != parity or w.data_ptr() != ptr
+                    or _pair_second(w) is not w2 or (w2 is not None and w2.data_ptr() != ptr2) or isinstance(geom[0], tuple) != (w2 is not None)):
                 stale = True
                 break
     if stale:
@@ -113,9 +142,9 @@ def layout_all_weights(model):
     _, table, total, rows = plan
     lib = _lib.load()
     _lib.check(lib.frlw_conv_weight_layouts_batch(table.data_ptr(), len(rows), total, _stream(table.device)), "weight_layouts_batch")
-    for w, parity, cache, _ptr in rows:
-        _WREADY[id(w)] = (w._version, parity, cache.data_ptr())
-        _WCACHE_GEOM[id(w)] = (w._version, *parity)
+    for w, parity, cache, _ptr, w2, _ptr2 in rows:
+        _WREADY[id(w)] = (_ver(w, w2), parity, cache.data_ptr())
+        _WCACHE_GEOM[id(w)] = (_ver(w, w2), *parity)
     return True
 
 
@@ -179,16 +208,23 @@ def native_enabled():
 
 class _Rec:
     """What one BaseConv forward leaves for its backward beside the saved tensors (x, z, w, gamma, beta, stats)."""
-    __slots__ = ("geom", "wcache", "wparity", "wversion", "weight_ref")
+    __slots__ = ("geom", "wcache", "wparity", "wversion", "weight_ref", "weight2_ref", "split")
 
 
-def _fwd_one(x, weight, gamma, beta, stride, eps, run_mean, run_var, momentum, tracked, residual=None, out=None):
+def _slice_ok(out, shape):
+    return out.shape == shape and out.dtype == torch.float32 and out.stride()[1] == 1 and out.data_ptr() % 16 == 0
+
+
+def _fwd_one(x, weight, gamma, beta, stride, eps, run_mean, run_var, momentum, tracked, residual=None, out=None, pair=None):
     """One frlw_baseconv_train_fwd call: (y, tensors to save, _Rec).  ``x``: float32 NHWC storage.  ``residual``: added to y in
-    the pass that writes it; ``out``: a (B, Cout, Ho, Wo) channel slice of a wider channels_last tensor y is written into."""
+    the pass that writes it; ``out``: a (B, Cout, Ho, Wo) channel slice of a wider channels_last tensor y is written into.
+    ``pair`` = (weight2, gamma2, beta2, (eps2, run_mean2, run_var2, momentum2, tracked2), out2): a SECOND BaseConv reading the same
+    x, stacked along the output channels (frlw_baseconv_fuse_t::split) -- returns ((y, y2), tensors to save, _Rec)."""
     lib = _lib.load()
     dev = x.device
     B, Cin, H, W = x.shape
-    Cout, _, k, _ = weight.shape
+    C1, _, k, _ = weight.shape
+    Cout = C1 + (pair[0].shape[0] if pair is not None else 0)
     pad = (k - 1) // 2
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
     w = weight.detach().float().contiguous()
@@ -196,21 +232,44 @@ def _fwd_one(x, weight, gamma, beta, stride, eps, run_mean, run_var, momentum, t
     b = beta.detach().float().contiguous()
     z = torch.empty((B, Cout, Ho, Wo), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
     fuse = None
+    extra = ()
+    y_shape = (B, C1, Ho, Wo)
     if residual is not None or out is not None:
         res, res_rs = (None, 0) if residual is None else _rows_in_place(residual)
         y_rs = 0
         if out is not None:
-            assert out.shape == z.shape and out.dtype == torch.float32 and out.stride()[1] == 1 and out.data_ptr() % 16 == 0
+            assert _slice_ok(out, y_shape)
             y_rs = out.stride()[3]
         fuse = _lib.FrlwBaseconvFuse(residual=None if res is None else res.data_ptr(), residual_row_stride=res_rs, y_row_stride=y_rs)
-    y = out if out is not None else torch.empty_like(z)
+    y = out if out is not None else torch.empty(y_shape, dtype=torch.float32, device=dev, memory_format=torch.channels_last)
+    if pair is not None:
+        weight2, gamma2, beta2, cfg2, out2 = pair
+        w2, g2, b2 = weight2.detach().float().contiguous(), gamma2.detach().float().contiguous(), beta2.detach().float().contiguous()
+        y2_shape = (B, Cout - C1, Ho, Wo)
+        assert out2 is None or _slice_ok(out2, y2_shape)
+        y2 = out2 if out2 is not None else torch.empty(y2_shape, dtype=torch.float32, device=dev, memory_format=torch.channels_last)
+        fuse = fuse if fuse is not None else _lib.FrlwBaseconvFuse()
+        fuse.split, fuse.w2, fuse.gamma2, fuse.beta2 = C1, w2.data_ptr(), g2.data_ptr(), b2.data_ptr()
+        fuse.running_mean2 = cfg2[1].data_ptr() if cfg2[1] is not None else None
+        fuse.running_var2 = cfg2[2].data_ptr() if cfg2[2] is not None else None
+        fuse.num_batches_tracked2 = cfg2[4].data_ptr() if cfg2[4] is not None else None
+        fuse.y2, fuse.y2_row_stride = y2.data_ptr(), (y2.stride()[3] if out2 is not None else 0)
+        assert cfg2[0] == eps and cfg2[3] == momentum and (cfg2[1] is None) == (run_mean is None)
+        extra = (w2, g2, b2)
+        import weakref
+        _PAIRS[id(weight)] = weakref.ref(weight2)
     stats = torch.empty((3, Cout), dtype=torch.float32, device=dev)  # mean, biased variance, invstd
     sc = _scratch(dev, "block", lib.frlw_baseconv_train_scratch_bytes(B, H, W, Cin, Cout, k, stride), torch.uint8)
     wc = _weight_cache(lib, weight, Cin, Cout, k)  # both GEMM operands of this weight, laid out once per step
     parity = int(lib.frlw_conv2d_dgrad_parity(k, stride, H, W))
     prec = layer_precision(Cout, k, stride)
     # laid out already by layout_all_weights() for exactly this weight version, parity class, precision and buffer?
-    ready = _WREADY.get(id(weight)) == (weight._version, (parity, prec), wc.data_ptr()) and w.data_ptr() == weight.data_ptr()
+    weight2 = pair[0] if pair is not None else None
+    if pair is None and _PAIRS.get(id(weight)) is not None:
+        _PAIRS.pop(id(weight), None)  # this weight runs on its own again: its cache is laid out for itself
+    ver = _ver(weight, weight2)
+    ready = (_WREADY.get(id(weight)) == (ver, (parity, prec), wc.data_ptr()) and w.data_ptr() == weight.data_ptr()
+             and (weight2 is None or extra[0].data_ptr() == weight2.data_ptr()))
     _lib.check(lib.frlw_baseconv_train_fwd(x.data_ptr(), None if ready else w.data_ptr(), g.data_ptr(), b.data_ptr(), C.c_float(eps), B, H, W,
                                            Cin, Cout, k, stride, z.data_ptr(), y.data_ptr(), stats[0].data_ptr(),
                                            stats[1].data_ptr(), stats[2].data_ptr(),
@@ -224,18 +283,21 @@ def _fwd_one(x, weight, gamma, beta, stride, eps, run_mean, run_var, momentum, t
     # the data-gradient half of the cache depends on the parity class of (k, stride, H, W): a second forward of the same
     # layer on an input of another parity (shared layer, multi-scale graph) re-lays it -- remember what THIS forward wrote
     rec.wparity = (parity, prec)
-    _WCACHE_GEOM[id(weight)] = (weight._version, parity, prec)
-    rec.wversion = weight._version
+    _WCACHE_GEOM[id(weight)] = (ver, parity, prec)
+    rec.wversion = ver
     rec.weight_ref = weight
+    rec.weight2_ref = weight2
+    rec.split = C1 if pair is not None else 0
     rec.geom = (B, Cin, H, W, Cout, k, stride)
-    return y, (x, z, w, g, b, stats), rec
+    return (y if pair is None else (y, y2)), (x, z, w, g, b, stats) + extra, rec
 
 
-def _bwd_one(rec, saved, dy, need_dx, dx_add=None):
+def _bwd_one(rec, saved, dy, need_dx, dx_add=None, dy2=None):
     """One frlw_baseconv_train_bwd call: (dx or None, dw, dgamma, dbeta).  ``dx_add``: the gradient another consumer of the same
-    input has produced already, added to dx in the data gradient's epilogue (stride-1 layers)."""
+    input has produced already, added to dx in the data gradient's epilogue (stride-1 layers).  A stacked pair (rec.split): ``dy`` /
+    ``dy2`` are the two blocks' upstream gradients, dw / dgamma / dbeta come back stacked (the second block's rows from rec.split)."""
     lib = _lib.load()
-    x, z, w, g, b, stats = saved
+    x, z, w, g, b, stats = saved[:6]
     B, Cin, H, W, Cout, k, stride = rec.geom
     dev = dy.device
     dy, dy_rs = _rows_in_place(dy.float())
@@ -247,11 +309,17 @@ def _bwd_one(rec, saved, dy, need_dx, dx_add=None):
     if dx_add is not None and dx is not None:
         add, add_rs = _rows_in_place(dx_add.float())
         fuse = _lib.FrlwBaseconvFuse(dx_add=add.data_ptr(), dx_add_row_stride=add_rs)
+    if rec.split:
+        w2, g2, b2 = saved[6:9]
+        dy2, dy2_rs = _rows_in_place(dy2.float())
+        fuse = fuse if fuse is not None else _lib.FrlwBaseconvFuse()
+        fuse.split, fuse.w2, fuse.gamma2, fuse.beta2 = rec.split, w2.data_ptr(), g2.data_ptr(), b2.data_ptr()
+        fuse.dy2, fuse.dy2_row_stride = dy2.data_ptr(), dy2_rs
     sc = _scratch(dev, "block", lib.frlw_baseconv_train_scratch_bytes(B, H, W, Cin, Cout, k, stride), torch.uint8)
     # the operand cache belongs to the forward of THIS graph only while the weight (and the cache) are untouched
     # since: a second forward of the same layer before this backward would have overwritten it with the same
     # weights' layout (fine), an in-place weight update in between would not (then lay out again)
-    fresh = (rec.weight_ref._version == rec.wversion and _WCACHE.get(id(rec.weight_ref), (None, None))[1] is rec.wcache
+    fresh = (_ver(rec.weight_ref, rec.weight2_ref) == rec.wversion and _WCACHE.get(id(rec.weight_ref), (None, None))[1] is rec.wcache
              and _WCACHE_GEOM.get(id(rec.weight_ref)) == (rec.wversion, *rec.wparity))
     _lib.check(lib.frlw_baseconv_train_bwd(dy.data_ptr(), dy_rs, x.data_ptr(), z.data_ptr(), w.data_ptr(), g.data_ptr(),
                                            b.data_ptr(), stats[0].data_ptr(), stats[2].data_ptr(), B, H, W, Cin, Cout, k,
@@ -368,6 +436,40 @@ class _PairTrain(torch.autograd.Function):
         return (dx, *ga, *gb, None, None, None, None)
 
 
+class _PairStackTrain(torch.autograd.Function):
+    """Two stride-1 BaseConvs with the same kernel size reading the same x as ONE stacked block (frlw_baseconv_fuse_t::split): one
+    convolution with both blocks' output channels, one statistics / BatchNorm + SiLU pass writing the two activations to their
+    own destinations, and in the backward one BatchNorm backward reading the two upstream gradients where they lie, ONE data
+    gradient (the sum over both blocks by construction) and ONE weight gradient -- ten launches per pair and step less than
+    _PairTrain, and thin layers twice as wide.  Per element the contraction is summed in the same order as in the separate
+    blocks unless the stacked layer splits its contraction differently; the batch statistics are float64 sums over other slabs:
+    results agree with _PairTrain's to rounding (tests: 1e-5), not bit for bit."""
+
+    @staticmethod
+    def forward(ctx, x, wa, ga, ba, wb, gb, bb, stride, cfga, cfgb, into_b=None):
+        ctx.set_materialize_grads(False)
+        x = _nhwc(x.float())
+        (ya, yb), saved, ctx.rec = _fwd_one(x, wa, ga, ba, stride, *cfga,
+                                            pair=(wb, gb, bb, cfgb, into_b.t if into_b is not None else None))
+        ctx.save_for_backward(*saved)
+        return ya, yb
+
+    @staticmethod
+    def backward(ctx, dya, dyb):
+        if dya is None and dyb is None:
+            return (None,) * 11
+        t = ctx.saved_tensors
+        B, Cin, H, W, Cout, k, stride = ctx.rec.geom
+        h = ctx.rec.split
+        z = t[1]
+        if dya is None:
+            dya = torch.zeros((B, h, z.shape[2], z.shape[3]), dtype=torch.float32, device=z.device, memory_format=torch.channels_last)
+        if dyb is None:
+            dyb = torch.zeros((B, Cout - h, z.shape[2], z.shape[3]), dtype=torch.float32, device=z.device, memory_format=torch.channels_last)
+        dx, dw, dg, db = _bwd_one(ctx.rec, t, dya, ctx.needs_input_grad[0], dy2=dyb)
+        return dx, dw[:h], dg[:h], db[:h], dw[h:], dg[h:], db[h:], None, None, None, None
+
+
 def _bn_cfg(bn):
     """(eps, running_mean, running_var, momentum, num_batches_tracked on the device or None) of one forward, like
     nn.BatchNorm2d.forward; a cumulative-average module (momentum None) bumps its counter on the host here."""
@@ -423,11 +525,26 @@ def pair_train(x, ca, cb, into_b=None):
     """``(ca(x), cb(x))`` for two stride-1 BaseConv modules reading the same input, as one autograd node."""
     cfga, ta = _bn_cfg(ca.bn)
     cfgb, tb = _bn_cfg(cb.bn)
-    ya, yb = _PairTrain.apply(x, ca.conv.weight, ca.bn.weight, ca.bn.bias, cb.conv.weight, cb.bn.weight, cb.bn.bias,
+    node = _PairStackTrain if pair_stackable(ca, cb, cfga, cfgb) else _PairTrain
+    ya, yb = node.apply(x, ca.conv.weight, ca.bn.weight, ca.bn.bias, cb.conv.weight, cb.bn.weight, cb.bn.bias,
                               ca.conv.stride[0], cfga, cfgb, _Into(into_b) if into_b is not None else None)
     _bn_done(ca.bn, ta)
     _bn_done(cb.bn, tb)
     return ya, yb
+
+
+def stack_enabled():
+    """FRLW_TRAIN_STACK=0: a pair stays two blocks whose data gradients are summed in an epilogue (_PairTrain; A/B timing)."""
+    return os.environ.get("FRLW_TRAIN_STACK", "1") != "0"
+
+
+def pair_stackable(ca, cb, cfga, cfgb):
+    """Both blocks as ONE stacked block: same kernel size and input, channel counts multiples of 4, the same BatchNorm settings
+    (eps, momentum, both or neither tracking running statistics, counters both on the device or both absent)."""
+    return (stack_enabled() and ca.conv.kernel_size == cb.conv.kernel_size and ca.conv.out_channels % 4 == 0
+            and cb.conv.out_channels % 4 == 0 and cfga[0] == cfgb[0] and cfga[3] == cfgb[3]
+            and (cfga[1] is None) == (cfgb[1] is None) and (cfga[4] is None) == (cfgb[4] is None)
+            and layer_precision(ca.conv.out_channels + cb.conv.out_channels, ca.conv.kernel_size[0], 1) == layer_precision(ca.conv.out_channels, ca.conv.kernel_size[0], 1))
 
 
 def pair_eligible(x, ca, cb):

@@ -516,6 +516,8 @@ typedef struct frlw_weight_layout_item {
     int32_t Cout, Cin, k, dgrad_parity;
     int32_t precision, reserved;
     int64_t first;
+    const float *w2;   /* split > 0: output channels [split, Cout) come from this second weight (Cout - split, Cin, k, k): the */
+    int32_t split, reserved2; /* operands of two BaseConvs stacked along the output channels (frlw_baseconv_fuse_t::split) */
 } frlw_weight_layout_item_t;
 int frlw_conv_weight_layouts_batch(const frlw_weight_layout_item_t *items, int n, int64_t total, frlw_stream_t stream);
 /* z (B, Ho, Wo, Cout) = conv2d(x (B, H, W, Cin), w), padding (k - 1) / 2, stride 1 or 2.  scratch: optional split-K
@@ -582,6 +584,22 @@ typedef struct frlw_baseconv_fuse {
     int64_t y_row_stride;        /* forward */
     const float *dx_add;         /* backward; (B, H, W, Cin) rows */
     int64_t dx_add_row_stride;
+    /* split > 0: the call is TWO BaseConvs reading the same x (conv1 | conv2 of a CSPLayer, network_blocks.py:191-193), stacked
+     * along the output channels: Cout = both blocks' channels, channels [0, split) are the first block's (w, gamma, beta, running
+     * statistics, num_batches_tracked, y, dy: the call's own arguments; their rows are `split` wide by default), channels
+     * [split, Cout) the second block's (the fields below).  ONE convolution, ONE statistics / BatchNorm pass, ONE data gradient
+     * (dx is the sum over both blocks by construction) and ONE weight gradient do the work of two of each; z, dz, mean, var,
+     * invstd, dw, dgamma, dbeta are stacked (Cout wide; dw = (Cout, Cin, k, k): the second block's rows start at split).
+     * split % 4 == 0; no residual.  w_cache (when the caller lays the operands out itself): the operands of the STACKED weight. */
+    int32_t split, reserved2;
+    const float *w2;             /* (Cout - split, Cin, k, k) */
+    const float *gamma2, *beta2;
+    float *running_mean2, *running_var2;
+    int64_t *num_batches_tracked2;
+    float *y2;                   /* forward */
+    int64_t y2_row_stride;
+    const float *dy2;            /* backward */
+    int64_t dy2_row_stride;
 } frlw_baseconv_fuse_t;
 int64_t frlw_baseconv_weight_cache_floats(int Cin, int Cout, int k, int precision);
 int64_t frlw_baseconv_train_scratch_bytes(int B, int H, int W, int Cin, int Cout, int k, int stride);

@@ -115,7 +115,7 @@ def test_baseconv_fuse_struct_is_checked_on_the_host():
     size, answers for a well-formed struct: no GPU needed for either)."""
     import ctypes as C
     lib = _lib.load()
-    assert C.sizeof(_lib.FrlwBaseconvFuse) == 48
+    assert C.sizeof(_lib.FrlwBaseconvFuse) == 136
     p = C.c_void_p(0x1000)  # never dereferenced: both answers come from host-side argument checks
     good = _lib.FrlwBaseconvFuse(residual=0x2000, y_row_stride=64)
     bad = _lib.FrlwBaseconvFuse()

@@ -168,9 +168,11 @@ def test_fused_blocks_equal_the_unfused_sequence(block, monkeypatch):
             torch.nn.init.uniform_(p, 0.5, 1.5)
     m = m.cuda().train()
     ref = copy.deepcopy(m)
+    start = copy.deepcopy(m.state_dict())
     x = torch.randn(3, C, 16, 20, device="cuda").contiguous(memory_format=torch.channels_last)
     dy_wide = torch.randn(3, C + 32, 16, 20, device="cuda").contiguous(memory_format=torch.channels_last)
     monkeypatch.setenv("FRLW_TRAIN_FUSE", "1")
+    monkeypatch.setenv("FRLW_TRAIN_STACK", "0")  # (the stacked pair is compared to rounding below: its sums run in another order)
     probe = m(x.clone().requires_grad_(True))  # (a forward of its own: which autograd nodes does the fused module build?)
     names, todo = set(), [probe.grad_fn]
     while todo:
@@ -203,6 +205,36 @@ def test_fused_blocks_equal_the_unfused_sequence(block, monkeypatch):
     assert rel(y1.double(), y64.detach()) < TOL and rel(dx1.double(), x64.grad) < TOL
     for n, p in fresh.named_parameters():
         assert rel(g1[n].double(), p.grad) < TOL, n
+    if block == "bottleneck":
+        return
+    # conv1 | conv2 as ONE stacked block (_PairStackTrain: one convolution, one BatchNorm pass each way, one data and one weight
+    # gradient for both): the same numbers to rounding -- the contraction and the float64 statistics sums run over other tiles
+    monkeypatch.setenv("FRLW_NATIVE_TRAIN", "1")
+    monkeypatch.setenv("FRLW_TRAIN_FUSE", "1")
+    monkeypatch.setenv("FRLW_TRAIN_STACK", "1")
+    st = copy.deepcopy(ref)
+    st.load_state_dict(start)
+    probe = st(x.clone().requires_grad_(True))
+    names, todo = set(), [probe.grad_fn]
+    while todo:
+        fn = todo.pop()
+        if fn is not None and fn not in names:
+            names.add(fn)
+            todo += [f for f, _ in fn.next_functions]
+    assert "_PairStackTrainBackward" in {type(f).__name__ for f in names}
+    del probe
+    st.load_state_dict(start)
+    y2, dx2, g2, b2 = _grads_of(st, x, dy_wide, 16)
+    assert rel(y2, y1) < 1e-5 and rel(dx2, dx1) < 1e-5
+    for n in g1:
+        assert rel(g2[n], g1[n]) < 2e-5, n
+    for n in b1:
+        if b1[n].is_floating_point():
+            assert rel(b2[n], b1[n]) < 1e-5, n
+        else:
+            assert torch.equal(b2[n], b1[n]), n
+    for n, p in fresh.named_parameters():
+        assert rel(g2[n].double(), p.grad) < TOL, n
 
 
 def test_fused_train_step_equals_unfused(monkeypatch):
@@ -219,8 +251,10 @@ def test_fused_train_step_equals_unfused(monkeypatch):
     lab[:, 1] = torch.tensor([1, 100.0, 90.0, 30.0, 50.0])
     lab = lab.cuda()
     out = {}
-    for fuse in ("1", "0"):
-        monkeypatch.setenv("FRLW_TRAIN_FUSE", fuse)
+    monkeypatch.setenv("FRLW_TRAIN_STACK", "0")
+    for fuse in ("1", "0", "stack"):
+        monkeypatch.setenv("FRLW_TRAIN_FUSE", "0" if fuse == "0" else "1")
+        monkeypatch.setenv("FRLW_TRAIN_STACK", "1" if fuse == "stack" else "0")
         m = build_yolox(16, 2)
         m.load_state_dict(recipe_state_dict(m, seed=12))
         m = m.cuda().train()
@@ -234,3 +268,10 @@ def test_fused_train_step_equals_unfused(monkeypatch):
         assert torch.equal(out["1"][1][n], g), n
     for n, b in out["0"][2].items():
         assert torch.equal(out["1"][2][n], b), n
+    # ... and with the pairs as stacked blocks: the same step to rounding
+    assert out["stack"][0] == pytest.approx(out["1"][0], rel=1e-6)
+    for n, g in out["1"][1].items():
+        assert rel(out["stack"][1][n], g) < 1e-3, n   # (single gradients of a 65536x scaled loss pass through SimOTA's choices: 1e-3 like every train test)
+    for n, b in out["1"][2].items():
+        if b.is_floating_point():
+            assert rel(out["stack"][2][n], b) < 1e-5, n

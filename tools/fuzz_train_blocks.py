@@ -1,14 +1,20 @@
 """Fuzz of the train step's block nodes (yolox/train_ops.py: _BottleneckTrain, _PairTrain, destination slices) on random shapes:
 a Bottleneck / CSPLayer with FRLW_TRAIN_FUSE=1 against the same module with every BaseConv as its own autograd node
 (FRLW_TRAIN_FUSE=0) -- output, input gradient, every parameter gradient and every running statistic must be EQUAL (the fused
-additions are the same IEEE additions).   python tools/fuzz_train_blocks.py [cases] [seed]"""
+additions are the same IEEE additions); and a CSPLayer whose conv1 | conv2 run as ONE stacked block (FRLW_TRAIN_STACK=1) against
+the two-block pair: equal to rounding (1e-4 of the largest value; the sums run over other tiles).   python tools/fuzz_train_blocks.py [cases] [seed]"""
 import copy, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from frlw_evd_amd.yolox.network_blocks import Bottleneck, CSPLayer
 
-def run(module, x, dy_wide, lo, fuse):
+def rel(a, b):
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def run(module, x, dy_wide, lo, fuse, stack="0"):
     os.environ["FRLW_TRAIN_FUSE"] = fuse
+    os.environ["FRLW_TRAIN_STACK"] = stack
     xl = x.clone().requires_grad_(True)
     y = module(xl)
     y.backward(dy_wide[:, lo:lo + y.shape[1]])
@@ -39,6 +45,7 @@ for it in range(cases):
             torch.nn.init.uniform_(p, 0.5, 1.5)
     m = m.cuda().train()
     ref = copy.deepcopy(m)
+    st = copy.deepcopy(m)
     x = torch.randn(B, C, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
     pad = int(rng.choice([0, 4, 32]))
     dy_wide = torch.randn(B, Cout + pad, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
@@ -50,5 +57,12 @@ for it in range(cases):
     if not ok:
         bad += 1
         print(f"MISMATCH case {it}: {kind} C={C} Cout={Cout} B={B} H={H} W={W} pad={pad}")
+    if kind != "bottleneck":  # conv1 | conv2 as ONE stacked block: the same numbers to rounding (other summation tiles)
+        c = run(st, x, dy_wide, lo, "1", "1")
+        worst = max([rel(c[0], a[0]), rel(c[1], a[1])] + [rel(c[2][n], a[2][n]) for n in a[2]]
+                    + [rel(c[3][n], a[3][n]) for n in a[3] if a[3][n].is_floating_point()])
+        if not worst < 1e-4:
+            bad += 1
+            print(f"STACK MISMATCH case {it}: {kind} C={C} Cout={Cout} B={B} H={H} W={W} pad={pad}: {worst:.3g}")
 print(f"{cases} cases, {bad} mismatches")
 sys.exit(1 if bad else 0)
