@@ -11,6 +11,7 @@ cp "$(find $O -name '*kernel_stats.csv' | head -1)" $K/train_kernel_stats.csv
 (GRAPH=1 bash $R/tools/train_gaps.sh > /dev/null 2>&1; cp $R/gpurun_out/train_gaps/sequence.txt $K/train_sequence.txt; cp $R/gpurun_out/train_gaps/gaps.txt $K/train_gaps.txt)
 cd $R
 for f in 0 1 0 1; do FRLW_TRAIN_FUSE=$f python3 tools/train_ab.py 2>&1 | tail -1 >> $K/train_fuse_ab.txt; done
+for f in 0 1 0 1; do FRLW_TRAIN_STACK=$f python3 tools/train_ab.py 2>&1 | tail -1 >> $K/train_stack_ab.txt; done
 python3 bench.py > $K/bench.json 2> $K/bench.err; echo "bench rc=$?"; cp bench_detail.json $K/bench_detail.json
 python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $K/smoke.log 2>&1; tail -1 $K/smoke.log
 ls -la $K
