@@ -161,6 +161,8 @@ class Trainer:
         snap_opt = {p: {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in st.items()}
                     for p, st in self.optimizer.state.items()}
         snap_lr = [g["lr"].clone() if torch.is_tensor(g["lr"]) else g["lr"] for g in self.optimizer.param_groups]
+        if self._flat_ddp:
+            warmup = max(int(warmup), 1)  # (the flat gradient buffer is laid out from the gradients a backward has left)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
