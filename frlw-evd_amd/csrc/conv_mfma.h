@@ -675,7 +675,9 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &a)
                             const float4 rr = *(const float4 *)(a.res + (long long)b * a.r_bs + (long long)pix * a.r_cs + a.r_co + n);
                             v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
                         }
-                        *(float4 *)(a.y + (long long)b * a.y_bs + (long long)pix * a.y_cs + a.y_co + n) = make_float4(v[0], v[1], v[2], v[3]);
+                        long long yo = (long long)pix * a.y_cs;
+                        if (a.y_rp) { const int oy = pix / a.Wo; yo = (long long)oy * a.y_rp + (long long)(pix - oy * a.Wo) * a.y_cs; } // (a parity class of a stride-2 data gradient)
+                        *(float4 *)(a.y + (long long)b * a.y_bs + yo + a.y_co + n) = make_float4(v[0], v[1], v[2], v[3]);
                     }
                 }
             }
@@ -1201,7 +1203,7 @@ inline bool launch_conv(ConvArgs &c, float *scratch, long long scratch_floats, h
         grant_stats(64);
         const bool vec = ((c.Cout | c.Npad | c.y_cs | c.y_co | c.r_cs | c.r_co | c.y_rp) & 3) == 0 && (c.y_bs & 3) == 0 && (c.r_bs & 3) == 0;
         // the reduction inside the kernel (SK): float32 operand, uniform taps, vector rows, a counter per tile -- else k_splitk_reduce
-        if (c.splits > 1 && sk_counters && vec && c.prec == 0 && c.Cin % CONV_BK_SMALL == 0 && c.y_rp == 0 &&
+        if (c.splits > 1 && sk_counters && vec && c.prec == 0 && c.Cin % CONV_BK_SMALL == 0 &&
             (long long)((c.M + 63) / 64) * ((c.Npad + 63) / 64) <= 1024) {
             c.sk_counters = sk_counters;
             hipLaunchKernelGGL((k_conv_mfma_sk<CONV_BK_SMALL>), dim3((c.M + 63) / 64, (c.Npad + 63) / 64, c.splits), dim3(256), 0, s, c);

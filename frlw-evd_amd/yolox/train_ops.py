@@ -55,15 +55,18 @@ def _weight_cache(lib, weight, Cin, Cout, k):
     return hit[1]
 
 
-_PAIRS = {}  # id(first weight of a stacked pair) -> weakref of the second weight (set by the pair's forward; see _PairStackTrain)
+_PAIRS = {}  # id(first weight of a stacked pair) -> (weakref of it, weakref of the second weight); set by the pair's forward
 
 
 def _pair_second(w):
     """The second weight of the stacked pair whose first weight is ``w`` (None: ``w`` is an ordinary weight)."""
-    ref = _PAIRS.get(id(w))
-    w2 = ref() if ref is not None else None
-    if ref is not None and w2 is None:
+    refs = _PAIRS.get(id(w))
+    if refs is None:
+        return None
+    w2 = refs[1]()
+    if refs[0]() is not w or w2 is None:  # (an id reused by another tensor, or a pair whose second weight is gone)
         _PAIRS.pop(id(w), None)
+        return None
     return w2
 
 
@@ -257,7 +260,7 @@ def _fwd_one(x, weight, gamma, beta, stride, eps, run_mean, run_var, momentum, t
         assert cfg2[0] == eps and cfg2[3] == momentum and (cfg2[1] is None) == (run_mean is None)
         extra = (w2, g2, b2)
         import weakref
-        _PAIRS[id(weight)] = weakref.ref(weight2)
+        _PAIRS[id(weight)] = (weakref.ref(weight), weakref.ref(weight2))
     stats = torch.empty((3, Cout), dtype=torch.float32, device=dev)  # mean, biased variance, invstd
     sc = _scratch(dev, "block", lib.frlw_baseconv_train_scratch_bytes(B, H, W, Cin, Cout, k, stride), torch.uint8)
     wc = _weight_cache(lib, weight, Cin, Cout, k)  # both GEMM operands of this weight, laid out once per step
@@ -265,8 +268,8 @@ def _fwd_one(x, weight, gamma, beta, stride, eps, run_mean, run_var, momentum, t
     prec = layer_precision(Cout, k, stride)
     # laid out already by layout_all_weights() for exactly this weight version, parity class, precision and buffer?
     weight2 = pair[0] if pair is not None else None
-    if pair is None and _PAIRS.get(id(weight)) is not None:
-        _PAIRS.pop(id(weight), None)  # this weight runs on its own again: its cache is laid out for itself
+    if pair is None:
+        _PAIRS.pop(id(weight), None)  # this weight runs on its own (again): its cache is laid out for itself
     ver = _ver(weight, weight2)
     ready = (_WREADY.get(id(weight)) == (ver, (parity, prec), wc.data_ptr()) and w.data_ptr() == weight.data_ptr()
              and (weight2 is None or extra[0].data_ptr() == weight2.data_ptr()))
