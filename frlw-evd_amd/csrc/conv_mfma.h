@@ -642,6 +642,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &a)
             const int n = n0 + wc * 32 + ec;
             float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
             if (a.bias && n < a.Cout) bias4 = *(const float4 *)(a.bias + n);
+            float st_s[4] = {0.0f, 0.0f, 0.0f, 0.0f}, st_q[4] = {0.0f, 0.0f, 0.0f, 0.0f}; // a.stats: column sums of this lane's four rows
 #pragma unroll
             for (int tp = 0; tp < 4 / SK_ROWS; ++tp) { // two of the thread's four rows at a time: 16 loads in flight (the registers of 32 would cost the main loop a wavefront per SIMD)
                 f32x4 part[SK_ROWS][8];
@@ -663,6 +664,10 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &a)
 #pragma unroll
                     for (int z = 0; z < 8; ++z)
                         if (z < a.splits) { v[0] += part[tt][z][0]; v[1] += part[tt][z][1]; v[2] += part[tt][z][2]; v[3] += part[tt][z][3]; }
+                    if (a.stats && m < a.M) { // (workgroup-uniform pointer; train forward: no bias, no activation -- v is z)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { st_s[e] += v[e]; st_q[e] += v[e] * v[e]; }
+                    }
                     if (m < a.M && n < a.Cout) {
                         const float bb[4] = {bias4.x, bias4.y, bias4.z, bias4.w};
 #pragma unroll
@@ -679,6 +684,27 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &a)
                         if (a.y_rp) { const int oy = pix / a.Wo; yo = (long long)oy * a.y_rp + (long long)(pix - oy * a.Wo) * a.y_cs; } // (a parity class of a stride-2 data gradient)
                         *(float4 *)(a.y + (long long)b * a.y_bs + yo + a.y_co + n) = make_float4(v[0], v[1], v[2], v[3]);
                     }
+                }
+            }
+            if (a.stats) {
+                // BatchNorm statistics of the train step from the finished tile, like the unsplit epilogue below: float32 inside a
+                // wavefront's 32 rows (four rows per lane, then the eight lanes that share a column quad), float64 across the two
+                // wavefronts of a column half and in the stored slab (one slab per 64-row tile) -- k_bn_stats_partial goes away
+                // for the layers that split their contraction
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int off = 8; off <= 32; off <<= 1) { st_s[e] += __shfl_xor(st_s[e], off); st_q[e] += __shfl_xor(st_q[e], off); }
+                float2 *stg = (float2 *)smem; // [wavefront][32 columns] (the operand tiles are free: every wavefront is past the barrier above)
+                if (lane < 8) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) stg[wv * 32 + ec + e] = make_float2(st_s[e], st_q[e]);
+                }
+                __syncthreads();
+                if (wr == 0 && lane < 32) {
+                    const float2 v0 = stg[(0 * WCOLS + wc) * 32 + lane], v1 = stg[(1 * WCOLS + wc) * 32 + lane];
+                    const int nn = n0 + wc * 32 + lane;
+                    if (nn < a.Cout) *(double2 *)(a.stats + ((long long)blockIdx.x * a.Cout + nn) * 2) = make_double2((double)v0.x + (double)v1.x, (double)v0.y + (double)v1.y);
                 }
             }
             return;
@@ -1206,6 +1232,7 @@ inline bool launch_conv(ConvArgs &c, float *scratch, long long scratch_floats, h
         if (c.splits > 1 && sk_counters && vec && c.prec == 0 && c.Cin % CONV_BK_SMALL == 0 &&
             (long long)((c.M + 63) / 64) * ((c.Npad + 63) / 64) <= 1024) {
             c.sk_counters = sk_counters;
+            if (stats_ok && !c.bias && c.act == ACT_NONE && !c.res) { c.stats = stats_req; c.stats_rows = (c.M + 63) / 64; } // the last arriver has the whole tile
             hipLaunchKernelGGL((k_conv_mfma_sk<CONV_BK_SMALL>), dim3((c.M + 63) / 64, (c.Npad + 63) / 64, c.splits), dim3(256), 0, s, c);
             return true;
         }
